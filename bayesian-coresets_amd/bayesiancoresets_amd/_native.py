@@ -1,0 +1,274 @@
+"""ctypes binding of libbcx.so (the C ABI in include/bcx.h) and the host-side driver of one
+row shard.  There is NO CPU fallback: if the library is missing or no GPU is usable every
+solver constructor raises."""
+import ctypes
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(os.path.dirname(_HERE), "lib", "libbcx.so")
+
+ALG_GIGA, ALG_FW, ALG_OMP = 0, 1, 2
+F32, F64 = 0, 1
+OK, ERR_ARG, ERR_HIP, ERR_ZERO_ROW, ERR_ZERO_B, ERR_NOMEM, ERR_STATE = 0, -1, -2, -3, -4, -5, -6
+IT_OK, IT_FAIL_SELECT, IT_FAIL_REWEIGHT, IT_FAIL_MONOTONE = 0, 1, 2, 3
+REC_HDR = 4
+CHUNK_ROWS = 1024
+
+# every symbol include/bcx.h declares (checked by tests/test_abi.py)
+SYMBOLS = (
+    "bcx_create", "bcx_destroy", "bcx_last_error", "bcx_set_stream", "bcx_load_rows", "bcx_chunk_sums",
+    "bcx_finalize", "bcx_build_begin", "bcx_step_scan", "bcx_step_apply", "bcx_build_enqueue", "bcx_build_poll",
+    "bcx_step_scan_exact", "bcx_build_trace", "bcx_active_count", "bcx_get_weights", "bcx_error", "bcx_optimize",
+    "bcx_reset", "bcx_reached_numeric_limit", "bcx_get_vector", "bcx_get_norms", "bcx_time_scan",
+    "bcx_profile_scan", "bcx_profile_read", "bcx_version",
+)
+
+
+class Config(ctypes.Structure):
+    _fields_ = [
+        ("alg", ctypes.c_int32), ("store_dtype", ctypes.c_int32), ("keep_exact_rows", ctypes.c_int32),
+        ("device", ctypes.c_int32), ("d", ctypes.c_int32), ("world_size", ctypes.c_int32),
+        ("rank", ctypes.c_int32), ("refresh_every", ctypes.c_int32),
+        ("n_local", ctypes.c_int64), ("n_global", ctypes.c_int64), ("row_offset", ctypes.c_int64),
+    ]
+
+
+_lib = None
+
+
+def load():
+    """Load libbcx.so once; raise (never fall back) when it is absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            "libbcx.so not found at %s -- build it with `make -C bayesian-coresets_amd` "
+            "(or python -c 'import __graft_entry__ as g; g.build()'). There is no CPU fallback." % LIB_PATH)
+    lib = ctypes.CDLL(LIB_PATH)
+    vp, i32, i64, dbl = ctypes.c_void_p, ctypes.c_int32, ctypes.c_int64, ctypes.c_double
+    P = ctypes.POINTER
+    lib.bcx_version.restype = ctypes.c_char_p
+    lib.bcx_last_error.restype = ctypes.c_char_p
+    lib.bcx_last_error.argtypes = [vp]
+    sigs = {
+        "bcx_create": [P(Config), P(vp)],
+        "bcx_destroy": [vp],
+        "bcx_set_stream": [vp, vp],
+        "bcx_load_rows": [vp, vp, i32, i32, i64, i64, i64],
+        "bcx_chunk_sums": [vp, P(vp), P(i64), P(i64)],
+        "bcx_finalize": [vp, vp, vp, i64],
+        "bcx_build_begin": [vp, i64, dbl, P(i32)],
+        "bcx_step_scan": [vp, vp],
+        "bcx_step_scan_exact": [vp, vp],
+        "bcx_step_apply": [vp, vp],
+        "bcx_build_enqueue": [vp, i64],
+        "bcx_build_poll": [vp, P(i64), P(i32), P(i32)],
+        "bcx_build_trace": [vp, vp, vp, vp, i64, P(i64)],
+        "bcx_active_count": [vp, P(i64)],
+        "bcx_get_weights": [vp, vp, vp, i64, P(i64)],
+        "bcx_error": [vp, P(dbl)],
+        "bcx_optimize": [vp, dbl, P(i32)],
+        "bcx_reset": [vp],
+        "bcx_reached_numeric_limit": [vp, P(i32)],
+        "bcx_get_vector": [vp, i32, vp],
+        "bcx_get_norms": [vp, i64, i64, vp],
+        "bcx_time_scan": [vp, i32, i32, P(dbl), P(dbl)],
+        "bcx_profile_scan": [vp, i32],
+        "bcx_profile_read": [vp, P(dbl), P(i64)],
+    }
+    for name, args in sigs.items():
+        fn = getattr(lib, name)
+        fn.argtypes = args
+        fn.restype = ctypes.c_int
+    _lib = lib
+    return lib
+
+
+class EngineError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("bcx error %d: %s" % (code, msg))
+        self.code = code
+
+
+def _current_stream_ptr():
+    """Stream torch is currently issuing work on (so torch.distributed collectives and
+    torch.cuda events order correctly with the engine's kernels); NULL stream without torch."""
+    try:
+        import torch
+        if torch.cuda.is_available():
+            return int(torch.cuda.current_stream().cuda_stream)
+    except Exception:
+        pass
+    return 0
+
+
+class Engine(object):
+    """One row shard of the device solver.  Thin: every method is one or two ABI calls."""
+
+    def __init__(self, alg, n_local, d, n_global=None, row_offset=0, rank=0, world_size=1, device=0,
+                 store_dtype=F32, keep_exact_rows=True, refresh_every=0):
+        self.lib = load()
+        self.h = ctypes.c_void_p()
+        self.cfg = Config(alg=alg, store_dtype=store_dtype, keep_exact_rows=int(bool(keep_exact_rows)),
+                          device=device, d=d, world_size=world_size, rank=rank, refresh_every=refresh_every,
+                          n_local=n_local, n_global=n_local if n_global is None else n_global,
+                          row_offset=row_offset)
+        rc = self.lib.bcx_create(ctypes.byref(self.cfg), ctypes.byref(self.h))
+        if rc != OK:
+            msg = self.lib.bcx_last_error(None).decode()
+            self.h = ctypes.c_void_p()
+            raise EngineError(rc, msg)
+        self.d, self.n_local = d, n_local
+        self.rec_len = d + REC_HDR
+        self.use_current_stream()
+
+    # -- plumbing ---------------------------------------------------------
+    def _check(self, rc):
+        if rc != OK:
+            raise EngineError(rc, self.lib.bcx_last_error(self.h).decode())
+
+    def close(self):
+        if getattr(self, "h", None) and self.h.value:
+            self.lib.bcx_destroy(self.h)
+            self.h = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def use_current_stream(self):
+        self._check(self.lib.bcx_set_stream(self.h, ctypes.c_void_p(_current_stream_ptr())))
+
+    # -- ingest -----------------------------------------------------------
+    def load_host_rows(self, rows, row_begin=0):
+        """rows: C-contiguous (n, >=d) float32/float64 ndarray view (row stride in elements = ld)."""
+        assert rows.ndim == 2 and rows.strides[1] == rows.itemsize
+        dt = F64 if rows.dtype == np.float64 else F32
+        ld = rows.strides[0] // rows.itemsize
+        self._check(self.lib.bcx_load_rows(self.h, ctypes.c_void_p(rows.ctypes.data), 0, dt, row_begin,
+                                           rows.shape[0], ld))
+
+    def load_device_rows(self, ptr, n, ld, is_f64, row_begin=0):
+        self._check(self.lib.bcx_load_rows(self.h, ctypes.c_void_p(ptr), 1, F64 if is_f64 else F32, row_begin, n, ld))
+
+    def chunk_sums_info(self):
+        p, n, r = ctypes.c_void_p(), ctypes.c_int64(), ctypes.c_int64()
+        self._check(self.lib.bcx_chunk_sums(self.h, ctypes.byref(p), ctypes.byref(n), ctypes.byref(r)))
+        return p.value, n.value, r.value
+
+    def finalize(self, b=None, gathered_ptr=None, n_gathered=0):
+        bp = None
+        if b is not None:
+            b = np.ascontiguousarray(b, dtype=np.float64)
+            assert b.shape == (self.d,)
+            bp = ctypes.c_void_p(b.ctypes.data)
+        rc = self.lib.bcx_finalize(self.h, bp, ctypes.c_void_p(gathered_ptr) if gathered_ptr else None, n_gathered)
+        return rc
+
+    # -- build ------------------------------------------------------------
+    def build_begin(self, itrs, tol):
+        skip = ctypes.c_int32()
+        self._check(self.lib.bcx_build_begin(self.h, itrs, tol, ctypes.byref(skip)))
+        return bool(skip.value)
+
+    def step_scan(self, send_ptr=None, exact=False):
+        fn = self.lib.bcx_step_scan_exact if exact else self.lib.bcx_step_scan
+        self._check(fn(self.h, ctypes.c_void_p(send_ptr) if send_ptr else None))
+
+    def step_apply(self, recv_ptr=None):
+        self._check(self.lib.bcx_step_apply(self.h, ctypes.c_void_p(recv_ptr) if recv_ptr else None))
+
+    def enqueue(self, itrs):
+        self._check(self.lib.bcx_build_enqueue(self.h, itrs))
+
+    def poll(self):
+        n, ne, lim = ctypes.c_int64(), ctypes.c_int32(), ctypes.c_int32()
+        self._check(self.lib.bcx_build_poll(self.h, ctypes.byref(n), ctypes.byref(ne), ctypes.byref(lim)))
+        return n.value, bool(ne.value), bool(lim.value)
+
+    def trace(self, cap):
+        sel = np.empty(cap, dtype=np.int64)
+        err = np.empty(cap, dtype=np.float64)
+        status = np.empty(cap, dtype=np.int32)
+        n = ctypes.c_int64()
+        self._check(self.lib.bcx_build_trace(self.h, sel.ctypes.data, err.ctypes.data, status.ctypes.data, cap,
+                                             ctypes.byref(n)))
+        return sel[:n.value], err[:n.value], status[:n.value]
+
+    def run_build(self, itrs, tol):
+        """Single-shard build(): enqueue everything, fall back to the exact scan for the rare
+        iterations whose candidate window overflowed.  Returns (sel, err, status) of this call."""
+        if self.build_begin(itrs, tol):
+            return None
+        self.enqueue(itrs)
+        while True:
+            done, need_exact, limit = self.poll()
+            if not need_exact:
+                break
+            self.step_scan(exact=True)
+            self.step_apply()
+            done, need_exact, limit = self.poll()
+            if need_exact:
+                raise EngineError(ERR_STATE, "exact scan did not resolve the iteration")
+            if done < itrs and not limit:
+                self.enqueue(itrs - done)
+        return self.trace(itrs)
+
+    # -- read-out ---------------------------------------------------------
+    def sparse_weights(self):
+        k = ctypes.c_int64()
+        self._check(self.lib.bcx_active_count(self.h, ctypes.byref(k)))
+        idx = np.empty(k.value, dtype=np.int64)
+        w = np.empty(k.value, dtype=np.float64)
+        if k.value:
+            self._check(self.lib.bcx_get_weights(self.h, idx.ctypes.data, w.ctypes.data, k.value, ctypes.byref(k)))
+        return idx, w
+
+    def error(self):
+        e = ctypes.c_double()
+        self._check(self.lib.bcx_error(self.h, ctypes.byref(e)))
+        return e.value
+
+    def optimize(self, tol):
+        acc = ctypes.c_int32()
+        self._check(self.lib.bcx_optimize(self.h, tol, ctypes.byref(acc)))
+        return bool(acc.value)
+
+    def reset(self):
+        self._check(self.lib.bcx_reset(self.h))
+
+    def reached_numeric_limit(self):
+        v = ctypes.c_int32()
+        self._check(self.lib.bcx_reached_numeric_limit(self.h, ctypes.byref(v)))
+        return bool(v.value)
+
+    def vector(self, which):
+        out = np.empty(self.d, dtype=np.float64)
+        self._check(self.lib.bcx_get_vector(self.h, which, out.ctypes.data))
+        return out
+
+    def norms(self, begin=0, count=None):
+        count = self.n_local - begin if count is None else count
+        out = np.empty(count, dtype=np.float64)
+        if count:
+            self._check(self.lib.bcx_get_norms(self.h, begin, count, out.ctypes.data))
+        return out
+
+    # -- measurement ------------------------------------------------------
+    def time_scan(self, reps=20, exact=False):
+        ms, by = ctypes.c_double(), ctypes.c_double()
+        self._check(self.lib.bcx_time_scan(self.h, reps, int(exact), ctypes.byref(ms), ctypes.byref(by)))
+        return ms.value, by.value
+
+    def profile(self, on):
+        self._check(self.lib.bcx_profile_scan(self.h, int(on)))
+
+    def profile_read(self):
+        ms, n = ctypes.c_double(), ctypes.c_int64()
+        self._check(self.lib.bcx_profile_read(self.h, ctypes.byref(ms), ctypes.byref(n)))
+        return ms.value, n.value

@@ -1,0 +1,3 @@
+from .coreset import Coreset
+from .hilbert import HilbertCoreset
+from .sampling import UniformSamplingCoreset

@@ -1,0 +1,149 @@
+"""Device-backed sparse non-negative least squares solvers.
+
+Same constructor and methods as the reference base class (bayesiancoresets/snnls/snnls.py:8-106):
+``SparseNNLS(A, b)`` with ``A`` of shape d x N (columns = data points) and ``b`` of length d;
+``build(itrs)``, ``weights()``, ``error()``, ``size()``, ``optimize()``, ``reset()``; attributes
+``.A .b .w .reached_numeric_limit``.  The arithmetic runs in libbcx.so on the GPU; this class only
+moves data across the C ABI and maps status codes back onto the reference's warnings, exceptions
+and latch.  Extra keyword-only options (device, dtype, keep_exact_rows) default to the
+reference-compatible configuration.
+"""
+import numpy as np
+
+from .. import util
+from ..util.errors import NumericalPrecisionError
+from ..util.log import object_logger
+from .. import _native as nat
+
+
+def _as_row_matrix(A):
+    """Return (kind, rows): the N x d row-major view of the d x N argument without copying when
+    the caller passed ``vecs.T`` of a C-contiguous array (hilbert.py:24 does exactly that)."""
+    try:
+        import torch
+        if isinstance(A, torch.Tensor):
+            rows = A.t()
+            if not rows.is_contiguous():
+                rows = rows.contiguous()
+            return ("torch", rows)
+    except ImportError:
+        pass
+    A = np.asarray(A)
+    rows = A.T
+    if rows.dtype not in (np.float32, np.float64):
+        rows = rows.astype(np.float64)
+    if not rows.flags.c_contiguous:
+        rows = np.ascontiguousarray(rows)
+    return ("numpy", rows)
+
+
+class SparseNNLS(object):
+    _ALG = None  # set by subclasses
+
+    def __init__(self, A, b, check_error_monotone=True, *, device=0, dtype="float32", keep_exact_rows=True):
+        self.alg_name, self.log = object_logger(self)
+        self.A = A
+        self.b = b
+        self.check_error_monotone = check_error_monotone
+        self._w_cache = None
+        self._eng = None
+        if self._ALG is None:
+            raise NotImplementedError("SparseNNLS is abstract; use GIGA, FrankWolfe or OrthoPursuit")
+        kind, rows = _as_row_matrix(A)
+        self._N, self._d = int(rows.shape[0]), int(rows.shape[1])
+        store = nat.F64 if str(dtype) in ("float64", "f64", "double") else nat.F32
+        eng = nat.Engine(self._ALG, self._N, self._d, device=device, store_dtype=store,
+                         keep_exact_rows=keep_exact_rows)
+        self._eng = eng
+        if self._N:
+            if kind == "torch":
+                if rows.device.type != "cuda":
+                    eng.load_host_rows(rows.numpy())
+                else:
+                    eng.load_device_rows(rows.data_ptr(), self._N, rows.stride(0),
+                                         rows.element_size() == 8)
+            else:
+                eng.load_host_rows(rows)
+        bb = None if b is None else np.asarray(b, dtype=np.float64)
+        rc = eng.finalize(bb)
+        if rc == nat.ERR_ZERO_ROW:
+            raise ValueError(self.alg_name + ".__init__(): A must not have any 0 columns")   # giga.py:11-12
+        if rc == nat.ERR_ZERO_B:
+            raise NumericalPrecisionError("norm of b must be > 0")                            # giga.py:16-17
+        if rc != nat.OK:
+            raise nat.EngineError(rc, eng.lib.bcx_last_error(eng.h).decode())
+        self.reached_numeric_limit = False
+        self.last_trace = None
+
+    # ---- state ------------------------------------------------------------
+    @property
+    def w(self):
+        """Dense length-N weight vector (materialised lazily from the device's sparse list)."""
+        if self._w_cache is None:
+            idx, wv = self._eng.sparse_weights()
+            w = np.zeros(self._N)
+            w[idx] = wv
+            self._w_cache = w
+        return self._w_cache
+
+    def reset(self):
+        self._eng.reset()
+        self._w_cache = None
+        self.reached_numeric_limit = False
+
+    def size(self):
+        idx, wv = self._eng.sparse_weights()
+        return int((wv > 0).sum())
+
+    def weights(self):
+        return self.w.copy()
+
+    def error(self):
+        return self._eng.error()
+
+    # ---- the hot loop ------------------------------------------------------
+    def build(self, itrs):
+        if self.reached_numeric_limit:
+            self.log.warning("the numeric limit was already reached; returning. size = " + str(self.size())
+                             + ", error = " + str(self.error()))
+            return
+        if self._N == 0 or self._d == 0:
+            self.log.warning("there are no data, returning.")
+            return
+        self._eng.use_current_stream()
+        tr = self._eng.run_build(int(itrs), float(util.TOL))
+        self._w_cache = None
+        if tr is None:
+            return
+        self.last_trace = tr
+        sel, err, status = tr
+        for i in np.flatnonzero(status != nat.IT_OK):
+            what = {nat.IT_FAIL_SELECT: "select failed (cdirnrm < TOL)",
+                    nat.IT_FAIL_REWEIGHT: "reweight step lost precision",
+                    nat.IT_FAIL_MONOTONE: "Error not monotone"}[int(status[i])]
+            self.log.warning("numerical precision error: " + what + " at loop iteration " + str(int(i)))
+        if self._eng.reached_numeric_limit():
+            self.log.warning("iterative step failed a second time. Assuming numeric limit reached.")
+            self.reached_numeric_limit = True
+            self.log.warning("the numeric limit has been reached. No more points will be added. size = "
+                             + str(self.size()) + ", error = " + str(self.error()))
+
+    def optimize(self):
+        """Re-solve the weights on the current support (snnls.py:82-97)."""
+        accepted = self._eng.optimize(float(util.TOL))
+        self._w_cache = None
+        if not accepted:
+            self.log.warning("self.optimize() returned a solution with increasing error. "
+                             "Numeric limit possibly reached.")
+            self.reached_numeric_limit = True
+
+    # reference subclasses expose these after construction
+    @property
+    def Anorms(self):
+        return self._eng.norms()
+
+    @property
+    def An(self):
+        kind, rows = _as_row_matrix(self.A)
+        rows = rows.cpu().numpy() if kind == "torch" else rows
+        return (rows / self.Anorms[:, None]).T

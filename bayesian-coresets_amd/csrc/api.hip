@@ -1,0 +1,460 @@
+// api.hip -- host side of the C ABI declared in include/bcx.h.
+#include <stdio.h>
+#include <string.h>
+#include <algorithm>
+#include "bcx_internal.h"
+
+static thread_local std::string g_create_err;
+
+extern "C" const char* bcx_version(void) { return "bcx 0.1 gfx950"; }
+
+extern "C" const char* bcx_last_error(const bcx_solver* s) { return s ? s->err.c_str() : g_create_err.c_str(); }
+
+template <typename T> static hipError_t dev_alloc(T** p, size_t count, bool zero = true) {
+  *p = nullptr;
+  if (count == 0) count = 1;
+  hipError_t e = hipMalloc((void**)p, count * sizeof(T));
+  if (e != hipSuccess) return e;
+  if (zero) e = hipMemset(*p, 0, count * sizeof(T));
+  return e;
+}
+
+static int round_up(int x, int m) { return (x + m - 1) / m * m; }
+
+static void free_all(bcx_solver* s) {
+  void* ptrs[] = {s->An, s->A64, s->norms, s->chunk_sums, s->staging, s->st, s->b, s->bn, s->xw, s->q64, s->qst,
+                  s->tmp, s->partials, s->rec_local, s->act_idx, s->act_w, s->act_rows, s->act_norm, s->gram,
+                  s->hinv, s->cvec, s->plist, s->ppos, s->nn_x, s->nn_z, s->nn_wv, s->nn_tmp, s->tr_sel, s->tr_err,
+                  s->tr_status};
+  for (void* p : ptrs)
+    if (p) (void)hipFree(p);
+  for (auto& ev : s->prof_events) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
+}
+
+extern "C" int bcx_create(const bcx_config* cfg, bcx_solver** out) {
+  if (!cfg || !out) { g_create_err = "bcx_create: null argument"; return BCX_ERR_ARG; }
+  *out = nullptr;
+  if (cfg->alg < BCX_ALG_GIGA || cfg->alg > BCX_ALG_OMP || cfg->d < 1 || cfg->n_local < 0 ||
+      cfg->world_size < 1 || cfg->rank < 0 || cfg->rank >= cfg->world_size ||
+      (cfg->store_dtype != BCX_F32 && cfg->store_dtype != BCX_F64)) {
+    g_create_err = "bcx_create: invalid configuration";
+    return BCX_ERR_ARG;
+  }
+  const int maxd = cfg->store_dtype == BCX_F32 ? BCX_MAX_D : BCX_MAX_D / 2;
+  if (cfg->d > maxd) { g_create_err = "bcx_create: d exceeds the supported row length"; return BCX_ERR_ARG; }
+  if (cfg->n_local >= (int64_t)0x7fffffff) { g_create_err = "bcx_create: n_local must be < 2^31 per shard"; return BCX_ERR_ARG; }
+  if (cfg->row_offset % BCX_CHUNK_ROWS != 0) {
+    g_create_err = "bcx_create: row_offset must be a multiple of the chunk size (1024 rows)";
+    return BCX_ERR_ARG;
+  }
+  bcx_solver* s = new bcx_solver();
+  s->cfg = *cfg;
+  if (s->cfg.refresh_every == 0) s->cfg.refresh_every = 16;
+  hipError_t e = hipSetDevice(cfg->device);
+  if (e != hipSuccess) { g_create_err = std::string("hipSetDevice: ") + hipGetErrorString(e); delete s; return BCX_ERR_HIP; }
+  const int d = cfg->d;
+  const int64_t n = cfg->n_local;
+  s->elem = cfg->store_dtype == BCX_F32 ? 4 : 8;
+  s->ld = round_up(d, 16 / s->elem);
+  s->ld64 = round_up(d, 2);
+  s->n_chunks = (n + BCX_CHUNK_ROWS - 1) / BCX_CHUNK_ROWS;
+  bool ok = true;
+  auto chk = [&](hipError_t r) { if (r != hipSuccess && ok) { ok = false; g_create_err = std::string("hipMalloc: ") + hipGetErrorString(r); } };
+  chk(dev_alloc((char**)&s->An, (size_t)n * s->ld * s->elem));
+  if (cfg->keep_exact_rows && cfg->store_dtype == BCX_F32) chk(dev_alloc(&s->A64, (size_t)n * s->ld64));
+  chk(dev_alloc(&s->norms, (size_t)n));
+  chk(dev_alloc(&s->chunk_sums, (size_t)s->n_chunks * (d + 1)));
+  chk(dev_alloc(&s->st, 1));
+  chk(dev_alloc(&s->b, (size_t)d));
+  chk(dev_alloc(&s->bn, (size_t)d));
+  chk(dev_alloc(&s->xw, (size_t)d));
+  chk(dev_alloc(&s->q64, (size_t)2 * s->ld64));
+  chk(dev_alloc((char**)&s->qst, (size_t)2 * s->ld * s->elem));
+  chk(dev_alloc(&s->tmp, (size_t)4 * d));
+  s->n_partials = bcx_scan_grid(s);
+  chk(dev_alloc(&s->partials, (size_t)s->n_partials));
+  chk(dev_alloc(&s->rec_local, (size_t)(d + BCX_REC_HDR)));
+  if (!ok) { free_all(s); delete s; return BCX_ERR_NOMEM; }
+  *out = s;
+  return BCX_OK;
+}
+
+extern "C" int bcx_destroy(bcx_solver* s) {
+  if (!s) return BCX_OK;
+  (void)hipSetDevice(s->cfg.device);
+  (void)hipDeviceSynchronize();
+  free_all(s);
+  delete s;
+  return BCX_OK;
+}
+
+extern "C" int bcx_set_stream(bcx_solver* s, void* hip_stream) {
+  if (!s) return BCX_ERR_ARG;
+  s->stream = (hipStream_t)hip_stream;
+  return BCX_OK;
+}
+
+extern "C" int bcx_load_rows(bcx_solver* s, const void* src, int32_t src_is_device, int32_t src_dtype,
+                             int64_t row_begin, int64_t rows, int64_t ld) {
+  if (!s || (!src && rows > 0)) return BCX_ERR_ARG;
+  const int d = s->cfg.d;
+  if (rows == 0) return BCX_OK;
+  if (row_begin < 0 || rows < 0 || row_begin + rows > s->cfg.n_local || ld < d ||
+      (src_dtype != BCX_F32 && src_dtype != BCX_F64)) {
+    s->err = "bcx_load_rows: bad range, leading dimension or dtype";
+    return BCX_ERR_ARG;
+  }
+  if (row_begin % BCX_CHUNK_ROWS != 0 || (rows % BCX_CHUNK_ROWS != 0 && row_begin + rows != s->cfg.n_local)) {
+    s->err = "bcx_load_rows: pieces must start and end on 1024-row chunk boundaries (except the last)";
+    return BCX_ERR_ARG;
+  }
+  BCX_HIP(hipSetDevice(s->cfg.device));
+  const size_t esz = src_dtype == BCX_F64 ? 8 : 4;
+  if (src_is_device) {
+    int rc = bcx_launch_ingest(s, src, src_dtype, ld, row_begin, rows);
+    if (rc != BCX_OK) return rc;
+  } else if (s->A64 && src_dtype == BCX_F64) {
+    // host fp64 rows go straight to their final place; the ingest kernel then works in place
+    double* dst = s->A64 + (size_t)row_begin * s->ld64;
+    BCX_HIP(hipMemcpy2DAsync(dst, (size_t)s->ld64 * 8, src, (size_t)ld * 8, (size_t)d * 8, (size_t)rows,
+                             hipMemcpyHostToDevice, s->stream));
+    int rc = bcx_launch_ingest(s, dst, BCX_F64, s->ld64, row_begin, rows);
+    if (rc != BCX_OK) return rc;
+  } else {
+    // stage through a device buffer in pieces of <= 256 MiB
+    const int64_t piece = std::max<int64_t>(BCX_CHUNK_ROWS,
+                                            ((int64_t)(256u << 20) / (int64_t)(d * esz)) / BCX_CHUNK_ROWS * BCX_CHUNK_ROWS);
+    const size_t need = (size_t)std::min(piece, rows) * d * esz;
+    if (s->staging_bytes < need) {
+      if (s->staging) BCX_HIP(hipFree(s->staging));
+      s->staging = nullptr; s->staging_bytes = 0;
+      BCX_HIP(hipMalloc(&s->staging, need));
+      s->staging_bytes = need;
+    }
+    for (int64_t r = 0; r < rows; r += piece) {
+      const int64_t m = std::min(piece, rows - r);
+      BCX_HIP(hipMemcpy2DAsync(s->staging, (size_t)d * esz, (const char*)src + (size_t)r * ld * esz, (size_t)ld * esz,
+                               (size_t)d * esz, (size_t)m, hipMemcpyHostToDevice, s->stream));
+      int rc = bcx_launch_ingest(s, s->staging, src_dtype, d, row_begin + r, m);
+      if (rc != BCX_OK) return rc;
+      BCX_HIP(hipStreamSynchronize(s->stream));  // staging buffer is reused
+    }
+  }
+  s->rows_loaded += rows;
+  return BCX_OK;
+}
+
+extern "C" int bcx_chunk_sums(bcx_solver* s, const void** dev_ptr, int64_t* n_chunks, int64_t* chunk_rows) {
+  if (!s) return BCX_ERR_ARG;
+  if (dev_ptr) *dev_ptr = s->chunk_sums;
+  if (n_chunks) *n_chunks = s->n_chunks;
+  if (chunk_rows) *chunk_rows = BCX_CHUNK_ROWS;
+  return BCX_OK;
+}
+
+static int read_state(bcx_solver* s, DevState* h) {
+  BCX_HIP(hipStreamSynchronize(s->stream));
+  BCX_HIP(hipMemcpy(h, s->st, sizeof(DevState), hipMemcpyDeviceToHost));
+  return BCX_OK;
+}
+
+extern "C" int bcx_finalize(bcx_solver* s, const double* b_host, const void* gathered_sums_dev, int64_t n_gathered) {
+  if (!s) return BCX_ERR_ARG;
+  BCX_HIP(hipSetDevice(s->cfg.device));
+  if (s->rows_loaded < s->cfg.n_local) { s->err = "bcx_finalize: not all rows were loaded"; return BCX_ERR_STATE; }
+  if (b_host) BCX_HIP(hipMemcpyAsync(s->b, b_host, (size_t)s->cfg.d * 8, hipMemcpyHostToDevice, s->stream));
+  int rc = bcx_launch_finalize(s, b_host != nullptr, (const double*)gathered_sums_dev, n_gathered);
+  if (rc != BCX_OK) return rc;
+  DevState h;
+  rc = read_state(s, &h);
+  if (rc != BCX_OK) return rc;
+  if (h.zero_row != 0) {
+    char buf[128];
+    snprintf(buf, sizeof buf, "A must not have any 0 columns (local row %d has zero norm)", h.zero_row - 1);
+    s->err = buf;
+    return BCX_ERR_ZERO_ROW;
+  }
+  if (s->cfg.alg == BCX_ALG_GIGA && h.bnorm == 0.0) { s->err = "norm of b must be > 0"; return BCX_ERR_ZERO_B; }
+  s->finalized = true;
+  return BCX_OK;
+}
+
+// ---- capacity management -----------------------------------------------------------------
+template <typename T> static int grow(bcx_solver* s, T** p, size_t old_count, size_t new_count) {
+  T* q = nullptr;
+  BCX_HIP(dev_alloc(&q, new_count));
+  if (*p && old_count) BCX_HIP(hipMemcpy(q, *p, old_count * sizeof(T), hipMemcpyDeviceToDevice));
+  if (*p) BCX_HIP(hipFree(*p));
+  *p = q;
+  return BCX_OK;
+}
+
+static int ensure_slots(bcx_solver* s, int64_t need) {
+  if (need <= s->cap) return BCX_OK;
+  int64_t ncap = std::max<int64_t>(need, std::max<int64_t>(256, s->cap * 2));
+  const size_t d = (size_t)s->cfg.d;
+  int rc;
+  if ((rc = grow(s, &s->act_idx, (size_t)s->cap, (size_t)ncap))) return rc;
+  if ((rc = grow(s, &s->act_w, (size_t)s->cap, (size_t)ncap))) return rc;
+  if ((rc = grow(s, &s->act_norm, (size_t)s->cap, (size_t)ncap))) return rc;
+  if ((rc = grow(s, &s->act_rows, (size_t)s->cap * d, (size_t)ncap * d))) return rc;
+  s->cap = ncap;
+  return BCX_OK;
+}
+
+int bcx_ensure_gram(bcx_solver* s, int64_t need);  // nnls.hip
+
+static int ensure_trace(bcx_solver* s, int64_t need) {
+  if (need <= s->trace_cap) return BCX_OK;
+  int64_t ncap = std::max<int64_t>(need, 1024);
+  int rc;
+  if ((rc = grow(s, &s->tr_sel, 0, (size_t)ncap))) return rc;
+  if ((rc = grow(s, &s->tr_err, 0, (size_t)ncap))) return rc;
+  if ((rc = grow(s, &s->tr_status, 0, (size_t)ncap))) return rc;
+  s->trace_cap = ncap;
+  return BCX_OK;
+}
+
+// ---- build ---------------------------------------------------------------------------------
+extern "C" int bcx_build_begin(bcx_solver* s, int64_t itrs, double tol, int32_t* skip) {
+  if (!s || !skip) return BCX_ERR_ARG;
+  if (!s->finalized) { s->err = "bcx_build_begin: call bcx_finalize first"; return BCX_ERR_STATE; }
+  BCX_HIP(hipSetDevice(s->cfg.device));
+  *skip = 0;
+  DevState h;
+  int rc = read_state(s, &h);
+  if (rc != BCX_OK) return rc;
+  if (h.limit || s->cfg.n_global == 0 || itrs <= 0) { *skip = 1; return BCX_OK; }   // snnls.py:32-38
+  if ((rc = ensure_slots(s, (int64_t)h.k + itrs))) return rc;
+  if (s->cfg.alg == BCX_ALG_OMP && (rc = bcx_ensure_gram(s, (int64_t)h.k + itrs))) return rc;
+  if ((rc = ensure_trace(s, itrs))) return rc;
+  return bcx_launch_begin(s, itrs, tol);
+}
+
+static int prof_begin(bcx_solver* s) {
+  if (!s->profile) return BCX_OK;
+  if (s->prof_used == s->prof_events.size()) {
+    hipEvent_t a, b;
+    BCX_HIP(hipEventCreate(&a));
+    BCX_HIP(hipEventCreate(&b));
+    s->prof_events.emplace_back(a, b);
+  }
+  BCX_HIP(hipEventRecord(s->prof_events[s->prof_used].first, s->stream));
+  return BCX_OK;
+}
+static int prof_end(bcx_solver* s) {
+  if (!s->profile) return BCX_OK;
+  BCX_HIP(hipEventRecord(s->prof_events[s->prof_used].second, s->stream));
+  s->prof_used++;
+  return BCX_OK;
+}
+
+static int step_scan(bcx_solver* s, void* send_dev, int exact) {
+  if (!s->finalized) { s->err = "solver not finalized"; return BCX_ERR_STATE; }
+  double* send = send_dev ? (double*)send_dev : s->rec_local;
+  int rc;
+  if (exact && (rc = bcx_launch_resume_exact(s))) return rc;
+  if ((rc = prof_begin(s))) return rc;
+  if ((rc = bcx_launch_scan(s, exact))) return rc;
+  if ((rc = prof_end(s))) return rc;
+  return bcx_launch_resolve(s, send, exact);
+}
+
+extern "C" int bcx_step_scan(bcx_solver* s, void* send_dev) { return s ? step_scan(s, send_dev, 0) : BCX_ERR_ARG; }
+extern "C" int bcx_step_scan_exact(bcx_solver* s, void* send_dev) { return s ? step_scan(s, send_dev, 1) : BCX_ERR_ARG; }
+
+extern "C" int bcx_step_apply(bcx_solver* s, const void* recv_dev) {
+  if (!s) return BCX_ERR_ARG;
+  return bcx_launch_apply(s, recv_dev ? (const double*)recv_dev : s->rec_local);
+}
+
+extern "C" int bcx_build_enqueue(bcx_solver* s, int64_t itrs) {
+  if (!s) return BCX_ERR_ARG;
+  if (s->cfg.world_size != 1) { s->err = "bcx_build_enqueue is single-shard; use bcx_step_scan/apply"; return BCX_ERR_ARG; }
+  const int exact = s->cfg.store_dtype == BCX_F64;
+  for (int64_t i = 0; i < itrs; ++i) {
+    int rc = step_scan(s, nullptr, 0);
+    (void)exact;
+    if (rc != BCX_OK) return rc;
+    if ((rc = bcx_launch_apply(s, s->rec_local))) return rc;
+  }
+  return BCX_OK;
+}
+
+extern "C" int bcx_build_poll(bcx_solver* s, int64_t* n_done, int32_t* need_exact, int32_t* limit) {
+  if (!s) return BCX_ERR_ARG;
+  DevState h;
+  int rc = read_state(s, &h);
+  if (rc != BCX_OK) return rc;
+  if (n_done) *n_done = h.it;
+  if (need_exact) *need_exact = (h.halt == HALT_NEED_EXACT);
+  if (limit) *limit = h.limit;
+  if (s->profile) {
+    for (size_t i = 0; i < s->prof_used; ++i) {
+      float ms = 0.f;
+      if (hipEventElapsedTime(&ms, s->prof_events[i].first, s->prof_events[i].second) == hipSuccess) {
+        s->prof_ms += ms;
+        s->prof_launches++;
+      }
+    }
+    s->prof_used = 0;
+  }
+  return BCX_OK;
+}
+
+extern "C" int bcx_build_trace(bcx_solver* s, int64_t* sel, double* err, int32_t* status, int64_t cap, int64_t* n_out) {
+  if (!s) return BCX_ERR_ARG;
+  DevState h;
+  int rc = read_state(s, &h);
+  if (rc != BCX_OK) return rc;
+  const int64_t n = std::min<int64_t>(h.it, cap);
+  if (n > 0) {
+    if (sel) BCX_HIP(hipMemcpy(sel, s->tr_sel, (size_t)n * 8, hipMemcpyDeviceToHost));
+    if (err) BCX_HIP(hipMemcpy(err, s->tr_err, (size_t)n * 8, hipMemcpyDeviceToHost));
+    if (status) BCX_HIP(hipMemcpy(status, s->tr_status, (size_t)n * 4, hipMemcpyDeviceToHost));
+  }
+  if (n_out) *n_out = n;
+  return BCX_OK;
+}
+
+// ---- read-out ------------------------------------------------------------------------------
+extern "C" int bcx_active_count(bcx_solver* s, int64_t* k) {
+  if (!s || !k) return BCX_ERR_ARG;
+  DevState h;
+  int rc = read_state(s, &h);
+  if (rc != BCX_OK) return rc;
+  *k = h.k;
+  return BCX_OK;
+}
+
+extern "C" int bcx_get_weights(bcx_solver* s, int64_t* idx, double* w, int64_t cap, int64_t* k) {
+  if (!s || !k) return BCX_ERR_ARG;
+  DevState h;
+  int rc = read_state(s, &h);
+  if (rc != BCX_OK) return rc;
+  const int64_t n = std::min<int64_t>(h.k, cap);
+  if (n > 0) {
+    if (idx) BCX_HIP(hipMemcpy(idx, s->act_idx, (size_t)n * 8, hipMemcpyDeviceToHost));
+    if (w) BCX_HIP(hipMemcpy(w, s->act_w, (size_t)n * 8, hipMemcpyDeviceToHost));
+  }
+  *k = h.k;
+  return BCX_OK;
+}
+
+extern "C" int bcx_error(bcx_solver* s, double* err) {
+  if (!s || !err) return BCX_ERR_ARG;
+  if (!s->finalized) { s->err = "solver not finalized"; return BCX_ERR_STATE; }
+  int rc = bcx_launch_error_refresh(s);
+  if (rc != BCX_OK) return rc;
+  DevState h;
+  if ((rc = read_state(s, &h))) return rc;
+  *err = h.err;
+  return BCX_OK;
+}
+
+extern "C" int bcx_reached_numeric_limit(bcx_solver* s, int32_t* limit) {
+  if (!s || !limit) return BCX_ERR_ARG;
+  DevState h;
+  int rc = read_state(s, &h);
+  if (rc != BCX_OK) return rc;
+  *limit = h.limit;
+  return BCX_OK;
+}
+
+extern "C" int bcx_reset(bcx_solver* s) {
+  if (!s) return BCX_ERR_ARG;
+  if (!s->finalized) return BCX_OK;
+  // w = 0, reached_numeric_limit = False (snnls.py:18-20); b, norms and the matrix stay
+  DevState h;
+  int rc = read_state(s, &h);
+  if (rc != BCX_OK) return rc;
+  h.k = 0; h.limit = 0; h.retried = 0; h.active = 0; h.halt = HALT_NONE; h.since_refresh = 0; h.exact_mode = 0;
+  h.err = h.bnorm; h.nw = 1.0; h.it = 0; h.itrs = 0;
+  BCX_HIP(hipMemcpy(s->st, &h, sizeof h, hipMemcpyHostToDevice));
+  BCX_HIP(hipMemset(s->xw, 0, (size_t)s->cfg.d * 8));
+  // error() with an empty list must give ||b|| computed the same way as after finalize
+  return bcx_launch_error_refresh(s);
+}
+
+extern "C" int bcx_optimize(bcx_solver* s, double tol, int32_t* accepted) {
+  if (!s || !accepted) return BCX_ERR_ARG;
+  if (!s->finalized) { s->err = "solver not finalized"; return BCX_ERR_STATE; }
+  DevState h;
+  int rc = read_state(s, &h);
+  if (rc != BCX_OK) return rc;
+  if ((rc = bcx_ensure_gram(s, std::max<int64_t>(h.k, 1)))) return rc;
+  if ((rc = bcx_launch_optimize(s, tol))) return rc;
+  DevState h2;
+  if ((rc = read_state(s, &h2))) return rc;
+  *accepted = h2.limit ? 0 : 1;
+  return BCX_OK;
+}
+
+// ---- introspection / measurement ---------------------------------------------------------------
+extern "C" int bcx_get_vector(bcx_solver* s, int32_t which, double* out) {
+  if (!s || !out) return BCX_ERR_ARG;
+  const double* src = nullptr;
+  switch (which) {
+    case 0: src = s->b; break;
+    case 1: src = s->xw; break;
+    case 2: src = s->q64; break;
+    case 3: src = s->q64 + s->ld64; break;
+    default: return BCX_ERR_ARG;
+  }
+  BCX_HIP(hipStreamSynchronize(s->stream));
+  BCX_HIP(hipMemcpy(out, src, (size_t)s->cfg.d * 8, hipMemcpyDeviceToHost));
+  return BCX_OK;
+}
+
+extern "C" int bcx_get_norms(bcx_solver* s, int64_t begin, int64_t count, double* out) {
+  if (!s || !out || begin < 0 || begin + count > s->cfg.n_local) return BCX_ERR_ARG;
+  BCX_HIP(hipStreamSynchronize(s->stream));
+  BCX_HIP(hipMemcpy(out, s->norms + begin, (size_t)count * 8, hipMemcpyDeviceToHost));
+  return BCX_OK;
+}
+
+extern "C" int bcx_time_scan(bcx_solver* s, int32_t reps, int32_t exact, double* ms_per_launch, double* bytes_per_launch) {
+  if (!s || reps < 1) return BCX_ERR_ARG;
+  if (!s->finalized) { s->err = "solver not finalized"; return BCX_ERR_STATE; }
+  BCX_HIP(hipSetDevice(s->cfg.device));
+  // the scan only runs while the state machine is active: force it for the measurement
+  DevState h;
+  int rc = read_state(s, &h);
+  if (rc != BCX_OK) return rc;
+  DevState forced = h;
+  forced.active = 1;
+  BCX_HIP(hipMemcpy(s->st, &forced, sizeof forced, hipMemcpyHostToDevice));
+  hipEvent_t e0, e1;
+  BCX_HIP(hipEventCreate(&e0));
+  BCX_HIP(hipEventCreate(&e1));
+  for (int i = 0; i < 3; ++i) if ((rc = bcx_launch_scan(s, exact))) return rc;
+  BCX_HIP(hipEventRecord(e0, s->stream));
+  for (int i = 0; i < reps; ++i) if ((rc = bcx_launch_scan(s, exact))) return rc;
+  BCX_HIP(hipEventRecord(e1, s->stream));
+  BCX_HIP(hipEventSynchronize(e1));
+  float ms = 0.f;
+  BCX_HIP(hipEventElapsedTime(&ms, e0, e1));
+  BCX_HIP(hipEventDestroy(e0));
+  BCX_HIP(hipEventDestroy(e1));
+  BCX_HIP(hipMemcpy(s->st, &h, sizeof h, hipMemcpyHostToDevice));
+  if (ms_per_launch) *ms_per_launch = (double)ms / reps;
+  const bool raw64 = exact && s->cfg.store_dtype == BCX_F32 && s->A64;
+  if (bytes_per_launch) *bytes_per_launch = (double)s->cfg.n_local * s->cfg.d * (raw64 ? 8.0 : (double)s->elem);
+  return BCX_OK;
+}
+
+extern "C" int bcx_profile_scan(bcx_solver* s, int32_t on) {
+  if (!s) return BCX_ERR_ARG;
+  s->profile = on != 0;
+  s->prof_ms = 0.0;
+  s->prof_launches = 0;
+  s->prof_used = 0;
+  return BCX_OK;
+}
+
+extern "C" int bcx_profile_read(bcx_solver* s, double* scan_ms_total, int64_t* scan_launches) {
+  if (!s) return BCX_ERR_ARG;
+  if (scan_ms_total) *scan_ms_total = s->prof_ms;
+  if (scan_launches) *scan_launches = s->prof_launches;
+  return BCX_OK;
+}

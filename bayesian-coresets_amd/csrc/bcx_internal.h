@@ -1,0 +1,125 @@
+// Internal definitions shared by the gfx950 kernels and the C-ABI host layer.
+// Not part of the public boundary (that is include/bcx.h).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string>
+#include <utility>
+#include <vector>
+#include "../../include/bcx.h"
+
+#define BCX_CHUNK_ROWS 1024      // rows per column-sum chunk (fixed summation tree, shard-count independent)
+#define BCX_MAX_CAND 64          // candidate rows re-scored in fp64 per shard per iteration
+#define BCX_REC_HDR 4            // record header doubles: score, global index, norm, flags
+#define BCX_REC_VALID 1.0
+#define BCX_REC_OVERFLOW 2.0
+#define BCX_MAX_D 4096
+#define BCX_SCAN_THREADS 256
+#define BCX_APPLY_THREADS 256
+
+enum { HALT_NONE = 0, HALT_DONE = 1, HALT_LIMIT = 2, HALT_NEED_EXACT = 3 };
+
+// Per-workgroup result of the correlation scan: the two best upper bounds with
+// their local row indices, a bound on everything else the workgroup saw, and
+// the best lower bound.  (For fp64 storage U == L == the score.)
+struct ScanPartial {
+  double U1, U2, U3, L;
+  int32_t i1, i2;
+};
+
+// Replicated solver state (device resident; every shard holds an identical copy).
+struct DevState {
+  int64_t itrs;        // loop iterations requested by the current build() call
+  int64_t it;          // loop iterations consumed so far in this call
+  int32_t active;      // kernels of the current call do work only while this is 1
+  int32_t halt;        // HALT_*
+  int32_t retried;     // retried_already (snnls.py:40)
+  int32_t limit;       // reached_numeric_limit
+  int32_t k;           // slots in the sparse weight list
+  int32_t since_refresh;
+  int32_t exact_mode;  // current iteration's scan was exact (no candidate window)
+  int32_t zero_row;    // first zero-norm local row + 1 (0 = none)
+  double tol;          // bc.util.TOL at build() time
+  double err;          // ||A w - b||
+  double nw;           // ||A w|| (1 when zero, giga.py:23)
+  double bnorm;        // ||b||
+  double sigma;        // sum of row norms (frankwolfe.py:25)
+  double qscale;       // norm of the query vector (error bound of the fp32 scan scales with it)
+};
+
+struct bcx_solver {
+  bcx_config cfg;
+  hipStream_t stream = nullptr;
+  std::string err;
+  int ld = 0;               // row stride (elements) of the stored normalised matrix
+  int elem = 4;             // bytes per stored element
+  int ld64 = 0;             // row stride (doubles) of A64 / q64 (d rounded up to even)
+  void* An = nullptr;       // n_local x ld, fp32 or fp64, rows normalised to unit norm
+  double* A64 = nullptr;    // n_local x ld64 raw rows (optional)
+  double* norms = nullptr;  // n_local
+  double* chunk_sums = nullptr;  // n_chunks x (d+1)
+  int64_t n_chunks = 0;
+  void* staging = nullptr;  // upload staging when raw rows are not kept
+  size_t staging_bytes = 0;
+  DevState* st = nullptr;
+  double* b = nullptr;      // d
+  double* bn = nullptr;     // d (GIGA)
+  double* xw = nullptr;     // d
+  double* q64 = nullptr;    // 2 x ld64 query vectors (fp64, used by the exact re-score)
+  void* qst = nullptr;      // 2 x ld query vectors in storage precision (read by the scan)
+  double* tmp = nullptr;    // 4 x d scratch
+  ScanPartial* partials = nullptr;
+  int n_partials = 0;
+  double* rec_local = nullptr;   // (d+4) record produced by this shard when world_size == 1
+  // sparse weight list (selection order), grown on demand
+  int64_t cap = 0;
+  int64_t* act_idx = nullptr;    // global row index per slot
+  double* act_w = nullptr;       // weight per slot
+  double* act_rows = nullptr;    // cap x d raw rows of the slots (replicated)
+  double* act_norm = nullptr;    // norm per slot
+  // OMP / optimize(): Gram system over the slots
+  double* gram = nullptr;        // cap x cap
+  double* hinv = nullptr;        // cap x cap inverse of the passive block
+  double* cvec = nullptr;        // cap : a_j . b
+  int32_t* plist = nullptr;      // passive list (slot ids)
+  int32_t* ppos = nullptr;       // slot -> position in plist or -1
+  double* nn_x = nullptr;        // cap
+  double* nn_z = nullptr;        // cap
+  double* nn_wv = nullptr;       // cap
+  double* nn_tmp = nullptr;      // 2*cap
+  int64_t gram_cap = 0;
+  // trace of the current build() call
+  int64_t trace_cap = 0;
+  int64_t* tr_sel = nullptr;
+  double* tr_err = nullptr;
+  int32_t* tr_status = nullptr;
+  bool finalized = false;
+  int64_t rows_loaded = 0;
+  // measurement
+  bool profile = false;
+  double prof_ms = 0.0;
+  int64_t prof_launches = 0;
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_events;
+  size_t prof_used = 0;
+};
+
+// ---- kernel launchers (defined in the .hip files) ------------------------
+int bcx_launch_ingest(bcx_solver* s, const void* src, int src_dtype, int64_t ld_src, int64_t row_begin, int64_t rows);
+int bcx_launch_finalize(bcx_solver* s, int have_b, const double* gathered, int64_t n_gathered);
+int bcx_launch_scan(bcx_solver* s, int exact);
+int bcx_launch_resolve(bcx_solver* s, double* send_dev, int exact);
+int bcx_launch_begin(bcx_solver* s, int64_t itrs, double tol);
+int bcx_launch_apply(bcx_solver* s, const double* recv_dev);
+int bcx_launch_resume_exact(bcx_solver* s);
+int bcx_launch_error_refresh(bcx_solver* s);
+int bcx_launch_optimize(bcx_solver* s, double tol);
+int bcx_scan_grid(const bcx_solver* s);
+
+#define BCX_HIP(call)                                                        \
+  do {                                                                       \
+    hipError_t _e = (call);                                                  \
+    if (_e != hipSuccess) {                                                  \
+      s->err = std::string(#call) + ": " + hipGetErrorString(_e);            \
+      return BCX_ERR_HIP;                                                    \
+    }                                                                        \
+  } while (0)

@@ -1,0 +1,134 @@
+// ingest.hip -- constructor work of the reference solvers, one fused pass per row:
+//   Anorms = sqrt((A**2).sum(axis=0)); An = A / Anorms      giga.py:10-13, frankwolfe.py:10-13, orthopursuit.py:12-15
+//   b = vecs.sum(axis=0)                                    hilbert.py:24
+//   sum(Anorms)                                             frankwolfe.py:22,25
+// HBM-bound: reads N*d source elements once, writes N*d stored elements once.
+#include "bcx_internal.h"
+#include "dev_util.h"
+
+// One workgroup per chunk of BCX_CHUNK_ROWS rows; one wave per row, lanes stride the columns
+// (coalesced 512-byte segments of the fp64 source).  Column sums are accumulated per wave in
+// LDS (each lane owns its columns -> no conflicts, fixed order) and combined wave 0..3.
+template <typename TS, typename TD>
+__global__ __launch_bounds__(256) void ingest_kernel(const TS* src, int64_t ld_src, int64_t row_begin,
+                                                     int64_t rows, int d, TD* __restrict__ An, int ld, int ld64,
+                                                     double* A64, double* __restrict__ norms,
+                                                     double* __restrict__ chunk_sums, DevState* st) {
+  extern __shared__ double lds[];  // 4 * d column accumulators + 4 norm accumulators
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  double* colacc = lds + (size_t)wave * d;
+  for (int c = lane; c < d; c += 64) colacc[c] = 0.0;
+  double normacc = 0.0;
+  const int64_t chunk = blockIdx.x;
+  const int64_t r0 = chunk * BCX_CHUNK_ROWS;
+  const int64_t r1 = (r0 + BCX_CHUNK_ROWS < rows) ? r0 + BCX_CHUNK_ROWS : rows;
+  for (int64_t r = r0 + wave; r < r1; r += 4) {
+    const TS* x = src + r * ld_src;
+    double ss = 0.0;
+    for (int c = lane; c < d; c += 64) {
+      double v = (double)x[c];
+      ss += v * v;
+    }
+    ss = wave_allsum(ss);
+    const double nrm = sqrt(ss);
+    const int64_t lr = row_begin + r;
+    if (lane == 0) {
+      norms[lr] = nrm;
+      if (!(nrm > 0.0)) {
+        // remember the smallest offending local row (+1); 0 means "none"
+        const int32_t want = (int32_t)(lr + 1);
+        int32_t cur = atomicCAS(&st->zero_row, 0, want);
+        while (cur != 0 && cur > want) {
+          const int32_t prev = atomicCAS(&st->zero_row, cur, want);
+          if (prev == cur) break;
+          cur = prev;
+        }
+      }
+    }
+    normacc += nrm;
+    TD* y = An + lr * (int64_t)ld;
+    double* raw = A64 ? A64 + lr * (int64_t)ld64 : nullptr;
+    for (int c = lane; c < d; c += 64) {
+      double v = (double)x[c];  // second touch hits L1/L2
+      colacc[c] += v;
+      y[c] = (TD)(v / nrm);
+      if (raw && (const void*)raw != (const void*)x) raw[c] = v;
+    }
+  }
+  __syncthreads();
+  const int64_t gchunk = row_begin / BCX_CHUNK_ROWS + chunk;
+  double* out = chunk_sums + gchunk * (int64_t)(d + 1);
+  for (int c = threadIdx.x; c < d; c += blockDim.x)
+    out[c] = ((lds[c] + lds[d + c]) + lds[2 * (size_t)d + c]) + lds[3 * (size_t)d + c];
+  double* nacc = lds + 4 * (size_t)d;
+  __syncthreads();
+  if (lane == 0) nacc[wave] = normacc;
+  __syncthreads();
+  if (threadIdx.x == 0) out[d] = ((nacc[0] + nacc[1]) + nacc[2]) + nacc[3];
+}
+
+int bcx_launch_ingest(bcx_solver* s, const void* src, int src_dtype, int64_t ld_src, int64_t row_begin, int64_t rows) {
+  const int d = s->cfg.d;
+  const int64_t nblk = (rows + BCX_CHUNK_ROWS - 1) / BCX_CHUNK_ROWS;
+  const size_t shmem = (4 * (size_t)d + 4) * sizeof(double);
+  dim3 grid((unsigned)nblk), block(256);
+#define LAUNCH(TS, TD)                                                                                        \
+  hipLaunchKernelGGL((ingest_kernel<TS, TD>), grid, block, shmem, s->stream, (const TS*)src, ld_src, row_begin, \
+                     rows, d, (TD*)s->An, s->ld, s->ld64, s->A64, s->norms, s->chunk_sums, s->st)
+  if (src_dtype == BCX_F64) {
+    if (s->cfg.store_dtype == BCX_F32) LAUNCH(double, float); else LAUNCH(double, double);
+  } else {
+    if (s->cfg.store_dtype == BCX_F32) LAUNCH(float, float); else LAUNCH(float, double);
+  }
+#undef LAUNCH
+  BCX_HIP(hipGetLastError());
+  return BCX_OK;
+}
+
+// Finish construction: b and sum(Anorms) from the chunk sums in global chunk order
+// (or b from the caller), ||b||, bn = b/||b|| (giga.py:15-18), and the zero state
+// xw = 0, err = ||b|| (snnls.py:15,29).
+__global__ __launch_bounds__(256) void finalize_kernel(int d, int have_b, const double* __restrict__ sums,
+                                                       int64_t n_sums, double* __restrict__ b, double* __restrict__ bn,
+                                                       double* __restrict__ xw, DevState* st) {
+  __shared__ double scratch[BCX_SCRATCH];
+  for (int c = threadIdx.x; c < d; c += blockDim.x) {
+    if (!have_b) {
+      double acc = 0.0;
+      for (int64_t j = 0; j < n_sums; ++j) acc += sums[j * (int64_t)(d + 1) + c];
+      b[c] = acc;
+    }
+    xw[c] = 0.0;
+  }
+  double sig = 0.0;
+  if (threadIdx.x == 0)
+    for (int64_t j = 0; j < n_sums; ++j) sig += sums[j * (int64_t)(d + 1) + d];
+  __syncthreads();
+  double v[1] = {0.0};
+  for (int c = threadIdx.x; c < d; c += blockDim.x) v[0] += b[c] * b[c];
+  block_allsum<1>(v, scratch);
+  const double bnorm = sqrt(v[0]);
+  for (int c = threadIdx.x; c < d; c += blockDim.x) bn[c] = b[c] / bnorm;
+  if (threadIdx.x == 0) {
+    st->bnorm = bnorm;
+    st->sigma = sig;
+    st->err = bnorm;
+    st->nw = 1.0;
+    st->k = 0;
+    st->limit = 0;
+    st->retried = 0;
+    st->active = 0;
+    st->halt = HALT_NONE;
+    st->since_refresh = 0;
+    st->qscale = 1.0;
+  }
+}
+
+int bcx_launch_finalize(bcx_solver* s, int have_b, const double* gathered, int64_t n_gathered) {
+  const double* sums = gathered ? gathered : s->chunk_sums;
+  const int64_t n = gathered ? n_gathered : s->n_chunks;
+  hipLaunchKernelGGL(finalize_kernel, dim3(1), dim3(256), 0, s->stream, s->cfg.d, have_b, sums, n, s->b, s->bn, s->xw,
+                     s->st);
+  BCX_HIP(hipGetLastError());
+  return BCX_OK;
+}

@@ -1,0 +1,289 @@
+// scan.hip -- the N-way correlation scan with fused arg-max: the one kernel that streams the
+// N x d matrix of normalised rows every greedy iteration (HBM-bound, N*d*sizeof(elem) bytes).
+//
+//   FW / OMP : score[n] = An[n] . (b - A w)                         frankwolfe.py:16-17, orthopursuit.py:18-19
+//   GIGA     : s0 = An[n] . cdir, s1 = An[n] . xw_hat,
+//              score[n] = s0 / sqrt(1 - s1^2)  (masked -> s0/inf)   giga.py:31-38
+//   arg-max with first-index tie-break (ndarray.argmax)
+//
+// Mapping (wave64): a group of G lanes owns one row; lane `sub` of the group loads the 16-byte
+// pieces sub, sub+G, ... of that row (fully coalesced: one wave-wide load covers 1 KiB of
+// contiguous row data), multiplies them with the matching query pieces held in REGISTERS (a lane
+// always touches the same columns), and the G partial sums are combined with a butterfly.  A
+// workgroup of 4 waves walks the rows with a grid stride; UR row-steps are issued back to back so
+// every lane keeps CH*UR independent 16-byte loads in flight.
+//
+// The fp32 scan does not decide the arg-max alone: every row gets a rigorous interval
+// [L, U] around its exact score (forward error bound of the fp32 dot product), each workgroup
+// reports its two largest U (with row ids), a bound U3 on all its other rows, and its largest L.
+// resolve.hip re-scores in fp64 every row whose U reaches the global max L; if a workgroup's
+// U3 reaches it too the iteration is redone with the exact kernel.  With fp64 storage U = L =
+// score and the result is the arg-max itself.
+#include "bcx_internal.h"
+#include "dev_util.h"
+
+template <typename T> struct VecOf;
+template <> struct VecOf<float> { typedef float4 type; static constexpr int EPL = 4; };
+template <> struct VecOf<double> { typedef double2 type; static constexpr int EPL = 2; };
+
+template <typename T> __device__ __forceinline__ T vdot(const float4& a, const float4& b, T acc) {
+  acc = fmaf(a.x, b.x, acc); acc = fmaf(a.y, b.y, acc); acc = fmaf(a.z, b.z, acc); acc = fmaf(a.w, b.w, acc);
+  return acc;
+}
+__device__ __forceinline__ double vdot(const double2& a, const double2& b, double acc) {
+  acc = fma(a.x, b.x, acc); acc = fma(a.y, b.y, acc);
+  return acc;
+}
+__device__ __forceinline__ float4 vzero(float4*) { return make_float4(0.f, 0.f, 0.f, 0.f); }
+__device__ __forceinline__ double2 vzero(double2*) { return make_double2(0.0, 0.0); }
+
+template <typename T, int G> __device__ __forceinline__ T group_allsum(T v) {
+#pragma unroll
+  for (int off = G / 2; off >= 1; off >>= 1) v += __shfl_xor(v, off, BCX_WAVE);
+  return v;
+}
+
+struct ScanArgs {
+  const void* An;     // n x ldv vectors of 16 bytes
+  const void* q;      // 2 x ldv vectors (query 0, query 1) in storage precision
+  const DevState* st;
+  ScanPartial* out;
+  const double* norms; // non-null: rows are RAW fp64 rows, divide the dot products by the row norm
+  int64_t n;
+  int ldv;            // row stride in 16-byte vectors
+  int qstride;        // distance between query 0 and query 1 in 16-byte vectors
+  int nvec;           // 16-byte vectors that hold data in a row (<= ldv)
+  float err_coef;     // |fp32 score - exact score| <= err_coef * qscale   (0 for fp64 storage)
+};
+
+template <typename T> struct Track {
+  T U1, U2, U3, L;
+  int i1, i2;
+};
+
+template <typename T> __device__ __forceinline__ bool better(T ua, int ia, T ub, int ib) {
+  return ua > ub || (ua == ub && ia < ib);
+}
+
+template <typename T> __device__ __forceinline__ Track<T> merge(const Track<T>& a, const Track<T>& b) {
+  const bool bf = better<T>(b.U1, b.i1, a.U1, a.i1);
+  const Track<T>& p = bf ? b : a;  // holds the overall best
+  const Track<T>& q = bf ? a : b;
+  Track<T> r;
+  r.U1 = p.U1; r.i1 = p.i1;
+  T third;
+  if (better<T>(p.U2, p.i2, q.U1, q.i1)) { r.U2 = p.U2; r.i2 = p.i2; third = q.U1; }
+  else { r.U2 = q.U1; r.i2 = q.i1; third = p.U2 > q.U2 ? p.U2 : q.U2; }
+  T u3 = p.U3 > q.U3 ? p.U3 : q.U3;
+  r.U3 = third > u3 ? third : u3;
+  r.L = a.L > b.L ? a.L : b.L;
+  return r;
+}
+
+template <typename T> __device__ __forceinline__ Track<T> shfl_track(const Track<T>& t, int off) {
+  Track<T> r;
+  r.U1 = __shfl_xor(t.U1, off, BCX_WAVE); r.U2 = __shfl_xor(t.U2, off, BCX_WAVE);
+  r.U3 = __shfl_xor(t.U3, off, BCX_WAVE); r.L = __shfl_xor(t.L, off, BCX_WAVE);
+  r.i1 = __shfl_xor(t.i1, off, BCX_WAVE); r.i2 = __shfl_xor(t.i2, off, BCX_WAVE);
+  return r;
+}
+
+// Interval of the GIGA score given s0,s1 known to +-e (fp32 path).  Rows whose |s1| may reach 1
+// (parallel to the current iterate: the singular mask of giga.py:33-36) get U = +inf so that the
+// fp64 re-score decides.
+__device__ __forceinline__ void giga_interval(float s0, float s1, float e, float& U, float& L) {
+  const float a = fabsf(s1);
+  const float ahi = a + e;
+  if (!(ahi < 1.0f)) { U = INFINITY; L = -INFINITY; return; }
+  const float alo = fmaxf(a - e, 0.0f);
+  // 1 - x^2 as (1-x)(1+x): the subtraction is exact for x >= 0.5
+  const float dmin = __builtin_amdgcn_sqrtf((1.0f - ahi) * (1.0f + ahi));  // smallest possible denominator
+  const float dmax = __builtin_amdgcn_sqrtf((1.0f - alo) * (1.0f + alo));
+  const float hi = s0 + e, lo = s0 - e;
+  const float rmin = __builtin_amdgcn_rcpf(dmin), rmax = __builtin_amdgcn_rcpf(dmax);
+  U = hi > 0.0f ? hi * rmin : hi * rmax;
+  L = lo > 0.0f ? lo * rmax : lo * rmin;
+  U += fabsf(U) * 4e-6f + 1e-37f;  // slack for the approximate sqrt/rcp and the rounding of this arithmetic
+  L -= fabsf(L) * 4e-6f + 1e-37f;
+}
+// Exact-mode score, same masking as giga.py:33-38.
+__device__ __forceinline__ double giga_score(double s0, double s1) {
+  const bool ok = (s1 > -1.0 + 1e-14) && (1.0 - s1 * s1 > 0.0);
+  const double den = ok ? sqrt(1.0 - s1 * s1) : INFINITY;
+  return s0 / den;
+}
+
+template <typename T, bool DUAL, int G, int CH>
+__global__ __launch_bounds__(BCX_SCAN_THREADS) void scan_kernel(ScanArgs a) {
+  if (!a.st->active) return;
+  typedef typename VecOf<T>::type V;
+  constexpr int RPW = 64 / G;                       // rows per wave per step
+  constexpr int UR = (CH >= 8) ? 1 : (8 / CH > 4 ? 4 : 8 / CH);  // row steps in flight
+  constexpr int WAVES = BCX_SCAN_THREADS / 64;
+  constexpr int RPB = WAVES * RPW * UR;             // rows per workgroup per trip
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int sub = lane % G, rsub = lane / G;
+
+  // query pieces for this lane's columns -> registers
+  V q0[CH], q1[CH];
+  int voff[CH];
+#pragma unroll
+  for (int c = 0; c < CH; ++c) {
+    const int v = c * G + sub;
+    const bool ok = v < a.nvec;
+    voff[c] = ok ? v : 0;  // clamp: the load stays inside the row, the zero query kills the product
+    q0[c] = ok ? ((const V*)a.q)[v] : vzero((V*)nullptr);
+    if (DUAL) q1[c] = ok ? ((const V*)a.q)[a.qstride + v] : vzero((V*)nullptr);
+  }
+  const T e = (T)(a.err_coef * (float)a.st->qscale);
+
+  Track<T> tr;
+  tr.U1 = tr.U2 = tr.U3 = tr.L = -INFINITY;
+  tr.i1 = tr.i2 = 0x7fffffff;
+
+  const V* base = (const V*)a.An;
+  const int64_t n = a.n;
+  for (int64_t r0 = (int64_t)blockIdx.x * RPB; r0 < n; r0 += (int64_t)gridDim.x * RPB) {
+    V x[UR][CH];
+    int64_t row[UR];
+#pragma unroll
+    for (int u = 0; u < UR; ++u) {
+      row[u] = r0 + (int64_t)(u * WAVES + wave) * RPW + rsub;
+      const int64_t rc = row[u] < n ? row[u] : n - 1;
+      const V* p = base + rc * a.ldv;
+#pragma unroll
+      for (int c = 0; c < CH; ++c) x[u][c] = p[voff[c]];
+    }
+#pragma unroll
+    for (int u = 0; u < UR; ++u) {
+      T s0 = 0, s1 = 0;
+#pragma unroll
+      for (int c = 0; c < CH; ++c) {
+        s0 = vdot(x[u][c], q0[c], s0);
+        if (DUAL) s1 = vdot(x[u][c], q1[c], s1);
+      }
+      s0 = group_allsum<T, G>(s0);
+      if (DUAL) s1 = group_allsum<T, G>(s1);
+      if (sizeof(T) == 8 && a.norms) {
+        const T nr = (T)a.norms[row[u] < n ? row[u] : n - 1];
+        s0 /= nr;
+        if (DUAL) s1 /= nr;
+      }
+      T U, L;
+      if (sizeof(T) == 4) {
+        if (DUAL) {
+          float Uf, Lf;
+          giga_interval((float)s0, (float)s1, (float)e, Uf, Lf);
+          U = Uf; L = Lf;
+        } else {
+          const T ee = e + fabsf((float)s0) * 2e-7f;
+          U = s0 + ee; L = s0 - ee;
+        }
+      } else {
+        U = L = DUAL ? (T)giga_score((double)s0, (double)s1) : s0;
+      }
+      if (!(row[u] < n)) { U = -INFINITY; L = -INFINITY; }
+      const int ri = (int)row[u];
+      // rows arrive in increasing order within a lane, so strict '>' keeps the lowest index on ties
+      if (U > tr.U1) { tr.U3 = tr.U2; tr.U2 = tr.U1; tr.i2 = tr.i1; tr.U1 = U; tr.i1 = ri; }
+      else if (U > tr.U2) { tr.U3 = tr.U2; tr.U2 = U; tr.i2 = ri; }
+      else if (U > tr.U3) { tr.U3 = U; }
+      tr.L = L > tr.L ? L : tr.L;
+    }
+  }
+  // combine the row groups of a wave (lanes with equal `sub` hold distinct row groups)
+#pragma unroll
+  for (int off = G; off < 64; off <<= 1) tr = merge<T>(tr, shfl_track<T>(tr, off));
+  __shared__ Track<T> wtr[WAVES];
+  if (lane == 0) wtr[wave] = tr;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    Track<T> r = wtr[0];
+#pragma unroll
+    for (int w = 1; w < WAVES; ++w) r = merge<T>(r, wtr[w]);
+    ScanPartial o;
+    o.U1 = (double)r.U1; o.U2 = (double)r.U2; o.U3 = (double)r.U3; o.L = (double)r.L;
+    o.i1 = r.i1; o.i2 = r.i2;
+    a.out[blockIdx.x] = o;
+  }
+}
+
+// ---- host side ----------------------------------------------------------------------------
+static int pick_group(int nvec) {  // lanes per row
+  int g = 1;
+  while (g < 64 && g < nvec) g <<= 1;
+  return g;
+}
+
+int bcx_scan_grid(const bcx_solver* s) {
+  // enough workgroups to fill 256 CUs x 8 resident workgroups, never more than the rows need
+  const int64_t n = s->cfg.n_local;
+  int64_t want = (n + 15) / 16;
+  if (want < 1) want = 1;
+  if (want > 2048) want = 2048;
+  return (int)want;
+}
+
+template <typename T, bool DUAL>
+static int launch_t(bcx_solver* s, const ScanArgs& a, int G, int CH, int grid) {
+  dim3 g(grid), b(BCX_SCAN_THREADS);
+#define L(GG, CC)                                                                                    \
+  if (G == GG && CH == CC) {                                                                         \
+    hipLaunchKernelGGL((scan_kernel<T, DUAL, GG, CC>), g, b, 0, s->stream, a);                       \
+    return BCX_OK;                                                                                   \
+  }
+  L(1, 1) L(2, 1) L(4, 1) L(8, 1) L(16, 1) L(32, 1) L(64, 1) L(64, 2) L(64, 4) L(64, 8) L(64, 16)
+#undef L
+  s->err = "scan: unsupported row length";
+  return BCX_ERR_ARG;
+}
+
+int bcx_launch_scan(bcx_solver* s, int exact) {
+  // storage fp64            : fp64 kernel over the normalised rows
+  // storage fp32, exact == 0: fp32 kernel (interval scan)
+  // storage fp32, exact == 1: fp64 kernel over the RAW rows (A64) when they are resident, else the
+  //                           fp32 kernel again (resolve then takes its arg-max as is)
+  const int d = s->cfg.d;
+  const bool raw64 = exact && s->cfg.store_dtype == BCX_F32 && s->A64 != nullptr;
+  const bool f64 = (s->cfg.store_dtype == BCX_F64) || raw64;
+  ScanArgs a;
+  a.st = s->st;
+  a.out = s->partials;
+  a.n = s->cfg.n_local;
+  a.norms = nullptr;
+  const int epl = f64 ? 2 : 4;
+  if (raw64) {
+    a.An = s->A64;
+    a.norms = s->norms;
+    a.q = s->q64;
+    a.ldv = s->ld64 / 2;
+    a.qstride = s->ld64 / 2;
+  } else {
+    a.An = s->An;
+    a.q = s->qst;
+    a.ldv = s->ld / epl;
+    a.qstride = s->ld / epl;
+  }
+  const int nvec = (d + epl - 1) / epl;
+  a.nvec = nvec;
+  const int G = pick_group(nvec);
+  int CH = (nvec + G - 1) / G;
+  int chp = 1;
+  while (chp < CH) chp <<= 1;
+  CH = chp;
+  // forward error bound of the fp32 dot product: storage rounding of row and query (2u) plus a
+  // summation depth of 4*CH fused multiply-adds and log2(G) butterfly adds, u = 2^-24, times
+  // sum|a_i q_i| <= |a||q| (1 + few u).  30% head room.
+  const double u = 5.9604644775390625e-08;
+  int lg = 0;
+  while ((1 << lg) < G) ++lg;
+  a.err_coef = f64 ? 0.0f : (float)(1.3 * u * (4.0 * CH + lg + 3.0));
+  const bool dual = s->cfg.alg == BCX_ALG_GIGA;
+  const int grid = s->n_partials;
+  int rc;
+  if (f64) rc = dual ? launch_t<double, true>(s, a, G, CH, grid) : launch_t<double, false>(s, a, G, CH, grid);
+  else rc = dual ? launch_t<float, true>(s, a, G, CH, grid) : launch_t<float, false>(s, a, G, CH, grid);
+  if (rc != BCX_OK) return rc;
+  BCX_HIP(hipGetLastError());
+  return BCX_OK;
+}

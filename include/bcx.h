@@ -1,0 +1,147 @@
+/*
+ * bcx.h -- C ABI of the MI355X (gfx950) coreset-construction engine.
+ *
+ * One shared library (libbcx.so, built by hipcc --offload-arch=gfx950) replaces
+ * the NumPy/SciPy arithmetic behind the reference's sparse-NNLS solvers.  The
+ * reference (trevorcampbell/bayesian-coresets @ v0.9.1) has no FFI of its own
+ * (it is pure Python), so each entry point below names the reference interface
+ * whose work it takes over; INTEGRATION.md shows the ctypes stub a maintainer
+ * of the reference would add.
+ *
+ * Conventions: plain C types only; every function returns an int status
+ * (BCX_OK == 0, negative == error, message via bcx_last_error); no C++
+ * exception crosses the boundary; the opaque handle owns all device memory;
+ * outputs are caller-allocated HOST buffers unless a parameter says "dev";
+ * device pointers are passed as const void* (from torch.Tensor.data_ptr()).
+ * One host thread per handle.
+ */
+#ifndef BCX_H
+#define BCX_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct bcx_solver bcx_solver;
+
+/* ---- enums ---------------------------------------------------------- */
+enum { BCX_ALG_GIGA = 0, BCX_ALG_FW = 1, BCX_ALG_OMP = 2 };
+enum { BCX_F32 = 0, BCX_F64 = 1 };
+
+/* return codes */
+enum {
+  BCX_OK = 0,
+  BCX_ERR_ARG = -1,        /* bad argument / call order */
+  BCX_ERR_HIP = -2,        /* HIP runtime failure (message has hipGetErrorString) */
+  BCX_ERR_ZERO_ROW = -3,   /* a data row has zero norm: reference raises ValueError (giga.py:11-12) */
+  BCX_ERR_ZERO_B = -4,     /* ||b|| == 0 for GIGA: reference raises NumericalPrecisionError (giga.py:16-17) */
+  BCX_ERR_NOMEM = -5,
+  BCX_ERR_STATE = -6       /* solver not initialised / already latched where not allowed */
+};
+
+/* per-iteration status written to the trace (snnls.py:41-74 outcome of one loop iteration) */
+enum {
+  BCX_IT_OK = 0,            /* step accepted */
+  BCX_IT_FAIL_SELECT = 1,   /* NumericalPrecisionError raised inside _select   (giga.py:28-29) */
+  BCX_IT_FAIL_REWEIGHT = 2, /* NumericalPrecisionError raised inside _reweight (giga.py:50-51, frankwolfe.py:33-34) */
+  BCX_IT_FAIL_MONOTONE = 3  /* error increased, weights reverted               (snnls.py:58-61) */
+};
+
+typedef struct bcx_config {
+  int32_t alg;             /* BCX_ALG_*                                                          */
+  int32_t store_dtype;     /* BCX_F32: normalised rows stored fp32 (default); BCX_F64: exact mode */
+  int32_t keep_exact_rows; /* 1: also keep the raw fp64 rows resident (exact reweight + fp64 rescue) */
+  int32_t device;          /* HIP device ordinal                                                  */
+  int32_t d;               /* projection dimension (columns of the N x d vector matrix)           */
+  int32_t world_size;      /* number of row shards (1 = single GPU)                               */
+  int32_t rank;            /* this shard                                                          */
+  int32_t refresh_every;   /* recompute xw = sum_j w_j A[:,j] from the active rows every this many accepted steps (0 = default 16) */
+  int64_t n_local;         /* rows held by this shard                                             */
+  int64_t n_global;        /* rows over all shards                                                */
+  int64_t row_offset;      /* global index of local row 0 (contiguous row blocks, lowest index wins ties) */
+} bcx_config;
+
+/* ---- lifetime -------------------------------------------------------- */
+/* Replaces SparseNNLS.__init__ storage (snnls/snnls.py:9-16): allocates An (N x d, store_dtype),
+ * norms (fp64), optional raw rows (fp64) and the replicated O(d) solver state. */
+int bcx_create(const bcx_config* cfg, bcx_solver** out);
+int bcx_destroy(bcx_solver* s);
+/* Last error text for this handle (or for a failed bcx_create when s == NULL). */
+const char* bcx_last_error(const bcx_solver* s);
+/* Use the caller's HIP stream (torch.cuda.current_stream().cuda_stream); NULL = default stream. */
+int bcx_set_stream(bcx_solver* s, void* hip_stream);
+
+/* ---- ingest: GIGA/FW/OMP constructors (giga.py:8-13, frankwolfe.py:7-13, orthopursuit.py:9-15) --- */
+/* Copy `rows` rows starting at local row `row_begin` from src (host or device memory, fp32 or fp64,
+ * row-major with leading dimension ld elements), compute their norms (fp64), store the normalised
+ * rows and accumulate per-chunk column sums / norm sums.  May be called repeatedly (row shards,
+ * streaming upload).  A zero-norm row is reported by bcx_finalize (BCX_ERR_ZERO_ROW). */
+int bcx_load_rows(bcx_solver* s, const void* src, int32_t src_is_device, int32_t src_dtype,
+                  int64_t row_begin, int64_t rows, int64_t ld);
+/* Number of row chunks on this shard and rows per chunk; chunk sums are (d+1) doubles each:
+ * d column sums followed by the sum of row norms.  Device pointer for the all-gather across shards. */
+int bcx_chunk_sums(bcx_solver* s, const void** dev_ptr, int64_t* n_chunks, int64_t* chunk_rows);
+/* Finish construction.  b_host (d doubles) overrides the column sums when non-NULL -- the reference
+ * solver constructors take b from the caller (snnls.py:9; hilbert.py:24 passes vecs.sum(axis=0)).
+ * gathered_sums_dev (optional): chunk sums of ALL shards in global chunk order (n_gathered chunks),
+ * summed in that fixed order so b and sum(Anorms) are bit-identical for any shard count.
+ * Returns BCX_ERR_ZERO_ROW / BCX_ERR_ZERO_B exactly where the reference constructors raise. */
+int bcx_finalize(bcx_solver* s, const double* b_host, const void* gathered_sums_dev, int64_t n_gathered);
+
+/* ---- the hot loop: SparseNNLS.build (snnls.py:31-79) ---------------------------------------- */
+/* Begin a build() call of `itrs` loop iterations (resets the per-call retry flag, snnls.py:40;
+ * tol is bc.util.TOL read at call time, giga.py:28).  Returns 1 in *skip if the reference would
+ * return immediately (latched numeric limit snnls.py:32-34, or no data :36-38). */
+int bcx_build_begin(bcx_solver* s, int64_t itrs, double tol, int32_t* skip);
+/* Enqueue one greedy iteration up to the shard exchange: correlation scan over the local rows
+ * (giga.py:31-38 / frankwolfe.py:16-17 / orthopursuit.py:18-26) + exact fp64 re-score of the
+ * candidates; writes this shard's record {score, global index, norm, flags, row[d]} (d+4 doubles)
+ * to send_dev.  Asynchronous on the stream. */
+int bcx_step_scan(bcx_solver* s, void* send_dev);
+/* Enqueue the replicated part: pick the winner among world_size records at recv_dev (max score,
+ * lowest global index), OMP negative direction (orthopursuit.py:27-35), reweight
+ * (giga.py:40-64 / frankwolfe.py:19-40 / orthopursuit.py:37-42), monotone check / revert / retry /
+ * latch (snnls.py:56-74), and the next query vector.  Asynchronous on the stream. */
+int bcx_step_apply(bcx_solver* s, const void* recv_dev);
+/* Single-shard convenience: enqueue up to `itrs` whole iterations (scan + apply) without host
+ * round trips. */
+int bcx_build_enqueue(bcx_solver* s, int64_t itrs);
+/* Synchronise and report.  *n_done = loop iterations consumed so far in this build() call;
+ * *need_exact = 1 if the engine stopped before an iteration because the fp32 candidate window
+ * overflowed (tie-heavy data) -- call bcx_step_scan_exact for that iteration and continue;
+ * *limit = reached_numeric_limit (snnls.py:67). */
+int bcx_build_poll(bcx_solver* s, int64_t* n_done, int32_t* need_exact, int32_t* limit);
+/* Exact (all-fp64) variant of bcx_step_scan used for the overflow fallback and by store_dtype F64. */
+int bcx_step_scan_exact(bcx_solver* s, void* send_dev);
+/* Copy the trace of this build() call: per loop iteration the selected global index (-1 if select
+ * failed), the error after the iteration and a BCX_IT_* status.  Arrays sized >= n_done. */
+int bcx_build_trace(bcx_solver* s, int64_t* sel, double* err, int32_t* status, int64_t cap, int64_t* n_out);
+
+/* ---- read-out: weights()/size()/error() (snnls.py:22-29), optimize() (:82-97), reset() (:18-20) -- */
+int bcx_active_count(bcx_solver* s, int64_t* k);                 /* entries in the sparse weight list (any weight) */
+int bcx_get_weights(bcx_solver* s, int64_t* idx, double* w, int64_t cap, int64_t* k); /* selection order */
+int bcx_error(bcx_solver* s, double* err);
+int bcx_optimize(bcx_solver* s, double tol, int32_t* accepted);
+int bcx_reset(bcx_solver* s);
+int bcx_reached_numeric_limit(bcx_solver* s, int32_t* limit);
+
+/* ---- introspection / measurement ------------------------------------------------------------ */
+/* Copy replicated vectors to the host for tests: which = 0:b 1:xw 2:query0 3:query1 (d doubles). */
+int bcx_get_vector(bcx_solver* s, int32_t which, double* out);
+/* Copy row norms of local rows [begin, begin+count) (Anorms, frankwolfe.py:10). */
+int bcx_get_norms(bcx_solver* s, int64_t begin, int64_t count, double* out);
+/* Time `reps` launches of the correlation-scan kernel alone with hipEvents on the solver's stream;
+ * returns the mean milliseconds per launch and the algorithmic bytes one launch reads. */
+int bcx_time_scan(bcx_solver* s, int32_t reps, int32_t exact, double* ms_per_launch, double* bytes_per_launch);
+/* Sum of scan-kernel time recorded by hipEvents during bcx_build_enqueue (enable with on=1). */
+int bcx_profile_scan(bcx_solver* s, int32_t on);
+int bcx_profile_read(bcx_solver* s, double* scan_ms_total, int64_t* scan_launches);
+/* Library/arch identification, e.g. "bcx 0.1 gfx950". */
+const char* bcx_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BCX_H */

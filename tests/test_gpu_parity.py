@@ -1,0 +1,138 @@
+"""GPU parity: the HIP engine (through the C ABI / Python mirror) against the golden vectors
+produced by the reference and against the CPU oracle on the same seeded inputs.
+Indices must be bit-exact; weights within 1e-5 relative (BASELINE.json north_star)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+WEIGHT_RTOL = 1e-5   # north_star tolerance for weights
+ERR_RTOL = 1e-7      # per-iteration error ||Aw-b||
+
+
+def _solver(bc, alg):
+    return {"giga": bc.snnls.GIGA, "fw": bc.snnls.FrankWolfe, "omp": bc.snnls.OrthoPursuit}[alg]
+
+
+def _run(bc, X, alg, itrs, **kw):
+    s = _solver(bc, alg)(X.T, X.sum(axis=0), **kw)
+    s.build(itrs)
+    return s
+
+
+def _check(s, golden, key, weight_rtol=WEIGHT_RTOL):
+    sel, err, status = s.last_trace
+    gsel = golden[key + "sel"]
+    ok = status == 0
+    assert np.array_equal(sel[sel >= 0], gsel), "selection sequence differs from the reference"
+    gerr = golden[key + "err"]
+    n = min(int(ok.sum()), len(gerr))
+    np.testing.assert_allclose(err[ok][:n], gerr[:n], rtol=ERR_RTOL, atol=1e-9)
+    w = s.weights()
+    idx = np.flatnonzero(w > 0)
+    assert np.array_equal(idx, golden[key + "idx"])
+    np.testing.assert_allclose(w[idx], golden[key + "w"], rtol=weight_rtol)
+    np.testing.assert_allclose(s.error(), float(golden[key + "final_err"]), rtol=ERR_RTOL, atol=1e-9)
+
+
+@pytest.fixture(scope="module")
+def bc():
+    import bayesiancoresets_amd as bc
+    return bc
+
+
+@pytest.mark.parametrize("alg", ("giga", "fw", "omp"))
+@pytest.mark.parametrize("itrs", (12, 100))
+def test_F1_axis_ties(bc, golden, alg, itrs):
+    """X = eye(N): every score ties on every iteration -> first-index tie-break, overflow fallback."""
+    X = np.eye(100)
+    s = _run(bc, X, alg, itrs)
+    _check(s, golden, "F1_%s_%d_" % (alg, itrs))
+    assert list(s.last_trace[0][:12]) == list(range(12))
+
+
+@pytest.mark.parametrize("alg", ("giga", "fw", "omp"))
+@pytest.mark.parametrize("dtype", ("float32", "float64"))
+def test_F9_small(bc, golden, normal_inputs, alg, dtype):
+    X = normal_inputs(7, 3000, 64, "F9_input_sha256")
+    s = _run(bc, X, alg, 60, dtype=dtype)
+    _check(s, golden, "F9_%s_" % alg)
+
+
+@pytest.mark.parametrize("alg", ("giga", "fw", "omp"))
+@pytest.mark.parametrize("dtype", ("float32", "float64"))
+def test_F2_normal_10k(bc, golden, normal_inputs, alg, dtype):
+    X = normal_inputs(1, 10000, 100, "F2_input_sha256")
+    s = _run(bc, X, alg, 100, dtype=dtype)
+    _check(s, golden, "F2_%s_" % alg)
+
+
+@pytest.mark.parametrize("alg", ("giga", "fw"))
+def test_no_exact_rows_mode(bc, golden, normal_inputs, alg):
+    """fp32-only storage (no resident fp64 rows): same selections, weights to fp32-row accuracy."""
+    X = normal_inputs(7, 3000, 64, "F9_input_sha256")
+    s = _run(bc, X, alg, 60, keep_exact_rows=False)
+    sel = s.last_trace[0]
+    assert np.array_equal(sel[sel >= 0], golden["F9_%s_sel" % alg])
+    w = s.weights()
+    idx = np.flatnonzero(w > 0)
+    assert np.array_equal(idx, golden["F9_%s_idx" % alg])
+    np.testing.assert_allclose(w[idx], golden["F9_%s_w" % alg], rtol=1e-4)
+
+
+@pytest.mark.parametrize("alg", ("giga", "fw", "omp"))
+def test_incremental_build_matches_single_call(bc, normal_inputs, alg):
+    """build() keeps state on the device across calls (examples/synthetic_vectors/main.py:91-94)."""
+    X = normal_inputs(7, 3000, 64, "F9_input_sha256")
+    a = _run(bc, X, alg, 40)
+    b = _solver(bc, alg)(X.T, X.sum(axis=0))
+    for step in (1, 1, 3, 5, 10, 20):
+        b.build(step)
+    np.testing.assert_allclose(a.weights(), b.weights(), rtol=1e-12, atol=0)
+    assert a.error() == pytest.approx(b.error(), rel=1e-12)
+
+
+@pytest.mark.parametrize("alg", ("giga", "fw", "omp"))
+def test_against_oracle_random_shape(bc, alg):
+    """Fresh seeded input (not in the golden file): HIP engine vs the CPU oracle, d not a multiple of 4."""
+    from oracle.snnls_oracle import SnnlsOracle
+    X = np.random.RandomState(123).randn(5000, 50) * np.random.RandomState(5).uniform(0.1, 10, size=(5000, 1))
+    o = SnnlsOracle(X.T, X.sum(axis=0), alg=alg)
+    o.build(40)
+    s = _run(bc, X, alg, 40)
+    sel = s.last_trace[0]
+    assert np.array_equal(sel, np.array([t[0] for t in o.trace]))
+    w, ow = s.weights(), o.weights()
+    assert np.array_equal(np.flatnonzero(w > 0), np.flatnonzero(ow > 0))
+    np.testing.assert_allclose(w[w > 0], ow[ow > 0], rtol=WEIGHT_RTOL)
+    np.testing.assert_allclose(s.error(), o.error(), rtol=ERR_RTOL)
+
+
+def test_monotone_error_property(bc, normal_inputs):
+    X = normal_inputs(1, 10000, 100, "F2_input_sha256")
+    for alg in ("giga", "fw"):
+        s = _run(bc, X, alg, 150)
+        sel, err, status = s.last_trace
+        e = err[status == 0]
+        assert np.all(np.diff(e[1:]) <= 0.0), "accepted steps must not increase the error (snnls.py:58)"
+
+
+def test_error_paths(bc):
+    X = np.random.RandomState(0).randn(2048, 8)
+    X[700] = 0.0
+    for alg in ("giga", "fw", "omp"):
+        with pytest.raises(ValueError):
+            _solver(bc, alg)(X.T, X.sum(axis=0))
+    Y = np.random.RandomState(0).randn(64, 8)
+    with pytest.raises(bc.util.errors.NumericalPrecisionError):
+        bc.snnls.GIGA(Y.T, np.zeros(8))
+
+
+def test_reset(bc, normal_inputs):
+    X = normal_inputs(7, 3000, 64, "F9_input_sha256")
+    s = _run(bc, X, "giga", 20)
+    w1 = s.weights()
+    s.reset()
+    assert s.size() == 0 and s.error() == pytest.approx(np.sqrt((X.sum(axis=0) ** 2).sum()), rel=1e-13)
+    s.build(20)
+    np.testing.assert_array_equal(w1, s.weights())
