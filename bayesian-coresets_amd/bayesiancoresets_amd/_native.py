@@ -18,7 +18,7 @@ CHUNK_ROWS = 1024
 
 # every symbol include/bcx.h declares (checked by tests/test_abi.py)
 SYMBOLS = (
-    "bcx_create", "bcx_destroy", "bcx_last_error", "bcx_set_stream", "bcx_load_rows", "bcx_chunk_sums",
+    "bcx_create", "bcx_destroy", "bcx_last_error", "bcx_set_stream", "bcx_load_rows", "bcx_chunk_sums", "bcx_export_chunk_sums",
     "bcx_finalize", "bcx_build_begin", "bcx_step_scan", "bcx_step_apply", "bcx_build_enqueue", "bcx_build_poll",
     "bcx_step_scan_exact", "bcx_build_trace", "bcx_active_count", "bcx_get_weights", "bcx_error", "bcx_optimize",
     "bcx_reset", "bcx_reached_numeric_limit", "bcx_get_vector", "bcx_get_norms", "bcx_time_scan",
@@ -59,6 +59,7 @@ def load():
         "bcx_set_stream": [vp, vp],
         "bcx_load_rows": [vp, vp, i32, i32, i64, i64, i64],
         "bcx_chunk_sums": [vp, P(vp), P(i64), P(i64)],
+        "bcx_export_chunk_sums": [vp, vp, i64],
         "bcx_finalize": [vp, vp, vp, i64],
         "bcx_build_begin": [vp, i64, dbl, P(i32)],
         "bcx_step_scan": [vp, vp],
@@ -161,6 +162,9 @@ class Engine(object):
         self._check(self.lib.bcx_chunk_sums(self.h, ctypes.byref(p), ctypes.byref(n), ctypes.byref(r)))
         return p.value, n.value, r.value
 
+    def export_chunk_sums(self, dst_ptr, cap_chunks):
+        self._check(self.lib.bcx_export_chunk_sums(self.h, ctypes.c_void_p(dst_ptr), cap_chunks))
+
     def finalize(self, b=None, gathered_ptr=None, n_gathered=0):
         bp = None
         if b is not None:
@@ -169,6 +173,37 @@ class Engine(object):
             bp = ctypes.c_void_p(b.ctypes.data)
         rc = self.lib.bcx_finalize(self.h, bp, ctypes.c_void_p(gathered_ptr) if gathered_ptr else None, n_gathered)
         return rc
+
+    # -- tensor-level protocol used by sharded.ShardedSolver -----------------
+    def tensor_device(self):
+        import torch
+        return torch.device("cuda", self.cfg.device)
+
+    def load_rows_any(self, rows, row_begin=0):
+        try:
+            import torch
+            if isinstance(rows, torch.Tensor):
+                if rows.device.type == "cuda":
+                    assert rows.stride(1) == 1
+                    self.load_device_rows(rows.data_ptr(), rows.shape[0], rows.stride(0),
+                                          rows.element_size() == 8, row_begin)
+                    return
+                rows = rows.numpy()
+        except ImportError:
+            pass
+        self.load_host_rows(np.ascontiguousarray(rows), row_begin)
+
+    def export_chunk_sums_tensor(self, t, cap_chunks):
+        self.export_chunk_sums(t.data_ptr(), cap_chunks)
+
+    def finalize_any(self, b, gathered, n_gathered):
+        return self.finalize(b, gathered.data_ptr() if gathered is not None else None, n_gathered)
+
+    def step_scan_tensor(self, send, exact=False):
+        self.step_scan(send.data_ptr(), exact)
+
+    def step_apply_tensor(self, recv):
+        self.step_apply(recv.data_ptr())
 
     # -- build ------------------------------------------------------------
     def build_begin(self, itrs, tol):

@@ -24,7 +24,7 @@ static int round_up(int x, int m) { return (x + m - 1) / m * m; }
 static void free_all(bcx_solver* s) {
   void* ptrs[] = {s->An, s->A64, s->norms, s->chunk_sums, s->staging, s->st, s->b, s->bn, s->xw, s->q64, s->qst,
                   s->tmp, s->partials, s->rec_local, s->act_idx, s->act_w, s->act_rows, s->act_norm, s->gram,
-                  s->hinv, s->cvec, s->plist, s->ppos, s->nn_x, s->nn_z, s->nn_wv, s->nn_tmp, s->tr_sel, s->tr_err,
+                  s->hinv, s->cvec, s->plist, s->ppos, s->nn_x, s->nn_z, s->nn_wv, s->nn_tmp, s->nn_flag, s->nn_wbak, s->tr_sel, s->tr_err,
                   s->tr_status};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
@@ -70,7 +70,7 @@ extern "C" int bcx_create(const bcx_config* cfg, bcx_solver** out) {
   chk(dev_alloc(&s->xw, (size_t)d));
   chk(dev_alloc(&s->q64, (size_t)2 * s->ld64));
   chk(dev_alloc((char**)&s->qst, (size_t)2 * s->ld * s->elem));
-  chk(dev_alloc(&s->tmp, (size_t)4 * d));
+  chk(dev_alloc(&s->tmp, (size_t)20 * d));
   s->n_partials = bcx_scan_grid(s);
   chk(dev_alloc(&s->partials, (size_t)s->n_partials));
   chk(dev_alloc(&s->rec_local, (size_t)(d + BCX_REC_HDR)));
@@ -152,6 +152,13 @@ extern "C" int bcx_chunk_sums(bcx_solver* s, const void** dev_ptr, int64_t* n_ch
   return BCX_OK;
 }
 
+extern "C" int bcx_export_chunk_sums(bcx_solver* s, void* dst_dev, int64_t cap_chunks) {
+  if (!s || !dst_dev || cap_chunks < s->n_chunks) return BCX_ERR_ARG;
+  BCX_HIP(hipMemcpyAsync(dst_dev, s->chunk_sums, (size_t)s->n_chunks * (s->cfg.d + 1) * 8, hipMemcpyDeviceToDevice,
+                         s->stream));
+  return BCX_OK;
+}
+
 static int read_state(bcx_solver* s, DevState* h) {
   BCX_HIP(hipStreamSynchronize(s->stream));
   BCX_HIP(hipMemcpy(h, s->st, sizeof(DevState), hipMemcpyDeviceToHost));
@@ -202,7 +209,34 @@ static int ensure_slots(bcx_solver* s, int64_t need) {
   return BCX_OK;
 }
 
-int bcx_ensure_gram(bcx_solver* s, int64_t need);  // nnls.hip
+int bcx_ensure_gram(bcx_solver* s, int64_t need) {
+  if (need <= s->gram_cap) return BCX_OK;
+  const int64_t ncap = std::max<int64_t>((need + 63) / 64 * 64, std::max<int64_t>(256, s->gram_cap * 2));
+  const size_t oc = (size_t)s->gram_cap, nc = (size_t)ncap;
+  // gram / hinv change their leading dimension: copy row by row
+  double* g2 = nullptr; double* h2 = nullptr;
+  BCX_HIP(dev_alloc(&g2, nc * nc));
+  BCX_HIP(dev_alloc(&h2, nc * nc));
+  if (oc) {
+    BCX_HIP(hipMemcpy2D(g2, nc * 8, s->gram, oc * 8, oc * 8, oc, hipMemcpyDeviceToDevice));
+    BCX_HIP(hipMemcpy2D(h2, nc * 8, s->hinv, oc * 8, oc * 8, oc, hipMemcpyDeviceToDevice));
+    BCX_HIP(hipFree(s->gram));
+    BCX_HIP(hipFree(s->hinv));
+  }
+  s->gram = g2; s->hinv = h2;
+  int rc;
+  if ((rc = grow(s, &s->cvec, oc, nc))) return rc;
+  if ((rc = grow(s, &s->plist, oc, nc))) return rc;
+  if ((rc = grow(s, &s->ppos, oc, nc))) return rc;
+  if ((rc = grow(s, &s->nn_x, oc, nc))) return rc;
+  if ((rc = grow(s, &s->nn_z, 0, nc))) return rc;
+  if ((rc = grow(s, &s->nn_wv, 0, nc))) return rc;
+  if ((rc = grow(s, &s->nn_tmp, 0, 4 * nc))) return rc;
+  if ((rc = grow(s, &s->nn_flag, 0, nc))) return rc;
+  if ((rc = grow(s, &s->nn_wbak, 0, nc))) return rc;
+  s->gram_cap = ncap;
+  return BCX_OK;
+}
 
 static int ensure_trace(bcx_solver* s, int64_t need) {
   if (need <= s->trace_cap) return BCX_OK;
@@ -368,7 +402,7 @@ extern "C" int bcx_reset(bcx_solver* s) {
   DevState h;
   int rc = read_state(s, &h);
   if (rc != BCX_OK) return rc;
-  h.k = 0; h.limit = 0; h.retried = 0; h.active = 0; h.halt = HALT_NONE; h.since_refresh = 0; h.exact_mode = 0;
+  h.k = 0; h.np = 0; h.hvalid = 1; h.limit = 0; h.retried = 0; h.active = 0; h.halt = HALT_NONE; h.since_refresh = 0; h.exact_mode = 0;
   h.err = h.bnorm; h.nw = 1.0; h.it = 0; h.itrs = 0;
   BCX_HIP(hipMemcpy(s->st, &h, sizeof h, hipMemcpyHostToDevice));
   BCX_HIP(hipMemset(s->xw, 0, (size_t)s->cfg.d * 8));
@@ -382,6 +416,7 @@ extern "C" int bcx_optimize(bcx_solver* s, double tol, int32_t* accepted) {
   DevState h;
   int rc = read_state(s, &h);
   if (rc != BCX_OK) return rc;
+  if ((rc = ensure_slots(s, std::max<int64_t>(h.k, 1)))) return rc;
   if ((rc = bcx_ensure_gram(s, std::max<int64_t>(h.k, 1)))) return rc;
   if ((rc = bcx_launch_optimize(s, tol))) return rc;
   DevState h2;

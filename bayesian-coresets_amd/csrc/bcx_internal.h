@@ -39,6 +39,8 @@ struct DevState {
   int32_t since_refresh;
   int32_t exact_mode;  // current iteration's scan was exact (no candidate window)
   int32_t zero_row;    // first zero-norm local row + 1 (0 = none)
+  int32_t np;          // size of the passive set P (OMP / optimize)
+  int32_t hvalid;      // hinv == inverse of gram[P,P] and P == {slots with weight > 0}
   double tol;          // bc.util.TOL at build() time
   double err;          // ||A w - b||
   double nw;           // ||A w|| (1 when zero, giga.py:23)
@@ -86,7 +88,9 @@ struct bcx_solver {
   double* nn_x = nullptr;        // cap
   double* nn_z = nullptr;        // cap
   double* nn_wv = nullptr;       // cap
-  double* nn_tmp = nullptr;      // 2*cap
+  double* nn_tmp = nullptr;      // 4*cap position scratch
+  int32_t* nn_flag = nullptr;    // cap: bit0 in problem set S, bit1 rejected, bit2 remove
+  double* nn_wbak = nullptr;     // cap: weights before the step (revert on monotone failure)
   int64_t gram_cap = 0;
   // trace of the current build() call
   int64_t trace_cap = 0;

@@ -121,6 +121,8 @@ __global__ __launch_bounds__(256) void finalize_kernel(int d, int have_b, const 
     st->halt = HALT_NONE;
     st->since_refresh = 0;
     st->qscale = 1.0;
+    st->np = 0;
+    st->hvalid = 1;
   }
 }
 

@@ -1,4 +1,545 @@
+// nnls.hip -- the dense re-weight step: non-negative least squares on the active columns.
+//   OMP reweight : w[f] = 1; w[active] = nnls(A[:, active], b)        orthopursuit.py:37-42
+//   optimize()   : w[active] = nnls(A[:, active], b), keep unless worse   snnls.py:82-97
+// The reference calls scipy.optimize.nnls (Lawson-Hanson active set on the d x k matrix, cold start).
+// Here the k active rows are replicated on every shard, their Gram matrix G = V V^T (k x k) and
+// c = V b are kept on the device, and the same active-set iteration runs on the normal equations:
+// the passive block's inverse H = inv(G[P,P]) is maintained by bordering (add a column) and
+// rank-1 deletion (drop a column), every solve is followed by one step of iterative refinement
+// against G.  NNLS solutions are unique for independent columns, so warm starting from the
+// previous passive set gives the reference's result.  The Gram matrix of optimize() is a small
+// GEMM and runs on the fp64 matrix cores (v_mfma_f64_16x16x4_f64); everything else is
+// latency-bound single-workgroup work.
 #include "bcx_internal.h"
-int bcx_ensure_gram(bcx_solver* s, int64_t) { return BCX_OK; }
-int bcx_launch_apply_omp(bcx_solver* s, const double*) { s->err = "OMP not built"; return BCX_ERR_STATE; }
-int bcx_launch_optimize(bcx_solver* s, double) { s->err = "optimize not built"; return BCX_ERR_STATE; }
+#include "dev_util.h"
+#include "apply_common.h"
+
+#define NN_THREADS 1024
+#define FLAG_INS 1
+#define FLAG_REJ 2
+#define FLAG_RM 4
+
+struct NnlsArgs {
+  ApplyArgs a;
+  double* gram;
+  double* hinv;
+  int64_t ldg;
+  double* cvec;
+  int32_t* plist;
+  int32_t* ppos;
+  double* x;       // per slot
+  double* z;       // per position
+  double* t0;      // per position scratch
+  double* t1;
+  double* t2;
+  int32_t* flag;   // per slot
+  double* wbak;    // per slot
+};
+
+// ---- small workgroup-wide helpers ---------------------------------------------------------------
+// arg-max of (val, idx): larger val wins, ties -> smaller idx.  Entries with idx < 0 are ignored.
+struct ArgBest { double v; int i; };
+static __device__ ArgBest block_argbest(double v, int i, double* scratch) {
+  __shared__ double sv[16];
+  __shared__ int si[16];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  if (i < 0) v = -INFINITY;
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) {
+    const double ov = __shfl_xor(v, off, BCX_WAVE);
+    const int oi = __shfl_xor(i, off, BCX_WAVE);
+    if (oi >= 0 && (i < 0 || ov > v || (ov == v && oi < i))) { v = ov; i = oi; }
+  }
+  if (lane == 0) { sv[wave] = v; si[wave] = i; }
+  __syncthreads();
+  ArgBest r; r.v = sv[0]; r.i = si[0];
+  for (int w = 1; w < nw; ++w)
+    if (si[w] >= 0 && (r.i < 0 || sv[w] > r.v || (sv[w] == r.v && si[w] < r.i))) { r.v = sv[w]; r.i = si[w]; }
+  __syncthreads();
+  return r;
+}
+
+// y[a] = sum_b M[b*ld + a] * v[b], a < p  (M symmetric: reading column a as row entries is coalesced)
+static __device__ void mv_sym(const double* M, int64_t ld, int p, const double* v, double* y) {
+  for (int a = threadIdx.x; a < p; a += blockDim.x) {
+    double acc = 0.0;
+    for (int b = 0; b < p; ++b) acc += M[(size_t)b * ld + a] * v[b];
+    y[a] = acc;
+  }
+  __syncthreads();
+}
+// y[a] = sum_b G[plist[b]][plist[a]] * v[b]
+static __device__ void mv_gram(const NnlsArgs& n, int p, const double* v, double* y) {
+  for (int a = threadIdx.x; a < p; a += blockDim.x) {
+    const int ca = n.plist[a];
+    double acc = 0.0;
+    for (int b = 0; b < p; ++b) acc += n.gram[(size_t)n.plist[b] * n.ldg + ca] * v[b];
+    y[a] = acc;
+  }
+  __syncthreads();
+}
+
+// Add slot to the passive set: H' = inverse of the bordered matrix.  False when the column is
+// numerically dependent on P (Schur complement not positive).
+static __device__ bool border_add(const NnlsArgs& n, int slot, double* scratch) {
+  DevState* st = n.a.st;
+  const int p = st->np;
+  const int64_t ld = n.ldg;
+  for (int a = threadIdx.x; a < p; a += blockDim.x) n.t0[a] = n.gram[(size_t)slot * ld + n.plist[a]];
+  __syncthreads();
+  mv_sym(n.hinv, ld, p, n.t0, n.t1);   // u = H g
+  double v[1] = {0.0};
+  for (int a = threadIdx.x; a < p; a += blockDim.x) v[0] += n.t0[a] * n.t1[a];
+  block_allsum<1>(v, scratch);
+  const double gff = n.gram[(size_t)slot * ld + slot];
+  const double s = gff - v[0];
+  if (!(s > 1e-12 * gff)) return false;
+  const double inv = 1.0 / s;
+  for (int idx = threadIdx.x; idx < p * p; idx += blockDim.x) {
+    const int r = idx / p, c = idx - r * p;
+    n.hinv[(size_t)r * ld + c] += n.t1[r] * n.t1[c] * inv;
+  }
+  for (int a = threadIdx.x; a < p; a += blockDim.x) {
+    const double e = -n.t1[a] * inv;
+    n.hinv[(size_t)p * ld + a] = e;
+    n.hinv[(size_t)a * ld + p] = e;
+  }
+  if (threadIdx.x == 0) {
+    n.hinv[(size_t)p * ld + p] = inv;
+    n.plist[p] = slot;
+    n.ppos[slot] = p;
+    st->np = p + 1;
+  }
+  __syncthreads();
+  return true;
+}
+
+// Remove position q from the passive set (rank-1 downdate of H, then move the last position into q).
+static __device__ void border_del(const NnlsArgs& n, int q) {
+  DevState* st = n.a.st;
+  const int p = st->np, last = p - 1;
+  const int64_t ld = n.ldg;
+  for (int a = threadIdx.x; a < p; a += blockDim.x) n.t0[a] = n.hinv[(size_t)a * ld + q];
+  __syncthreads();
+  const double hqq = n.t0[q];
+  for (int idx = threadIdx.x; idx < p * p; idx += blockDim.x) {
+    const int r = idx / p, c = idx - r * p;
+    n.hinv[(size_t)r * ld + c] -= n.t0[r] * n.t0[c] / hqq;
+  }
+  __syncthreads();
+  const int gone = n.plist[q];
+  if (q != last) {
+    for (int a = threadIdx.x; a < p; a += blockDim.x) n.t1[a] = n.hinv[(size_t)last * ld + a];
+    __syncthreads();
+    for (int a = threadIdx.x; a < last; a += blockDim.x) {
+      if (a == q) continue;
+      n.hinv[(size_t)q * ld + a] = n.t1[a];
+      n.hinv[(size_t)a * ld + q] = n.t1[a];
+    }
+    if (threadIdx.x == 0) {
+      n.hinv[(size_t)q * ld + q] = n.t1[last];
+      const int moved = n.plist[last];
+      n.plist[q] = moved;
+      n.ppos[moved] = q;
+    }
+  }
+  if (threadIdx.x == 0) { n.ppos[gone] = -1; st->np = last; }
+  __syncthreads();
+}
+
+// z = argmin over the passive set: z = H c_P, then one refinement step z += H (c_P - G_PP z).
+static __device__ void passive_solve(const NnlsArgs& n) {
+  const int p = n.a.st->np;
+  for (int a = threadIdx.x; a < p; a += blockDim.x) n.t0[a] = n.cvec[n.plist[a]];
+  __syncthreads();
+  mv_sym(n.hinv, n.ldg, p, n.t0, n.z);
+  mv_gram(n, p, n.z, n.t1);
+  for (int a = threadIdx.x; a < p; a += blockDim.x) n.t1[a] = n.t0[a] - n.t1[a];
+  __syncthreads();
+  mv_sym(n.hinv, n.ldg, p, n.t1, n.t2);
+  for (int a = threadIdx.x; a < p; a += blockDim.x) n.z[a] += n.t2[a];
+  __syncthreads();
+}
+
+// Lawson-Hanson active-set iteration over the slots flagged FLAG_INS, warm-started from the
+// current passive set / x.  On return x[j] > 0 exactly for j in P, x[j] = 0 elsewhere.
+static __device__ void nnls_run(const NnlsArgs& n, int k, double tolscale, double* scratch) {
+  DevState* st = n.a.st;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  const int max_outer = 3 * k + 16;
+  for (int outer = 0; outer < max_outer; ++outer) {
+    // dual vector w = c - G x on the candidates (S \ P, not rejected): one wave per candidate
+    const int p = st->np;
+    for (int j = wave; j < k; j += nw) {
+      const int fl = n.flag[j];
+      if (!(fl & FLAG_INS) || (fl & FLAG_REJ) || n.ppos[j] >= 0) continue;
+      double acc = 0.0;
+      for (int a = lane; a < p; a += 64) {
+        const int ca = n.plist[a];
+        acc += n.gram[(size_t)j * n.ldg + ca] * n.x[ca];
+      }
+      acc = wave_allsum(acc);
+      if (lane == 0) n.t2[j] = n.cvec[j] - acc;
+    }
+    __syncthreads();
+    double bv = -INFINITY; int bi = -1;
+    for (int j = threadIdx.x; j < k; j += blockDim.x) {
+      const int fl = n.flag[j];
+      if (!(fl & FLAG_INS) || (fl & FLAG_REJ) || n.ppos[j] >= 0) continue;
+      const double wv = n.t2[j];
+      if (wv > tolscale * n.a.act_norm[j] && (bi < 0 || wv > bv)) { bv = wv; bi = j; }
+    }
+    const ArgBest best = block_argbest(bv, bi, scratch);
+    if (best.i < 0) break;
+    if (!border_add(n, best.i, scratch)) {
+      if (threadIdx.x == 0) n.flag[best.i] |= FLAG_REJ;
+      __syncthreads();
+      continue;
+    }
+    if (threadIdx.x == 0) n.x[best.i] = 0.0;
+    __syncthreads();
+    for (int inner = 0; inner < max_outer; ++inner) {
+      passive_solve(n);
+      const int pp = st->np;
+      // feasibility: all z > 0 ?  else step length alpha = min x/(x - z) over z <= 0
+      double amin = INFINITY; int apos = -1;
+      for (int a = threadIdx.x; a < pp; a += blockDim.x) {
+        const double za = n.z[a];
+        if (!(za > 0.0)) {
+          const double xa = n.x[n.plist[a]];
+          double al = xa / (xa - za);
+          if (!(al == al)) al = 0.0;                 // 0/0: a zero weight asked to go further down
+          if (apos < 0 || al < amin) { amin = al; apos = a; }
+        }
+      }
+      const ArgBest worst = block_argbest(-amin, apos, scratch);   // smallest alpha, lowest position
+      if (worst.i < 0) {
+        for (int a = threadIdx.x; a < pp; a += blockDim.x) n.x[n.plist[a]] = n.z[a];
+        __syncthreads();
+        break;
+      }
+      const double alpha = -worst.v;
+      for (int a = threadIdx.x; a < pp; a += blockDim.x) {
+        const int c = n.plist[a];
+        const double xa = n.x[c];
+        const double xn = xa + alpha * (n.z[a] - xa);
+        const bool rm = (a == worst.i) || !(xn > 0.0);
+        n.x[c] = rm ? 0.0 : xn;
+        if (rm) n.flag[c] |= FLAG_RM;
+      }
+      __syncthreads();
+      // drop flagged positions, highest position first (the element moved into a hole was already checked)
+      for (;;) {
+        const int pq = st->np;
+        int cand = -1;
+        for (int a = threadIdx.x; a < pq; a += blockDim.x)
+          if (n.flag[n.plist[a]] & FLAG_RM) cand = a > cand ? a : cand;
+        const ArgBest top = block_argbest((double)cand, cand, scratch);
+        if (top.i < 0) break;
+        const int slot = n.plist[top.i];
+        if (threadIdx.x == 0) {
+          n.flag[slot] &= ~FLAG_RM;
+          if (slot == best.i && inner == 0) n.flag[slot] |= FLAG_REJ;   // LH safeguard: do not re-pick at once
+        }
+        __syncthreads();
+        border_del(n, top.i);
+      }
+      if (st->np == 0) break;
+    }
+  }
+}
+
+// xw = sum_{j in P} x_j * row_j  -> out[0..d), using S column segments of the slot range
+static __device__ void passive_combination(const NnlsArgs& n, double* out, double* part) {
+  const ApplyArgs& a = n.a;
+  const int d = a.d, p = a.st->np;
+  int S = blockDim.x / ((d + 63) / 64 * 64);
+  if (S < 1) S = 1;
+  if (S > 16) S = 16;
+  const int cols = (d + 63) / 64 * 64;
+  for (int t = threadIdx.x; t < S * cols; t += blockDim.x) {
+    const int seg = t / cols, j = t - seg * cols;
+    if (j >= d) continue;
+    double acc = 0.0;
+    for (int q = seg; q < p; q += S) {
+      const int c = n.plist[q];
+      acc += n.x[c] * a.act_rows[(size_t)c * d + j];
+    }
+    part[(size_t)seg * d + j] = acc;
+  }
+  __syncthreads();
+  for (int j = threadIdx.x; j < d; j += blockDim.x) {
+    double acc = part[j];
+    for (int s = 1; s < S; ++s) acc += part[(size_t)s * d + j];
+    out[j] = acc;
+  }
+  __syncthreads();
+}
+
+// Rebuild H = inv(G[P,P]) for P = {slots with weight > 0} by successive bordering.
+static __device__ void rebuild_passive(const NnlsArgs& n, int k, double* scratch) {
+  DevState* st = n.a.st;
+  if (threadIdx.x == 0) st->np = 0;
+  for (int j = threadIdx.x; j < k; j += blockDim.x) { n.ppos[j] = -1; n.x[j] = n.a.act_w[j] > 0.0 ? n.a.act_w[j] : 0.0; }
+  __syncthreads();
+  for (int j = 0; j < k; ++j) {
+    if (!(n.a.act_w[j] > 0.0)) continue;
+    (void)border_add(n, j, scratch);
+  }
+  if (threadIdx.x == 0) st->hvalid = 1;
+  __syncthreads();
+}
+
+// ---- OMP apply --------------------------------------------------------------------------------
+__global__ __launch_bounds__(NN_THREADS) void apply_omp_kernel(NnlsArgs n) {
+  const ApplyArgs& a = n.a;
+  DevState* st = a.st;
+  if (!st->active) return;
+  __shared__ double scratch[BCX_SCRATCH];
+  __shared__ int s_win, s_overflow, s_slot, s_npos, s_status;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = blockDim.x >> 6, d = a.d;
+  const int recw = d + BCX_REC_HDR;
+  if (tid == 0) {
+    int win = -1, ovf = 0;
+    for (int r = 0; r < a.world; ++r) {
+      const double* rec = a.recs + (size_t)r * recw;
+      if (rec[3] == BCX_REC_OVERFLOW) ovf = 1;
+      if (rec[3] != BCX_REC_VALID) continue;
+      if (win < 0) { win = r; continue; }
+      const double* best = a.recs + (size_t)win * recw;
+      if (rec[0] > best[0] || (rec[0] == best[0] && rec[1] < best[1])) win = r;
+    }
+    s_win = win; s_overflow = ovf; s_slot = 0x7fffffff; s_npos = 0; s_status = BCX_IT_OK;
+  }
+  __syncthreads();
+  if (s_overflow) { if (tid == 0) { st->active = 0; st->halt = HALT_NEED_EXACT; } return; }
+  if (s_win < 0) { if (tid == 0) { st->active = 0; st->halt = HALT_DONE; } return; }
+  const double* rec = a.recs + (size_t)s_win * recw;
+  const int k = st->k;
+  // size() and the negative direction over the active set: -An[j].residual   orthopursuit.py:27-31
+  int npos = 0;
+  for (int s = tid; s < k; s += blockDim.x) if (a.act_w[s] > 0.0) ++npos;
+  if (npos) atomicAdd(&s_npos, npos);
+  for (int j = wave; j < k; j += nw) {
+    if (!(a.act_w[j] > 0.0)) continue;
+    const double nr = a.act_norm[j];
+    double acc = 0.0;
+    for (int i = lane; i < d; i += 64) acc += (a.act_rows[(size_t)j * d + i] / nr) * a.q64[i];
+    acc = wave_allsum(acc);
+    if (lane == 0) n.t2[j] = -acc;
+  }
+  __syncthreads();
+  const bool checked = s_npos > 0;
+  int64_t f = (int64_t)rec[1];
+  const double* xf = rec + BCX_REC_HDR;
+  double nf = rec[2];
+  int slot = -1;
+  if (checked) {
+    // first max of -dots over the active indices in increasing index order == (value desc, global index asc)
+    double bv = -INFINITY; int bi = -1; int64_t bidx = 0;
+    for (int j = tid; j < k; j += blockDim.x) {
+      if (!(a.act_w[j] > 0.0)) continue;
+      const double v = n.t2[j];
+      if (bi < 0 || v > bv || (v == bv && a.act_idx[j] < bidx)) { bv = v; bi = j; bidx = a.act_idx[j]; }
+    }
+    // reduce on (value, global index): encode the tie-break by a second pass
+    const double vmax = block_allmax(bi >= 0 ? bv : -INFINITY, scratch);
+    int64_t myidx = (bi >= 0 && bv == vmax) ? bidx : (int64_t)0x7fffffffffffffffLL;
+    // min global index among the maxima
+    __shared__ unsigned long long s_minidx;
+    if (tid == 0) s_minidx = 0x7fffffffffffffffULL;
+    __syncthreads();
+    if (bi >= 0 && bv == vmax) atomicMin(&s_minidx, (unsigned long long)myidx);
+    __syncthreads();
+    const double pos = rec[0];
+    if (!(pos >= vmax)) {                                   // orthopursuit.py:32-35
+      f = (int64_t)s_minidx;
+    }
+  }
+  for (int s = tid; s < k; s += blockDim.x) if (a.act_idx[s] == f) atomicMin(&s_slot, s);
+  __syncthreads();
+  slot = s_slot == 0x7fffffff ? -1 : s_slot;
+  const bool fresh = slot < 0;
+  if (fresh) slot = k;
+  const int k1 = fresh ? k + 1 : k;
+  // backup, new slot data, Gram row
+  for (int j = tid; j < k; j += blockDim.x) n.wbak[j] = a.act_w[j];
+  if (fresh) {
+    for (int i = tid; i < d; i += blockDim.x) a.act_rows[(size_t)slot * d + i] = xf[i];
+    if (tid == 0) { a.act_idx[slot] = f; a.act_norm[slot] = nf; a.act_w[slot] = 0.0; n.ppos[slot] = -1; n.x[slot] = 0.0; }
+    __syncthreads();
+    for (int j = wave; j <= k; j += nw) {
+      double acc = 0.0;
+      for (int i = lane; i < d; i += 64) acc += a.act_rows[(size_t)slot * d + i] * a.act_rows[(size_t)j * d + i];
+      acc = wave_allsum(acc);
+      if (lane == 0) { n.gram[(size_t)slot * n.ldg + j] = acc; n.gram[(size_t)j * n.ldg + slot] = acc; }
+    }
+    if (wave == nw - 1) {
+      double acc = 0.0;
+      for (int i = lane; i < d; i += 64) acc += a.act_rows[(size_t)slot * d + i] * a.b[i];
+      acc = wave_allsum(acc);
+      if (lane == 0) n.cvec[slot] = acc;
+    }
+  }
+  __syncthreads();
+  if (!st->hvalid) rebuild_passive(n, k, scratch);
+  // problem set S = support U {f}   (w[f] = 1 then active = w > 0: orthopursuit.py:38-39)
+  for (int j = tid; j < k1; j += blockDim.x) {
+    const bool in = (j == slot) || (a.act_w[j] > 0.0);
+    n.flag[j] = in ? FLAG_INS : 0;
+    if (n.ppos[j] < 0) n.x[j] = 0.0;
+  }
+  __syncthreads();
+  const double eps = 2.220446049250313e-16;
+  const double tolscale = 10.0 * eps * (double)(d > k1 ? d : k1) * st->bnorm;
+  nnls_run(n, k1, tolscale, scratch);
+  // candidate state: xw' and its error
+  passive_combination(n, a.tmp, a.tmp + 4 * (size_t)d);
+  double v[2] = {0.0, 0.0};
+  for (int j = tid; j < d; j += blockDim.x) {
+    const double x = a.tmp[j], r = x - a.b[j];
+    v[0] += r * r; v[1] += x * x;
+  }
+  block_allsum<2>(v, scratch);
+  const double new_err = sqrt(v[0]);
+  int status = BCX_IT_OK;
+  if (checked && new_err > st->err) status = BCX_IT_FAIL_MONOTONE;      // snnls.py:58
+  if (status == BCX_IT_OK) {
+    for (int j = tid; j < k1; j += blockDim.x) a.act_w[j] = (n.ppos[j] >= 0) ? n.x[j] : 0.0;
+    for (int j = tid; j < d; j += blockDim.x) a.xw[j] = a.tmp[j];
+    if (tid == 0) {
+      st->k = k1;
+      st->err = new_err;
+      const double nwn = sqrt(v[1]);
+      st->nw = nwn == 0.0 ? 1.0 : nwn;
+      st->since_refresh = 0;
+      if (checked) st->retried = 0;
+    }
+  } else {
+    // revert: weights as before (snnls.py:60), a freshly added slot is dropped, passive data rebuilt lazily
+    for (int j = tid; j < k; j += blockDim.x) a.act_w[j] = n.wbak[j];
+    if (tid == 0) st->hvalid = 0;
+  }
+  __syncthreads();
+  if (tid == 0) {
+    const int64_t it = st->it;
+    a.tr_sel[it] = f; a.tr_err[it] = st->err; a.tr_status[it] = status;
+    st->it = it + 1;
+    st->exact_mode = 0;
+    if (status != BCX_IT_OK) {
+      if (st->retried) { st->limit = 1; st->active = 0; st->halt = HALT_LIMIT; }
+      else st->retried = 1;
+    }
+  }
+  __syncthreads();
+  if (!st->active) return;
+  prepare_next(a, scratch);
+}
+
+static void fill_nnls_args(bcx_solver* s, NnlsArgs& n, const double* recs) {
+  fill_apply_args(s, n.a, recs);
+  n.a.refresh_every = 0;   // OMP recomputes xw from the passive set on every step
+  n.gram = s->gram; n.hinv = s->hinv; n.ldg = s->gram_cap;
+  n.cvec = s->cvec; n.plist = s->plist; n.ppos = s->ppos;
+  n.x = s->nn_x; n.z = s->nn_z;
+  n.t0 = s->nn_tmp; n.t1 = s->nn_tmp + s->gram_cap; n.t2 = s->nn_tmp + 2 * s->gram_cap;
+  n.flag = s->nn_flag; n.wbak = s->nn_wbak;
+}
+
+int bcx_launch_apply_omp(bcx_solver* s, const double* recv_dev) {
+  NnlsArgs n;
+  fill_nnls_args(s, n, recv_dev);
+  hipLaunchKernelGGL(apply_omp_kernel, dim3(1), dim3(NN_THREADS), 0, s->stream, n);
+  BCX_HIP(hipGetLastError());
+  return BCX_OK;
+}
+
+// ---- optimize(): Gram matrix on the fp64 matrix cores + cold-start NNLS ---------------------------
+typedef double v4d __attribute__((ext_vector_type(4)));
+
+// G[i][j] = row_i . row_j for i, j < k.  One wave per 16 x 16 tile, K-loop in steps of 4 with
+// v_mfma_f64_16x16x4_f64: A[i][kk] = rows[I*16+i][k0+kk], B[kk][j] = rows[J*16+j][k0+kk].
+__global__ __launch_bounds__(256) void gram_mfma_kernel(const double* __restrict__ rows, int k, int d,
+                                                        double* __restrict__ G, int64_t ldg) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int I = blockIdx.x, J = blockIdx.y * 4 + wave;
+  if (J * 16 >= k) return;
+  const int ri = I * 16 + (lane & 15), rj = J * 16 + (lane & 15), kk = lane >> 4;
+  const bool vi = ri < k, vj = rj < k;
+  const double* pa = rows + (size_t)(vi ? ri : 0) * d;
+  const double* pb = rows + (size_t)(vj ? rj : 0) * d;
+  v4d acc = {0.0, 0.0, 0.0, 0.0};
+  for (int k0 = 0; k0 < d; k0 += 4) {
+    const int c = k0 + kk;
+    const double av = (vi && c < d) ? pa[c] : 0.0;
+    const double bv = (vj && c < d) ? pb[c] : 0.0;
+    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc, 0, 0, 0);
+  }
+  // f64 C/D layout: col = lane & 15, row = (lane >> 4) + 4 * reg
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int row = I * 16 + (lane >> 4) + 4 * r, col = J * 16 + (lane & 15);
+    if (row < k && col < k) G[(size_t)row * ldg + col] = acc[r];
+  }
+}
+
+__global__ __launch_bounds__(NN_THREADS) void optimize_kernel(NnlsArgs n, double tol) {
+  const ApplyArgs& a = n.a;
+  DevState* st = a.st;
+  __shared__ double scratch[BCX_SCRATCH];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = blockDim.x >> 6, d = a.d;
+  const int k = st->k;
+  refresh_state(a, scratch, k > 0);                 // prev_cost = error()   snnls.py:84
+  const double prev_cost = st->err;
+  for (int j = tid; j < k; j += blockDim.x) n.wbak[j] = a.act_w[j];
+  for (int j = tid; j < d; j += blockDim.x) a.tmp[2 * (size_t)d + j] = a.xw[j];
+  for (int j = wave; j < k; j += nw) {              // c = V b
+    double acc = 0.0;
+    for (int i = lane; i < d; i += 64) acc += a.act_rows[(size_t)j * d + i] * a.b[i];
+    acc = wave_allsum(acc);
+    if (lane == 0) n.cvec[j] = acc;
+  }
+  if (tid == 0) st->np = 0;
+  for (int j = tid; j < k; j += blockDim.x) {
+    n.ppos[j] = -1; n.x[j] = 0.0;
+    n.flag[j] = (a.act_w[j] > 0.0) ? FLAG_INS : 0;   // nz_idcs = w > 0   snnls.py:86
+  }
+  __syncthreads();
+  const double eps = 2.220446049250313e-16;
+  const double tolscale = 10.0 * eps * (double)(d > k ? d : k) * st->bnorm;
+  nnls_run(n, k, tolscale, scratch);
+  for (int j = tid; j < k; j += blockDim.x)
+    if (n.flag[j] & FLAG_INS) a.act_w[j] = (n.ppos[j] >= 0) ? n.x[j] : 0.0;
+  __syncthreads();
+  passive_combination(n, a.xw, a.tmp + 4 * (size_t)d);
+  refresh_state(a, scratch, false);
+  const double new_cost = st->err;
+  if (new_cost > prev_cost * (1.0 + tol)) {         // snnls.py:91-97
+    for (int j = tid; j < k; j += blockDim.x) a.act_w[j] = n.wbak[j];
+    for (int j = tid; j < d; j += blockDim.x) a.xw[j] = a.tmp[2 * (size_t)d + j];
+    __syncthreads();
+    refresh_state(a, scratch, false);
+    if (tid == 0) { st->limit = 1; st->hvalid = 0; }
+  } else if (tid == 0) {
+    st->hvalid = 1;
+    st->since_refresh = 0;
+  }
+}
+
+int bcx_launch_optimize(bcx_solver* s, double tol) {
+  DevState h;
+  BCX_HIP(hipStreamSynchronize(s->stream));
+  BCX_HIP(hipMemcpy(&h, s->st, sizeof h, hipMemcpyDeviceToHost));
+  const int k = h.k;
+  if (k > 0) {
+    const int tiles = (k + 15) / 16;
+    hipLaunchKernelGGL(gram_mfma_kernel, dim3(tiles, (tiles + 3) / 4), dim3(256), 0, s->stream, s->act_rows, k,
+                       s->cfg.d, s->gram, (int64_t)s->gram_cap);
+    BCX_HIP(hipGetLastError());
+  }
+  NnlsArgs n;
+  fill_nnls_args(s, n, nullptr);
+  hipLaunchKernelGGL(optimize_kernel, dim3(1), dim3(NN_THREADS), 0, s->stream, n, tol);
+  BCX_HIP(hipGetLastError());
+  return BCX_OK;
+}

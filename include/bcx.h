@@ -83,6 +83,9 @@ int bcx_load_rows(bcx_solver* s, const void* src, int32_t src_is_device, int32_t
 /* Number of row chunks on this shard and rows per chunk; chunk sums are (d+1) doubles each:
  * d column sums followed by the sum of row norms.  Device pointer for the all-gather across shards. */
 int bcx_chunk_sums(bcx_solver* s, const void** dev_ptr, int64_t* n_chunks, int64_t* chunk_rows);
+/* Copy this shard's chunk sums into a caller-owned device buffer (e.g. a torch tensor that is then
+ * all-gathered); asynchronous on the stream.  cap_chunks >= n_chunks. */
+int bcx_export_chunk_sums(bcx_solver* s, void* dst_dev, int64_t cap_chunks);
 /* Finish construction.  b_host (d doubles) overrides the column sums when non-NULL -- the reference
  * solver constructors take b from the caller (snnls.py:9; hilbert.py:24 passes vecs.sum(axis=0)).
  * gathered_sums_dev (optional): chunk sums of ALL shards in global chunk order (n_gathered chunks),
