@@ -50,7 +50,8 @@ class ShardedSolver(object):
         factory = engine_factory or nat.Engine
         if device is None:
             device = torch.cuda.current_device() if torch.cuda.is_available() else 0
-        self.engine = factory(alg, self.n_local, self.d, n_global=self.n_global, row_offset=self.row_begin,
+        self.engine = factory(alg, self.n_local, self.d, n_global=self.n_global,
+                              row_offset=self.row_begin if self.n_local > 0 else 0,
                               rank=self.rank, world_size=self.world, device=device, **engine_kw)
         self.tdev = self.engine.tensor_device() if hasattr(self.engine, "tensor_device") else torch.device("cuda", device)
         rec = self.d + nat.REC_HDR

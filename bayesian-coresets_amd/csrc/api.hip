@@ -324,13 +324,16 @@ extern "C" int bcx_build_poll(bcx_solver* s, int64_t* n_done, int32_t* need_exac
   if (need_exact) *need_exact = (h.halt == HALT_NEED_EXACT);
   if (limit) *limit = h.limit;
   if (s->profile) {
+    // launches issued after the state machine stopped (end of call, latch) return at once: keep only
+    // launches that did the scan (within 4x of the slowest one of this batch)
+    std::vector<float> ms(s->prof_used, 0.f);
+    float mx = 0.f;
     for (size_t i = 0; i < s->prof_used; ++i) {
-      float ms = 0.f;
-      if (hipEventElapsedTime(&ms, s->prof_events[i].first, s->prof_events[i].second) == hipSuccess) {
-        s->prof_ms += ms;
-        s->prof_launches++;
-      }
+      if (hipEventElapsedTime(&ms[i], s->prof_events[i].first, s->prof_events[i].second) != hipSuccess) ms[i] = 0.f;
+      mx = std::max(mx, ms[i]);
     }
+    for (size_t i = 0; i < s->prof_used; ++i)
+      if (ms[i] > 0.25f * mx) { s->prof_ms += ms[i]; s->prof_launches++; }
     s->prof_used = 0;
   }
   return BCX_OK;

@@ -1,0 +1,89 @@
+"""world_size-2 gloo test (CPU, no GPU): the row-sharded orchestration in
+bayesiancoresets_amd/sharded.py -- shard bounds on chunk boundaries, chunk-sum all-gather in global
+chunk order, one all-gather of (d+4)-double records per greedy iteration, replicated apply --
+reproduces the single-process oracle.  The GPU engine is replaced by tests/fake_engine.py."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, alg, itrs, N, d, out_dir):
+    for p in (ROOT, os.path.join(ROOT, "bayesian-coresets_amd"), os.path.join(ROOT, "tests")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from fake_engine import FakeEngine
+    from bayesiancoresets_amd.sharded import ShardedSolver
+    X = np.random.RandomState(11).randn(N, d)
+    FakeEngine.FULL = X
+    s = ShardedSolver(alg, N, d, engine_factory=FakeEngine)
+    s.load_local(X[s.row_begin:s.row_end])
+    rc = s.finalize(None)
+    assert rc == 0
+    tr = s.build(itrs)
+    idx, w = s.sparse_weights()
+    np.savez(os.path.join(out_dir, "r%d.npz" % rank), sel=tr[0], err=tr[1], idx=idx, w=w, b=s.engine.b,
+             bounds=np.array(s.bounds))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("alg,name", ((0, "giga"), (1, "fw"), (2, "omp")))
+def test_two_shards_match_single_process(tmp_path, alg, name):
+    from oracle.snnls_oracle import SnnlsOracle
+    N, d, itrs, world = 5000, 24, 15, 2
+    port = _free_port()
+    mp.spawn(_worker, args=(world, port, alg, itrs, N, d, str(tmp_path)), nprocs=world, join=True)
+    r0, r1 = np.load(tmp_path / "r0.npz"), np.load(tmp_path / "r1.npz")
+    # replicated state is identical on both ranks
+    for k in ("sel", "err", "idx", "w", "b"):
+        assert np.array_equal(r0[k], r1[k]), k
+    # shard boundaries are multiples of the 1024-row chunk and cover [0, N)
+    bounds = r0["bounds"]
+    assert bounds[0][0] == 0 and bounds[-1][1] == N and all(b[0] % 1024 == 0 for b in bounds)
+    X = np.random.RandomState(11).randn(N, d)
+    np.testing.assert_allclose(r0["b"], X.sum(axis=0), rtol=1e-12, atol=1e-12)
+    o = SnnlsOracle(X.T, r0["b"], alg=name, mode="onepass")
+    o.build(itrs)
+    assert np.array_equal(r0["sel"], np.array([t[0] for t in o.trace]))
+    ow = o.weights()
+    assert np.array_equal(np.sort(r0["idx"]), np.flatnonzero(ow != 0))
+    w = np.zeros(N)
+    w[r0["idx"]] = r0["w"]
+    np.testing.assert_allclose(w, ow, rtol=1e-12, atol=0)
+
+
+def test_shard_bounds_properties():
+    sys.path.insert(0, os.path.join(ROOT, "bayesian-coresets_amd"))
+    from bayesiancoresets_amd.sharded import shard_bounds
+    for n in (0, 1, 1023, 1024, 1025, 10_000_000, 5_000_001):
+        for world in (1, 2, 3, 4, 8):
+            bounds, per = shard_bounds(n, world)
+            assert len(bounds) == world
+            assert bounds[0][0] == 0 and bounds[-1][1] == n
+            for (lo, hi), (lo2, hi2) in zip(bounds, bounds[1:]):
+                assert hi == lo2 and lo <= hi
+            assert all(lo % 1024 == 0 for lo, hi in bounds if hi > lo)
+            # every rank but the last non-empty one holds exactly `per` chunks -> gathered chunk sums are
+            # already in global order with padding only at the end
+            sizes = [hi - lo for lo, hi in bounds]
+            nonempty = [s for s in sizes if s > 0]
+            assert all(s == per * 1024 for s in nonempty[:-1])
