@@ -59,6 +59,19 @@ class ShardedSolver(object):
         self.recv = torch.zeros(self.world * rec, dtype=torch.float64, device=self.tdev)
         self.reached_numeric_limit = False
         self.last_trace = None
+        self._flat_gather = True
+
+    def _all_gather(self, recv, send):
+        """all_gather_into_tensor (one RCCL call); backends without it (gloo on device tensors) get the
+        list form over views of the same receive buffer."""
+        if self._flat_gather:
+            try:
+                self.dist.all_gather_into_tensor(recv, send, group=self.group)
+                return
+            except (RuntimeError, NotImplementedError):
+                self._flat_gather = False
+        views = list(recv.view(self.world, -1).unbind(0))
+        self.dist.all_gather(views, send, group=self.group)
 
     # ---- construction ------------------------------------------------------
     def load_local(self, rows, local_row_begin=0):
@@ -74,7 +87,7 @@ class ShardedSolver(object):
             mine = torch.zeros(per * (self.d + 1), dtype=torch.float64, device=self.tdev)
             self.engine.export_chunk_sums_tensor(mine, per)
             allc = torch.zeros(self.world * per * (self.d + 1), dtype=torch.float64, device=self.tdev)
-            dist.all_gather_into_tensor(allc, mine, group=self.group)
+            self._all_gather(allc, mine)
             keep = allc
             gathered_ptr = allc
             n_gathered = (self.n_global + CHUNK_ROWS - 1) // CHUNK_ROWS
@@ -93,7 +106,7 @@ class ShardedSolver(object):
     def _one_iteration(self, exact=False):
         self.engine.step_scan_tensor(self.send, exact)
         if self.world > 1:
-            self.dist.all_gather_into_tensor(self.recv, self.send, group=self.group)
+            self._all_gather(self.recv, self.send)
             self.engine.step_apply_tensor(self.recv)
         else:
             self.engine.step_apply_tensor(self.send)

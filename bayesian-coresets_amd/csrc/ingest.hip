@@ -7,22 +7,23 @@
 #include "dev_util.h"
 
 // One workgroup per chunk of BCX_CHUNK_ROWS rows; one wave per row, lanes stride the columns
-// (coalesced 512-byte segments of the fp64 source).  Column sums are accumulated per wave in
-// LDS (each lane owns its columns -> no conflicts, fixed order) and combined wave 0..3.
+// (coalesced 512-byte segments of the fp64 source), up to 16 waves per workgroup.  Column sums are
+// accumulated per wave in LDS (each lane owns its columns -> no conflicts, fixed order) and
+// combined wave 0..nw-1; nw depends only on d, so the summation tree is reproducible.
 template <typename TS, typename TD>
-__global__ __launch_bounds__(256) void ingest_kernel(const TS* src, int64_t ld_src, int64_t row_begin,
-                                                     int64_t rows, int d, TD* __restrict__ An, int ld, int ld64,
-                                                     double* A64, double* __restrict__ norms,
-                                                     double* __restrict__ chunk_sums, DevState* st) {
-  extern __shared__ double lds[];  // 4 * d column accumulators + 4 norm accumulators
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+__global__ __launch_bounds__(1024) void ingest_kernel(const TS* src, int64_t ld_src, int64_t row_begin,
+                                                      int64_t rows, int d, TD* __restrict__ An, int ld, int ld64,
+                                                      double* A64, double* __restrict__ norms,
+                                                      double* __restrict__ chunk_sums, DevState* st) {
+  extern __shared__ double lds[];  // nw * d column accumulators + nw norm accumulators
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
   double* colacc = lds + (size_t)wave * d;
   for (int c = lane; c < d; c += 64) colacc[c] = 0.0;
   double normacc = 0.0;
   const int64_t chunk = blockIdx.x;
   const int64_t r0 = chunk * BCX_CHUNK_ROWS;
   const int64_t r1 = (r0 + BCX_CHUNK_ROWS < rows) ? r0 + BCX_CHUNK_ROWS : rows;
-  for (int64_t r = r0 + wave; r < r1; r += 4) {
+  for (int64_t r = r0 + wave; r < r1; r += nw) {
     const TS* x = src + r * ld_src;
     double ss = 0.0;
     for (int c = lane; c < d; c += 64) {
@@ -48,33 +49,49 @@ __global__ __launch_bounds__(256) void ingest_kernel(const TS* src, int64_t ld_s
     normacc += nrm;
     TD* y = An + lr * (int64_t)ld;
     double* raw = A64 ? A64 + lr * (int64_t)ld64 : nullptr;
+    const bool copy_raw = raw && (const void*)raw != (const void*)x;
     for (int c = lane; c < d; c += 64) {
       double v = (double)x[c];  // second touch hits L1/L2
       colacc[c] += v;
       y[c] = (TD)(v / nrm);
-      if (raw && (const void*)raw != (const void*)x) raw[c] = v;
+      if (copy_raw) raw[c] = v;
     }
   }
   __syncthreads();
   const int64_t gchunk = row_begin / BCX_CHUNK_ROWS + chunk;
   double* out = chunk_sums + gchunk * (int64_t)(d + 1);
-  for (int c = threadIdx.x; c < d; c += blockDim.x)
-    out[c] = ((lds[c] + lds[d + c]) + lds[2 * (size_t)d + c]) + lds[3 * (size_t)d + c];
-  double* nacc = lds + 4 * (size_t)d;
+  for (int c = threadIdx.x; c < d; c += blockDim.x) {
+    double acc = lds[c];
+    for (int w = 1; w < nw; ++w) acc += lds[(size_t)w * d + c];
+    out[c] = acc;
+  }
+  double* nacc = lds + (size_t)nw * d;
   __syncthreads();
   if (lane == 0) nacc[wave] = normacc;
   __syncthreads();
-  if (threadIdx.x == 0) out[d] = ((nacc[0] + nacc[1]) + nacc[2]) + nacc[3];
+  if (threadIdx.x == 0) {
+    double acc = nacc[0];
+    for (int w = 1; w < nw; ++w) acc += nacc[w];
+    out[d] = acc;
+  }
 }
 
 int bcx_launch_ingest(bcx_solver* s, const void* src, int src_dtype, int64_t ld_src, int64_t row_begin, int64_t rows) {
   const int d = s->cfg.d;
   const int64_t nblk = (rows + BCX_CHUNK_ROWS - 1) / BCX_CHUNK_ROWS;
-  const size_t shmem = (4 * (size_t)d + 4) * sizeof(double);
-  dim3 grid((unsigned)nblk), block(256);
+  int nw = (int)((144 * 1024) / ((size_t)d * 8));   // column accumulators must fit the 160 KiB LDS
+  if (nw > 16) nw = 16;
+  if (nw < 1) nw = 1;
+  const size_t shmem = ((size_t)nw * d + nw) * sizeof(double);
+  dim3 grid((unsigned)nblk), block(64 * nw);
 #define LAUNCH(TS, TD)                                                                                        \
-  hipLaunchKernelGGL((ingest_kernel<TS, TD>), grid, block, shmem, s->stream, (const TS*)src, ld_src, row_begin, \
-                     rows, d, (TD*)s->An, s->ld, s->ld64, s->A64, s->norms, s->chunk_sums, s->st)
+  do {                                                                                                        \
+    auto kfn = ingest_kernel<TS, TD>;                                                                         \
+    if (shmem > 48 * 1024)                                                                                    \
+      BCX_HIP(hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));  \
+    hipLaunchKernelGGL(kfn, grid, block, shmem, s->stream, (const TS*)src, ld_src, row_begin, rows, d,        \
+                       (TD*)s->An, s->ld, s->ld64, s->A64, s->norms, s->chunk_sums, s->st);                   \
+  } while (0)
   if (src_dtype == BCX_F64) {
     if (s->cfg.store_dtype == BCX_F32) LAUNCH(double, float); else LAUNCH(double, double);
   } else {

@@ -112,16 +112,23 @@ def main():
                            keep_exact_rows=not args.no_exact_rows)
     # ---- synthetic data, generated shard-locally, resident before timing ------------------
     lo, hi = solver.row_begin, solver.row_end
+    SUPER = 32 * GEN_BLOCK   # rows handed to the engine per ingest call (1 GiB of fp64 at d=512)
+    buf = torch.empty(SUPER, args.dim, dtype=torch.float64, device="cuda")
     r = lo
     while r < hi:
-        blk = r // GEN_BLOCK
-        b0 = blk * GEN_BLOCK
-        m = min(GEN_BLOCK, args.rows - b0)
-        x = gen_block(torch, args.seed, blk, m, args.dim, "cuda")
-        a, b = max(lo, b0), min(hi, b0 + m)
-        solver.load_local(x[a - b0:b - b0], a - lo)
-        r = b
+        s0 = (r // GEN_BLOCK) * GEN_BLOCK                 # first generation block touching row r
+        s1 = min(((hi + GEN_BLOCK - 1) // GEN_BLOCK) * GEN_BLOCK, s0 + SUPER, 
+                 ((args.rows + GEN_BLOCK - 1) // GEN_BLOCK) * GEN_BLOCK)
+        for b0 in range(s0, s1, GEN_BLOCK):
+            m = min(GEN_BLOCK, args.rows - b0)
+            g = torch.Generator(device="cuda")
+            g.manual_seed(args.seed * 1_000_003 + b0 // GEN_BLOCK)
+            torch.randn(m, args.dim, dtype=torch.float64, device="cuda", generator=g, out=buf[b0 - s0:b0 - s0 + m])
+        a, b = max(lo, s0), min(hi, s1, args.rows)
+        solver.load_local(buf[a - s0:b - s0], a - lo)
         torch.cuda.synchronize()
+        r = b
+    del buf
     rc = solver.finalize(None)
     if rc != nat.OK:
         raise SystemExit("finalize failed: %d" % rc)

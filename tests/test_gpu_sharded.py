@@ -1,0 +1,74 @@
+"""GPU: the row-sharded driver with the REAL engine, two ranks sharing cuda:0 over gloo (RCCL
+refuses two ranks on one device; the transport is the only thing substituted).  World size 2 must
+reproduce world size 1 bit-for-bit: same b (chunk sums in global order), same selections, same
+weights (SURVEY.md section 8e determinism requirement)."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _data(N, d):
+    return np.random.RandomState(21).randn(N, d)
+
+
+def _worker(rank, world, port, alg, itrs, N, d, out_dir):
+    for p in (ROOT, os.path.join(ROOT, "bayesian-coresets_amd")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    import torch
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from bayesiancoresets_amd.sharded import ShardedSolver
+    X = _data(N, d)
+    s = ShardedSolver(alg, N, d, device=0)
+    s.load_local(torch.from_numpy(X[s.row_begin:s.row_end]).cuda())
+    torch.cuda.synchronize()
+    assert s.finalize(None) == 0
+    tr = s.build(itrs)
+    idx, w = s.sparse_weights()
+    b = s.engine.vector(0)
+    np.savez(os.path.join(out_dir, "w%d_r%d.npz" % (world, rank)), sel=tr[0], err=tr[1], status=tr[2], idx=idx, w=w, b=b)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("alg,name", ((0, "giga"), (1, "fw"), (2, "omp")))
+def test_two_shards_on_one_gpu_match_one_shard(tmp_path, alg, name):
+    import torch.multiprocessing as mp
+    from oracle.snnls_oracle import SnnlsOracle
+    N, d, itrs = 9000, 40, 30
+    for world in (1, 2, 3):
+        mp.spawn(_worker, args=(world, _free_port(), alg, itrs, N, d, str(tmp_path)), nprocs=world, join=True)
+    ref = np.load(tmp_path / "w1_r0.npz")
+    for world in (2, 3):
+        for rank in range(world):
+            r = np.load(tmp_path / ("w%d_r%d.npz" % (world, rank)))
+            for k in ("sel", "err", "status", "idx", "w", "b"):
+                assert np.array_equal(ref[k], r[k]), (world, rank, k)
+    # and the whole thing matches the CPU oracle
+    X = _data(N, d)
+    o = SnnlsOracle(X.T, X.sum(axis=0), alg=name)
+    o.build(itrs)
+    assert np.array_equal(ref["sel"], np.array([t[0] for t in o.trace]))
+    w = np.zeros(N)
+    w[ref["idx"]] = ref["w"]
+    ow = o.weights()
+    assert np.array_equal(np.flatnonzero(w > 0), np.flatnonzero(ow > 0))
+    np.testing.assert_allclose(w[w > 0], ow[ow > 0], rtol=1e-5)
