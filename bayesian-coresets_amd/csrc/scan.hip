@@ -19,8 +19,16 @@
 // resolve.hip re-scores in fp64 every row whose U reaches the global max L; if a workgroup's
 // U3 reaches it too the iteration is redone with the exact kernel.  With fp64 storage U = L =
 // score and the result is the arg-max itself.
+#include <stdlib.h>
 #include "bcx_internal.h"
 #include "dev_util.h"
+
+#ifndef BCX_LOADS_IN_FLIGHT
+#define BCX_LOADS_IN_FLIGHT 8   // independent 16-byte loads per lane per trip
+#endif
+#ifndef BCX_UR_MAX
+#define BCX_UR_MAX 4
+#endif
 
 template <typename T> struct VecOf;
 template <> struct VecOf<float> { typedef float4 type; static constexpr int EPL = 4; };
@@ -37,10 +45,54 @@ __device__ __forceinline__ double vdot(const double2& a, const double2& b, doubl
 __device__ __forceinline__ float4 vzero(float4*) { return make_float4(0.f, 0.f, 0.f, 0.f); }
 __device__ __forceinline__ double2 vzero(double2*) { return make_double2(0.0, 0.0); }
 
-template <typename T, int G> __device__ __forceinline__ T group_allsum(T v) {
-#pragma unroll
-  for (int off = G / 2; off >= 1; off >>= 1) v += __shfl_xor(v, off, BCX_WAVE);
+// ---- cross-lane sums without LDS traffic (gfx950: DPP inside a row of 16 lanes, v_permlane16_swap /
+// v_permlane32_swap across rows).  Lane mappings verified with tools/probe/lane_probe.hip.
+typedef unsigned v2u __attribute__((ext_vector_type(2)));
+template <int CTRL> __device__ __forceinline__ float dpp_mov(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, false));
+}
+// lanes 0-31 <- a[l] + a[l+32], lanes 32-63 <- b[l-32] + b[l]
+__device__ __forceinline__ float swap32_add(float a, float b) {
+  const v2u r = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, a), __builtin_bit_cast(unsigned, b), false, false);
+  const unsigned x = r.x, y = r.y;   // (indexing r[0]/r[1] through a bit_cast is miscompiled by ROCm 7.2: both read element 0)
+  return __uint_as_float(x) + __uint_as_float(y);
+}
+// rows of 16 lanes: (a.r0+a.r1, b.r0+b.r1, a.r2+a.r3, b.r2+b.r3)
+__device__ __forceinline__ float swap16_add(float a, float b) {
+  const v2u r = __builtin_amdgcn_permlane16_swap(__builtin_bit_cast(unsigned, a), __builtin_bit_cast(unsigned, b), false, false);
+  const unsigned x = r.x, y = r.y;   // (indexing r[0]/r[1] through a bit_cast is miscompiled by ROCm 7.2: both read element 0)
+  return __uint_as_float(x) + __uint_as_float(y);
+}
+template <int G> __device__ __forceinline__ float group_allsum_f32(float v) {
+  if (G >= 2) v += dpp_mov<0xB1>(v);    // quad_perm [1,0,3,2]
+  if (G >= 4) v += dpp_mov<0x4E>(v);    // quad_perm [2,3,0,1]
+  if (G >= 8) v += dpp_mov<0x141>(v);   // row_half_mirror
+  if (G >= 16) v += dpp_mov<0x140>(v);  // row_mirror
+  if (G >= 32) v = swap16_add(v, v);
+  if (G >= 64) v = swap32_add(v, v);
   return v;
+}
+// Four wave-wide partial sums -> one register: the 16-lane row r of the result holds, in every lane,
+// the total of input {0, 2, 1, 3}[r].  10 VALU instructions for four 64-lane reductions.
+__device__ __forceinline__ float reduce4_rows(float p0, float p1, float p2, float p3) {
+  const float m01 = swap32_add(p0, p1);
+  const float m23 = swap32_add(p2, p3);
+  float m = swap16_add(m01, m23);
+  m += dpp_mov<0xB1>(m);
+  m += dpp_mov<0x4E>(m);
+  m += dpp_mov<0x141>(m);
+  m += dpp_mov<0x140>(m);
+  return m;
+}
+
+template <typename T, int G> __device__ __forceinline__ T group_allsum(T v) {
+  if constexpr (sizeof(T) == 4) {
+    return group_allsum_f32<G>(v);
+  } else {
+#pragma unroll
+    for (int off = G / 2; off >= 1; off >>= 1) v += __shfl_xor(v, off, BCX_WAVE);
+    return v;
+  }
 }
 
 struct ScanArgs {
@@ -94,17 +146,19 @@ template <typename T> __device__ __forceinline__ Track<T> shfl_track(const Track
 __device__ __forceinline__ void giga_interval(float s0, float s1, float e, float& U, float& L) {
   const float a = fabsf(s1);
   const float ahi = a + e;
-  if (!(ahi < 1.0f)) { U = INFINITY; L = -INFINITY; return; }
+  const bool sure = ahi < 1.0f;          // false also for NaN
+  const float ah = sure ? ahi : 0.5f;    // keep the arithmetic finite on the masked branch
   const float alo = fmaxf(a - e, 0.0f);
   // 1 - x^2 as (1-x)(1+x): the subtraction is exact for x >= 0.5
-  const float dmin = __builtin_amdgcn_sqrtf((1.0f - ahi) * (1.0f + ahi));  // smallest possible denominator
-  const float dmax = __builtin_amdgcn_sqrtf((1.0f - alo) * (1.0f + alo));
+  const float rmin = __builtin_amdgcn_rsqf((1.0f - ah) * (1.0f + ah));   // 1 / smallest possible denominator
+  const float rmax = __builtin_amdgcn_rsqf((1.0f - alo) * (1.0f + alo)); // 1 / largest possible denominator
   const float hi = s0 + e, lo = s0 - e;
-  const float rmin = __builtin_amdgcn_rcpf(dmin), rmax = __builtin_amdgcn_rcpf(dmax);
-  U = hi > 0.0f ? hi * rmin : hi * rmax;
-  L = lo > 0.0f ? lo * rmax : lo * rmin;
-  U += fabsf(U) * 4e-6f + 1e-37f;  // slack for the approximate sqrt/rcp and the rounding of this arithmetic
-  L -= fabsf(L) * 4e-6f + 1e-37f;
+  float u = hi > 0.0f ? hi * rmin : hi * rmax;
+  float l = lo > 0.0f ? lo * rmax : lo * rmin;
+  u += fabsf(u) * 4e-6f + 1e-37f;  // slack for the approximate rsq and the rounding of this arithmetic
+  l -= fabsf(l) * 4e-6f + 1e-37f;
+  U = sure ? u : INFINITY;
+  L = sure ? l : -INFINITY;
 }
 // Exact-mode score, same masking as giga.py:33-38.
 __device__ __forceinline__ double giga_score(double s0, double s1) {
@@ -113,16 +167,29 @@ __device__ __forceinline__ double giga_score(double s0, double s1) {
   return s0 / den;
 }
 
+// rows arrive in increasing order within a lane, so strict '>' keeps the lowest index on ties
+template <typename T> __device__ __forceinline__ void track_update(Track<T>& tr, T U, T L, int ri) {
+  const bool g1 = U > tr.U1, g2 = U > tr.U2, g3 = U > tr.U3;
+  tr.U3 = g2 ? tr.U2 : (g3 ? U : tr.U3);
+  tr.i2 = g1 ? tr.i1 : (g2 ? ri : tr.i2);
+  tr.U2 = g1 ? tr.U1 : (g2 ? U : tr.U2);
+  tr.i1 = g1 ? ri : tr.i1;
+  tr.U1 = g1 ? U : tr.U1;
+  tr.L = L > tr.L ? L : tr.L;
+}
+
 template <typename T, bool DUAL, int G, int CH>
 __global__ __launch_bounds__(BCX_SCAN_THREADS) void scan_kernel(ScanArgs a) {
   if (!a.st->active) return;
   typedef typename VecOf<T>::type V;
   constexpr int RPW = 64 / G;                       // rows per wave per step
-  constexpr int UR = (CH >= 8) ? 1 : (8 / CH > 4 ? 4 : 8 / CH);  // row steps in flight
+  constexpr int UR = (CH >= BCX_LOADS_IN_FLIGHT) ? 1 : (BCX_LOADS_IN_FLIGHT / CH > BCX_UR_MAX ? BCX_UR_MAX : BCX_LOADS_IN_FLIGHT / CH);  // row steps in flight
   constexpr int WAVES = BCX_SCAN_THREADS / 64;
   constexpr int RPB = WAVES * RPW * UR;             // rows per workgroup per trip
+  constexpr bool PACK4 = (sizeof(T) == 4) && G == 64 && UR == 4;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int sub = lane % G, rsub = lane / G;
+  const int myu = ((lane >> 4) & 1) * 2 + (lane >> 5);   // PACK4: which of the 4 rows this 16-lane row tracks
 
   // query pieces for this lane's columns -> registers
   V q0[CH], q1[CH];
@@ -154,46 +221,67 @@ __global__ __launch_bounds__(BCX_SCAN_THREADS) void scan_kernel(ScanArgs a) {
 #pragma unroll
       for (int c = 0; c < CH; ++c) x[u][c] = p[voff[c]];
     }
+    // keep all CH*UR loads of the trip in flight: without this fence hipcc interleaves load/wait/FMA
+    // through one register quad to save VGPRs, which serialises the HBM round trips of a wave
+    __builtin_amdgcn_sched_barrier(0);
+    if constexpr (PACK4) {
+      // four rows per trip: transposed reduction, then every 16-lane row of the wave tracks one row
+      float a0[4], a1[4];
 #pragma unroll
-    for (int u = 0; u < UR; ++u) {
-      T s0 = 0, s1 = 0;
+      for (int u = 0; u < 4; ++u) {
+        float t0 = 0.f, t1 = 0.f;
 #pragma unroll
-      for (int c = 0; c < CH; ++c) {
-        s0 = vdot(x[u][c], q0[c], s0);
-        if (DUAL) s1 = vdot(x[u][c], q1[c], s1);
-      }
-      s0 = group_allsum<T, G>(s0);
-      if (DUAL) s1 = group_allsum<T, G>(s1);
-      if (sizeof(T) == 8 && a.norms) {
-        const T nr = (T)a.norms[row[u] < n ? row[u] : n - 1];
-        s0 /= nr;
-        if (DUAL) s1 /= nr;
-      }
-      T U, L;
-      if (sizeof(T) == 4) {
-        if (DUAL) {
-          float Uf, Lf;
-          giga_interval((float)s0, (float)s1, (float)e, Uf, Lf);
-          U = Uf; L = Lf;
-        } else {
-          const T ee = e + fabsf((float)s0) * 2e-7f;
-          U = s0 + ee; L = s0 - ee;
+        for (int c = 0; c < CH; ++c) {
+          t0 = vdot(x[u][c], q0[c], t0);
+          if (DUAL) t1 = vdot(x[u][c], q1[c], t1);
         }
-      } else {
-        U = L = DUAL ? (T)giga_score((double)s0, (double)s1) : s0;
+        a0[u] = t0; a1[u] = t1;
       }
-      if (!(row[u] < n)) { U = -INFINITY; L = -INFINITY; }
-      const int ri = (int)row[u];
-      // rows arrive in increasing order within a lane, so strict '>' keeps the lowest index on ties
-      if (U > tr.U1) { tr.U3 = tr.U2; tr.U2 = tr.U1; tr.i2 = tr.i1; tr.U1 = U; tr.i1 = ri; }
-      else if (U > tr.U2) { tr.U3 = tr.U2; tr.U2 = U; tr.i2 = ri; }
-      else if (U > tr.U3) { tr.U3 = U; }
-      tr.L = L > tr.L ? L : tr.L;
+      const float s0 = reduce4_rows(a0[0], a0[1], a0[2], a0[3]);
+      const float s1 = DUAL ? reduce4_rows(a1[0], a1[1], a1[2], a1[3]) : 0.f;
+      const int64_t myrow = r0 + (int64_t)(myu * WAVES + wave);
+      float U, L;
+      if (DUAL) giga_interval(s0, s1, (float)e, U, L);
+      else { const float ee = (float)e + fabsf(s0) * 2e-7f; U = s0 + ee; L = s0 - ee; }
+      if (!(myrow < n)) { U = -INFINITY; L = -INFINITY; }
+      track_update<T>(tr, (T)U, (T)L, (int)myrow);
+    } else {
+#pragma unroll
+      for (int u = 0; u < UR; ++u) {
+        T s0 = 0, s1 = 0;
+#pragma unroll
+        for (int c = 0; c < CH; ++c) {
+          s0 = vdot(x[u][c], q0[c], s0);
+          if (DUAL) s1 = vdot(x[u][c], q1[c], s1);
+        }
+        s0 = group_allsum<T, G>(s0);
+        if (DUAL) s1 = group_allsum<T, G>(s1);
+        if (sizeof(T) == 8 && a.norms) {
+          const T nr = (T)a.norms[row[u] < n ? row[u] : n - 1];
+          s0 /= nr;
+          if (DUAL) s1 /= nr;
+        }
+        T U, L;
+        if (sizeof(T) == 4) {
+          if (DUAL) {
+            float Uf, Lf;
+            giga_interval((float)s0, (float)s1, (float)e, Uf, Lf);
+            U = Uf; L = Lf;
+          } else {
+            const T ee = e + fabsf((float)s0) * 2e-7f;
+            U = s0 + ee; L = s0 - ee;
+          }
+        } else {
+          U = L = DUAL ? (T)giga_score((double)s0, (double)s1) : s0;
+        }
+        if (!(row[u] < n)) { U = -INFINITY; L = -INFINITY; }
+        track_update<T>(tr, U, L, (int)row[u]);
+      }
     }
   }
   // combine the row groups of a wave (lanes with equal `sub` hold distinct row groups)
 #pragma unroll
-  for (int off = G; off < 64; off <<= 1) tr = merge<T>(tr, shfl_track<T>(tr, off));
+  for (int off = PACK4 ? 16 : G; off < 64; off <<= 1) tr = merge<T>(tr, shfl_track<T>(tr, off));
   __shared__ Track<T> wtr[WAVES];
   if (lane == 0) wtr[wave] = tr;
   __syncthreads();
@@ -220,7 +308,9 @@ int bcx_scan_grid(const bcx_solver* s) {
   const int64_t n = s->cfg.n_local;
   int64_t want = (n + 15) / 16;
   if (want < 1) want = 1;
-  if (want > 2048) want = 2048;
+  int64_t cap = 2048;
+  if (const char* e = getenv("BCX_SCAN_GRID")) { const long v = atol(e); if (v > 0) cap = v; }
+  if (want > cap) want = cap;
   return (int)want;
 }
 

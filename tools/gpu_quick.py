@@ -27,6 +27,12 @@ def run(alg, N, d, store=nat.F32, keep=False, iters=50):
           % (alg, N, d, store, keep, ms, by / ms / 1e6, by / ms / 1e6 / 80.0, iters, (t1 - t0) * 1e3, (t1 - t0) * 1e3 / iters, ne, done, err[-1] if len(err) else -1, int((st != 0).sum())), flush=True)
     eng.close()
 
+if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "sweep":
+    run(nat.ALG_GIGA, 1000000, 256, iters=20)
+    run(nat.ALG_FW, 1250000, 512, iters=20)
+    run(nat.ALG_FW, 4000000, 512, iters=20)
+    sys.exit(0)
+
 if __name__ == "__main__":
     print(torch.cuda.get_device_name(0))
     run(nat.ALG_FW, 1000000, 256)
