@@ -49,7 +49,7 @@ extern "C" int bcx_create(const bcx_config* cfg, bcx_solver** out) {
   }
   bcx_solver* s = new bcx_solver();
   s->cfg = *cfg;
-  if (s->cfg.refresh_every == 0) s->cfg.refresh_every = 16;
+  if (s->cfg.refresh_every == 0) s->cfg.refresh_every = 64;
   hipError_t e = hipSetDevice(cfg->device);
   if (e != hipSuccess) { g_create_err = std::string("hipSetDevice: ") + hipGetErrorString(e); delete s; return BCX_ERR_HIP; }
   const int d = cfg->d;

@@ -78,11 +78,17 @@ static __device__ void refresh_state(const ApplyArgs& a, double* scratch, bool r
   for (int j = threadIdx.x; j < d; j += blockDim.x) {
     double x;
     if (recompute_xw) {
+      // fixed slot order; 8 independent loads per step so the L2 latencies overlap
       x = 0.0;
-      for (int s = 0; s < k; ++s) {
-        const double w = a.act_w[s];
-        if (w != 0.0) x += w * a.act_rows[(size_t)s * d + j];
+      int s = 0;
+      for (; s + 8 <= k; s += 8) {
+        double r[8], w[8];
+#pragma unroll
+        for (int t = 0; t < 8; ++t) { w[t] = a.act_w[s + t]; r[t] = a.act_rows[(size_t)(s + t) * d + j]; }
+#pragma unroll
+        for (int t = 0; t < 8; ++t) x += w[t] * r[t];
       }
+      for (; s < k; ++s) x += a.act_w[s] * a.act_rows[(size_t)s * d + j];
       a.xw[j] = x;
     } else {
       x = a.xw[j];

@@ -57,7 +57,7 @@ typedef struct bcx_config {
   int32_t d;               /* projection dimension (columns of the N x d vector matrix)           */
   int32_t world_size;      /* number of row shards (1 = single GPU)                               */
   int32_t rank;            /* this shard                                                          */
-  int32_t refresh_every;   /* recompute xw = sum_j w_j A[:,j] from the active rows every this many accepted steps (0 = default 16) */
+  int32_t refresh_every;   /* recompute xw = sum_j w_j A[:,j] from the active rows every this many accepted steps (0 = default 64) */
   int64_t n_local;         /* rows held by this shard                                             */
   int64_t n_global;        /* rows over all shards                                                */
   int64_t row_offset;      /* global index of local row 0 (contiguous row blocks, lowest index wins ties) */

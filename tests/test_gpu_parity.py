@@ -203,3 +203,83 @@ def test_hilbert_coreset_api(bc, golden, normal_inputs):
     assert alg.size() == 0 and alg.snnls.size() == 0
     with pytest.raises(TypeError):
         bc.HilbertCoreset(X, IDProjector(), snnls=bc.snnls.GIGA, bogus=1)
+
+
+# ---- numeric-limit regime and the config-1 harness (F3) -------------------------------
+def test_F4_giga_latch(bc, golden, normal_inputs):
+    """GIGA driven to the numeric limit: same 429 selections, then select fails twice in a row
+    (cdirnrm < TOL, giga.py:28) and the solver latches (snnls.py:63-72) at the same place."""
+    X = normal_inputs(1, 10000, 100, "F2_input_sha256")
+    s = _run(bc, X, "giga", int(golden["F4_giga_itrs"]))
+    sel, err, status = s.last_trace
+    assert np.array_equal(sel[sel >= 0], golden["F4_giga_sel"])
+    assert len(sel) == len(golden["F4_giga_sel"]) + 2 and list(status[-2:]) == [1, 1] and list(sel[-2:]) == [-1, -1]
+    assert s.reached_numeric_limit is True and bool(golden["F4_giga_limit"])
+    assert s.size() == int(golden["F4_giga_size"])
+    np.testing.assert_allclose(s.error(), float(golden["F4_giga_final_err"]), rtol=1e-3)
+    w = s.weights()
+    assert np.array_equal(np.flatnonzero(w > 0), golden["F4_giga_idx"])
+    gw = golden["F4_giga_w"]   # at the numeric limit weights ~1e-10 of the largest carry only rounding noise
+    np.testing.assert_allclose(w[w > 0], gw, rtol=WEIGHT_RTOL, atol=WEIGHT_ATOL_REL * gw.max())
+    # latched: further build() calls return immediately (snnls.py:32-34)
+    s.build(10)
+    assert s.size() == int(golden["F4_giga_size"])
+
+
+def test_F4_fw_400(bc, golden, normal_inputs):
+    X = normal_inputs(1, 10000, 100, "F2_input_sha256")
+    s = _run(bc, X, "fw", 400)
+    sel, err, status = s.last_trace
+    assert np.array_equal(sel, golden["F4_fw_sel"])
+    assert s.size() == int(golden["F4_fw_size"]) and not s.reached_numeric_limit
+    np.testing.assert_allclose(s.error(), float(golden["F4_fw_final_err"]), rtol=1e-4)
+    np.testing.assert_allclose(err, golden["F4_fw_err"], rtol=1e-4)
+
+
+def test_F4_omp_past_k_equals_d(bc, golden, normal_inputs):
+    """OMP for 140 iterations at d = 100: the active set saturates at d points, no latch, no exception;
+    once k = d the scores are rounding noise, so selections are compared only while k < d."""
+    X = normal_inputs(1, 10000, 100, "F2_input_sha256")
+    s = _run(bc, X, "omp", 140)
+    sel = s.last_trace[0]
+    assert np.array_equal(sel[:100], golden["F4_omp_sel"][:100])
+    assert s.size() == 100 and not s.reached_numeric_limit
+    assert s.error() < 1e-10
+
+
+@pytest.mark.parametrize("alg", ("giga", "fw", "omp"))
+def test_F3_harness_trial1(bc, golden, normal_inputs, alg):
+    """examples/synthetic_vectors/main.py:82-99 with the Ms schedule: incremental build, get(), error()."""
+    X = normal_inputs(1, 10000, 100, "F3_t1_input_sha256")
+
+    class IDProjector(bc.Projector):
+        def update(self, wts, pts):
+            pass
+
+        def project(self, pts, grad=False):
+            return pts
+
+    Ms = golden["F3_Ms"]
+    a = bc.HilbertCoreset(X, IDProjector(), snnls=_solver(bc, alg))
+    csize, err = [], []
+    for m in range(len(Ms)):
+        a.build(int(Ms[m] if m == 0 else Ms[m] - Ms[m - 1]))
+        wts, pts, idcs = a.get()
+        csize.append((wts > 0).sum())
+        err.append(a.error())
+    csize, err = np.array(csize, dtype=float), np.array(err)
+    k = "F3_t1_%s_" % alg
+    gc, ge = golden[k + "csize"], golden[k + "err"]
+    # away from the numeric limit everything matches; near it (error ~1e-9 of ||b||) FW's accept/reject
+    # tests become rounding-dependent, so FW is compared up to M = 429 and OMP errors while k < d
+    upto = {"giga": len(Ms), "fw": int(np.searchsorted(Ms, 429)) + 1, "omp": len(Ms)}[alg]
+    assert np.array_equal(csize[:upto], gc[:upto])
+    sane = ge[:upto] > 1e-6
+    np.testing.assert_allclose(err[:upto][sane], ge[:upto][sane], rtol=1e-6)
+    if alg != "fw":
+        assert a.snnls.reached_numeric_limit == bool(golden[k + "limit"])
+    if alg == "giga":
+        wts, pts, idcs = a.get()
+        assert np.array_equal(idcs, golden[k + "idcs"])
+        np.testing.assert_allclose(wts, golden[k + "wts"], rtol=WEIGHT_RTOL,
+                                   atol=WEIGHT_ATOL_REL * golden[k + "wts"].max())
