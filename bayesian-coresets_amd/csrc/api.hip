@@ -40,7 +40,7 @@ extern "C" int bcx_create(const bcx_config* cfg, bcx_solver** out) {
     g_create_err = "bcx_create: invalid configuration";
     return BCX_ERR_ARG;
   }
-  const int maxd = cfg->store_dtype == BCX_F32 ? BCX_MAX_D : BCX_MAX_D / 2;
+  const int maxd = BCX_MAX_D;
   if (cfg->d > maxd) { g_create_err = "bcx_create: d exceeds the supported row length"; return BCX_ERR_ARG; }
   if (cfg->n_local >= (int64_t)0x7fffffff) { g_create_err = "bcx_create: n_local must be < 2^31 per shard"; return BCX_ERR_ARG; }
   if (cfg->row_offset % BCX_CHUNK_ROWS != 0) {
@@ -72,7 +72,7 @@ extern "C" int bcx_create(const bcx_config* cfg, bcx_solver** out) {
   chk(dev_alloc((char**)&s->qst, (size_t)2 * s->ld * s->elem));
   chk(dev_alloc(&s->tmp, (size_t)20 * d));
   s->n_partials = bcx_scan_grid(s);
-  chk(dev_alloc(&s->partials, (size_t)s->n_partials));
+  chk(dev_alloc((char**)&s->partials, (size_t)s->n_partials * BCX_PARTIAL_BYTES));
   chk(dev_alloc(&s->rec_local, (size_t)(d + BCX_REC_HDR)));
   if (!ok) { free_all(s); delete s; return BCX_ERR_NOMEM; }
   *out = s;
@@ -283,7 +283,7 @@ static int prof_end(bcx_solver* s) {
   return BCX_OK;
 }
 
-static int step_scan(bcx_solver* s, void* send_dev, int exact) {
+static int step_scan(bcx_solver* s, void* send_dev, int exact, bool with_tail) {
   if (!s->finalized) { s->err = "solver not finalized"; return BCX_ERR_STATE; }
   double* send = send_dev ? (double*)send_dev : s->rec_local;
   int rc;
@@ -291,11 +291,12 @@ static int step_scan(bcx_solver* s, void* send_dev, int exact) {
   if ((rc = prof_begin(s))) return rc;
   if ((rc = bcx_launch_scan(s, exact))) return rc;
   if ((rc = prof_end(s))) return rc;
+  if (with_tail) return bcx_launch_tail(s, exact);   // resolve + apply in one launch (single shard, GIGA/FW)
   return bcx_launch_resolve(s, send, exact);
 }
 
-extern "C" int bcx_step_scan(bcx_solver* s, void* send_dev) { return s ? step_scan(s, send_dev, 0) : BCX_ERR_ARG; }
-extern "C" int bcx_step_scan_exact(bcx_solver* s, void* send_dev) { return s ? step_scan(s, send_dev, 1) : BCX_ERR_ARG; }
+extern "C" int bcx_step_scan(bcx_solver* s, void* send_dev) { return s ? step_scan(s, send_dev, 0, false) : BCX_ERR_ARG; }
+extern "C" int bcx_step_scan_exact(bcx_solver* s, void* send_dev) { return s ? step_scan(s, send_dev, 1, false) : BCX_ERR_ARG; }
 
 extern "C" int bcx_step_apply(bcx_solver* s, const void* recv_dev) {
   if (!s) return BCX_ERR_ARG;
@@ -305,12 +306,11 @@ extern "C" int bcx_step_apply(bcx_solver* s, const void* recv_dev) {
 extern "C" int bcx_build_enqueue(bcx_solver* s, int64_t itrs) {
   if (!s) return BCX_ERR_ARG;
   if (s->cfg.world_size != 1) { s->err = "bcx_build_enqueue is single-shard; use bcx_step_scan/apply"; return BCX_ERR_ARG; }
-  const int exact = s->cfg.store_dtype == BCX_F64;
+  const bool fuse = s->cfg.alg != BCX_ALG_OMP;
   for (int64_t i = 0; i < itrs; ++i) {
-    int rc = step_scan(s, nullptr, 0);
-    (void)exact;
+    int rc = step_scan(s, nullptr, 0, fuse);
     if (rc != BCX_OK) return rc;
-    if ((rc = bcx_launch_apply(s, s->rec_local))) return rc;
+    if (!fuse && (rc = bcx_launch_apply(s, s->rec_local))) return rc;
   }
   return BCX_OK;
 }

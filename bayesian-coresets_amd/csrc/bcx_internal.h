@@ -13,19 +13,27 @@
 #define BCX_REC_HDR 4            // record header doubles: score, global index, norm, flags
 #define BCX_REC_VALID 1.0
 #define BCX_REC_OVERFLOW 2.0
-#define BCX_MAX_D 4096
+#define BCX_MAX_D 2048          // 5 LDS vectors of d doubles in the apply kernels
 #define BCX_SCAN_THREADS 256
 #define BCX_APPLY_THREADS 256
 
 enum { HALT_NONE = 0, HALT_DONE = 1, HALT_LIMIT = 2, HALT_NEED_EXACT = 3 };
 
-// Per-workgroup result of the correlation scan: the two best upper bounds with
-// their local row indices, a bound on everything else the workgroup saw, and
-// the best lower bound.  (For fp64 storage U == L == the score.)
-struct ScanPartial {
-  double U1, U2, U3, L;
-  int32_t i1, i2;
+// Per-workgroup result of the correlation scan, stored as separate arrays (coalesced reads in the
+// resolve step): the two best upper bounds with their local row indices, a bound on everything else
+// the workgroup saw, and the best lower bound.  (For fp64 storage U == L == the score.)
+struct PartialView {
+  double *U1, *U2, *U3, *L;
+  int32_t *i1, *i2;
 };
+#define BCX_PARTIAL_BYTES 40   // per workgroup: 4 doubles + 2 int32
+#define BCX_MAX_PARTIALS 2048
+static inline __host__ __device__ PartialView partial_view(void* base, int n) {
+  PartialView v;
+  v.U1 = (double*)base; v.U2 = v.U1 + n; v.U3 = v.U2 + n; v.L = v.U3 + n;
+  v.i1 = (int32_t*)(v.L + n); v.i2 = v.i1 + n;
+  return v;
+}
 
 // Replicated solver state (device resident; every shard holds an identical copy).
 struct DevState {
@@ -70,7 +78,7 @@ struct bcx_solver {
   double* q64 = nullptr;    // 2 x ld64 query vectors (fp64, used by the exact re-score)
   void* qst = nullptr;      // 2 x ld query vectors in storage precision (read by the scan)
   double* tmp = nullptr;    // 4 x d scratch
-  ScanPartial* partials = nullptr;
+  void* partials = nullptr;     // PartialView storage
   int n_partials = 0;
   double* rec_local = nullptr;   // (d+4) record produced by this shard when world_size == 1
   // sparse weight list (selection order), grown on demand
@@ -114,6 +122,7 @@ int bcx_launch_scan(bcx_solver* s, int exact);
 int bcx_launch_resolve(bcx_solver* s, double* send_dev, int exact);
 int bcx_launch_begin(bcx_solver* s, int64_t itrs, double tol);
 int bcx_launch_apply(bcx_solver* s, const double* recv_dev);
+int bcx_launch_tail(bcx_solver* s, int exact);
 int bcx_launch_resume_exact(bcx_solver* s);
 int bcx_launch_error_refresh(bcx_solver* s);
 int bcx_launch_optimize(bcx_solver* s, double tol);

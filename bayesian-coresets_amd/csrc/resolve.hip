@@ -1,19 +1,21 @@
-// resolve.hip -- the O(d) fp64 part of a greedy iteration, single-workgroup kernels:
-//   resolve_kernel : scan partials -> candidate rows -> exact fp64 re-score -> this shard's record
-//   apply_kernel   : winner over all shards' records, reweight, monotone check / revert /
-//                    retry / latch (snnls.py:41-74), next query vector
-//   begin_kernel   : start of a build() call (snnls.py:31-40) + first query
-// All state is replicated: every shard runs the same code on the same gathered records, so
-// xw, weights and the trace stay bit-identical across shards.
+// resolve.hip -- the O(d) fp64 tail of a greedy iteration: single-workgroup, latency-bound kernels.
+//   resolve_kernel      : scan partials -> candidate rows -> exact fp64 re-score -> this shard's record
+//   apply_kernel<ALG>   : winner over all shards' records, reweight, monotone check / revert / retry /
+//                         latch (snnls.py:41-74), next query vector
+//   tail_kernel<ALG>    : both of the above in one launch (single shard)
+//   begin_kernel        : start of a build() call (snnls.py:31-40) + first query
+// All state is replicated: every shard runs the same code on the same gathered records, so xw,
+// weights and the trace stay bit-identical across shards.
+//
+// Latency design: the replicated vectors (xw, b, bn) are staged into LDS at kernel entry (they do not
+// depend on the scan), every phase issues all of its independent global loads before the first use,
+// and reductions stay in registers (DPP / permlane butterflies) with one LDS exchange per workgroup sum.
 #include "bcx_internal.h"
 #include "dev_util.h"
 #include "apply_common.h"
 
-// ------------------------------------------------------------------------------------------
-// resolve
-// ------------------------------------------------------------------------------------------
 struct ResolveArgs {
-  const ScanPartial* partials;
+  PartialView pv;
   int n_partials;
   DevState* st;
   const void* An;
@@ -28,155 +30,380 @@ struct ResolveArgs {
   int64_t n_local;
   int64_t row_offset;
   int exact;      // take the arg-max of the partials as is (fp64 scan, or fallback without raw rows)
-  double* rec;    // out: d + 4 doubles
+  double* rec;    // out: d + 4 doubles (may be null inside tail_kernel)
 };
 
-__device__ __forceinline__ double giga_score64(double s0, double s1) {
+// result of resolve, in LDS
+struct Winner {
+  double score, norm, flags;
+  int64_t gidx;
+  int lrow;
+};
+
+#define PP_MAX 8   // partials per thread (n_partials <= 2048, 256 threads)
+
+static __device__ __forceinline__ double giga_score64(double s0, double s1) {
   const bool ok = (s1 > -1.0 + 1e-14) && (1.0 - s1 * s1 > 0.0);   // giga.py:33
   const double den = ok ? sqrt(1.0 - s1 * s1) : INFINITY;          // giga.py:35-36
   return s0 / den;                                                 // giga.py:38
 }
 
-__device__ __forceinline__ double row_elem(const ResolveArgs& a, int64_t i, int j, double nrm) {
-  // normalised element An[i][j] in fp64: raw/norm when the raw rows are resident (giga.py:13)
-  if (a.A64) return a.A64[i * (int64_t)a.ld64 + j] / nrm;
-  if (a.store_f64) return ((const double*)a.An)[i * (int64_t)a.ld + j];
-  return (double)((const float*)a.An)[i * (int64_t)a.ld + j];
+static __device__ __forceinline__ double raw_elem(const ResolveArgs& a, int64_t i, int j, double nrm) {
+  if (a.A64) return a.A64[i * (int64_t)a.ld64 + j];
+  if (a.store_f64) return ((const double*)a.An)[i * (int64_t)a.ld + j] * nrm;
+  return (double)((const float*)a.An)[i * (int64_t)a.ld + j] * nrm;
 }
 
-__global__ __launch_bounds__(256) void resolve_kernel(ResolveArgs a) {
-  if (!a.st->active) return;
-  __shared__ double scratch[BCX_SCRATCH];
-  __shared__ int cand[BCX_MAX_CAND];
+// Partials -> candidates -> exact scores -> winner (LDS `win`); raw winner row to xf_lds (optional)
+// and the record to a.rec (optional).  All 256 threads.
+static __device__ void resolve_core(const ResolveArgs& a, Winner* win, double* xf_lds, double* scratch) {
+  __shared__ int cand_p[BCX_MAX_CAND];      // partial id * 2 + which
+  __shared__ int cand[BCX_MAX_CAND];        // local row
   __shared__ double cscore[BCX_MAX_CAND];
-  __shared__ int ncand, overflow, winner;
-  __shared__ double wscore;
+  __shared__ int ncand, overflow, minrow;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwaves = blockDim.x >> 6;
-  if (tid == 0) { ncand = 0; overflow = 0; winner = -1; wscore = -INFINITY; }
-  __syncthreads();
+  const int np = a.n_partials;
   const bool exact = a.exact || a.st->exact_mode;
-  if (exact) {
-    // arg-max of the per-workgroup maxima, lowest index on ties
-    double bu = -INFINITY; int bi = 0x7fffffff;
-    for (int p = tid; p < a.n_partials; p += blockDim.x) {
-      const ScanPartial sp = a.partials[p];
-      if (sp.U1 > bu || (sp.U1 == bu && sp.i1 < bi)) { bu = sp.U1; bi = sp.i1; }
-    }
+  // one round trip: this thread's partial bounds
+  double u1[PP_MAX], u2[PP_MAX], u3[PP_MAX], lo[PP_MAX];
 #pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) {
-      const double ou = __shfl_xor(bu, off, BCX_WAVE); const int oi = __shfl_xor(bi, off, BCX_WAVE);
-      if (ou > bu || (ou == bu && oi < bi)) { bu = ou; bi = oi; }
+  for (int t = 0; t < PP_MAX; ++t) {
+    const int p = tid + t * 256;
+    const bool ok = p < np;
+    u1[t] = ok ? a.pv.U1[p] : -INFINITY;
+    u2[t] = ok ? a.pv.U2[p] : -INFINITY;
+    u3[t] = ok ? a.pv.U3[p] : -INFINITY;
+    lo[t] = ok ? a.pv.L[p] : -INFINITY;
+  }
+  if (tid == 0) { ncand = 0; overflow = 0; minrow = 0x7fffffff; }
+  double lmax = -INFINITY;
+#pragma unroll
+  for (int t = 0; t < PP_MAX; ++t) lmax = fmax(lmax, exact ? u1[t] : lo[t]);
+  const double Lstar = block_allmax(lmax, scratch);   // (exact: the maximum score itself)
+#pragma unroll
+  for (int t = 0; t < PP_MAX; ++t) {
+    const int p = tid + t * 256;
+    if (u1[t] > -INFINITY && u1[t] >= Lstar) {
+      const int slot = atomicAdd(&ncand, 1);
+      if (slot < BCX_MAX_CAND) cand_p[slot] = p * 2;
     }
-    __shared__ double wu[4]; __shared__ int wi[4];
-    if (lane == 0) { wu[wave] = bu; wi[wave] = bi; }
+    if (!exact) {
+      if (u2[t] > -INFINITY && u2[t] >= Lstar) {
+        const int slot = atomicAdd(&ncand, 1);
+        if (slot < BCX_MAX_CAND) cand_p[slot] = p * 2 + 1;
+      }
+      if (u3[t] > -INFINITY && u3[t] >= Lstar) overflow = 1;
+    }
+  }
+  __syncthreads();
+  int nc = ncand;
+  const bool storm = nc > BCX_MAX_CAND;
+  if (storm && !exact) overflow = 1;
+  if (storm && exact) {
+    // exact scores tie across more than 64 workgroups: the lowest row among the maxima wins
+#pragma unroll
+    for (int t = 0; t < PP_MAX; ++t) {
+      const int p = tid + t * 256;
+      if (p < np && u1[t] == Lstar) atomicMin(&minrow, a.pv.i1[p]);
+    }
     __syncthreads();
+    if (tid == 0) cand[0] = minrow;
+    nc = 1;
+  } else if (tid < nc) {
+    const int cp = cand_p[tid];
+    cand[tid] = (cp & 1) ? a.pv.i2[cp >> 1] : a.pv.i1[cp >> 1];
+  }
+  __syncthreads();
+  if (overflow || nc == 0) {
     if (tid == 0) {
-      for (int w = 0; w < nwaves; ++w)
-        if (wu[w] > bu || (wu[w] == bu && wi[w] < bi)) { bu = wu[w]; bi = wi[w]; }
-      if (bi != 0x7fffffff && bu > -INFINITY) { cand[0] = bi; ncand = 1; }
+      win->score = -INFINITY; win->gidx = -1; win->norm = 0.0; win->lrow = -1;
+      win->flags = overflow ? BCX_REC_OVERFLOW : 0.0;
+      if (a.rec) { a.rec[0] = -INFINITY; a.rec[1] = -1.0; a.rec[2] = 0.0; a.rec[3] = win->flags; }
     }
     __syncthreads();
-  } else {
-    double lmax = -INFINITY;
-    for (int p = tid; p < a.n_partials; p += blockDim.x) lmax = fmax(lmax, a.partials[p].L);
-    const double Lstar = block_allmax(lmax, scratch);
-    for (int p = tid; p < a.n_partials; p += blockDim.x) {
-      const ScanPartial sp = a.partials[p];
-      if (sp.U1 > -INFINITY && sp.U1 >= Lstar) {
-        const int slot = atomicAdd(&ncand, 1);
-        if (slot < BCX_MAX_CAND) cand[slot] = sp.i1;
-      }
-      if (sp.U2 > -INFINITY && sp.U2 >= Lstar) {
-        const int slot = atomicAdd(&ncand, 1);
-        if (slot < BCX_MAX_CAND) cand[slot] = sp.i2;
-      }
-      if (sp.U3 > -INFINITY && sp.U3 >= Lstar) overflow = 1;
-    }
-    __syncthreads();
-    if (ncand > BCX_MAX_CAND) overflow = 1;
-    __syncthreads();
-  }
-  double* rec = a.rec;
-  if (overflow) {
-    if (tid == 0) { rec[0] = -INFINITY; rec[1] = -1.0; rec[2] = 0.0; rec[3] = BCX_REC_OVERFLOW; }
     return;
   }
-  const int nc = ncand;
-  if (nc == 0) {
-    if (tid == 0) { rec[0] = -INFINITY; rec[1] = -1.0; rec[2] = 0.0; rec[3] = 0.0; }
-    return;
-  }
-  // exact fp64 score of every candidate: one wave per candidate
+  // exact fp64 score of every candidate, one wave per candidate; norm, row and query loads are independent
   const double* q0 = a.q64;
   const double* q1 = a.q64 + a.ld64;
+  const bool dual = a.alg == BCX_ALG_GIGA;
   for (int c = wave; c < nc; c += nwaves) {
     const int64_t i = cand[c];
     const double nrm = a.norms[i];
     double s0 = 0.0, s1 = 0.0;
     for (int j = lane; j < a.d; j += 64) {
-      const double v = row_elem(a, i, j, nrm);
+      const double v = raw_elem(a, i, j, 1.0);
       s0 += v * q0[j];
-      if (a.alg == BCX_ALG_GIGA) s1 += v * q1[j];
+      if (dual) s1 += v * q1[j];
     }
     s0 = wave_allsum(s0);
-    if (a.alg == BCX_ALG_GIGA) s1 = wave_allsum(s1);
-    if (lane == 0) cscore[c] = (a.alg == BCX_ALG_GIGA) ? giga_score64(s0, s1) : s0;
+    if (dual) s1 = wave_allsum(s1);
+    if (a.A64) { s0 /= nrm; s1 /= nrm; }     // An = A / Anorms (giga.py:13); stored rows are already normalised
+    if (lane == 0) cscore[c] = dual ? giga_score64(s0, s1) : s0;
   }
   __syncthreads();
   if (tid == 0) {
     int best = 0;
     for (int c = 1; c < nc; ++c)
       if (cscore[c] > cscore[best] || (cscore[c] == cscore[best] && cand[c] < cand[best])) best = c;
-    // NaN scores never win a '>' comparison; if candidate 0 is NaN and another is not, prefer the other
-    if (cscore[best] != cscore[best])
+    if (cscore[best] != cscore[best])   // NaN never wins '>' : prefer any finite candidate
       for (int c = 0; c < nc; ++c) if (cscore[c] == cscore[c]) { best = c; break; }
-    winner = cand[best];
-    wscore = cscore[best];
+    win->lrow = cand[best];
+    win->score = cscore[best];
+    win->gidx = a.row_offset + cand[best];
+    win->flags = BCX_REC_VALID;
   }
   __syncthreads();
-  const int64_t wrow = winner;
+  const int64_t wrow = win->lrow;
   const double nrm = a.norms[wrow];
   if (tid == 0) {
-    rec[0] = wscore;
-    rec[1] = (double)(a.row_offset + wrow);
-    rec[2] = nrm;
-    rec[3] = BCX_REC_VALID;
+    win->norm = nrm;
+    if (a.rec) { a.rec[0] = win->score; a.rec[1] = (double)win->gidx; a.rec[2] = nrm; a.rec[3] = BCX_REC_VALID; }
   }
   for (int j = tid; j < a.d; j += blockDim.x) {
-    double raw;
-    if (a.A64) raw = a.A64[wrow * (int64_t)a.ld64 + j];
-    else if (a.store_f64) raw = ((const double*)a.An)[wrow * (int64_t)a.ld + j] * nrm;
-    else raw = (double)((const float*)a.An)[wrow * (int64_t)a.ld + j] * nrm;
-    rec[BCX_REC_HDR + j] = raw;
+    const double raw = raw_elem(a, wrow, j, nrm);
+    if (xf_lds) xf_lds[j] = raw;
+    if (a.rec) a.rec[BCX_REC_HDR + j] = raw;
+  }
+  __syncthreads();
+}
+
+// ------------------------------------------------------------------------------------------
+// apply (GIGA / Frank-Wolfe); OMP lives in nnls.hip
+// ------------------------------------------------------------------------------------------
+struct StateVecs {   // LDS copies, d doubles each
+  double *xw, *b, *bn, *xf, *tx;
+};
+
+static __device__ __forceinline__ StateVecs carve(double* dyn, int d) {
+  StateVecs v;
+  v.xw = dyn; v.b = dyn + d; v.bn = dyn + 2 * (size_t)d; v.xf = dyn + 3 * (size_t)d; v.tx = dyn + 4 * (size_t)d;
+  return v;
+}
+
+static __device__ __forceinline__ void stage_state(const ApplyArgs& a, const StateVecs& v) {
+  for (int j = threadIdx.x; j < a.d; j += blockDim.x) {
+    v.xw[j] = a.xw[j];
+    v.b[j] = a.b[j];
+    v.bn[j] = a.bn[j];
   }
 }
 
-int bcx_launch_resolve(bcx_solver* s, double* send_dev, int exact) {
-  ResolveArgs a;
-  a.partials = s->partials;
-  a.n_partials = s->n_partials;
-  a.st = s->st;
-  a.An = s->An;
-  a.store_f64 = s->cfg.store_dtype == BCX_F64;
-  a.ld = s->ld;
-  a.A64 = s->A64;
-  a.ld64 = s->ld64;
-  a.norms = s->norms;
-  a.q64 = s->q64;
-  a.d = s->cfg.d;
-  a.alg = s->cfg.alg;
-  a.n_local = s->cfg.n_local;
-  a.row_offset = s->cfg.row_offset;
-  a.exact = exact || a.store_f64;
-  a.rec = send_dev;
-  hipLaunchKernelGGL(resolve_kernel, dim3(1), dim3(256), 0, s->stream, a);
-  BCX_HIP(hipGetLastError());
-  return BCX_OK;
+// Reweight with the winner (f, nf, xf in LDS), commit or fail, trace, next query.
+template <int ALG>
+static __device__ void apply_core(const ApplyArgs& a, const StateVecs& v, int64_t f, double nf, double* scratch) {
+  DevState* st = a.st;
+  __shared__ int s_slot, s_npos;
+  const int tid = threadIdx.x, d = a.d;
+  const int k = st->k;
+  const double nw = st->nw, err0 = st->err, bnorm = st->bnorm, sigma = st->sigma, tol = st->tol;
+  const int64_t it = st->it, itrs = st->itrs;
+  const int retried = st->retried, since = st->since_refresh;
+  if (tid == 0) { s_slot = 0x7fffffff; s_npos = 0; }
+  __syncthreads();
+  // slot of f in the sparse weight list, and size() > 0  (snnls.py:44)
+  {
+    int npos = 0, slot = 0x7fffffff;
+    for (int s = tid; s < k; s += blockDim.x) {
+      const int64_t id = a.act_idx[s];
+      const double w = a.act_w[s];
+      if (id == f) slot = s;
+      if (w > 0.0) ++npos;
+    }
+    if (slot != 0x7fffffff) atomicMin(&s_slot, slot);
+    if (npos) atomicAdd(&s_npos, npos);
+  }
+  __syncthreads();
+  const bool checked = s_npos > 0;
+  const int slot = s_slot == 0x7fffffff ? -1 : s_slot;
+  const double wf_old = slot >= 0 ? a.act_w[slot] : 0.0;
+  int status = BCX_IT_OK;
+  double alpha = 0.0, beta = 0.0;
+  if (ALG == BCX_ALG_GIGA) {
+    // giga.py:42-61
+    double r[3] = {0.0, 0.0, 0.0};
+    for (int j = tid; j < d; j += blockDim.x) {
+      const double xh = v.xw[j] / nw, fh = v.xf[j] / nf, bj = v.bn[j];
+      r[0] += bj * fh; r[1] += bj * xh; r[2] += xh * fh;
+    }
+    block_allsum<3>(r, scratch);
+    const double gA = r[0] - r[1] * r[2];
+    const double gB = r[1] - r[0] * r[2];
+    if (gA <= 0.0 || gB < 0.0) {
+      status = BCX_IT_FAIL_REWEIGHT;
+    } else {
+      const double ca = gB / (gA + gB) / nw;
+      const double cb = gA / (gA + gB) / nf;
+      double u[2] = {0.0, 0.0};
+      for (int j = tid; j < d; j += blockDim.x) {
+        const double x = ca * v.xw[j] + cb * v.xf[j];
+        u[0] += x * x;
+        u[1] += x * v.bn[j];
+      }
+      block_allsum<2>(u, scratch);
+      const double nx = sqrt(u[0]);
+      const double scale = bnorm / nx * (u[1] / nx);     // giga.py:58
+      alpha = ca * scale; beta = cb * scale;
+    }
+  } else {
+    // frankwolfe.py:19-37
+    if (!checked) {
+      alpha = 0.0; beta = sigma / nf;
+    } else {
+      const double sc = sigma / nf;
+      double r[2] = {0.0, 0.0};
+      for (int j = tid; j < d; j += blockDim.x) {
+        const double vv = sc * v.xf[j] - v.xw[j];
+        r[0] += vv * (v.b[j] - v.xw[j]);
+        r[1] += vv * vv;
+      }
+      block_allsum<2>(r, scratch);
+      const double gnum = r[0], gden = r[1];
+      if (gnum < 0.0 || gden == 0.0 || gnum > gden) status = BCX_IT_FAIL_REWEIGHT;
+      else { alpha = 1.0 - gnum / gden; beta = sc * gnum / gden; }
+    }
+  }
+  double new_err = err0, new_nw = nw, tdot = 0.0, wf_new = 0.0;
+  if (status == BCX_IT_OK) {
+    // w <- alpha*w ; w[f] <- max(0, w[f] + beta)   giga.py:63-64 / frankwolfe.py:39-40
+    const double wf_scaled = alpha * wf_old;
+    wf_new = fmax(0.0, wf_scaled + beta);
+    const double delta = wf_new - wf_scaled;
+    double r[3] = {0.0, 0.0, 0.0};
+    for (int j = tid; j < d; j += blockDim.x) {
+      const double x = alpha * v.xw[j] + delta * v.xf[j];   // = A w'
+      v.tx[j] = x;
+      const double e = x - v.b[j];
+      r[0] += e * e; r[1] += x * x;
+      if (ALG == BCX_ALG_GIGA) r[2] += v.bn[j] * x;
+    }
+    block_allsum<3>(r, scratch);
+    new_err = sqrt(r[0]);
+    const double n2 = sqrt(r[1]);
+    new_nw = n2 == 0.0 ? 1.0 : n2;
+    tdot = r[2];
+    if (checked && new_err > err0) status = BCX_IT_FAIL_MONOTONE;   // snnls.py:58
+  }
+  bool limit = false;
+  if (status == BCX_IT_OK) {
+    for (int s = tid; s < k; s += blockDim.x)
+      if (s != slot) a.act_w[s] = alpha * a.act_w[s];
+    for (int j = tid; j < d; j += blockDim.x) { const double x = v.tx[j]; a.xw[j] = x; v.xw[j] = x; }
+    const int dst = slot >= 0 ? slot : k;
+    if (slot < 0)
+      for (int j = tid; j < d; j += blockDim.x) a.act_rows[(size_t)dst * d + j] = v.xf[j];
+    if (tid == 0) {
+      a.act_w[dst] = wf_new;
+      if (slot < 0) { a.act_idx[dst] = f; a.act_norm[dst] = nf; st->k = k + 1; }
+      st->err = new_err;
+      st->nw = new_nw;
+      st->since_refresh = since + 1;
+      if (checked) st->retried = 0;                        // snnls.py:62
+    }
+  } else {
+    limit = retried != 0;                                  // snnls.py:63-72
+  }
+  if (tid == 0) {
+    a.tr_sel[it] = f; a.tr_err[it] = (status == BCX_IT_OK) ? new_err : err0; a.tr_status[it] = status;
+    st->it = it + 1;
+    st->exact_mode = 0;
+    if (status != BCX_IT_OK) {
+      if (limit) { st->limit = 1; st->active = 0; st->halt = HALT_LIMIT; }
+      else st->retried = 1;
+    }
+  }
+  if (limit) return;
+  // ---- next query ----
+  const bool fast = status == BCX_IT_OK && it + 1 < itrs &&
+                    !(a.refresh_every > 0 && since + 1 >= a.refresh_every);
+  if (fast) {
+    if (ALG != BCX_ALG_GIGA) {
+      for (int j = tid; j < d; j += blockDim.x) store_query(a, 0, j, v.b[j] - v.xw[j]);   // frankwolfe.py:16
+      if (tid == 0) st->qscale = new_err;
+      return;
+    }
+    // giga.py:21-30 on the new iterate
+    const double t = tdot / new_nw;
+    double c2[1] = {0.0};
+    for (int j = tid; j < d; j += blockDim.x) {
+      const double c = v.bn[j] - t * (v.xw[j] / new_nw);
+      v.tx[j] = c;
+      c2[0] += c * c;
+    }
+    block_allsum<1>(c2, scratch);
+    const double cn = sqrt(c2[0]);
+    if (!(cn < tol)) {
+      for (int j = tid; j < d; j += blockDim.x) {
+        store_query(a, 0, j, v.tx[j] / cn);
+        store_query(a, 1, j, v.xw[j] / new_nw);
+      }
+      if (tid == 0) st->qscale = 1.0;
+      return;
+    }
+  }
+  // slow path: end of call, refresh due, failed step or failing select -- generic state machine
+  __syncthreads();
+  prepare_next(a, scratch);
 }
 
-// ------------------------------------------------------------------------------------------
-// apply (GIGA / Frank-Wolfe); OMP lives in nnls.hip and reuses the helpers below
-// ------------------------------------------------------------------------------------------
+// ---- kernels --------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void resolve_kernel(ResolveArgs a) {
+  if (!a.st->active) return;
+  __shared__ double scratch[BCX_SCRATCH];
+  __shared__ Winner win;
+  resolve_core(a, &win, nullptr, scratch);
+}
+
+template <int ALG>
+__global__ __launch_bounds__(BCX_APPLY_THREADS) void apply_kernel(ApplyArgs a) {
+  DevState* st = a.st;
+  if (!st->active) return;
+  extern __shared__ double dyn[];
+  __shared__ double scratch[BCX_SCRATCH];
+  __shared__ int s_win, s_overflow;
+  const StateVecs v = carve(dyn, a.d);
+  stage_state(a, v);
+  const int tid = threadIdx.x, d = a.d;
+  const int recw = d + BCX_REC_HDR;
+  if (tid == 0) {
+    int win = -1, ovf = 0;
+    for (int r = 0; r < a.world; ++r) {
+      const double* rec = a.recs + (size_t)r * recw;
+      if (rec[3] == BCX_REC_OVERFLOW) ovf = 1;
+      if (rec[3] != BCX_REC_VALID) continue;
+      if (win < 0) { win = r; continue; }
+      const double* best = a.recs + (size_t)win * recw;
+      if (rec[0] > best[0] || (rec[0] == best[0] && rec[1] < best[1])) win = r;
+    }
+    s_win = win; s_overflow = ovf;
+  }
+  __syncthreads();
+  if (s_overflow) { if (tid == 0) { st->active = 0; st->halt = HALT_NEED_EXACT; } return; }
+  if (s_win < 0) { if (tid == 0) { st->active = 0; st->halt = HALT_DONE; } return; }
+  const double* rec = a.recs + (size_t)s_win * recw;
+  for (int j = tid; j < d; j += blockDim.x) v.xf[j] = rec[BCX_REC_HDR + j];
+  const int64_t f = (int64_t)rec[1];
+  const double nf = rec[2];
+  __syncthreads();
+  apply_core<ALG>(a, v, f, nf, scratch);
+}
+
+// single shard: resolve + apply in one launch
+template <int ALG>
+__global__ __launch_bounds__(BCX_APPLY_THREADS) void tail_kernel(ResolveArgs r, ApplyArgs a) {
+  DevState* st = a.st;
+  if (!st->active) return;
+  extern __shared__ double dyn[];
+  __shared__ double scratch[BCX_SCRATCH];
+  __shared__ Winner win;
+  const StateVecs v = carve(dyn, a.d);
+  stage_state(a, v);
+  resolve_core(r, &win, v.xf, scratch);
+  if (win.flags == BCX_REC_OVERFLOW) { if (threadIdx.x == 0) { st->active = 0; st->halt = HALT_NEED_EXACT; } return; }
+  if (win.flags != BCX_REC_VALID) { if (threadIdx.x == 0) { st->active = 0; st->halt = HALT_DONE; } return; }
+  apply_core<ALG>(a, v, win.gidx, win.norm, scratch);
+}
+
 __global__ __launch_bounds__(BCX_APPLY_THREADS) void begin_kernel(ApplyArgs a, int64_t itrs, double tol) {
   __shared__ double scratch[BCX_SCRATCH];
   DevState* st = a.st;
@@ -193,159 +420,46 @@ __global__ __launch_bounds__(64) void resume_exact_kernel(DevState* st) {
   if (threadIdx.x == 0 && st->halt == HALT_NEED_EXACT) { st->active = 1; st->halt = HALT_NONE; st->exact_mode = 1; }
 }
 
-template <int ALG>
-__global__ __launch_bounds__(BCX_APPLY_THREADS) void apply_kernel(ApplyArgs a) {
-  DevState* st = a.st;
-  if (!st->active) return;
+// error() outside a build: refresh xw from the slots and recompute err (snnls.py:28-29)
+__global__ __launch_bounds__(BCX_APPLY_THREADS) void error_refresh_kernel(ApplyArgs a) {
   __shared__ double scratch[BCX_SCRATCH];
-  __shared__ int s_win, s_overflow, s_slot, s_npos, s_status;
-  __shared__ double s_alpha, s_beta;
-  const int tid = threadIdx.x, d = a.d;
-  const int recw = d + BCX_REC_HDR;
-  if (tid == 0) {
-    int win = -1, ovf = 0;
-    for (int r = 0; r < a.world; ++r) {
-      const double* rec = a.recs + (size_t)r * recw;
-      if (rec[3] == BCX_REC_OVERFLOW) ovf = 1;
-      if (rec[3] != BCX_REC_VALID) continue;
-      if (win < 0) { win = r; continue; }
-      const double* best = a.recs + (size_t)win * recw;
-      if (rec[0] > best[0] || (rec[0] == best[0] && rec[1] < best[1])) win = r;
-    }
-    s_win = win; s_overflow = ovf; s_slot = 0x7fffffff; s_npos = 0; s_status = BCX_IT_OK;
-  }
-  __syncthreads();
-  if (s_overflow) {
-    if (tid == 0) { st->active = 0; st->halt = HALT_NEED_EXACT; }
-    return;
-  }
-  if (s_win < 0) {  // no data anywhere: nothing to select (snnls.py:36-38 is handled by the host)
-    if (tid == 0) { st->active = 0; st->halt = HALT_DONE; }
-    return;
-  }
-  const double* rec = a.recs + (size_t)s_win * recw;
-  const int64_t f = (int64_t)rec[1];
-  const double nf = rec[2];
-  const double* xf = rec + BCX_REC_HDR;
-  const int k = st->k;
-  // slot of f in the sparse weight list, and size() > 0  (snnls.py:44)
-  int npos = 0;
-  for (int s = tid; s < k; s += blockDim.x) {
-    if (a.act_idx[s] == f) atomicMin(&s_slot, s);
-    if (a.act_w[s] > 0.0) ++npos;
-  }
-  if (npos) atomicAdd(&s_npos, npos);
-  __syncthreads();
-  const bool checked = s_npos > 0;
-  const int slot = s_slot == 0x7fffffff ? -1 : s_slot;
-  const double wf_old = slot >= 0 ? a.act_w[slot] : 0.0;
-  const double nw = st->nw;
+  refresh_state(a, scratch, a.st->k > 0);
+}
 
-  if (ALG == BCX_ALG_GIGA) {
-    // giga.py:42-61
-    double v[3] = {0.0, 0.0, 0.0};
-    for (int j = tid; j < d; j += blockDim.x) {
-      const double xh = a.xw[j] / nw, fh = xf[j] / nf, bj = a.bn[j];
-      v[0] += bj * fh; v[1] += bj * xh; v[2] += xh * fh;
-    }
-    block_allsum<3>(v, scratch);
-    const double gA = v[0] - v[1] * v[2];
-    const double gB = v[1] - v[0] * v[2];
-    if (gA <= 0.0 || gB < 0.0) {
-      if (tid == 0) s_status = BCX_IT_FAIL_REWEIGHT;
-    } else {
-      const double ca = gB / (gA + gB) / nw;
-      const double cb = gA / (gA + gB) / nf;
-      double u0[1] = {0.0}, u1[1] = {0.0};
-      for (int j = tid; j < d; j += blockDim.x) {
-        const double x = ca * a.xw[j] + cb * xf[j];
-        a.tmp[d + j] = x;
-        u0[0] += x * x;
-      }
-      block_allsum<1>(u0, scratch);
-      const double nx = sqrt(u0[0]);
-      for (int j = tid; j < d; j += blockDim.x) u1[0] += (a.tmp[d + j] / nx) * a.bn[j];
-      block_allsum<1>(u1, scratch);
-      const double scale = st->bnorm / nx * u1[0];
-      if (tid == 0) { s_alpha = ca * scale; s_beta = cb * scale; }
-    }
-  } else {
-    // frankwolfe.py:19-37
-    if (!checked) {
-      if (tid == 0) { s_alpha = 0.0; s_beta = st->sigma / nf; }
-    } else {
-      const double sc = st->sigma / nf;
-      double v[2] = {0.0, 0.0};
-      for (int j = tid; j < d; j += blockDim.x) {
-        const double vv = sc * xf[j] - a.xw[j];
-        v[0] += vv * (a.b[j] - a.xw[j]);
-        v[1] += vv * vv;
-      }
-      block_allsum<2>(v, scratch);
-      const double gnum = v[0], gden = v[1];
-      if (gnum < 0.0 || gden == 0.0 || gnum > gden) {
-        if (tid == 0) s_status = BCX_IT_FAIL_REWEIGHT;
-      } else if (tid == 0) {
-        s_alpha = 1.0 - gnum / gden;
-        s_beta = sc * gnum / gden;
-      }
-    }
-  }
-  __syncthreads();
-  double new_err = st->err, new_nw2 = 0.0, wf_new = 0.0;
-  if (s_status == BCX_IT_OK) {
-    // w <- alpha*w ; w[f] <- max(0, w[f] + beta)   giga.py:63-64 / frankwolfe.py:39-40
-    const double alpha = s_alpha, beta = s_beta;
-    const double wf_scaled = alpha * wf_old;
-    wf_new = fmax(0.0, wf_scaled + beta);
-    const double delta = wf_new - wf_scaled;
-    double v[2] = {0.0, 0.0};
-    for (int j = tid; j < d; j += blockDim.x) {
-      const double x = alpha * a.xw[j] + delta * xf[j];   // = A w'
-      a.tmp[j] = x;
-      const double r = x - a.b[j];
-      v[0] += r * r; v[1] += x * x;
-    }
-    block_allsum<2>(v, scratch);
-    new_err = sqrt(v[0]); new_nw2 = v[1];
-    if (checked && new_err > st->err) {                    // snnls.py:58
-      if (tid == 0) s_status = BCX_IT_FAIL_MONOTONE;
-    }
-  }
-  __syncthreads();
-  const int status = s_status;
-  if (status == BCX_IT_OK) {
-    const double alpha = s_alpha;
-    for (int s = tid; s < k; s += blockDim.x)
-      if (s != slot) a.act_w[s] = alpha * a.act_w[s];
-    for (int j = tid; j < d; j += blockDim.x) a.xw[j] = a.tmp[j];
-    const int dst = slot >= 0 ? slot : k;
-    if (slot < 0)
-      for (int j = tid; j < d; j += blockDim.x) a.act_rows[(size_t)dst * d + j] = xf[j];
-    if (tid == 0) {
-      a.act_w[dst] = wf_new;
-      if (slot < 0) { a.act_idx[dst] = f; a.act_norm[dst] = nf; st->k = k + 1; }
-      st->err = new_err;
-      const double nwn = sqrt(new_nw2);
-      st->nw = nwn == 0.0 ? 1.0 : nwn;
-      st->since_refresh += 1;
-      if (checked) st->retried = 0;                        // snnls.py:62
-    }
-  }
-  __syncthreads();
-  if (tid == 0) {
-    const int64_t it = st->it;
-    a.tr_sel[it] = f; a.tr_err[it] = st->err; a.tr_status[it] = status;
-    st->it = it + 1;
-    st->exact_mode = 0;
-    if (status != BCX_IT_OK) {                             // snnls.py:63-72
-      if (st->retried) { st->limit = 1; st->active = 0; st->halt = HALT_LIMIT; }
-      else st->retried = 1;
-    }
-  }
-  __syncthreads();
-  if (!st->active) return;
-  prepare_next(a, scratch);
+// ---- launchers -------------------------------------------------------------------------------
+static void fill_resolve_args(bcx_solver* s, ResolveArgs& a, double* send_dev, int exact) {
+  a.pv = partial_view(s->partials, s->n_partials);
+  a.n_partials = s->n_partials;
+  a.st = s->st;
+  a.An = s->An;
+  a.store_f64 = s->cfg.store_dtype == BCX_F64;
+  a.ld = s->ld;
+  a.A64 = s->A64;
+  a.ld64 = s->ld64;
+  a.norms = s->norms;
+  a.q64 = s->q64;
+  a.d = s->cfg.d;
+  a.alg = s->cfg.alg;
+  a.n_local = s->cfg.n_local;
+  a.row_offset = s->cfg.row_offset;
+  // the raw fp64 scan already produced exact scores; without raw rows the fp32 arg-max is taken as is
+  a.exact = exact || a.store_f64;
+  a.rec = send_dev;
+}
+
+static size_t vec_lds_bytes(const bcx_solver* s) { return 5 * (size_t)s->cfg.d * sizeof(double); }
+
+template <typename K> static int allow_lds(bcx_solver* s, K kfn, size_t bytes) {
+  if (bytes > 48 * 1024) BCX_HIP(hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+  return BCX_OK;
+}
+
+int bcx_launch_resolve(bcx_solver* s, double* send_dev, int exact) {
+  ResolveArgs a;
+  fill_resolve_args(s, a, send_dev, exact);
+  hipLaunchKernelGGL(resolve_kernel, dim3(1), dim3(256), 0, s->stream, a);
+  BCX_HIP(hipGetLastError());
+  return BCX_OK;
 }
 
 int bcx_launch_begin(bcx_solver* s, int64_t itrs, double tol) {
@@ -368,18 +482,36 @@ int bcx_launch_apply(bcx_solver* s, const double* recv_dev) {
   if (s->cfg.alg == BCX_ALG_OMP) return bcx_launch_apply_omp(s, recv_dev);
   ApplyArgs a;
   fill_apply_args(s, a, recv_dev);
-  if (s->cfg.alg == BCX_ALG_GIGA)
-    hipLaunchKernelGGL((apply_kernel<BCX_ALG_GIGA>), dim3(1), dim3(BCX_APPLY_THREADS), 0, s->stream, a);
-  else
-    hipLaunchKernelGGL((apply_kernel<BCX_ALG_FW>), dim3(1), dim3(BCX_APPLY_THREADS), 0, s->stream, a);
+  const size_t lds = vec_lds_bytes(s);
+  int rc;
+  if (s->cfg.alg == BCX_ALG_GIGA) {
+    if ((rc = allow_lds(s, apply_kernel<BCX_ALG_GIGA>, lds))) return rc;
+    hipLaunchKernelGGL((apply_kernel<BCX_ALG_GIGA>), dim3(1), dim3(BCX_APPLY_THREADS), lds, s->stream, a);
+  } else {
+    if ((rc = allow_lds(s, apply_kernel<BCX_ALG_FW>, lds))) return rc;
+    hipLaunchKernelGGL((apply_kernel<BCX_ALG_FW>), dim3(1), dim3(BCX_APPLY_THREADS), lds, s->stream, a);
+  }
   BCX_HIP(hipGetLastError());
   return BCX_OK;
 }
 
-// error() outside a build: refresh xw from the slots and recompute err (snnls.py:28-29)
-__global__ __launch_bounds__(BCX_APPLY_THREADS) void error_refresh_kernel(ApplyArgs a) {
-  __shared__ double scratch[BCX_SCRATCH];
-  refresh_state(a, scratch, a.st->k > 0);
+// single shard, GIGA / FW: resolve + apply fused
+int bcx_launch_tail(bcx_solver* s, int exact) {
+  ResolveArgs r;
+  fill_resolve_args(s, r, nullptr, exact);
+  ApplyArgs a;
+  fill_apply_args(s, a, nullptr);
+  const size_t lds = vec_lds_bytes(s);
+  int rc;
+  if (s->cfg.alg == BCX_ALG_GIGA) {
+    if ((rc = allow_lds(s, tail_kernel<BCX_ALG_GIGA>, lds))) return rc;
+    hipLaunchKernelGGL((tail_kernel<BCX_ALG_GIGA>), dim3(1), dim3(BCX_APPLY_THREADS), lds, s->stream, r, a);
+  } else {
+    if ((rc = allow_lds(s, tail_kernel<BCX_ALG_FW>, lds))) return rc;
+    hipLaunchKernelGGL((tail_kernel<BCX_ALG_FW>), dim3(1), dim3(BCX_APPLY_THREADS), lds, s->stream, r, a);
+  }
+  BCX_HIP(hipGetLastError());
+  return BCX_OK;
 }
 
 int bcx_launch_error_refresh(bcx_solver* s) {

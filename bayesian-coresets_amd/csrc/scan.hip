@@ -99,7 +99,7 @@ struct ScanArgs {
   const void* An;     // n x ldv vectors of 16 bytes
   const void* q;      // 2 x ldv vectors (query 0, query 1) in storage precision
   const DevState* st;
-  ScanPartial* out;
+  PartialView out;
   const double* norms; // non-null: rows are RAW fp64 rows, divide the dot products by the row norm
   int64_t n;
   int ldv;            // row stride in 16-byte vectors
@@ -289,10 +289,9 @@ __global__ __launch_bounds__(BCX_SCAN_THREADS) void scan_kernel(ScanArgs a) {
     Track<T> r = wtr[0];
 #pragma unroll
     for (int w = 1; w < WAVES; ++w) r = merge<T>(r, wtr[w]);
-    ScanPartial o;
-    o.U1 = (double)r.U1; o.U2 = (double)r.U2; o.U3 = (double)r.U3; o.L = (double)r.L;
-    o.i1 = r.i1; o.i2 = r.i2;
-    a.out[blockIdx.x] = o;
+    const int b = blockIdx.x;
+    a.out.U1[b] = (double)r.U1; a.out.U2[b] = (double)r.U2; a.out.U3[b] = (double)r.U3; a.out.L[b] = (double)r.L;
+    a.out.i1[b] = r.i1; a.out.i2[b] = r.i2;
   }
 }
 
@@ -308,8 +307,8 @@ int bcx_scan_grid(const bcx_solver* s) {
   const int64_t n = s->cfg.n_local;
   int64_t want = (n + 15) / 16;
   if (want < 1) want = 1;
-  int64_t cap = 2048;
-  if (const char* e = getenv("BCX_SCAN_GRID")) { const long v = atol(e); if (v > 0) cap = v; }
+  int64_t cap = BCX_MAX_PARTIALS;
+  if (const char* e = getenv("BCX_SCAN_GRID")) { const long v = atol(e); if (v > 0 && v < cap) cap = v; }
   if (want > cap) want = cap;
   return (int)want;
 }
@@ -322,7 +321,7 @@ static int launch_t(bcx_solver* s, const ScanArgs& a, int G, int CH, int grid) {
     hipLaunchKernelGGL((scan_kernel<T, DUAL, GG, CC>), g, b, 0, s->stream, a);                       \
     return BCX_OK;                                                                                   \
   }
-  L(1, 1) L(2, 1) L(4, 1) L(8, 1) L(16, 1) L(32, 1) L(64, 1) L(64, 2) L(64, 4) L(64, 8) L(64, 16)
+  L(1, 1) L(2, 1) L(4, 1) L(8, 1) L(16, 1) L(32, 1) L(64, 1) L(64, 2) L(64, 4) L(64, 8) L(64, 16)   // d <= 2048
 #undef L
   s->err = "scan: unsupported row length";
   return BCX_ERR_ARG;
@@ -338,7 +337,7 @@ int bcx_launch_scan(bcx_solver* s, int exact) {
   const bool f64 = (s->cfg.store_dtype == BCX_F64) || raw64;
   ScanArgs a;
   a.st = s->st;
-  a.out = s->partials;
+  a.out = partial_view(s->partials, s->n_partials);
   a.n = s->cfg.n_local;
   a.norms = nullptr;
   const int epl = f64 ? 2 : 4;
