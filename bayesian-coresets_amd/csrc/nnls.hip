@@ -59,11 +59,20 @@ static __device__ ArgBest block_argbest(double v, int i, double* scratch) {
   return r;
 }
 
-// y[a] = sum_b M[b*ld + a] * v[b], a < p  (M symmetric: reading column a as row entries is coalesced)
+// y[a] = sum_b M[b*ld + a] * v[b], a < p  (M symmetric: reading column a as row entries is coalesced).
+// 8 independent loads per step so the L2 latencies overlap; fixed summation order.
 static __device__ void mv_sym(const double* M, int64_t ld, int p, const double* v, double* y) {
   for (int a = threadIdx.x; a < p; a += blockDim.x) {
     double acc = 0.0;
-    for (int b = 0; b < p; ++b) acc += M[(size_t)b * ld + a] * v[b];
+    int b = 0;
+    for (; b + 8 <= p; b += 8) {
+      double m[8];
+#pragma unroll
+      for (int t = 0; t < 8; ++t) m[t] = M[(size_t)(b + t) * ld + a];
+#pragma unroll
+      for (int t = 0; t < 8; ++t) acc += m[t] * v[b + t];
+    }
+    for (; b < p; ++b) acc += M[(size_t)b * ld + a] * v[b];
     y[a] = acc;
   }
   __syncthreads();
@@ -73,7 +82,15 @@ static __device__ void mv_gram(const NnlsArgs& n, int p, const double* v, double
   for (int a = threadIdx.x; a < p; a += blockDim.x) {
     const int ca = n.plist[a];
     double acc = 0.0;
-    for (int b = 0; b < p; ++b) acc += n.gram[(size_t)n.plist[b] * n.ldg + ca] * v[b];
+    int b = 0;
+    for (; b + 8 <= p; b += 8) {
+      double m[8];
+#pragma unroll
+      for (int t = 0; t < 8; ++t) m[t] = n.gram[(size_t)n.plist[b + t] * n.ldg + ca];
+#pragma unroll
+      for (int t = 0; t < 8; ++t) acc += m[t] * v[b + t];
+    }
+    for (; b < p; ++b) acc += n.gram[(size_t)n.plist[b] * n.ldg + ca] * v[b];
     y[a] = acc;
   }
   __syncthreads();
@@ -291,12 +308,20 @@ static __device__ void rebuild_passive(const NnlsArgs& n, int k, double* scratch
 }
 
 // ---- OMP apply --------------------------------------------------------------------------------
+// Typical step: one new column joins the support and every weight stays positive.  Then the NNLS
+// solution on S u {f} follows from the bordered inverse in closed form (u = H g, s = G_ff - g.u,
+// t = (c_f - g.x)/s, x <- x - t u, x_f = t): two passes over H instead of a full active-set solve.
+// Anything else (a weight would turn non-positive, dependent column, stale inverse, periodic
+// re-solve) goes through nnls_run, which gives the same unique solution.
+#define OMP_RESOLVE_EVERY 8
 __global__ __launch_bounds__(NN_THREADS) void apply_omp_kernel(NnlsArgs n) {
   const ApplyArgs& a = n.a;
   DevState* st = a.st;
   if (!st->active) return;
   __shared__ double scratch[BCX_SCRATCH];
-  __shared__ int s_win, s_overflow, s_slot, s_npos, s_status;
+  __shared__ int s_win, s_overflow, s_slot, s_npos, s_bad;
+  __shared__ unsigned long long s_minidx;
+  __shared__ double s_gff, s_cf;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = blockDim.x >> 6, d = a.d;
   const int recw = d + BCX_REC_HDR;
   if (tid == 0) {
@@ -309,101 +334,142 @@ __global__ __launch_bounds__(NN_THREADS) void apply_omp_kernel(NnlsArgs n) {
       const double* best = a.recs + (size_t)win * recw;
       if (rec[0] > best[0] || (rec[0] == best[0] && rec[1] < best[1])) win = r;
     }
-    s_win = win; s_overflow = ovf; s_slot = 0x7fffffff; s_npos = 0; s_status = BCX_IT_OK;
+    s_win = win; s_overflow = ovf; s_slot = 0x7fffffff; s_npos = 0; s_bad = 0;
+    s_minidx = 0x7fffffffffffffffULL;
   }
   __syncthreads();
   if (s_overflow) { if (tid == 0) { st->active = 0; st->halt = HALT_NEED_EXACT; } return; }
   if (s_win < 0) { if (tid == 0) { st->active = 0; st->halt = HALT_DONE; } return; }
   const double* rec = a.recs + (size_t)s_win * recw;
+  const double* xf = rec + BCX_REC_HDR;
   const int k = st->k;
-  // size() and the negative direction over the active set: -An[j].residual   orthopursuit.py:27-31
+  const double err0 = st->err;
+  // one pass over the replicated rows: -An[j].residual for the active ones (orthopursuit.py:27-31)
+  // and row_j . xf (the Gram row of the positive-direction candidate); the extra "row k" is xf itself
+  for (int j = wave; j <= k; j += nw) {
+    const double* row = (j < k) ? a.act_rows + (size_t)j * d : xf;
+    double a0 = 0.0, a1 = 0.0;
+    for (int i = lane; i < d; i += 64) {
+      const double rv = row[i];
+      a0 += rv * xf[i];
+      a1 += rv * ((j < k) ? a.q64[i] : a.b[i]);
+    }
+    a0 = wave_allsum(a0);
+    a1 = wave_allsum(a1);
+    if (lane == 0) {
+      if (j < k) { n.t0[j] = a0; n.t2[j] = -(a1 / a.act_norm[j]); }
+      else { s_gff = a0; s_cf = a1; }
+    }
+  }
   int npos = 0;
   for (int s = tid; s < k; s += blockDim.x) if (a.act_w[s] > 0.0) ++npos;
   if (npos) atomicAdd(&s_npos, npos);
-  for (int j = wave; j < k; j += nw) {
-    if (!(a.act_w[j] > 0.0)) continue;
-    const double nr = a.act_norm[j];
-    double acc = 0.0;
-    for (int i = lane; i < d; i += 64) acc += (a.act_rows[(size_t)j * d + i] / nr) * a.q64[i];
-    acc = wave_allsum(acc);
-    if (lane == 0) n.t2[j] = -acc;
-  }
   __syncthreads();
   const bool checked = s_npos > 0;
   int64_t f = (int64_t)rec[1];
-  const double* xf = rec + BCX_REC_HDR;
-  double nf = rec[2];
-  int slot = -1;
+  const double nf = rec[2];
   if (checked) {
-    // first max of -dots over the active indices in increasing index order == (value desc, global index asc)
+    // first maximum of -dots over the active indices in index order == (value desc, global index asc)
     double bv = -INFINITY; int bi = -1; int64_t bidx = 0;
     for (int j = tid; j < k; j += blockDim.x) {
       if (!(a.act_w[j] > 0.0)) continue;
-      const double v = n.t2[j];
-      if (bi < 0 || v > bv || (v == bv && a.act_idx[j] < bidx)) { bv = v; bi = j; bidx = a.act_idx[j]; }
+      const double vv = n.t2[j];
+      if (bi < 0 || vv > bv || (vv == bv && a.act_idx[j] < bidx)) { bv = vv; bi = j; bidx = a.act_idx[j]; }
     }
-    // reduce on (value, global index): encode the tie-break by a second pass
     const double vmax = block_allmax(bi >= 0 ? bv : -INFINITY, scratch);
-    int64_t myidx = (bi >= 0 && bv == vmax) ? bidx : (int64_t)0x7fffffffffffffffLL;
-    // min global index among the maxima
-    __shared__ unsigned long long s_minidx;
-    if (tid == 0) s_minidx = 0x7fffffffffffffffULL;
+    if (bi >= 0 && bv == vmax) atomicMin(&s_minidx, (unsigned long long)bidx);
     __syncthreads();
-    if (bi >= 0 && bv == vmax) atomicMin(&s_minidx, (unsigned long long)myidx);
-    __syncthreads();
-    const double pos = rec[0];
-    if (!(pos >= vmax)) {                                   // orthopursuit.py:32-35
-      f = (int64_t)s_minidx;
-    }
+    if (!(rec[0] >= vmax)) f = (int64_t)s_minidx;          // orthopursuit.py:32-35
   }
   for (int s = tid; s < k; s += blockDim.x) if (a.act_idx[s] == f) atomicMin(&s_slot, s);
   __syncthreads();
-  slot = s_slot == 0x7fffffff ? -1 : s_slot;
+  int slot = s_slot == 0x7fffffff ? -1 : s_slot;
   const bool fresh = slot < 0;
   if (fresh) slot = k;
   const int k1 = fresh ? k + 1 : k;
-  // backup, new slot data, Gram row
   for (int j = tid; j < k; j += blockDim.x) n.wbak[j] = a.act_w[j];
   if (fresh) {
+    // new slot: row, Gram row (from the pass above), c = row . b
     for (int i = tid; i < d; i += blockDim.x) a.act_rows[(size_t)slot * d + i] = xf[i];
-    if (tid == 0) { a.act_idx[slot] = f; a.act_norm[slot] = nf; a.act_w[slot] = 0.0; n.ppos[slot] = -1; n.x[slot] = 0.0; }
-    __syncthreads();
-    for (int j = wave; j <= k; j += nw) {
-      double acc = 0.0;
-      for (int i = lane; i < d; i += 64) acc += a.act_rows[(size_t)slot * d + i] * a.act_rows[(size_t)j * d + i];
-      acc = wave_allsum(acc);
-      if (lane == 0) { n.gram[(size_t)slot * n.ldg + j] = acc; n.gram[(size_t)j * n.ldg + slot] = acc; }
+    for (int j = tid; j < k; j += blockDim.x) {
+      const double g = n.t0[j];
+      n.gram[(size_t)slot * n.ldg + j] = g;
+      n.gram[(size_t)j * n.ldg + slot] = g;
     }
-    if (wave == nw - 1) {
-      double acc = 0.0;
-      for (int i = lane; i < d; i += 64) acc += a.act_rows[(size_t)slot * d + i] * a.b[i];
-      acc = wave_allsum(acc);
-      if (lane == 0) n.cvec[slot] = acc;
+    if (tid == 0) {
+      a.act_idx[slot] = f; a.act_norm[slot] = nf; a.act_w[slot] = 0.0; n.ppos[slot] = -1; n.x[slot] = 0.0;
+      n.gram[(size_t)slot * n.ldg + slot] = s_gff;
+      n.cvec[slot] = s_cf;
     }
   }
   __syncthreads();
   if (!st->hvalid) rebuild_passive(n, k, scratch);
-  // problem set S = support U {f}   (w[f] = 1 then active = w > 0: orthopursuit.py:38-39)
-  for (int j = tid; j < k1; j += blockDim.x) {
-    const bool in = (j == slot) || (a.act_w[j] > 0.0);
-    n.flag[j] = in ? FLAG_INS : 0;
-    if (n.ppos[j] < 0) n.x[j] = 0.0;
-  }
-  __syncthreads();
   const double eps = 2.220446049250313e-16;
   const double tolscale = 10.0 * eps * (double)(d > k1 ? d : k1) * st->bnorm;
-  nnls_run(n, k1, tolscale, scratch);
+  const int p = st->np;
+  bool done = n.ppos[slot] >= 0;          // f already carries weight: the NNLS problem is unchanged
+  if (!done && (st->since_refresh % OMP_RESOLVE_EVERY) != OMP_RESOLVE_EVERY - 1) {
+    // closed-form bordered step
+    for (int q = tid; q < p; q += blockDim.x) n.t0[q] = n.gram[(size_t)slot * n.ldg + n.plist[q]];
+    __syncthreads();
+    mv_sym(n.hinv, n.ldg, p, n.t0, n.t1);                 // u = H g
+    double r[2] = {0.0, 0.0};
+    for (int q = tid; q < p; q += blockDim.x) { r[0] += n.t0[q] * n.t1[q]; r[1] += n.t0[q] * n.x[n.plist[q]]; }
+    block_allsum<2>(r, scratch);
+    const double gff = n.gram[(size_t)slot * n.ldg + slot];
+    const double sc = gff - r[0];
+    const double wvf = n.cvec[slot] - r[1];
+    if (!(wvf > tolscale * a.act_norm[slot])) {
+      done = true;                                        // dual not positive: f gets weight 0
+    } else if (sc > 1e-12 * gff) {
+      const double t = wvf / sc;
+      for (int q = tid; q < p; q += blockDim.x)
+        if (!(n.x[n.plist[q]] - t * n.t1[q] > 0.0)) s_bad = 1;
+      __syncthreads();
+      if (!s_bad && t > 0.0) {
+        const double inv = 1.0 / sc;
+        for (int q = tid; q < p; q += blockDim.x) n.x[n.plist[q]] -= t * n.t1[q];
+        for (int idx = tid; idx < p * p; idx += blockDim.x) {
+          const int rr = idx / p, cc = idx - rr * p;
+          n.hinv[(size_t)rr * n.ldg + cc] += n.t1[rr] * n.t1[cc] * inv;
+        }
+        for (int q = tid; q < p; q += blockDim.x) {
+          const double e = -n.t1[q] * inv;
+          n.hinv[(size_t)p * n.ldg + q] = e;
+          n.hinv[(size_t)q * n.ldg + p] = e;
+        }
+        if (tid == 0) {
+          n.hinv[(size_t)p * n.ldg + p] = inv;
+          n.plist[p] = slot; n.ppos[slot] = p; n.x[slot] = t;
+          st->np = p + 1;
+        }
+        done = true;
+      }
+    }
+    __syncthreads();
+  }
+  if (!done) {
+    // general active-set solve on S = support U {f}   (w[f] = 1 then active = w > 0: orthopursuit.py:38-39)
+    for (int j = tid; j < k1; j += blockDim.x) {
+      const bool in = (j == slot) || (a.act_w[j] > 0.0);
+      n.flag[j] = in ? FLAG_INS : 0;
+      if (n.ppos[j] < 0) n.x[j] = 0.0;
+    }
+    __syncthreads();
+    nnls_run(n, k1, tolscale, scratch);
+  }
+  __syncthreads();
   // candidate state: xw' and its error
   passive_combination(n, a.tmp, a.tmp + 4 * (size_t)d);
   double v[2] = {0.0, 0.0};
   for (int j = tid; j < d; j += blockDim.x) {
-    const double x = a.tmp[j], r = x - a.b[j];
-    v[0] += r * r; v[1] += x * x;
+    const double x = a.tmp[j], rr = x - a.b[j];
+    v[0] += rr * rr; v[1] += x * x;
   }
   block_allsum<2>(v, scratch);
   const double new_err = sqrt(v[0]);
   int status = BCX_IT_OK;
-  if (checked && new_err > st->err) status = BCX_IT_FAIL_MONOTONE;      // snnls.py:58
+  if (checked && new_err > err0) status = BCX_IT_FAIL_MONOTONE;      // snnls.py:58
   if (status == BCX_IT_OK) {
     for (int j = tid; j < k1; j += blockDim.x) a.act_w[j] = (n.ppos[j] >= 0) ? n.x[j] : 0.0;
     for (int j = tid; j < d; j += blockDim.x) a.xw[j] = a.tmp[j];
@@ -412,7 +478,7 @@ __global__ __launch_bounds__(NN_THREADS) void apply_omp_kernel(NnlsArgs n) {
       st->err = new_err;
       const double nwn = sqrt(v[1]);
       st->nw = nwn == 0.0 ? 1.0 : nwn;
-      st->since_refresh = 0;
+      st->since_refresh += 1;
       if (checked) st->retried = 0;
     }
   } else {
