@@ -5,9 +5,9 @@
     alg.build(1000); wts, pts, idcs = alg.get()
 
 Namespace mirrors bayesiancoresets/__init__.py:1-2 for the components on that path
-(SURVEY.md section 8); SparseVI / BPSVI coresets are out of scope of this engine."""
-from .coreset import Coreset, HilbertCoreset, UniformSamplingCoreset
-from .projector import BlackBoxProjector, Projector
+(SURVEY.md section 8); the batch pseudocoreset (BPSVI) is out of scope of this engine."""
+from .coreset import Coreset, HilbertCoreset, UniformSamplingCoreset, SparseVICoreset
+from .projector import BlackBoxProjector, Projector, DeviceProjector
 from . import snnls
 from . import util
 

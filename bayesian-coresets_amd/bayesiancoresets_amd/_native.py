@@ -21,8 +21,9 @@ SYMBOLS = (
     "bcx_create", "bcx_destroy", "bcx_last_error", "bcx_set_stream", "bcx_load_rows", "bcx_chunk_sums", "bcx_export_chunk_sums",
     "bcx_finalize", "bcx_build_begin", "bcx_step_scan", "bcx_step_apply", "bcx_build_enqueue", "bcx_build_poll",
     "bcx_step_scan_exact", "bcx_build_trace", "bcx_active_count", "bcx_get_weights", "bcx_error", "bcx_optimize",
-    "bcx_reset", "bcx_reached_numeric_limit", "bcx_get_vector", "bcx_get_norms", "bcx_time_scan",
+    "bcx_reset", "bcx_reached_numeric_limit", "bcx_get_vector", "bcx_get_norms", "bcx_argmax_correlation", "bcx_time_scan",
     "bcx_profile_scan", "bcx_profile_read", "bcx_version",
+    "bcx_project_write", "bcx_project_colsum", "bcx_project_select", "bcx_project_last_error",
 )
 
 
@@ -76,10 +77,17 @@ def load():
         "bcx_reached_numeric_limit": [vp, P(i32)],
         "bcx_get_vector": [vp, i32, vp],
         "bcx_get_norms": [vp, i64, i64, vp],
+        "bcx_argmax_correlation": [vp, vp, P(i64), P(dbl)],
         "bcx_time_scan": [vp, i32, i32, P(dbl), P(dbl)],
         "bcx_profile_scan": [vp, i32],
         "bcx_profile_read": [vp, P(dbl), P(i64)],
     }
+    proj_common = [vp, i32, vp, i64, i64, i32, i32, vp, i32, i32, dbl]
+    sigs["bcx_project_write"] = proj_common + [vp, i64, vp]
+    sigs["bcx_project_colsum"] = proj_common + [vp, vp]
+    sigs["bcx_project_select"] = proj_common + [vp, dbl, vp, vp]
+    lib.bcx_project_last_error.restype = ctypes.c_char_p
+    lib.bcx_project_last_error.argtypes = []
     for name, args in sigs.items():
         fn = getattr(lib, name)
         fn.argtypes = args
@@ -293,6 +301,14 @@ class Engine(object):
         if count:
             self._check(self.lib.bcx_get_norms(self.h, begin, count, out.ctypes.data))
         return out
+
+    def argmax_correlation(self, query):
+        q = np.ascontiguousarray(query, dtype=np.float64)
+        assert q.shape == (self.d,)
+        idx, score = ctypes.c_int64(), ctypes.c_double()
+        self._check(self.lib.bcx_argmax_correlation(self.h, ctypes.c_void_p(q.ctypes.data), ctypes.byref(idx),
+                                                    ctypes.byref(score)))
+        return idx.value, score.value
 
     # -- measurement ------------------------------------------------------
     def time_scan(self, reps=20, exact=False):

@@ -1,3 +1,4 @@
 from .coreset import Coreset
 from .hilbert import HilbertCoreset
 from .sampling import UniformSamplingCoreset
+from .sparsevi import SparseVICoreset

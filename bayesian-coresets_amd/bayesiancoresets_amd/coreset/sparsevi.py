@@ -1,0 +1,122 @@
+"""Sparse variational-inference coreset (reference: bayesiancoresets/coreset/sparsevi.py:6-79).
+
+Each greedy step re-projects the whole data set at the current weighted posterior, picks the point
+most correlated with the residual, then runs ``opt_itrs`` projected-ADAM steps on the weights, each
+of which needs the column sums of a fresh projection.  The host loop below is the reference's; the
+N-sized work runs on the GPU:
+
+* with a ``DeviceProjector`` nothing of size N x S is ever stored: ``project_colsum`` (gradient,
+  sparsevi.py:70-74) and ``project_select`` (correlation arg-max, sparsevi.py:49-56) are fused
+  projection kernels (csrc/proj.hip);
+* with any other projector (user callbacks produce a host array) the projected vectors are handed to
+  the same device engine as the Hilbert coresets: one ingest pass gives the row norms and column sums,
+  one correlation scan gives the arg-max (``bcx_argmax_correlation``).
+Random subsampling (``n_subsample_select`` / ``n_subsample_opt``) follows sparsevi.py:32-35.
+"""
+import numpy as np
+
+from .coreset import Coreset
+from ..util.opt import nn_opt
+from ..projector import DeviceProjector
+from .. import _native as nat
+
+
+class SparseVICoreset(Coreset):
+    def __init__(self, data, ll_projector, n_subsample_select=None, n_subsample_opt=None, opt_itrs=100,
+                 step_sched=lambda i: 1.0 / (1.0 + i), **kw):
+        self.data = data
+        self.ll_projector = ll_projector
+        n = data.shape[0]
+        self.n_subsample_select = None if n_subsample_select is None else min(n, n_subsample_select)
+        self.n_subsample_opt = None if n_subsample_opt is None else min(n, n_subsample_opt)
+        self.step_sched = step_sched
+        self.opt_itrs = opt_itrs
+        self._engine = None
+        super().__init__(**kw)
+        self.pts = np.zeros((0, data.shape[1]))
+
+    def reset(self):
+        super().reset()
+        self.pts = np.zeros((0, self.data.shape[1]))
+
+    def _build(self, itrs):
+        for _ in range(itrs):
+            self._select()
+            self._optimize()
+
+    # ---- N-sized pieces ------------------------------------------------------------
+    def _subsample(self, n_subsample):
+        if n_subsample is None:
+            return None, self.data, 1.0
+        sub = np.random.randint(self.data.shape[0], size=n_subsample)           # sparsevi.py:33
+        return sub, self.data[sub], self.data.shape[0] / n_subsample
+
+    def _engine_for(self, vecs):
+        """Hand host-resident projected vectors to the device engine: norms + column sums in one pass."""
+        n, s = vecs.shape
+        eng = self._engine
+        if eng is None or eng.n_local != n or eng.d != s:
+            if eng is not None:
+                eng.close()
+            eng = nat.Engine(nat.ALG_FW, n, s, keep_exact_rows=True)
+            self._engine = eng
+        eng.use_current_stream()
+        eng.load_rows_any(vecs)
+        rc = eng.finalize(None)
+        if rc not in (nat.OK, nat.ERR_ZERO_ROW):
+            raise nat.EngineError(rc, eng.lib.bcx_last_error(eng.h).decode())
+        return eng
+
+    def _corevecs(self):
+        if self.pts.shape[0] == 0:
+            return None
+        cv = self.ll_projector.project(self.pts)
+        return cv.cpu().numpy() if hasattr(cv, "cpu") else np.asarray(cv)
+
+    def _residual(self, n_subsample, w):
+        """(resid, sub_idcs, points, engine-or-None, corevecs) after updating the projector at (w, pts)."""
+        self.ll_projector.update(w, self.pts)                                     # sparsevi.py:25
+        sub, pts, scaling = self._subsample(n_subsample)
+        eng = None
+        if isinstance(self.ll_projector, DeviceProjector):
+            colsum = self.ll_projector.project_colsum(pts)
+        else:
+            vecs = self.ll_projector.project(pts)
+            eng = self._engine_for(np.ascontiguousarray(vecs))
+            colsum = eng.vector(0)                                                # vecs.sum(axis=0)
+        corevecs = self._corevecs()
+        S = colsum.shape[0]
+        if corevecs is None:
+            corevecs = np.zeros((0, S))
+        resid = scaling * colsum - w.dot(corevecs)                                # sparsevi.py:47 / :72
+        return resid, sub, pts, eng, corevecs
+
+    # ---- sparsevi.py:44-67 ------------------------------------------------------------
+    def _select(self):
+        resid, sub, pts, eng, corevecs = self._residual(self.n_subsample_select, self.wts)
+        S = resid.shape[0]
+        if eng is None:
+            best, row = self.ll_projector.project_select(pts, resid)
+        else:
+            row, score = eng.argmax_correlation(resid)                            # An . resid
+            best = score / S
+        if corevecs.shape[0]:
+            corecorrs = np.fabs(corevecs.dot(resid) / np.sqrt((corevecs ** 2).sum(axis=1))) / S
+        else:
+            corecorrs = np.zeros(0)
+        if corecorrs.size == 0 or best > corecorrs.max():                         # sparsevi.py:56
+            f = int(sub[row]) if sub is not None else int(row)
+            if f not in self.idcs:                                                # sparsevi.py:60
+                self.wts = np.append(self.wts, 0.0)
+                self.idcs = np.append(self.idcs, f).astype(np.int64)
+                self.pts = np.vstack((self.pts, self.data[f][None, :]))
+
+    # ---- sparsevi.py:69-76 ------------------------------------------------------------
+    def _optimize(self):
+        def grd(w):
+            resid, sub, pts, eng, corevecs = self._residual(self.n_subsample_opt, w)
+            return -corevecs.dot(resid) / corevecs.shape[1]
+        self.wts = nn_opt(self.wts, grd, opt_itrs=self.opt_itrs, step_sched=self.step_sched)
+
+    def error(self):
+        return 0.0   # as in the reference (sparsevi.py:78-79: KL estimate not implemented)

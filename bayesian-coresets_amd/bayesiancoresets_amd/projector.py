@@ -38,3 +38,120 @@ class BlackBoxProjector(Projector):
         glls = self.grad_loglikelihood(pts, self.samples)
         glls -= glls.mean(axis=2)[:, :, np.newaxis]
         return lls, glls
+
+
+class DeviceProjector(Projector):
+    """Monte-Carlo projection evaluated on the GPU for the reference's example likelihoods.
+
+    Same contract as ``BlackBoxProjector`` (projector.py:11-32): ``update(wts, pts)`` draws
+    ``samples = sampler(S, wts, pts)`` on the host (an S x D array), ``project(pts)`` returns the
+    N x S matrix of log-likelihoods minus their row means -- here as a ``torch`` tensor resident on the
+    GPU (fp64), produced by one fused kernel (Z Theta^T on the fp64 matrix cores + likelihood epilogue,
+    csrc/proj.hip).  ``HilbertCoreset`` ingests it without a host copy; ``SparseVICoreset`` uses the
+    two fused consumers ``project_colsum`` / ``project_select`` that never materialise N x S.
+
+    family: "logistic"  rows z = y*x,            model_lr.py:25-32
+            "poisson"   rows z = [x, y],         model_poiss.py:25-38
+            "linreg"    rows z = [x, y], sigsq,  model_linreg.py:4-10
+    """
+    FAMILIES = {"logistic": 0, "poisson": 1, "linreg": 2}
+
+    def __init__(self, family, sampler, projection_dimension, sigsq=1.0, device=0):
+        if family not in self.FAMILIES:
+            raise ValueError("family must be one of %s" % sorted(self.FAMILIES))
+        from . import _native
+        import torch
+        self._nat, self._torch = _native, torch
+        self._lib = _native.load()
+        if not torch.cuda.is_available():
+            raise RuntimeError("DeviceProjector needs a GPU (there is no CPU fallback)")
+        self.family, self._fam = family, self.FAMILIES[family]
+        self.sampler = sampler
+        self.projection_dimension = projection_dimension
+        self.sigsq = float(sigsq)
+        self.device = torch.device("cuda", device)
+        self._cache_key, self._cache_val = None, None
+        self._work = None
+        self.update(np.array([]), np.array([]))
+
+    # -- plumbing -----------------------------------------------------------
+    def _stream(self):
+        return int(self._torch.cuda.current_stream(self.device).cuda_stream)
+
+    def _check(self, rc):
+        if rc != 0:
+            raise self._nat.EngineError(rc, self._lib.bcx_project_last_error().decode())
+
+    def _dev(self, pts):
+        """Device copy of a host array, cached by identity (SparseVI projects the same ``data`` at
+        every step); device tensors pass through."""
+        torch = self._torch
+        if isinstance(pts, torch.Tensor):
+            t = pts.to(self.device, dtype=torch.float64)
+            return t if t.is_contiguous() else t.contiguous()
+        arr = np.atleast_2d(np.asarray(pts, dtype=np.float64))
+        key = (id(pts), arr.shape)
+        if arr.shape[0] >= 4096 and self._cache_key == key:
+            return self._cache_val
+        t = torch.from_numpy(np.ascontiguousarray(arr)).to(self.device)
+        if arr.shape[0] >= 4096:
+            self._cache_key, self._cache_val, self._cache_ref = key, t, pts
+        return t
+
+    def _dims(self, Z):
+        cols = Z.shape[1]
+        if self._fam == 0:
+            return cols, -1
+        return cols - 1, cols - 1
+
+    def _common(self, Z):
+        D, ycol = self._dims(Z)
+        if self.theta.shape[1] != D:
+            raise ValueError("sampler returned %d-dimensional parameters for %d features" % (self.theta.shape[1], D))
+        return [self._stream(), self._fam, Z.data_ptr(), Z.shape[0], Z.stride(0), D, ycol, self.theta.data_ptr(),
+                self.theta.shape[0], self.theta.stride(0), self.sigsq]
+
+    # -- Projector interface ---------------------------------------------------
+    def update(self, wts, pts):
+        self.samples = np.atleast_2d(np.asarray(self.sampler(self.projection_dimension, wts, pts), dtype=np.float64))
+        self.theta = self._torch.from_numpy(np.ascontiguousarray(self.samples)).to(self.device)
+
+    def project(self, pts, grad=False):
+        if grad:
+            raise NotImplementedError("gradient projections are not on the device path")
+        torch = self._torch
+        Z = self._dev(pts)
+        N, S = Z.shape[0], self.theta.shape[0]
+        out = torch.empty((N, S), dtype=torch.float64, device=self.device)
+        rowsum = torch.empty(max(N, 1), dtype=torch.float64, device=self.device)
+        if N:
+            self._check(self._lib.bcx_project_write(*self._common(Z), out.data_ptr(), S, rowsum.data_ptr()))
+        return out
+
+    # -- fused consumers (SparseVI) -------------------------------------------------
+    def _workspace(self, S):
+        torch = self._torch
+        if self._work is None or self._work.numel() < 2048 * max(S, 2):
+            self._work = torch.empty(2048 * max(S, 2), dtype=torch.float64, device=self.device)
+        return self._work
+
+    def project_colsum(self, pts):
+        """sum_n vecs[n, :] as a length-S ndarray, without forming vecs."""
+        torch = self._torch
+        Z = self._dev(pts)
+        S = self.theta.shape[0]
+        col = torch.empty(S, dtype=torch.float64, device=self.device)
+        self._check(self._lib.bcx_project_colsum(*self._common(Z), col.data_ptr(), self._workspace(S).data_ptr()))
+        return col.cpu().numpy()
+
+    def project_select(self, pts, resid):
+        """(max_n corr_n, arg-max row) with corr_n = vecs[n].resid / ||vecs[n]|| / S (first maximum)."""
+        torch = self._torch
+        Z = self._dev(pts)
+        S = self.theta.shape[0]
+        r = torch.from_numpy(np.ascontiguousarray(resid, dtype=np.float64)).to(self.device)
+        res = torch.empty(2, dtype=torch.float64, device=self.device)
+        self._check(self._lib.bcx_project_select(*self._common(Z), r.data_ptr(), float(np.sum(resid)), res.data_ptr(),
+                                                 self._workspace(S).data_ptr()))
+        h = res.cpu()
+        return float(h[0]), int(h[1:2].view(torch.int64)[0])

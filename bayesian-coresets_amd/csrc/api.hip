@@ -2,6 +2,7 @@
 #include <stdio.h>
 #include <string.h>
 #include <algorithm>
+#include <cmath>
 #include "bcx_internal.h"
 
 static thread_local std::string g_create_err;
@@ -478,6 +479,50 @@ extern "C" int bcx_time_scan(bcx_solver* s, int32_t reps, int32_t exact, double*
   if (ms_per_launch) *ms_per_launch = (double)ms / reps;
   const bool raw64 = exact && s->cfg.store_dtype == BCX_F32 && s->A64;
   if (bytes_per_launch) *bytes_per_launch = (double)s->cfg.n_local * s->cfg.d * (raw64 ? 8.0 : (double)s->elem);
+  return BCX_OK;
+}
+
+// One N-way correlation scan with a caller-supplied query: arg-max_n An[n] . q (first maximum) and the
+// exact fp64 score.  This is the select step of SparseVI on already projected vectors
+// (sparsevi.py:49-56: corrs = vecs.dot(resid)/||vecs||/S, argmax).  Single-query algorithms only.
+extern "C" int bcx_argmax_correlation(bcx_solver* s, const double* query_host, int64_t* idx, double* score) {
+  if (!s || !query_host || !idx || !score) return BCX_ERR_ARG;
+  if (!s->finalized) { s->err = "solver not finalized"; return BCX_ERR_STATE; }
+  if (s->cfg.alg == BCX_ALG_GIGA) { s->err = "bcx_argmax_correlation needs a single-query solver (FW/OMP)"; return BCX_ERR_ARG; }
+  BCX_HIP(hipSetDevice(s->cfg.device));
+  const int d = s->cfg.d;
+  DevState h;
+  int rc = read_state(s, &h);
+  if (rc != BCX_OK) return rc;
+  std::vector<double> q64((size_t)s->ld64, 0.0);
+  double qn = 0.0;
+  for (int j = 0; j < d; ++j) { q64[j] = query_host[j]; qn += query_host[j] * query_host[j]; }
+  BCX_HIP(hipMemcpy(s->q64, q64.data(), (size_t)s->ld64 * 8, hipMemcpyHostToDevice));
+  if (s->cfg.store_dtype == BCX_F64) {
+    std::vector<double> qs((size_t)s->ld, 0.0);
+    for (int j = 0; j < d; ++j) qs[j] = query_host[j];
+    BCX_HIP(hipMemcpy(s->qst, qs.data(), (size_t)s->ld * 8, hipMemcpyHostToDevice));
+  } else {
+    std::vector<float> qs((size_t)s->ld, 0.f);
+    for (int j = 0; j < d; ++j) qs[j] = (float)query_host[j];
+    BCX_HIP(hipMemcpy(s->qst, qs.data(), (size_t)s->ld * 4, hipMemcpyHostToDevice));
+  }
+  DevState forced = h;
+  forced.active = 1; forced.exact_mode = 0; forced.qscale = sqrt(qn);
+  double rec[BCX_REC_HDR];
+  for (int attempt = 0; attempt < 2; ++attempt) {
+    forced.exact_mode = attempt;
+    BCX_HIP(hipMemcpy(s->st, &forced, sizeof forced, hipMemcpyHostToDevice));
+    if ((rc = bcx_launch_scan(s, attempt))) return rc;
+    if ((rc = bcx_launch_resolve(s, s->rec_local, attempt))) return rc;
+    BCX_HIP(hipStreamSynchronize(s->stream));
+    BCX_HIP(hipMemcpy(rec, s->rec_local, sizeof rec, hipMemcpyDeviceToHost));
+    if (rec[3] != BCX_REC_OVERFLOW) break;
+  }
+  BCX_HIP(hipMemcpy(s->st, &h, sizeof h, hipMemcpyHostToDevice));
+  if (rec[3] != BCX_REC_VALID) { s->err = "no rows to scan"; return BCX_ERR_STATE; }
+  *idx = (int64_t)rec[1];
+  *score = rec[0];
   return BCX_OK;
 }
 

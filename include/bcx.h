@@ -135,12 +135,35 @@ int bcx_reached_numeric_limit(bcx_solver* s, int32_t* limit);
 int bcx_get_vector(bcx_solver* s, int32_t which, double* out);
 /* Copy row norms of local rows [begin, begin+count) (Anorms, frankwolfe.py:10). */
 int bcx_get_norms(bcx_solver* s, int64_t begin, int64_t count, double* out);
+/* One N-way correlation scan with a caller-supplied query (d doubles, host): *idx = arg-max_n of
+ * An[n] . query (first maximum, global row index), *score = its exact fp64 value.  The select step of
+ * SparseVI on projected vectors (sparsevi.py:49-56).  FW / OMP handles only. */
+int bcx_argmax_correlation(bcx_solver* s, const double* query_host, int64_t* idx, double* score);
 /* Time `reps` launches of the correlation-scan kernel alone with hipEvents on the solver's stream;
  * returns the mean milliseconds per launch and the algorithmic bytes one launch reads. */
 int bcx_time_scan(bcx_solver* s, int32_t reps, int32_t exact, double* ms_per_launch, double* bytes_per_launch);
 /* Sum of scan-kernel time recorded by hipEvents during bcx_build_enqueue (enable with on=1). */
 int bcx_profile_scan(bcx_solver* s, int32_t on);
 int bcx_profile_read(bcx_solver* s, double* scan_ms_total, int64_t* scan_launches);
+/* ---- device-native projection (projector.py:19-21 with the example likelihoods) --------------------
+ * vecs[n][s] = loglik(z_n, theta_s) - mean over s, for family 0 = logistic (model_lr.py:25-32),
+ * 1 = Poisson/softplus (model_poiss.py:25-38), 2 = Gaussian linear regression (model_linreg.py:4-10;
+ * param = sigma^2).  Z_dev: N x ldz doubles (features in columns [0, D), response in column ycol for
+ * families 1 and 2), theta_dev: S x ldt doubles.  Stateless; asynchronous on `stream`.
+ *   write  : vecs (N x S) into out_dev; rowsum_dev = N doubles scratch
+ *   colsum : sum_n vecs[n][s] without materialising vecs (sparsevi.py:70-74); work_dev = 2048*S doubles
+ *   select : arg-max_n vecs[n].resid / ||vecs[n]|| / S (sparsevi.py:49-51) -> result_dev = {double, int64};
+ *            work_dev = 2048 doubles + 2048 int64 */
+int bcx_project_write(void* stream, int32_t family, const void* Z_dev, int64_t N, int64_t ldz, int32_t D,
+                      int32_t ycol, const void* theta_dev, int32_t S, int32_t ldt, double param,
+                      void* out_dev, int64_t ldo, void* rowsum_dev);
+int bcx_project_colsum(void* stream, int32_t family, const void* Z_dev, int64_t N, int64_t ldz, int32_t D,
+                       int32_t ycol, const void* theta_dev, int32_t S, int32_t ldt, double param,
+                       void* colsum_dev, void* work_dev);
+int bcx_project_select(void* stream, int32_t family, const void* Z_dev, int64_t N, int64_t ldz, int32_t D,
+                       int32_t ycol, const void* theta_dev, int32_t S, int32_t ldt, double param,
+                       const void* resid_dev, double resid_sum, void* result_dev, void* work_dev);
+const char* bcx_project_last_error(void);
 /* Library/arch identification, e.g. "bcx 0.1 gfx950". */
 const char* bcx_version(void);
 
