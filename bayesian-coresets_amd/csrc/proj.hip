@@ -60,92 +60,143 @@ __device__ __forceinline__ double row16_sum(double v) {
   return v;
 }
 
+struct __attribute__((aligned(8))) pd2 { double x, y; };   // two consecutive k values, 8-byte aligned
+
+// Register-blocked: a wave owns 32 rows x 64 columns of the product at a time (2 x 4 MFMA tiles).  The four
+// k-slots of an MFMA step are fed from a permuted k order -- lane group lk supplies k = 8t + 2 lk (+1) to
+// steps 2t (2t+1) -- so every lane fetches its A and B operands for two steps with ONE 16-byte load:
+// 6 loads per 16 MFMAs instead of 2 loads per MFMA.
 template <int FAM, int MODE>
 __global__ __launch_bounds__(256) void proj_kernel(ProjArgs p) {
   extern __shared__ double lds[];            // COLSUM: 4 x S column accumulators
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int li = lane & 15, lk = lane >> 4;
   const int S = p.S, D = p.D;
-  const int ntile_c = (S + 15) / 16;
+  const int ngroup_c = (S + 63) / 64;
   double* colacc = lds + (size_t)wave * S;
   if (MODE == PMODE_COLSUM) {
     for (int c = lane; c < S; c += 64) colacc[c] = 0.0;
   }
   double bestv = -INFINITY;
   int64_t besti = 0x7fffffffffffffffLL;
-  const int64_t ntile_r = (p.N + 15) / 16;
-  for (int64_t tr = (int64_t)blockIdx.x * 4 + wave; tr < ntile_r; tr += (int64_t)gridDim.x * 4) {
-    const int64_t r0 = tr * 16;
-    const int64_t arow = r0 + li;
-    const bool avalid = arow < p.N;
-    const double* zrow = p.Z + (avalid ? arow : 0) * p.ldz;
-    // responses / per-row constants of the 4 rows this lane's accumulator registers belong to
-    double yv[4], c0[4];
+  const double clin = (FAM == FAM_LINREG) ? -0.5 * log(2.0 * 3.14159265358979323846 * p.param) : 0.0;
+  const int64_t nblk_r = (p.N + 31) / 32;
+  for (int64_t br = (int64_t)blockIdx.x * 4 + wave; br < nblk_r; br += (int64_t)gridDim.x * 4) {
+    const int64_t r0 = br * 32;
+    const double* zrow[2];
+    bool avalid[2];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int64_t row = r0 + lk + 4 * r;
-      const double y = (p.ycol >= 0 && row < p.N) ? p.Z[row * p.ldz + p.ycol] : 0.0;
-      yv[r] = y;
-      c0[r] = (FAM == FAM_POISSON) ? lgamma(y + 1.0)
-            : (FAM == FAM_LINREG) ? -0.5 * log(2.0 * 3.14159265358979323846 * p.param) : 0.0;
+    for (int tr = 0; tr < 2; ++tr) {
+      const int64_t arow = r0 + 16 * tr + li;
+      avalid[tr] = arow < p.N;
+      zrow[tr] = p.Z + (avalid[tr] ? arow : 0) * p.ldz;
     }
-    double rs[4] = {0, 0, 0, 0}, rq[4] = {0, 0, 0, 0}, rd[4] = {0, 0, 0, 0};
-    for (int ct = 0; ct < ntile_c; ++ct) {
-      const int bcol = ct * 16 + li;
-      const bool bvalid = bcol < S;
-      const double* trow = p.theta + (size_t)(bvalid ? bcol : 0) * p.ldt;
-      pv4d acc = {0.0, 0.0, 0.0, 0.0};
-      for (int k0 = 0; k0 < D; k0 += 4) {
-        const int k = k0 + lk;
-        const double av = (avalid && k < D) ? zrow[k] : 0.0;
-        const double bv = (bvalid && k < D) ? trow[k] : 0.0;
-        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc, 0, 0, 0);
-      }
-      // f64 C/D layout: col = lane & 15, row = (lane >> 4) + 4 * reg
-      const int col = ct * 16 + li;
-      const bool cvalid = col < S;
-      const double rsd = (MODE == PMODE_SELECT && cvalid) ? p.resid[col] : 0.0;
-      double csum = 0.0;
+    // responses / per-row constants of the 8 rows this lane's accumulator registers belong to
+    double yv[2][4], c0[2][4];
+#pragma unroll
+    for (int tr = 0; tr < 2; ++tr)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const int64_t row = r0 + lk + 4 * r;
-        const bool ok = cvalid && row < p.N;
-        const double ll = ok ? loglik<FAM>(acc[r], yv[r], p.param, c0[r]) : 0.0;
-        if (MODE == PMODE_WRITE) {
-          if (ok) p.out[row * p.ldo + col] = ll;
-          rs[r] += ll;
-        } else if (MODE == PMODE_COLSUM) {
-          csum += ll;
-        } else {
-          rs[r] += ll; rq[r] += ll * ll; rd[r] += ll * rsd;
-        }
+        const int64_t row = r0 + 16 * tr + lk + 4 * r;
+        const double y = (p.ycol >= 0 && row < p.N) ? p.Z[row * p.ldz + p.ycol] : 0.0;
+        yv[tr][r] = y;
+        c0[tr][r] = (FAM == FAM_POISSON) ? lgamma(y + 1.0) : clin;
       }
-      if (MODE == PMODE_COLSUM) {
-        // add the 4 lane groups that hold the same column (xor 16, xor 32)
-        csum += bcx_xor16_f64(csum);
-        csum += bcx_xor32_f64(csum);
-        if (lk == 0 && cvalid) colacc[col] += csum;
+    double rs[2][4] = {}, rq[2][4] = {}, rd[2][4] = {};
+    for (int cg = 0; cg < ngroup_c; ++cg) {
+      const double* trow[4];
+      bool bvalid[4];
+#pragma unroll
+      for (int tc = 0; tc < 4; ++tc) {
+        const int bcol = cg * 64 + 16 * tc + li;
+        bvalid[tc] = bcol < S;
+        trow[tc] = p.theta + (size_t)(bvalid[tc] ? bcol : 0) * p.ldt;
+      }
+      pv4d acc[2][4];
+#pragma unroll
+      for (int tr = 0; tr < 2; ++tr)
+#pragma unroll
+        for (int tc = 0; tc < 4; ++tc) acc[tr][tc] = (pv4d){0.0, 0.0, 0.0, 0.0};
+      for (int k0 = 0; k0 < D; k0 += 8) {
+        const int k = k0 + 2 * lk;
+        pd2 av[2], bv[4];
+        if (k + 1 < D) {
+#pragma unroll
+          for (int tr = 0; tr < 2; ++tr) av[tr] = *(const pd2*)(zrow[tr] + k);
+#pragma unroll
+          for (int tc = 0; tc < 4; ++tc) bv[tc] = *(const pd2*)(trow[tc] + k);
+        } else {
+#pragma unroll
+          for (int tr = 0; tr < 2; ++tr) { av[tr].x = k < D ? zrow[tr][k] : 0.0; av[tr].y = 0.0; }
+#pragma unroll
+          for (int tc = 0; tc < 4; ++tc) { bv[tc].x = k < D ? trow[tc][k] : 0.0; bv[tc].y = 0.0; }
+        }
+#pragma unroll
+        for (int tr = 0; tr < 2; ++tr) if (!avalid[tr]) { av[tr].x = 0.0; av[tr].y = 0.0; }
+#pragma unroll
+        for (int tc = 0; tc < 4; ++tc) if (!bvalid[tc]) { bv[tc].x = 0.0; bv[tc].y = 0.0; }
+#pragma unroll
+        for (int tr = 0; tr < 2; ++tr)
+#pragma unroll
+          for (int tc = 0; tc < 4; ++tc) {
+            acc[tr][tc] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[tr].x, bv[tc].x, acc[tr][tc], 0, 0, 0);
+            acc[tr][tc] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[tr].y, bv[tc].y, acc[tr][tc], 0, 0, 0);
+          }
+      }
+      // f64 C/D layout: col = lane & 15, row = (lane >> 4) + 4 * reg
+#pragma unroll
+      for (int tc = 0; tc < 4; ++tc) {
+        const int col = cg * 64 + 16 * tc + li;
+        const bool cvalid = col < S;
+        const double rsd = (MODE == PMODE_SELECT && cvalid) ? p.resid[col] : 0.0;
+        double csum = 0.0;
+#pragma unroll
+        for (int tr = 0; tr < 2; ++tr)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int64_t row = r0 + 16 * tr + lk + 4 * r;
+            const bool ok = cvalid && row < p.N;
+            const double ll = ok ? loglik<FAM>(acc[tr][tc][r], yv[tr][r], p.param, c0[tr][r]) : 0.0;
+            if (MODE == PMODE_WRITE) {
+              if (ok) p.out[row * p.ldo + col] = ll;
+              rs[tr][r] += ll;
+            } else if (MODE == PMODE_COLSUM) {
+              csum += ll;
+            } else {
+              rs[tr][r] += ll; rq[tr][r] += ll * ll; rd[tr][r] += ll * rsd;
+            }
+          }
+        if (MODE == PMODE_COLSUM) {
+          // add the 4 lane groups that hold the same column (xor 16, xor 32)
+          csum += bcx_xor16_f64(csum);
+          csum += bcx_xor32_f64(csum);
+          if (lk == 0 && cvalid) colacc[col] += csum;
+        }
       }
     }
     if (MODE == PMODE_WRITE) {
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const double t = row16_sum(rs[r]);
-        const int64_t row = r0 + lk + 4 * r;
-        if (li == 0 && row < p.N) p.rowsum[row] = t;
-      }
+      for (int tr = 0; tr < 2; ++tr)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const double t = row16_sum(rs[tr][r]);
+          const int64_t row = r0 + 16 * tr + lk + 4 * r;
+          if (li == 0 && row < p.N) p.rowsum[row] = t;
+        }
     }
     if (MODE == PMODE_SELECT) {
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const double s1 = row16_sum(rs[r]), s2 = row16_sum(rq[r]), sd = row16_sum(rd[r]);
-        const int64_t row = r0 + lk + 4 * r;
-        const double mean = s1 / (double)S;
-        const double dot = sd - mean * p.resid_sum;                  // (ll - mean) . resid
-        const double nrm2 = s2 - (double)S * mean * mean;            // ||ll - mean||^2
-        const double corr = dot / sqrt(nrm2) / (double)S;            // sparsevi.py:51
-        if (row < p.N && (corr > bestv || (corr == bestv && row < besti))) { bestv = corr; besti = row; }
-      }
+      for (int tr = 0; tr < 2; ++tr)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const double s1 = row16_sum(rs[tr][r]), s2 = row16_sum(rq[tr][r]), sd = row16_sum(rd[tr][r]);
+          const int64_t row = r0 + 16 * tr + lk + 4 * r;
+          const double mean = s1 / (double)S;
+          const double dot = sd - mean * p.resid_sum;                  // (ll - mean) . resid
+          const double nrm2 = s2 - (double)S * mean * mean;            // ||ll - mean||^2
+          const double corr = dot / sqrt(nrm2) / (double)S;            // sparsevi.py:51
+          if (row < p.N && (corr > bestv || (corr == bestv && row < besti))) { bestv = corr; besti = row; }
+        }
     }
   }
   if (MODE == PMODE_COLSUM) {
@@ -229,7 +280,7 @@ extern "C" const char* bcx_project_last_error(void) { return g_proj_err.c_str();
   } while (0)
 
 static int proj_grid(int64_t N) {
-  int64_t tiles = (N + 15) / 16;
+  int64_t tiles = (N + 31) / 32;
   int64_t wg = (tiles + 3) / 4;
   if (wg > 2048) wg = 2048;
   if (wg < 1) wg = 1;

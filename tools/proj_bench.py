@@ -1,0 +1,31 @@
+"""dev: time the fused projection kernels (csrc/proj.hip)."""
+import sys, os, time
+import numpy as np
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "bayesian-coresets_amd"))
+import torch
+import bayesiancoresets_amd as bc
+
+def run(family, N, D, S, reps=5):
+    rs = np.random.RandomState(0)
+    cols = D if family == "logistic" else D + 1
+    Z = torch.randn(N, cols, dtype=torch.float64, device="cuda")
+    if family == "poisson":
+        Z[:, -1] = torch.poisson(torch.ones(N, dtype=torch.float64, device="cuda"))
+    theta = 0.1 * rs.randn(S, D)
+    prj = bc.DeviceProjector(family, lambda n, w, p: theta, S, sigsq=1.0)
+    resid = rs.randn(S)
+    for name, fn in (("colsum", lambda: prj.project_colsum(Z)), ("select", lambda: prj.project_select(Z, resid)),
+                     ("write", lambda: prj.project(Z))):
+        fn(); torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(reps): fn()
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / reps
+        fl = 2.0 * N * D * S
+        print("%-8s %-6s N=%d D=%d S=%d: %.2f ms  %.1f TFLOP/s(gemm)  %.2f Gelem/s" % (family, name, N, D, S, dt * 1e3, fl / dt / 1e12, N * S / dt / 1e9), flush=True)
+
+if __name__ == "__main__":
+    run("linreg", 1000000, 300, 256)
+    run("logistic", 1000000, 10, 512)
+    run("poisson", 1000000, 16, 256)
+    run("linreg", 1000000, 32, 64)
