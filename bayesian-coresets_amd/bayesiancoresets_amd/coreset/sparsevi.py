@@ -23,7 +23,17 @@ from .. import _native as nat
 
 class SparseVICoreset(Coreset):
     def __init__(self, data, ll_projector, n_subsample_select=None, n_subsample_opt=None, opt_itrs=100,
-                 step_sched=lambda i: 1.0 / (1.0 + i), **kw):
+                 step_sched=lambda i: 1.0 / (1.0 + i), *, row_offset=0, group=None, **kw):
+        """``row_offset`` / ``group`` (keyword-only extension): row-sharded construction, one process per
+        GPU.  ``data`` is then this rank's contiguous block of rows starting at global row
+        ``row_offset``, the projector must be a ``DeviceProjector`` built with the same ``group`` and
+        ``row_offset``, and every rank must seed NumPy identically (the sampler is replicated)."""
+        self.row_offset, self.group = int(row_offset), group
+        self._sharded = group is not None
+        if self._sharded and (n_subsample_select is not None or n_subsample_opt is not None):
+            raise ValueError("random subsampling is not supported in row-sharded mode")
+        if self._sharded and not isinstance(ll_projector, DeviceProjector):
+            raise ValueError("row-sharded SparseVI needs a DeviceProjector")
         self.data = data
         self.ll_projector = ll_projector
         n = data.shape[0]
@@ -109,7 +119,20 @@ class SparseVICoreset(Coreset):
             if f not in self.idcs:                                                # sparsevi.py:60
                 self.wts = np.append(self.wts, 0.0)
                 self.idcs = np.append(self.idcs, f).astype(np.int64)
-                self.pts = np.vstack((self.pts, self.data[f][None, :]))
+                self.pts = np.vstack((self.pts, self._fetch_row(f)[None, :]))
+
+    def _fetch_row(self, f):
+        """data[f] for a global row index; in sharded mode the owning rank supplies it."""
+        if not self._sharded:
+            return np.asarray(self.data[f])
+        import torch
+        import torch.distributed as dist
+        lo = self.row_offset
+        buf = torch.zeros(self.data.shape[1], dtype=torch.float64, device=self.ll_projector.device)
+        if lo <= f < lo + self.data.shape[0]:
+            buf.copy_(torch.from_numpy(np.ascontiguousarray(self.data[f - lo], dtype=np.float64)))
+        dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group)
+        return buf.cpu().numpy()
 
     # ---- sparsevi.py:69-76 ------------------------------------------------------------
     def _optimize(self):

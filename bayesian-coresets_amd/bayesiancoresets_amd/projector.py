@@ -56,7 +56,11 @@ class DeviceProjector(Projector):
     """
     FAMILIES = {"logistic": 0, "poisson": 1, "linreg": 2}
 
-    def __init__(self, family, sampler, projection_dimension, sigsq=1.0, device=0):
+    def __init__(self, family, sampler, projection_dimension, sigsq=1.0, device=0, group=None, row_offset=0):
+        """``group`` / ``row_offset``: row-sharded use (one process per GPU, every rank constructs the
+        projector with the same sampler and seeds): ``pts`` passed to the fused consumers are this
+        rank's rows starting at global row ``row_offset``; column sums are all-reduced and the arg-max
+        is taken over all ranks (lowest global row wins ties)."""
         if family not in self.FAMILIES:
             raise ValueError("family must be one of %s" % sorted(self.FAMILIES))
         from . import _native
@@ -70,6 +74,10 @@ class DeviceProjector(Projector):
         self.projection_dimension = projection_dimension
         self.sigsq = float(sigsq)
         self.device = torch.device("cuda", device)
+        self.group, self.row_offset = group, int(row_offset)
+        self._world = 1
+        if group is not None or (torch.distributed.is_available() and torch.distributed.is_initialized()):
+            self._world = torch.distributed.get_world_size(group)
         self._cache_key, self._cache_val = None, None
         self._work = None
         self.update(np.array([]), np.array([]))
@@ -141,7 +149,14 @@ class DeviceProjector(Projector):
         Z = self._dev(pts)
         S = self.theta.shape[0]
         col = torch.empty(S, dtype=torch.float64, device=self.device)
-        self._check(self._lib.bcx_project_colsum(*self._common(Z), col.data_ptr(), self._workspace(S).data_ptr()))
+        if Z.shape[0]:
+            self._check(self._lib.bcx_project_colsum(*self._common(Z), col.data_ptr(), self._workspace(S).data_ptr()))
+        else:
+            col.zero_()
+        if self._world > 1:
+            # every rank applied the centring correction with ITS raw sums; the correction is linear, so
+            # the all-reduced vector is the centred global column sum
+            torch.distributed.all_reduce(col, op=torch.distributed.ReduceOp.SUM, group=self.group)
         return col.cpu().numpy()
 
     def project_select(self, pts, resid):
@@ -151,7 +166,23 @@ class DeviceProjector(Projector):
         S = self.theta.shape[0]
         r = torch.from_numpy(np.ascontiguousarray(resid, dtype=np.float64)).to(self.device)
         res = torch.empty(2, dtype=torch.float64, device=self.device)
-        self._check(self._lib.bcx_project_select(*self._common(Z), r.data_ptr(), float(np.sum(resid)), res.data_ptr(),
-                                                 self._workspace(S).data_ptr()))
-        h = res.cpu()
-        return float(h[0]), int(h[1:2].view(torch.int64)[0])
+        if Z.shape[0]:
+            self._check(self._lib.bcx_project_select(*self._common(Z), r.data_ptr(), float(np.sum(resid)), res.data_ptr(),
+                                                     self._workspace(S).data_ptr()))
+            h = res.cpu()
+            best, row = float(h[0]), int(h[1:2].view(torch.int64)[0]) + self.row_offset
+        else:
+            best, row = -np.inf, -1
+        if self._world > 1:
+            mine = torch.tensor([best, float(row)], dtype=torch.float64, device=self.device)
+            allr = torch.empty(2 * self._world, dtype=torch.float64, device=self.device)
+            try:
+                torch.distributed.all_gather_into_tensor(allr, mine, group=self.group)
+            except (RuntimeError, NotImplementedError):
+                torch.distributed.all_gather(list(allr.view(self._world, 2).unbind(0)), mine, group=self.group)
+            recs = allr.cpu().numpy().reshape(self._world, 2)
+            best, row = -np.inf, -1
+            for v, i in recs:
+                if i >= 0 and (v > best or (v == best and i < row) or row < 0):
+                    best, row = float(v), int(i)
+        return best, row
