@@ -235,17 +235,32 @@ __global__ __launch_bounds__(256) void center_kernel(double* out, int64_t ldo, c
   }
 }
 
-// colsum[s] = sum over partials (fixed order), then the centring correction
-//   sum_n (ll[n][s] - mean_n) = raw[s] - (1/S) sum_s' raw[s']
-__global__ __launch_bounds__(256) void colsum_final_kernel(const double* part, int nparts, int S, double* colsum) {
+// colsum[s] = sum over the workgroup partials in a fixed order: one workgroup per 64 columns, four
+// partial-index segments per column combined 0..3 (8 independent loads in flight per thread).
+__global__ __launch_bounds__(256) void colsum_reduce_kernel(const double* part, int nparts, int S, double* colsum) {
+  __shared__ double seg[4][64];
+  const int c = blockIdx.x * 64 + (threadIdx.x & 63), sg = threadIdx.x >> 6;
+  double acc = 0.0;
+  if (c < S) {
+    int b = sg;
+    for (; b + 28 < nparts; b += 32) {
+      double v[8];
+#pragma unroll
+      for (int t = 0; t < 8; ++t) v[t] = part[(size_t)(b + 4 * t) * S + c];
+#pragma unroll
+      for (int t = 0; t < 8; ++t) acc += v[t];
+    }
+    for (; b < nparts; b += 4) acc += part[(size_t)b * S + c];
+  }
+  seg[sg][threadIdx.x & 63] = acc;
+  __syncthreads();
+  if (sg == 0 && c < S) colsum[c] = ((seg[0][threadIdx.x] + seg[1][threadIdx.x]) + seg[2][threadIdx.x]) + seg[3][threadIdx.x];
+}
+// the centring correction  sum_n (ll[n][s] - mean_n) = raw[s] - (1/S) sum_s' raw[s']
+__global__ __launch_bounds__(256) void colsum_center_kernel(int S, double* colsum) {
   __shared__ double scratch[BCX_SCRATCH];
   double tot[1] = {0.0};
-  for (int c = threadIdx.x; c < S; c += blockDim.x) {
-    double acc = 0.0;
-    for (int b = 0; b < nparts; ++b) acc += part[(size_t)b * S + c];
-    colsum[c] = acc;
-    tot[0] += acc;
-  }
+  for (int c = threadIdx.x; c < S; c += blockDim.x) tot[0] += colsum[c];
   block_allsum<1>(tot, scratch);
   const double corr = tot[0] / (double)S;
   for (int c = threadIdx.x; c < S; c += blockDim.x) colsum[c] -= corr;
@@ -348,7 +363,8 @@ extern "C" int bcx_project_colsum(void* stream, int32_t family, const void* Z_de
   const int grid = proj_grid(N);
   p.colpart = (double*)work_dev;
   if ((rc = launch_family<PMODE_COLSUM>(family, dim3(grid), 4 * (size_t)S * sizeof(double), st, p))) return rc;
-  hipLaunchKernelGGL(colsum_final_kernel, dim3(1), dim3(256), 0, st, p.colpart, grid, S, (double*)colsum_dev);
+  hipLaunchKernelGGL(colsum_reduce_kernel, dim3((S + 63) / 64), dim3(256), 0, st, p.colpart, grid, S, (double*)colsum_dev);
+  hipLaunchKernelGGL(colsum_center_kernel, dim3(1), dim3(256), 0, st, S, (double*)colsum_dev);
   PROJ_HIP(hipGetLastError());
   return BCX_OK;
 }

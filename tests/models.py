@@ -4,6 +4,7 @@ projection tests; the product never imports this):
   poisson    examples/common/model_poiss.py:25-38
   linreg     examples/common/model_linreg.py:4-10, weighted posterior :24-37"""
 import numpy as np
+import scipy.linalg as sl
 from scipy.special import gammaln
 
 from lr_workload import log_likelihood as logistic_log_likelihood  # noqa: F401
@@ -31,12 +32,12 @@ def linreg_weighted_post(th0, Sig0inv, sigsq, z, w):
         z = np.atleast_2d(z)
         X, Y = z[:, :-1], z[:, -1]
         L = np.linalg.cholesky(Sig0inv + (w[:, None] * X).T.dot(X) / sigsq)
-        U = np.linalg.solve(L, np.eye(L.shape[0])).T
+        U = sl.solve_triangular(L, np.eye(L.shape[0]), lower=True, check_finite=False).T
         mu = U.dot(U.T).dot(Sig0inv.dot(th0) + (w[:, None] * Y[:, None] * X).sum(axis=0) / sigsq)
     else:
         mu = th0
         L = np.linalg.cholesky(Sig0inv)
-        U = np.linalg.solve(L, np.eye(L.shape[0])).T
+        U = sl.solve_triangular(L, np.eye(L.shape[0]), lower=True, check_finite=False).T
     return mu, U
 
 
