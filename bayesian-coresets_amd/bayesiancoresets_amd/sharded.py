@@ -117,8 +117,11 @@ class ShardedSolver(object):
             return None
         remaining = itrs
         while True:
-            for _ in range(remaining):
-                self._one_iteration()
+            if self.world == 1 and hasattr(self.engine, "enqueue"):
+                self.engine.enqueue(remaining)       # single shard: scan + merged resolve/apply launches
+            else:
+                for _ in range(remaining):
+                    self._one_iteration()
             done, need_exact, limit = self.engine.poll()   # replicated state: same answer on every rank
             if need_exact:
                 self._one_iteration(exact=True)

@@ -102,9 +102,17 @@ def main():
         raise SystemExit("--gpus %d does not match WORLD_SIZE %d" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (no CPU fallback)")
+    # BENCH_SHARE_GPU=1 (testing only): all ranks share cuda:0 and talk over gloo -- RCCL refuses two ranks
+    # on one device; the driver's multi-GPU runs use one GPU per rank over RCCL ("nccl").
+    share = os.environ.get("BENCH_SHARE_GPU") == "1"
+    if share:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if share:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     alg = {"giga": nat.ALG_GIGA, "fw": nat.ALG_FW, "omp": nat.ALG_OMP}[args.alg]
     store = nat.F64 if args.dtype == "float64" else nat.F32
 
