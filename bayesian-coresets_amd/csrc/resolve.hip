@@ -132,13 +132,15 @@ static __device__ void resolve_core(const ResolveArgs& a, Winner* win, double* x
     const double nrm = a.norms[i];
     double s0 = 0.0, s1 = 0.0;
     for (int j = lane; j < a.d; j += 64) {
-      const double v = raw_elem(a, i, j, 1.0);
+      // An = A / Anorms element by element (giga.py:13): exactly +-1 for d = 1, so mathematically tied
+      // rows tie bit-for-bit as they do in the reference; stored rows are already normalised
+      double v = raw_elem(a, i, j, 1.0);
+      if (a.A64) v /= nrm;
       s0 += v * q0[j];
       if (dual) s1 += v * q1[j];
     }
     s0 = wave_allsum(s0);
     if (dual) s1 = wave_allsum(s1);
-    if (a.A64) { s0 /= nrm; s1 /= nrm; }     // An = A / Anorms (giga.py:13); stored rows are already normalised
     if (lane == 0) cscore[c] = dual ? giga_score64(s0, s1) : s0;
   }
   __syncthreads();

@@ -220,6 +220,13 @@ __global__ __launch_bounds__(BCX_SCAN_THREADS) void scan_kernel(ScanArgs a) {
       const V* p = base + rc * a.ldv;
 #pragma unroll
       for (int c = 0; c < CH; ++c) x[u][c] = p[voff[c]];
+      if constexpr (sizeof(T) == 8) {
+        if (a.norms) {   // raw fp64 rows: An = A / Anorms element by element (giga.py:13)
+          const double nr = a.norms[rc];
+#pragma unroll
+          for (int c = 0; c < CH; ++c) { x[u][c].x /= nr; x[u][c].y /= nr; }
+        }
+      }
     }
     // keep all CH*UR loads of the trip in flight: without this fence hipcc interleaves load/wait/FMA
     // through one register quad to save VGPRs, which serialises the HBM round trips of a wave
@@ -256,11 +263,6 @@ __global__ __launch_bounds__(BCX_SCAN_THREADS) void scan_kernel(ScanArgs a) {
         }
         s0 = group_allsum<T, G>(s0);
         if (DUAL) s1 = group_allsum<T, G>(s1);
-        if (sizeof(T) == 8 && a.norms) {
-          const T nr = (T)a.norms[row[u] < n ? row[u] : n - 1];
-          s0 /= nr;
-          if (DUAL) s1 /= nr;
-        }
         T U, L;
         if (sizeof(T) == 4) {
           if (DUAL) {

@@ -282,3 +282,87 @@ def test_F3_harness_trial1(bc, golden, normal_inputs, alg):
         assert np.array_equal(idcs, golden[k + "idcs"])
         np.testing.assert_allclose(wts, golden[k + "wts"], rtol=WEIGHT_RTOL,
                                    atol=WEIGHT_ATOL_REL * golden[k + "wts"].max())
+
+
+# ---- edge cases: ragged / tiny / maximal shapes, subsampling, empty input ------------------------------
+@pytest.mark.parametrize("N,d", ((1, 1), (5, 3), (1023, 7), (1025, 33), (2049, 1), (3000, 2048), (4097, 129)))
+@pytest.mark.parametrize("alg", ("giga", "fw", "omp"))
+def test_ragged_and_extreme_shapes(bc, alg, N, d):
+    from oracle.snnls_oracle import SnnlsOracle
+    X = np.random.RandomState(N * 31 + d).randn(N, d)
+    itrs = min(12, N + 2)
+    o = SnnlsOracle(X.T, X.sum(axis=0), alg=alg)
+    o.build(itrs)
+    s = _run(bc, X, alg, itrs)
+    sel, err, status = s.last_trace
+    otrace = o.trace
+    # compare while the oracle's error is above rounding noise (tiny problems converge exactly)
+    scale = np.sqrt((X.sum(axis=0) ** 2).sum())
+    n = 0
+    for t in otrace:
+        if t[2] != 0 or t[1] < 1e-9 * scale:
+            break
+        n += 1
+    n = max(n, 1)
+    assert np.array_equal(sel[:n], np.array([t[0] for t in otrace[:n]]))
+    np.testing.assert_allclose(err[:n], np.array([t[1] for t in otrace[:n]]), rtol=1e-7, atol=1e-9 * scale)
+
+
+def test_empty_input_warns_and_returns(bc):
+    """snnls.py:36-38: no data -> build() returns at once."""
+    X = np.zeros((0, 4))
+    s = bc.snnls.FrankWolfe(X.T, np.zeros(4))
+    s.build(5)
+    assert s.size() == 0 and s.weights().shape == (0,)
+
+
+def test_hilbert_subsample_branch(bc):
+    """hilbert.py:13-22: unique(randint) subsample, zero vectors dropped, indices map back to the data."""
+    from oracle.snnls_oracle import SnnlsOracle, hilbert_readout
+    X = np.random.RandomState(77).randn(6000, 24)
+    X[10] = 0.0
+    X[4000] = 0.0
+
+    class IDProjector(bc.Projector):
+        def update(self, wts, pts):
+            pass
+
+        def project(self, pts, grad=False):
+            return pts
+
+    np.random.seed(5)
+    c = bc.HilbertCoreset(X, IDProjector(), n_subsample=3000, snnls=bc.snnls.GIGA)
+    np.random.seed(5)
+    sub = np.unique(np.random.randint(6000, size=3000))
+    sub = sub[np.sqrt((X[sub] ** 2).sum(axis=1)) > 0]
+    assert np.array_equal(c.sub_idcs, sub)
+    c.build(20)
+    wts, pts, idcs = c.get()
+    V = X[sub]
+    o = SnnlsOracle(V.T, V.sum(axis=0), alg="giga")
+    o.build(20)
+    ow, oidx = hilbert_readout(o.weights(), sub)
+    assert np.array_equal(idcs, oidx)
+    np.testing.assert_allclose(wts, ow, rtol=WEIGHT_RTOL)
+    assert np.array_equal(pts, X[idcs])
+
+
+def test_float32_and_torch_inputs(bc):
+    """Rows may arrive as float32 host arrays or as torch tensors already resident on the GPU."""
+    import torch
+    from oracle.snnls_oracle import SnnlsOracle
+    X = np.random.RandomState(8).randn(5000, 48)
+    o = SnnlsOracle(X.T, X.sum(axis=0), alg="fw")
+    o.build(15)
+    want = np.array([t[0] for t in o.trace])
+    Xd = torch.from_numpy(X).cuda()
+    s = bc.snnls.FrankWolfe(Xd.t(), None)          # b from the device column sums
+    s.build(15)
+    assert np.array_equal(s.last_trace[0], want)
+    np.testing.assert_allclose(s._eng.vector(0), X.sum(axis=0), rtol=1e-12, atol=1e-12)
+    X32 = X.astype(np.float32)
+    o32 = SnnlsOracle(X32.astype(np.float64).T, X32.astype(np.float64).sum(axis=0), alg="fw")
+    o32.build(15)
+    s32 = bc.snnls.FrankWolfe(X32.T, X32.astype(np.float64).sum(axis=0))
+    s32.build(15)
+    assert np.array_equal(s32.last_trace[0], np.array([t[0] for t in o32.trace]))
