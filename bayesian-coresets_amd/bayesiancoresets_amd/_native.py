@@ -10,7 +10,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(os.path.dirname(_HERE), "lib", "libbcx.so")
 
 ALG_GIGA, ALG_FW, ALG_OMP = 0, 1, 2
-F32, F64 = 0, 1
+F32, F64, F16 = 0, 1, 2
 OK, ERR_ARG, ERR_HIP, ERR_ZERO_ROW, ERR_ZERO_B, ERR_NOMEM, ERR_STATE = 0, -1, -2, -3, -4, -5, -6
 IT_OK, IT_FAIL_SELECT, IT_FAIL_REWEIGHT, IT_FAIL_MONOTONE = 0, 1, 2, 3
 REC_HDR = 4

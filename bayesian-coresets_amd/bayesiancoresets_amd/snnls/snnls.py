@@ -51,7 +51,8 @@ class SparseNNLS(object):
             raise NotImplementedError("SparseNNLS is abstract; use GIGA, FrankWolfe or OrthoPursuit")
         kind, rows = _as_row_matrix(A)
         self._N, self._d = int(rows.shape[0]), int(rows.shape[1])
-        store = nat.F64 if str(dtype) in ("float64", "f64", "double") else nat.F32
+        dt = str(dtype)
+        store = nat.F64 if dt in ("float64", "f64", "double") else (nat.F16 if dt in ("float16", "f16", "half") else nat.F32)
         eng = nat.Engine(self._ALG, self._N, self._d, device=device, store_dtype=store,
                          keep_exact_rows=keep_exact_rows)
         self._eng = eng

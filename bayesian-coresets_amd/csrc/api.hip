@@ -37,7 +37,7 @@ extern "C" int bcx_create(const bcx_config* cfg, bcx_solver** out) {
   *out = nullptr;
   if (cfg->alg < BCX_ALG_GIGA || cfg->alg > BCX_ALG_OMP || cfg->d < 1 || cfg->n_local < 0 ||
       cfg->world_size < 1 || cfg->rank < 0 || cfg->rank >= cfg->world_size ||
-      (cfg->store_dtype != BCX_F32 && cfg->store_dtype != BCX_F64)) {
+      (cfg->store_dtype != BCX_F32 && cfg->store_dtype != BCX_F64 && cfg->store_dtype != BCX_F16)) {
     g_create_err = "bcx_create: invalid configuration";
     return BCX_ERR_ARG;
   }
@@ -55,14 +55,15 @@ extern "C" int bcx_create(const bcx_config* cfg, bcx_solver** out) {
   if (e != hipSuccess) { g_create_err = std::string("hipSetDevice: ") + hipGetErrorString(e); delete s; return BCX_ERR_HIP; }
   const int d = cfg->d;
   const int64_t n = cfg->n_local;
-  s->elem = cfg->store_dtype == BCX_F32 ? 4 : 8;
+  s->elem = cfg->store_dtype == BCX_F32 ? 4 : (cfg->store_dtype == BCX_F16 ? 2 : 8);
+  s->qelem = cfg->store_dtype == BCX_F64 ? 8 : 4;   // the query the scan reads: fp32 for fp32/fp16 rows
   s->ld = round_up(d, 16 / s->elem);
   s->ld64 = round_up(d, 2);
   s->n_chunks = (n + BCX_CHUNK_ROWS - 1) / BCX_CHUNK_ROWS;
   bool ok = true;
   auto chk = [&](hipError_t r) { if (r != hipSuccess && ok) { ok = false; g_create_err = std::string("hipMalloc: ") + hipGetErrorString(r); } };
   chk(dev_alloc((char**)&s->An, (size_t)n * s->ld * s->elem));
-  if (cfg->keep_exact_rows && cfg->store_dtype == BCX_F32) chk(dev_alloc(&s->A64, (size_t)n * s->ld64));
+  if (cfg->keep_exact_rows && cfg->store_dtype != BCX_F64) chk(dev_alloc(&s->A64, (size_t)n * s->ld64));
   chk(dev_alloc(&s->norms, (size_t)n));
   chk(dev_alloc(&s->chunk_sums, (size_t)s->n_chunks * (d + 1)));
   chk(dev_alloc(&s->st, 1));
@@ -70,7 +71,7 @@ extern "C" int bcx_create(const bcx_config* cfg, bcx_solver** out) {
   chk(dev_alloc(&s->bn, (size_t)d));
   chk(dev_alloc(&s->xw, (size_t)d));
   chk(dev_alloc(&s->q64, (size_t)2 * s->ld64));
-  chk(dev_alloc((char**)&s->qst, (size_t)2 * s->ld * s->elem));
+  chk(dev_alloc((char**)&s->qst, (size_t)2 * s->ld * s->qelem));
   chk(dev_alloc(&s->tmp, (size_t)20 * d));
   s->n_partials = bcx_scan_grid(s);
   chk(dev_alloc((char**)&s->partials, (size_t)s->n_partials * BCX_PARTIAL_BYTES));
@@ -477,7 +478,7 @@ extern "C" int bcx_time_scan(bcx_solver* s, int32_t reps, int32_t exact, double*
   BCX_HIP(hipEventDestroy(e1));
   BCX_HIP(hipMemcpy(s->st, &h, sizeof h, hipMemcpyHostToDevice));
   if (ms_per_launch) *ms_per_launch = (double)ms / reps;
-  const bool raw64 = exact && s->cfg.store_dtype == BCX_F32 && s->A64;
+  const bool raw64 = exact && s->cfg.store_dtype != BCX_F64 && s->A64;
   if (bytes_per_launch) *bytes_per_launch = (double)s->cfg.n_local * s->cfg.d * (raw64 ? 8.0 : (double)s->elem);
   return BCX_OK;
 }

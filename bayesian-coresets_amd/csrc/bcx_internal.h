@@ -63,6 +63,7 @@ struct bcx_solver {
   std::string err;
   int ld = 0;               // row stride (elements) of the stored normalised matrix
   int elem = 4;             // bytes per stored element
+  int qelem = 4;            // bytes per element of the storage-precision query
   int ld64 = 0;             // row stride (doubles) of A64 / q64 (d rounded up to even)
   void* An = nullptr;       // n_local x ld, fp32 or fp64, rows normalised to unit norm
   double* A64 = nullptr;    // n_local x ld64 raw rows (optional)

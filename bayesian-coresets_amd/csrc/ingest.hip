@@ -3,8 +3,12 @@
 //   b = vecs.sum(axis=0)                                    hilbert.py:24
 //   sum(Anorms)                                             frankwolfe.py:22,25
 // HBM-bound: reads N*d source elements once, writes N*d stored elements once.
+#include <hip/hip_fp16.h>
 #include "bcx_internal.h"
 #include "dev_util.h"
+
+template <typename TD> __device__ __forceinline__ TD to_store(double v) { return (TD)v; }
+template <> __device__ __forceinline__ __half to_store<__half>(double v) { return __float2half_rn((float)v); }
 
 // One workgroup per chunk of BCX_CHUNK_ROWS rows; one wave per row, lanes stride the columns
 // (coalesced 512-byte segments of the fp64 source), up to 16 waves per workgroup.  Column sums are
@@ -53,7 +57,7 @@ __global__ __launch_bounds__(1024) void ingest_kernel(const TS* src, int64_t ld_
     for (int c = lane; c < d; c += 64) {
       double v = (double)x[c];  // second touch hits L1/L2
       colacc[c] += v;
-      y[c] = (TD)(v / nrm);
+      y[c] = to_store<TD>(v / nrm);
       if (copy_raw) raw[c] = v;
     }
   }
@@ -92,10 +96,11 @@ int bcx_launch_ingest(bcx_solver* s, const void* src, int src_dtype, int64_t ld_
     hipLaunchKernelGGL(kfn, grid, block, shmem, s->stream, (const TS*)src, ld_src, row_begin, rows, d,        \
                        (TD*)s->An, s->ld, s->ld64, s->A64, s->norms, s->chunk_sums, s->st);                   \
   } while (0)
+  const int sd = s->cfg.store_dtype;
   if (src_dtype == BCX_F64) {
-    if (s->cfg.store_dtype == BCX_F32) LAUNCH(double, float); else LAUNCH(double, double);
+    if (sd == BCX_F32) LAUNCH(double, float); else if (sd == BCX_F16) LAUNCH(double, __half); else LAUNCH(double, double);
   } else {
-    if (s->cfg.store_dtype == BCX_F32) LAUNCH(float, float); else LAUNCH(float, double);
+    if (sd == BCX_F32) LAUNCH(float, float); else if (sd == BCX_F16) LAUNCH(float, __half); else LAUNCH(float, double);
   }
 #undef LAUNCH
   BCX_HIP(hipGetLastError());

@@ -10,6 +10,7 @@
 // Latency design: the replicated vectors (xw, b, bn) are staged into LDS at kernel entry (they do not
 // depend on the scan), every phase issues all of its independent global loads before the first use,
 // and reductions stay in registers (DPP / permlane butterflies) with one LDS exchange per workgroup sum.
+#include <hip/hip_fp16.h>
 #include "bcx_internal.h"
 #include "dev_util.h"
 #include "apply_common.h"
@@ -20,6 +21,7 @@ struct ResolveArgs {
   DevState* st;
   const void* An;
   int store_f64;
+  int store_f16;
   int ld;
   const double* A64;
   int ld64;
@@ -51,6 +53,7 @@ static __device__ __forceinline__ double giga_score64(double s0, double s1) {
 static __device__ __forceinline__ double raw_elem(const ResolveArgs& a, int64_t i, int j, double nrm) {
   if (a.A64) return a.A64[i * (int64_t)a.ld64 + j];
   if (a.store_f64) return ((const double*)a.An)[i * (int64_t)a.ld + j] * nrm;
+  if (a.store_f16) return (double)__half2float(((const __half*)a.An)[i * (int64_t)a.ld + j]) * nrm;
   return (double)((const float*)a.An)[i * (int64_t)a.ld + j] * nrm;
 }
 
@@ -435,6 +438,7 @@ static void fill_resolve_args(bcx_solver* s, ResolveArgs& a, double* send_dev, i
   a.st = s->st;
   a.An = s->An;
   a.store_f64 = s->cfg.store_dtype == BCX_F64;
+  a.store_f16 = s->cfg.store_dtype == BCX_F16;
   a.ld = s->ld;
   a.A64 = s->A64;
   a.ld64 = s->ld64;

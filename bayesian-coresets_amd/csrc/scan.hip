@@ -20,6 +20,8 @@
 // U3 reaches it too the iteration is redone with the exact kernel.  With fp64 storage U = L =
 // score and the result is the arg-max itself.
 #include <stdlib.h>
+#include <math.h>
+#include <hip/hip_fp16.h>
 #include "bcx_internal.h"
 #include "dev_util.h"
 
@@ -30,11 +32,16 @@
 #define BCX_UR_MAX 4
 #endif
 
-template <typename T> struct VecOf;
-template <> struct VecOf<float> { typedef float4 type; static constexpr int EPL = 4; };
-template <> struct VecOf<double> { typedef double2 type; static constexpr int EPL = 2; };
+// Storage types of the scanned matrix.  fp16 storage (half_t) halves the bytes per greedy iteration; it
+// accumulates in fp32 against an fp32 query and relies on the same interval + fp64 re-score machinery.
+struct half_t {};
+struct QH { float4 lo, hi; };   // the 8 fp32 query values matching one 16-byte piece of 8 halves
+template <typename ST> struct Stor;
+template <> struct Stor<float>  { typedef float4 V;  typedef float4 Q;  typedef float T;  static constexpr int EPL = 4; };
+template <> struct Stor<double> { typedef double2 V; typedef double2 Q; typedef double T; static constexpr int EPL = 2; };
+template <> struct Stor<half_t> { typedef uint4 V;   typedef QH Q;      typedef float T;  static constexpr int EPL = 8; };
 
-template <typename T> __device__ __forceinline__ T vdot(const float4& a, const float4& b, T acc) {
+__device__ __forceinline__ float vdot(const float4& a, const float4& b, float acc) {
   acc = fmaf(a.x, b.x, acc); acc = fmaf(a.y, b.y, acc); acc = fmaf(a.z, b.z, acc); acc = fmaf(a.w, b.w, acc);
   return acc;
 }
@@ -42,8 +49,27 @@ __device__ __forceinline__ double vdot(const double2& a, const double2& b, doubl
   acc = fma(a.x, b.x, acc); acc = fma(a.y, b.y, acc);
   return acc;
 }
-__device__ __forceinline__ float4 vzero(float4*) { return make_float4(0.f, 0.f, 0.f, 0.f); }
-__device__ __forceinline__ double2 vzero(double2*) { return make_double2(0.0, 0.0); }
+__device__ __forceinline__ float vdot(const uint4& a, const QH& b, float acc) {
+  const float2 f0 = __half22float2(*(const __half2*)&a.x), f1 = __half22float2(*(const __half2*)&a.y);
+  const float2 f2 = __half22float2(*(const __half2*)&a.z), f3 = __half22float2(*(const __half2*)&a.w);
+  acc = fmaf(f0.x, b.lo.x, acc); acc = fmaf(f0.y, b.lo.y, acc); acc = fmaf(f1.x, b.lo.z, acc); acc = fmaf(f1.y, b.lo.w, acc);
+  acc = fmaf(f2.x, b.hi.x, acc); acc = fmaf(f2.y, b.hi.y, acc); acc = fmaf(f3.x, b.hi.z, acc); acc = fmaf(f3.y, b.hi.w, acc);
+  return acc;
+}
+// query piece v of query `which` (0/1); qstride = distance between the two queries in pieces
+template <typename ST> __device__ __forceinline__ typename Stor<ST>::Q load_q(const void* q, int piece, bool ok) {
+  typedef typename Stor<ST>::Q Q;
+  if constexpr (sizeof(Q) == 32) {
+    QH r;
+    r.lo = ok ? ((const float4*)q)[2 * piece] : make_float4(0.f, 0.f, 0.f, 0.f);
+    r.hi = ok ? ((const float4*)q)[2 * piece + 1] : make_float4(0.f, 0.f, 0.f, 0.f);
+    return r;
+  } else {
+    Q z;
+    memset(&z, 0, sizeof z);
+    return ok ? ((const Q*)q)[piece] : z;
+  }
+}
 
 // ---- cross-lane sums without LDS traffic (gfx950: DPP inside a row of 16 lanes, v_permlane16_swap /
 // v_permlane32_swap across rows).  Lane mappings verified with tools/probe/lane_probe.hip.
@@ -178,10 +204,12 @@ template <typename T> __device__ __forceinline__ void track_update(Track<T>& tr,
   tr.L = L > tr.L ? L : tr.L;
 }
 
-template <typename T, bool DUAL, int G, int CH>
+template <typename ST, bool DUAL, int G, int CH>
 __global__ __launch_bounds__(BCX_SCAN_THREADS) void scan_kernel(ScanArgs a) {
   if (!a.st->active) return;
-  typedef typename VecOf<T>::type V;
+  typedef typename Stor<ST>::V V;
+  typedef typename Stor<ST>::Q Q;
+  typedef typename Stor<ST>::T T;
   constexpr int RPW = 64 / G;                       // rows per wave per step
   constexpr int UR = (CH >= BCX_LOADS_IN_FLIGHT) ? 1 : (BCX_LOADS_IN_FLIGHT / CH > BCX_UR_MAX ? BCX_UR_MAX : BCX_LOADS_IN_FLIGHT / CH);  // row steps in flight
   constexpr int WAVES = BCX_SCAN_THREADS / 64;
@@ -192,15 +220,15 @@ __global__ __launch_bounds__(BCX_SCAN_THREADS) void scan_kernel(ScanArgs a) {
   const int myu = ((lane >> 4) & 1) * 2 + (lane >> 5);   // PACK4: which of the 4 rows this 16-lane row tracks
 
   // query pieces for this lane's columns -> registers
-  V q0[CH], q1[CH];
+  Q q0[CH], q1[CH];
   int voff[CH];
 #pragma unroll
   for (int c = 0; c < CH; ++c) {
     const int v = c * G + sub;
     const bool ok = v < a.nvec;
     voff[c] = ok ? v : 0;  // clamp: the load stays inside the row, the zero query kills the product
-    q0[c] = ok ? ((const V*)a.q)[v] : vzero((V*)nullptr);
-    if (DUAL) q1[c] = ok ? ((const V*)a.q)[a.qstride + v] : vzero((V*)nullptr);
+    q0[c] = load_q<ST>(a.q, v, ok);
+    if (DUAL) q1[c] = load_q<ST>(a.q, a.qstride + v, ok);
   }
   const T e = (T)(a.err_coef * (float)a.st->qscale);
 
@@ -331,18 +359,20 @@ static int launch_t(bcx_solver* s, const ScanArgs& a, int G, int CH, int grid) {
 
 int bcx_launch_scan(bcx_solver* s, int exact) {
   // storage fp64            : fp64 kernel over the normalised rows
-  // storage fp32, exact == 0: fp32 kernel (interval scan)
-  // storage fp32, exact == 1: fp64 kernel over the RAW rows (A64) when they are resident, else the
-  //                           fp32 kernel again (resolve then takes its arg-max as is)
+  // storage fp32 / fp16, exact == 0: fp32-accumulating kernel (interval scan)
+  // storage fp32 / fp16, exact == 1: fp64 kernel over the RAW rows (A64) when they are resident, else the
+  //                           low-precision kernel again (resolve then takes its arg-max as is)
   const int d = s->cfg.d;
-  const bool raw64 = exact && s->cfg.store_dtype == BCX_F32 && s->A64 != nullptr;
-  const bool f64 = (s->cfg.store_dtype == BCX_F64) || raw64;
+  const int sd = s->cfg.store_dtype;
+  const bool raw64 = exact && sd != BCX_F64 && s->A64 != nullptr;
+  const bool f64 = (sd == BCX_F64) || raw64;
+  const bool f16 = !f64 && sd == BCX_F16;
   ScanArgs a;
   a.st = s->st;
   a.out = partial_view(s->partials, s->n_partials);
   a.n = s->cfg.n_local;
   a.norms = nullptr;
-  const int epl = f64 ? 2 : 4;
+  const int epl = f64 ? 2 : (f16 ? 8 : 4);
   if (raw64) {
     a.An = s->A64;
     a.norms = s->norms;
@@ -362,17 +392,23 @@ int bcx_launch_scan(bcx_solver* s, int exact) {
   int chp = 1;
   while (chp < CH) chp <<= 1;
   CH = chp;
-  // forward error bound of the fp32 dot product: storage rounding of row and query (2u) plus a
-  // summation depth of 4*CH fused multiply-adds and log2(G) butterfly adds, u = 2^-24, times
-  // sum|a_i q_i| <= |a||q| (1 + few u).  30% head room.
+  // forward error bound of the dot product, times |q|:
+  //   fp32 storage: rounding of row and query (2u) + summation depth (EPL*CH fused multiply-adds, log2 G
+  //                 butterfly adds), u = 2^-24; sum|a_i q_i| <= |a||q|.
+  //   fp16 storage: |a^_i - a_i| <= 2^-11 |a_i| + 2^-25 (subnormal spacing; |a_i| <= 1), so the storage term
+  //                 is 2^-11 |q| + 2^-25 sqrt(d) |q|, plus the fp32 terms above.
+  // 30% head room on the fp32 part, 2% on the fp16 storage term.
   const double u = 5.9604644775390625e-08;
   int lg = 0;
   while ((1 << lg) < G) ++lg;
-  a.err_coef = f64 ? 0.0f : (float)(1.3 * u * (4.0 * CH + lg + 3.0));
+  double coef = 1.3 * u * ((double)epl * CH + lg + 3.0);
+  if (f16) coef += 1.02 * (4.8828125e-4 + 2.9802322387695312e-08 * sqrt((double)d));
+  a.err_coef = f64 ? 0.0f : (float)coef;
   const bool dual = s->cfg.alg == BCX_ALG_GIGA;
   const int grid = s->n_partials;
   int rc;
   if (f64) rc = dual ? launch_t<double, true>(s, a, G, CH, grid) : launch_t<double, false>(s, a, G, CH, grid);
+  else if (f16) rc = dual ? launch_t<half_t, true>(s, a, G, CH, grid) : launch_t<half_t, false>(s, a, G, CH, grid);
   else rc = dual ? launch_t<float, true>(s, a, G, CH, grid) : launch_t<float, false>(s, a, G, CH, grid);
   if (rc != BCX_OK) return rc;
   BCX_HIP(hipGetLastError());

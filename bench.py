@@ -36,7 +36,8 @@ def parse():
     ap.add_argument("--rows", type=int, default=10_000_000)
     ap.add_argument("--dim", type=int, default=512)
     ap.add_argument("--seed", type=int, default=1)
-    ap.add_argument("--dtype", default="float32", choices=["float32", "float64"])
+    ap.add_argument("--dtype", default="float32", choices=["float32", "float64", "float16"],
+                    help="storage of the normalised rows (state and re-score are always fp64)")
     ap.add_argument("--no-exact-rows", action="store_true", help="do not keep the raw fp64 rows resident")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-rows", type=int, default=200_000, help="rows of the CPU-baseline sample")
@@ -114,7 +115,7 @@ def main():
         else:
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     alg = {"giga": nat.ALG_GIGA, "fw": nat.ALG_FW, "omp": nat.ALG_OMP}[args.alg]
-    store = nat.F64 if args.dtype == "float64" else nat.F32
+    store = {"float64": nat.F64, "float16": nat.F16}.get(args.dtype, nat.F32)
 
     solver = ShardedSolver(alg, args.rows, args.dim, device=local_rank, store_dtype=store,
                            keep_exact_rows=not args.no_exact_rows)
@@ -167,7 +168,7 @@ def main():
     steps_done = len(sel)
 
     if rank == 0:
-        bytes_per_launch = float(solver.n_local) * args.dim * (8 if store == nat.F64 else 4)
+        bytes_per_launch = float(solver.n_local) * args.dim * {nat.F64: 8, nat.F16: 2}.get(store, 4)
         avg_ms = scan_ms / max(scan_launches, 1)
         achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
         traffic = None
@@ -190,7 +191,7 @@ def main():
             "higher_is_better": True,
             "scaling": "strong",
             "vs_baseline": None,
-            "dtype": "f32 scan + f64 state" if store == nat.F32 else "f64",
+            "dtype": {nat.F32: "f32 scan + f64 state", nat.F16: "f16 rows, f32 scan + f64 state"}.get(store, "f64"),
             "data": "synthetic",
             "config": {
                 "workload": "synthetic randn N=%d d=%d, %s, %d row shard(s), M=%d greedy iterations"

@@ -28,7 +28,7 @@ typedef struct bcx_solver bcx_solver;
 
 /* ---- enums ---------------------------------------------------------- */
 enum { BCX_ALG_GIGA = 0, BCX_ALG_FW = 1, BCX_ALG_OMP = 2 };
-enum { BCX_F32 = 0, BCX_F64 = 1 };
+enum { BCX_F32 = 0, BCX_F64 = 1, BCX_F16 = 2 };   /* BCX_F16: storage of the normalised rows only */
 
 /* return codes */
 enum {
@@ -51,7 +51,8 @@ enum {
 
 typedef struct bcx_config {
   int32_t alg;             /* BCX_ALG_*                                                          */
-  int32_t store_dtype;     /* BCX_F32: normalised rows stored fp32 (default); BCX_F64: exact mode */
+  int32_t store_dtype;     /* BCX_F32: normalised rows stored fp32 (default); BCX_F64: exact mode;
+                              BCX_F16: fp16 rows (half the bytes per iteration; needs keep_exact_rows for the fp64 re-score) */
   int32_t keep_exact_rows; /* 1: also keep the raw fp64 rows resident (exact reweight + fp64 rescue) */
   int32_t device;          /* HIP device ordinal                                                  */
   int32_t d;               /* projection dimension (columns of the N x d vector matrix)           */

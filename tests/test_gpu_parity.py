@@ -55,7 +55,7 @@ def test_F1_axis_ties(bc, golden, alg, itrs):
 
 
 @pytest.mark.parametrize("alg", ("giga", "fw", "omp"))
-@pytest.mark.parametrize("dtype", ("float32", "float64"))
+@pytest.mark.parametrize("dtype", ("float32", "float64", "float16"))
 def test_F9_small(bc, golden, normal_inputs, alg, dtype):
     X = normal_inputs(7, 3000, 64, "F9_input_sha256")
     s = _run(bc, X, alg, 60, dtype=dtype)
@@ -63,7 +63,7 @@ def test_F9_small(bc, golden, normal_inputs, alg, dtype):
 
 
 @pytest.mark.parametrize("alg", ("giga", "fw", "omp"))
-@pytest.mark.parametrize("dtype", ("float32", "float64"))
+@pytest.mark.parametrize("dtype", ("float32", "float64", "float16"))
 def test_F2_normal_10k(bc, golden, normal_inputs, alg, dtype):
     X = normal_inputs(1, 10000, 100, "F2_input_sha256")
     s = _run(bc, X, alg, 100, dtype=dtype)
@@ -111,9 +111,10 @@ def test_against_oracle_random_shape(bc, alg):
     np.testing.assert_allclose(s.error(), o.error(), rtol=ERR_RTOL)
 
 
+@pytest.mark.parametrize("dtype", ("float32", "float16"))
 @pytest.mark.parametrize("alg", ("giga", "fw", "omp"))
 @pytest.mark.parametrize("d", (256, 512, 1024, 260))
-def test_wide_rows_against_oracle(bc, alg, d):
+def test_wide_rows_against_oracle(bc, alg, d, dtype):
     """d >= 256 takes the 64-lanes-per-row path of the scan kernel (4-row transposed reduction);
     d = 260 exercises the masked tail piece.  HIP engine vs CPU oracle on a fresh seeded input."""
     from oracle.snnls_oracle import SnnlsOracle
@@ -121,7 +122,7 @@ def test_wide_rows_against_oracle(bc, alg, d):
     X = np.random.RandomState(1000 + d).randn(N, d)
     o = SnnlsOracle(X.T, X.sum(axis=0), alg=alg)
     o.build(itrs)
-    s = _run(bc, X, alg, itrs)
+    s = _run(bc, X, alg, itrs, dtype=dtype)
     assert np.array_equal(s.last_trace[0], np.array([t[0] for t in o.trace]))
     w, ow = s.weights(), o.weights()
     assert np.array_equal(np.flatnonzero(w > 0), np.flatnonzero(ow > 0))

@@ -51,7 +51,7 @@ def test_oracle_on_lr_vectors(lr, alg):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("alg", ("giga", "fw", "omp"))
-@pytest.mark.parametrize("dtype", ("float32", "float64"))
+@pytest.mark.parametrize("dtype", ("float32", "float64", "float16"))
 def test_gpu_on_lr_vectors(lr, alg, dtype):
     """fp32 storage of the NORMALISED rows + fp64 norms keeps 16 decades of dynamic range exact enough
     for bit-exact selections and 1e-5 weights."""
