@@ -56,6 +56,21 @@ __device__ __forceinline__ float vdot(const uint4& a, const QH& b, float acc) {
   acc = fmaf(f2.x, b.hi.x, acc); acc = fmaf(f2.y, b.hi.y, acc); acc = fmaf(f3.x, b.hi.z, acc); acc = fmaf(f3.y, b.hi.w, acc);
   return acc;
 }
+// 16-byte streaming load of matrix data that no other workgroup touches again this launch: the
+// non-temporal hint (global_load_dwordx4 ... nt) keeps the one-shot stream from evicting useful lines
+typedef unsigned nt_u4 __attribute__((ext_vector_type(4)));
+template <typename V> __device__ __forceinline__ V stream_load(const V* p) {
+#ifdef BCX_NO_NT
+  return *p;
+#else
+  static_assert(sizeof(V) == 16, "16-byte pieces");
+  const nt_u4 r = __builtin_nontemporal_load((const nt_u4*)p);
+  V v;
+  __builtin_memcpy(&v, &r, 16);
+  return v;
+#endif
+}
+
 // query piece v of query `which` (0/1); qstride = distance between the two queries in pieces
 template <typename ST> __device__ __forceinline__ typename Stor<ST>::Q load_q(const void* q, int piece, bool ok) {
   typedef typename Stor<ST>::Q Q;
@@ -247,7 +262,7 @@ __global__ __launch_bounds__(BCX_SCAN_THREADS) void scan_kernel(ScanArgs a) {
       const int64_t rc = row[u] < n ? row[u] : n - 1;
       const V* p = base + rc * a.ldv;
 #pragma unroll
-      for (int c = 0; c < CH; ++c) x[u][c] = p[voff[c]];
+      for (int c = 0; c < CH; ++c) x[u][c] = stream_load(p + voff[c]);
       if constexpr (sizeof(T) == 8) {
         if (a.norms) {   // raw fp64 rows: An = A / Anorms element by element (giga.py:13)
           const double nr = a.norms[rc];
