@@ -73,8 +73,8 @@ extern "C" int bcx_create(const bcx_config* cfg, bcx_solver** out) {
   chk(dev_alloc(&s->q64, (size_t)2 * s->ld64));
   chk(dev_alloc((char**)&s->qst, (size_t)2 * s->ld * s->qelem));
   chk(dev_alloc(&s->tmp, (size_t)20 * d));
-  s->n_partials = bcx_scan_grid(s);
-  chk(dev_alloc((char**)&s->partials, (size_t)s->n_partials * BCX_PARTIAL_BYTES));
+  s->n_partials = 0;
+  chk(dev_alloc((char**)&s->partials, (size_t)bcx_scan_grid(s) * BCX_PARTIAL_BYTES));
   chk(dev_alloc(&s->rec_local, (size_t)(d + BCX_REC_HDR)));
   if (!ok) { free_all(s); delete s; return BCX_ERR_NOMEM; }
   *out = s;

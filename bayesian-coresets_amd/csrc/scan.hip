@@ -229,7 +229,7 @@ __global__ __launch_bounds__(BCX_SCAN_THREADS) void scan_kernel(ScanArgs a) {
   constexpr int UR = (CH >= BCX_LOADS_IN_FLIGHT) ? 1 : (BCX_LOADS_IN_FLIGHT / CH > BCX_UR_MAX ? BCX_UR_MAX : BCX_LOADS_IN_FLIGHT / CH);  // row steps in flight
   constexpr int WAVES = BCX_SCAN_THREADS / 64;
   constexpr int RPB = WAVES * RPW * UR;             // rows per workgroup per trip
-  constexpr bool PACK4 = (sizeof(T) == 4) && G == 64 && UR == 4;
+  constexpr bool PACK4 = (sizeof(T) == 4) && G == 64 && (UR % 4 == 0);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int sub = lane % G, rsub = lane / G;
   const int myu = ((lane >> 4) & 1) * 2 + (lane >> 5);   // PACK4: which of the 4 rows this 16-lane row tracks
@@ -275,26 +275,29 @@ __global__ __launch_bounds__(BCX_SCAN_THREADS) void scan_kernel(ScanArgs a) {
     // through one register quad to save VGPRs, which serialises the HBM round trips of a wave
     __builtin_amdgcn_sched_barrier(0);
     if constexpr (PACK4) {
-      // four rows per trip: transposed reduction, then every 16-lane row of the wave tracks one row
-      float a0[4], a1[4];
+      // four rows at a time: transposed reduction, then every 16-lane row of the wave tracks one row
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        float t0 = 0.f, t1 = 0.f;
+      for (int g4 = 0; g4 < UR / 4; ++g4) {
+        float a0[4], a1[4];
 #pragma unroll
-        for (int c = 0; c < CH; ++c) {
-          t0 = vdot(x[u][c], q0[c], t0);
-          if (DUAL) t1 = vdot(x[u][c], q1[c], t1);
+        for (int u = 0; u < 4; ++u) {
+          float t0 = 0.f, t1 = 0.f;
+#pragma unroll
+          for (int c = 0; c < CH; ++c) {
+            t0 = vdot(x[g4 * 4 + u][c], q0[c], t0);
+            if (DUAL) t1 = vdot(x[g4 * 4 + u][c], q1[c], t1);
+          }
+          a0[u] = t0; a1[u] = t1;
         }
-        a0[u] = t0; a1[u] = t1;
+        const float s0 = reduce4_rows(a0[0], a0[1], a0[2], a0[3]);
+        const float s1 = DUAL ? reduce4_rows(a1[0], a1[1], a1[2], a1[3]) : 0.f;
+        const int64_t myrow = r0 + (int64_t)((g4 * 4 + myu) * WAVES + wave);
+        float U, L;
+        if (DUAL) giga_interval(s0, s1, (float)e, U, L);
+        else { const float ee = (float)e + fabsf(s0) * 2e-7f; U = s0 + ee; L = s0 - ee; }
+        if (!(myrow < n)) { U = -INFINITY; L = -INFINITY; }
+        track_update<T>(tr, (T)U, (T)L, (int)myrow);
       }
-      const float s0 = reduce4_rows(a0[0], a0[1], a0[2], a0[3]);
-      const float s1 = DUAL ? reduce4_rows(a1[0], a1[1], a1[2], a1[3]) : 0.f;
-      const int64_t myrow = r0 + (int64_t)(myu * WAVES + wave);
-      float U, L;
-      if (DUAL) giga_interval(s0, s1, (float)e, U, L);
-      else { const float ee = (float)e + fabsf(s0) * 2e-7f; U = s0 + ee; L = s0 - ee; }
-      if (!(myrow < n)) { U = -INFINITY; L = -INFINITY; }
-      track_update<T>(tr, (T)U, (T)L, (int)myrow);
     } else {
 #pragma unroll
       for (int u = 0; u < UR; ++u) {
@@ -347,13 +350,19 @@ static int pick_group(int nvec) {  // lanes per row
   return g;
 }
 
-int bcx_scan_grid(const bcx_solver* s) {
-  // enough workgroups to fill 256 CUs x 8 resident workgroups, never more than the rows need
-  const int64_t n = s->cfg.n_local;
-  int64_t want = (n + 15) / 16;
+// Launch width.  Measured on MI355X (tools/scan_sweep*.sh, interleaved on one box): this stream runs
+// fastest with FEW resident waves that each keep many loads in flight -- about 32 KiB of outstanding
+// 16-byte loads per CU (4 waves x 8 loads, or 8 waves x 4 loads): 6.8-7.0 TB/s, against 6.0-6.4 TB/s
+// with the 8 workgroups per CU one would launch by reflex.  So: grid = 256 CUs x (8 / loads per lane).
+int bcx_scan_grid(const bcx_solver* s) { return BCX_MAX_PARTIALS; }   // capacity of the partial arrays
+
+static int scan_grid_for(int64_t n, int rows_per_block, int loads_per_lane, bool f64) {
+  int64_t want = (n + rows_per_block - 1) / rows_per_block;
   if (want < 1) want = 1;
-  int64_t cap = BCX_MAX_PARTIALS;
-  if (const char* e = getenv("BCX_SCAN_GRID")) { const long v = atol(e); if (v > 0 && v < cap) cap = v; }
+  int64_t cap = 256 * (int64_t)(8 / (loads_per_lane < 1 ? 1 : (loads_per_lane > 8 ? 8 : loads_per_lane)));
+  if (f64) cap = BCX_MAX_PARTIALS;   // the fp64 kernels reduce through LDS permutes and want the occupancy
+  if (const char* e = getenv("BCX_SCAN_GRID")) { const long v = atol(e); if (v > 0) cap = v; }
+  if (cap > BCX_MAX_PARTIALS) cap = BCX_MAX_PARTIALS;
   if (want > cap) want = cap;
   return (int)want;
 }
@@ -384,7 +393,6 @@ int bcx_launch_scan(bcx_solver* s, int exact) {
   const bool f16 = !f64 && sd == BCX_F16;
   ScanArgs a;
   a.st = s->st;
-  a.out = partial_view(s->partials, s->n_partials);
   a.n = s->cfg.n_local;
   a.norms = nullptr;
   const int epl = f64 ? 2 : (f16 ? 8 : 4);
@@ -420,7 +428,12 @@ int bcx_launch_scan(bcx_solver* s, int exact) {
   if (f16) coef += 1.02 * (4.8828125e-4 + 2.9802322387695312e-08 * sqrt((double)d));
   a.err_coef = f64 ? 0.0f : (float)coef;
   const bool dual = s->cfg.alg == BCX_ALG_GIGA;
-  const int grid = s->n_partials;
+  // mirror of the kernel's UR / RPB arithmetic
+  const int ur = (CH >= BCX_LOADS_IN_FLIGHT) ? 1 : (BCX_LOADS_IN_FLIGHT / CH > BCX_UR_MAX ? BCX_UR_MAX : BCX_LOADS_IN_FLIGHT / CH);
+  const int rpb = (BCX_SCAN_THREADS / 64) * (64 / G) * ur;
+  const int grid = scan_grid_for(a.n, rpb, CH * ur, f64);
+  s->n_partials = grid;                     // resolve reads exactly this launch's partials
+  a.out = partial_view(s->partials, grid);
   int rc;
   if (f64) rc = dual ? launch_t<double, true>(s, a, G, CH, grid) : launch_t<double, false>(s, a, G, CH, grid);
   else if (f16) rc = dual ? launch_t<half_t, true>(s, a, G, CH, grid) : launch_t<half_t, false>(s, a, G, CH, grid);

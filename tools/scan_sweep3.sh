@@ -1,0 +1,12 @@
+#!/bin/bash
+cd $GRAFT_REPO_ROOT/bayesian-coresets_amd
+for v in "8 8" "16 16" "32 16"; do
+  set -- $v
+  touch csrc/scan.hip
+  make EXTRA="-DBCX_LOADS_IN_FLIGHT=$1 -DBCX_UR_MAX=$2" >/dev/null 2>&1
+  for g in 256 384 512 768; do
+    echo "== loads=$1 urmax=$2 grid=$g"
+    BCX_SCAN_GRID=$g python ../tools/gpu_quick.py sweep 2>&1 | grep "alg=" | cut -c1-100
+  done
+done
+touch csrc/scan.hip; make >/dev/null 2>&1
