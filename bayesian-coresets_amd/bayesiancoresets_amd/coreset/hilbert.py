@@ -18,42 +18,59 @@ def _is_torch(x):
 
 class HilbertCoreset(Coreset):
     def __init__(self, data, ll_projector, n_subsample=None, snnls=GIGA, **kw):
-        if n_subsample is None:
-            sub_idcs = np.arange(data.shape[0])
-            vecs = ll_projector.project(data)
+        rows = None if n_subsample is None else self._draw_subsample(data.shape[0], n_subsample)
+        vecs = ll_projector.project(data if rows is None else data[rows])
+        if rows is None:
+            rows = np.arange(data.shape[0])
         else:
-            # hilbert.py:16-22: random subsample without duplicates, zero vectors dropped
-            sub_idcs = np.unique(np.random.randint(data.shape[0], size=n_subsample))
-            vecs = ll_projector.project(data[sub_idcs])
-            if _is_torch(vecs):
-                nonzero = ((vecs ** 2).sum(dim=1).sqrt() > 0.0).cpu().numpy()
-                if not nonzero.all():
-                    import torch
-                    vecs = vecs[torch.as_tensor(nonzero, device=vecs.device)]
-            else:
-                nonzero = np.sqrt((vecs ** 2).sum(axis=1)) > 0.0
-                vecs = vecs[nonzero, :]
-            sub_idcs = sub_idcs[nonzero]
-        # b = vecs.sum(axis=0) on the host when the vectors are host arrays (bit-identical to
-        # hilbert.py:24); a device-resident projection lets the engine form the column sums.
-        if _is_torch(vecs):
-            b = None if vecs.device.type == "cuda" else vecs.sum(dim=0).numpy()
-            self.snnls = snnls(vecs.t(), b)
-        else:
-            self.snnls = snnls(vecs.T, vecs.sum(axis=0))
-        self.sub_idcs = sub_idcs
+            # subsample branch only: zero vectors cannot change the coreset and would make the solver
+            # constructor raise (hilbert.py:19-22)
+            keep = self._nonzero_rows(vecs)
+            if not keep.all():
+                vecs = self._take_rows(vecs, keep)
+            rows = rows[keep]
+        self.snnls = self._make_solver(snnls, vecs)
+        self.sub_idcs = rows
         self.data = data
         super().__init__(**kw)
 
+    # ---- construction helpers ------------------------------------------------------------
+    @staticmethod
+    def _draw_subsample(n, n_subsample):
+        # randint then unique: cheap for huge n, duplicates removed (hilbert.py:16)
+        return np.unique(np.random.randint(n, size=n_subsample))
+
+    @staticmethod
+    def _nonzero_rows(vecs):
+        if _is_torch(vecs):
+            return ((vecs ** 2).sum(dim=1).sqrt() > 0.0).cpu().numpy()
+        return np.sqrt((vecs ** 2).sum(axis=1)) > 0.0
+
+    @staticmethod
+    def _take_rows(vecs, keep):
+        if _is_torch(vecs):
+            import torch
+            return vecs[torch.as_tensor(keep, device=vecs.device)]
+        return vecs[keep, :]
+
+    @staticmethod
+    def _make_solver(snnls, vecs):
+        """Solver on A = vecs^T, b = column sums (hilbert.py:24).  Host arrays: b is summed on the host
+        exactly as the reference does; a projection that already lives on the GPU lets the engine form it."""
+        if _is_torch(vecs):
+            b = None if vecs.device.type == "cuda" else vecs.sum(dim=0).numpy()
+            return snnls(vecs.t(), b)
+        return snnls(vecs.T, vecs.sum(axis=0))
+
+    # ---- Coreset interface ----------------------------------------------------------------
     def reset(self):
         self.snnls.reset()
         super().reset()
 
     def _read_solver(self):
         w = self.snnls.weights()
-        keep = w > 0
-        self.wts = w[keep]
-        self.idcs = self.sub_idcs[keep]
+        support = w > 0
+        self.wts, self.idcs = w[support], self.sub_idcs[support]
         self.pts = self.data[self.idcs]
 
     def _build(self, itrs):

@@ -209,7 +209,7 @@ def main():
                 "algorithmic_bytes_per_launch": bytes_per_launch,
             },
         }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:   # reported once, on the single-GPU run
             out["cpu_baseline"] = cpu_baseline(args, args.alg, torch)
         print(json.dumps(out), flush=True)
     if world > 1:
