@@ -261,6 +261,7 @@ extern "C" int bcx_build_begin(bcx_solver* s, int64_t itrs, double tol, int32_t*
   int rc = read_state(s, &h);
   if (rc != BCX_OK) return rc;
   if (h.limit || s->cfg.n_global == 0 || itrs <= 0) { *skip = 1; return BCX_OK; }   // snnls.py:32-38
+  s->k_ub = h.k;
   if ((rc = ensure_slots(s, (int64_t)h.k + itrs))) return rc;
   if (s->cfg.alg == BCX_ALG_OMP && (rc = bcx_ensure_gram(s, (int64_t)h.k + itrs))) return rc;
   if ((rc = ensure_trace(s, itrs))) return rc;

@@ -18,6 +18,7 @@
 #define BCX_APPLY_THREADS 256
 
 enum { HALT_NONE = 0, HALT_DONE = 1, HALT_LIMIT = 2, HALT_NEED_EXACT = 3 };
+enum { OMP_IDLE = 0, OMP_DONE = 1, OMP_FAST_TRY = 2, OMP_FAST_ACCEPT = 3, OMP_GENERAL = 4 };
 
 // Per-workgroup result of the correlation scan, stored as separate arrays (coalesced reads in the
 // resolve step): the two best upper bounds with their local row indices, a bound on everything else
@@ -49,6 +50,11 @@ struct DevState {
   int32_t zero_row;    // first zero-norm local row + 1 (0 = none)
   int32_t np;          // size of the passive set P (OMP / optimize)
   int32_t hvalid;      // hinv == inverse of gram[P,P] and P == {slots with weight > 0}
+  // multi-kernel OMP step (nnls.hip): decisions handed from kernel to kernel
+  int32_t omp_mode;    // OMP_* below
+  int32_t omp_slot, omp_fresh, omp_checked, omp_p;
+  int64_t omp_f;
+  double omp_nf, omp_gff, omp_cf, omp_t, omp_inv;
   double tol;          // bc.util.TOL at build() time
   double err;          // ||A w - b||
   double nw;           // ||A w|| (1 when zero, giga.py:23)
@@ -101,6 +107,7 @@ struct bcx_solver {
   int32_t* nn_flag = nullptr;    // cap: bit0 in problem set S, bit1 rejected, bit2 remove
   double* nn_wbak = nullptr;     // cap: weights before the step (revert on monotone failure)
   int64_t gram_cap = 0;
+  int64_t k_ub = 0;              // host upper bound of the slot count (grid sizing of the multi-kernel OMP step)
   // trace of the current build() call
   int64_t trace_cap = 0;
   int64_t* tr_sel = nullptr;

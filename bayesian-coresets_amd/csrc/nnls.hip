@@ -10,6 +10,8 @@
 // previous passive set gives the reference's result.  The Gram matrix of optimize() is a small
 // GEMM and runs on the fp64 matrix cores (v_mfma_f64_16x16x4_f64); everything else is
 // latency-bound single-workgroup work.
+#include <stdlib.h>
+#include <algorithm>
 #include "bcx_internal.h"
 #include "dev_util.h"
 #include "apply_common.h"
@@ -32,6 +34,7 @@ struct NnlsArgs {
   double* t0;      // per position scratch
   double* t1;
   double* t2;
+  double* t3;      // per slot: Gram-row candidate
   int32_t* flag;   // per slot
   double* wbak;    // per slot
 };
@@ -313,7 +316,7 @@ static __device__ void rebuild_passive(const NnlsArgs& n, int k, double* scratch
 // t = (c_f - g.x)/s, x <- x - t u, x_f = t): two passes over H instead of a full active-set solve.
 // Anything else (a weight would turn non-positive, dependent column, stale inverse, periodic
 // re-solve) goes through nnls_run, which gives the same unique solution.
-#define OMP_RESOLVE_EVERY 8
+#define OMP_RESOLVE_EVERY 32
 __global__ __launch_bounds__(NN_THREADS) void apply_omp_kernel(NnlsArgs n) {
   const ApplyArgs& a = n.a;
   DevState* st = a.st;
@@ -502,6 +505,317 @@ __global__ __launch_bounds__(NN_THREADS) void apply_omp_kernel(NnlsArgs n) {
   prepare_next(a, scratch);
 }
 
+// ---- OMP apply, multi-kernel form ----------------------------------------------------------------
+// The single-workgroup kernel above reads the k replicated rows three times and the inverse twice with
+// one CU; its time grows ~0.5 us per active point.  For larger active sets the same step is split into
+// phases that use the whole chip, chained by ordinary kernel boundaries (decisions travel in DevState):
+//   rows    (grid)  -An[j].r for the active rows and row_j . xf for all slots (+ xf.xf, xf.b)
+//   decide  (1 WG)  f, slot, new-slot data, g = G[slot, P]; chooses DONE / FAST_TRY / GENERAL
+//   matvec  (grid)  u = H g
+//   step    (1 WG)  Schur complement, step t, positivity -> FAST_ACCEPT (x updated) / DONE / GENERAL
+//   general (1 WG)  full active-set solve (rare)
+//   combine (grid)  xw' = sum_P x_j row_j; extra workgroups apply the bordered update of H
+//   finish  (1 WG)  error, monotone check, commit / revert, trace, next query
+static __device__ int omp_pick_record(const ApplyArgs& a, int* overflow) {
+  const int recw = a.d + BCX_REC_HDR;
+  int win = -1, ovf = 0;
+  for (int r = 0; r < a.world; ++r) {
+    const double* rec = a.recs + (size_t)r * recw;
+    if (rec[3] == BCX_REC_OVERFLOW) ovf = 1;
+    if (rec[3] != BCX_REC_VALID) continue;
+    if (win < 0) { win = r; continue; }
+    const double* best = a.recs + (size_t)win * recw;
+    if (rec[0] > best[0] || (rec[0] == best[0] && rec[1] < best[1])) win = r;
+  }
+  *overflow = ovf;
+  return win;
+}
+
+__global__ __launch_bounds__(256) void omp_rows_kernel(NnlsArgs n) {
+  const ApplyArgs& a = n.a;
+  DevState* st = a.st;
+  if (!st->active) return;
+  __shared__ int s_win, s_ovf;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, d = a.d;
+  if (threadIdx.x == 0) { int o; s_win = omp_pick_record(a, &o); s_ovf = o; }
+  __syncthreads();
+  if (s_ovf || s_win < 0) return;
+  const int k = st->k;
+  const int j = blockIdx.x * 4 + wave;
+  if (j > k) return;
+  const double* xf = a.recs + (size_t)s_win * (d + BCX_REC_HDR) + BCX_REC_HDR;
+  const double* row = (j < k) ? a.act_rows + (size_t)j * d : xf;
+  const double* other = (j < k) ? a.q64 : a.b;
+  double a0 = 0.0, a1 = 0.0;
+  for (int i = lane; i < d; i += 64) {
+    const double rv = row[i];
+    a0 += rv * xf[i];
+    a1 += rv * other[i];
+  }
+  a0 = wave_allsum(a0);
+  a1 = wave_allsum(a1);
+  if (lane == 0) {
+    if (j < k) { n.t3[j] = a0; n.t2[j] = -(a1 / a.act_norm[j]); }
+    else { st->omp_gff = a0; st->omp_cf = a1; }
+  }
+}
+
+__global__ __launch_bounds__(NN_THREADS) void omp_decide_kernel(NnlsArgs n) {
+  const ApplyArgs& a = n.a;
+  DevState* st = a.st;
+  if (!st->active) return;
+  __shared__ double scratch[BCX_SCRATCH];
+  __shared__ int s_win, s_ovf, s_slot, s_npos;
+  __shared__ unsigned long long s_minidx;
+  const int tid = threadIdx.x, d = a.d;
+  if (tid == 0) {
+    int o; s_win = omp_pick_record(a, &o); s_ovf = o;
+    s_slot = 0x7fffffff; s_npos = 0; s_minidx = 0x7fffffffffffffffULL;
+    st->omp_mode = OMP_IDLE;
+  }
+  __syncthreads();
+  if (s_ovf) { if (tid == 0) { st->active = 0; st->halt = HALT_NEED_EXACT; } return; }
+  if (s_win < 0) { if (tid == 0) { st->active = 0; st->halt = HALT_DONE; } return; }
+  const double* rec = a.recs + (size_t)s_win * (d + BCX_REC_HDR);
+  const double* xf = rec + BCX_REC_HDR;
+  const int k = st->k;
+  int npos = 0;
+  for (int s = tid; s < k; s += blockDim.x) if (a.act_w[s] > 0.0) ++npos;
+  if (npos) atomicAdd(&s_npos, npos);
+  __syncthreads();
+  const bool checked = s_npos > 0;
+  int64_t f = (int64_t)rec[1];
+  const double nf = rec[2];
+  if (checked) {
+    double bv = -INFINITY; int bi = -1; int64_t bidx = 0;
+    for (int j = tid; j < k; j += blockDim.x) {
+      if (!(a.act_w[j] > 0.0)) continue;
+      const double vv = n.t2[j];
+      if (bi < 0 || vv > bv || (vv == bv && a.act_idx[j] < bidx)) { bv = vv; bi = j; bidx = a.act_idx[j]; }
+    }
+    const double vmax = block_allmax(bi >= 0 ? bv : -INFINITY, scratch);
+    if (bi >= 0 && bv == vmax) atomicMin(&s_minidx, (unsigned long long)bidx);
+    __syncthreads();
+    if (!(rec[0] >= vmax)) f = (int64_t)s_minidx;          // orthopursuit.py:32-35
+  }
+  for (int s = tid; s < k; s += blockDim.x) if (a.act_idx[s] == f) atomicMin(&s_slot, s);
+  __syncthreads();
+  int slot = s_slot == 0x7fffffff ? -1 : s_slot;
+  const bool fresh = slot < 0;
+  if (fresh) slot = k;
+  for (int j = tid; j < k; j += blockDim.x) n.wbak[j] = a.act_w[j];
+  if (fresh) {
+    for (int i = tid; i < d; i += blockDim.x) a.act_rows[(size_t)slot * d + i] = xf[i];
+    for (int j = tid; j < k; j += blockDim.x) {
+      const double g = n.t3[j];
+      n.gram[(size_t)slot * n.ldg + j] = g;
+      n.gram[(size_t)j * n.ldg + slot] = g;
+    }
+    if (tid == 0) {
+      a.act_idx[slot] = f; a.act_norm[slot] = nf; a.act_w[slot] = 0.0; n.ppos[slot] = -1; n.x[slot] = 0.0;
+      n.gram[(size_t)slot * n.ldg + slot] = st->omp_gff;
+      n.cvec[slot] = st->omp_cf;
+    }
+  }
+  __syncthreads();
+  const int p = st->np;
+  int mode;
+  if (!st->hvalid) mode = OMP_GENERAL;
+  else if (n.ppos[slot] >= 0) mode = OMP_DONE;             // f already carries weight: nothing changes
+  else if ((st->since_refresh % OMP_RESOLVE_EVERY) == OMP_RESOLVE_EVERY - 1) mode = OMP_GENERAL;
+  else {
+    mode = OMP_FAST_TRY;
+    for (int q = tid; q < p; q += blockDim.x) n.t0[q] = n.gram[(size_t)slot * n.ldg + n.plist[q]];
+  }
+  if (tid == 0) {
+    st->omp_mode = mode; st->omp_slot = slot; st->omp_fresh = fresh; st->omp_checked = checked;
+    st->omp_f = f; st->omp_nf = nf; st->omp_p = p;
+  }
+}
+
+// u[a] = sum_b H[b][a] g[b]: one workgroup per 64 columns, the four waves take b = w, w+4, ...
+__global__ __launch_bounds__(256) void omp_mv_kernel(NnlsArgs n) {
+  DevState* st = n.a.st;
+  if (!st->active || st->omp_mode != OMP_FAST_TRY) return;
+  __shared__ double seg[4][64];
+  const int p = st->omp_p;
+  const int a0 = blockIdx.x * 64;
+  if (a0 >= p) return;
+  const int col = a0 + (threadIdx.x & 63), w = threadIdx.x >> 6;
+  double acc = 0.0;
+  if (col < p) {
+    int b = w;
+    for (; b + 28 < p; b += 32) {
+      double m[8];
+#pragma unroll
+      for (int t = 0; t < 8; ++t) m[t] = n.hinv[(size_t)(b + 4 * t) * n.ldg + col];
+#pragma unroll
+      for (int t = 0; t < 8; ++t) acc += m[t] * n.t0[b + 4 * t];
+    }
+    for (; b < p; b += 4) acc += n.hinv[(size_t)b * n.ldg + col] * n.t0[b];
+  }
+  seg[w][threadIdx.x & 63] = acc;
+  __syncthreads();
+  if (w == 0 && col < p) n.t1[col] = ((seg[0][threadIdx.x] + seg[1][threadIdx.x]) + seg[2][threadIdx.x]) + seg[3][threadIdx.x];
+}
+
+__global__ __launch_bounds__(NN_THREADS) void omp_step_kernel(NnlsArgs n) {
+  const ApplyArgs& a = n.a;
+  DevState* st = a.st;
+  if (!st->active || st->omp_mode != OMP_FAST_TRY) return;
+  __shared__ double scratch[BCX_SCRATCH];
+  __shared__ int s_bad;
+  const int tid = threadIdx.x, d = a.d;
+  const int p = st->omp_p, slot = st->omp_slot;
+  const int k1 = st->k + (st->omp_fresh ? 1 : 0);
+  if (tid == 0) s_bad = 0;
+  double r[2] = {0.0, 0.0};
+  for (int q = tid; q < p; q += blockDim.x) { r[0] += n.t0[q] * n.t1[q]; r[1] += n.t0[q] * n.x[n.plist[q]]; }
+  block_allsum<2>(r, scratch);
+  const double eps = 2.220446049250313e-16;
+  const double tolscale = 10.0 * eps * (double)(d > k1 ? d : k1) * st->bnorm;
+  const double gff = n.gram[(size_t)slot * n.ldg + slot];
+  const double sc = gff - r[0];
+  const double wvf = n.cvec[slot] - r[1];
+  int mode = OMP_GENERAL;
+  if (!(wvf > tolscale * a.act_norm[slot])) {
+    mode = OMP_DONE;                                        // dual not positive: f gets weight 0
+  } else if (sc > 1e-12 * gff) {
+    const double t = wvf / sc;
+    for (int q = tid; q < p; q += blockDim.x)
+      if (!(n.x[n.plist[q]] - t * n.t1[q] > 0.0)) s_bad = 1;
+    __syncthreads();
+    if (!s_bad && t > 0.0) {
+      for (int q = tid; q < p; q += blockDim.x) n.x[n.plist[q]] -= t * n.t1[q];
+      if (tid == 0) {
+        n.plist[p] = slot; n.ppos[slot] = p; n.x[slot] = t;
+        st->np = p + 1;
+        st->omp_t = t; st->omp_inv = 1.0 / sc;
+      }
+      mode = OMP_FAST_ACCEPT;
+    }
+  }
+  __syncthreads();
+  if (tid == 0) st->omp_mode = mode;
+}
+
+// H <- [[H + u u^T / s, -u/s], [-u^T/s, 1/s]]   (p = size before the insertion); runs inside the
+// combine launch on the workgroups beyond the column blocks
+static __device__ void omp_rank1_part(const NnlsArgs& n, int wg, int nwg) {
+  DevState* st = n.a.st;
+  if (st->omp_mode != OMP_FAST_ACCEPT) return;
+  const int p = st->omp_p;
+  const double inv = st->omp_inv;
+  const int64_t total = (int64_t)p * p;
+  for (int64_t idx = (int64_t)wg * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)nwg * blockDim.x) {
+    const int rr = (int)(idx / p), cc = (int)(idx - (int64_t)rr * p);
+    n.hinv[(size_t)rr * n.ldg + cc] += n.t1[rr] * n.t1[cc] * inv;
+  }
+  for (int q = wg * blockDim.x + threadIdx.x; q < p; q += nwg * blockDim.x) {
+    const double e = -n.t1[q] * inv;
+    n.hinv[(size_t)p * n.ldg + q] = e;
+    n.hinv[(size_t)q * n.ldg + p] = e;
+  }
+  if (wg == 0 && threadIdx.x == 0) n.hinv[(size_t)p * n.ldg + p] = inv;
+}
+
+__global__ __launch_bounds__(NN_THREADS) void omp_general_kernel(NnlsArgs n) {
+  const ApplyArgs& a = n.a;
+  DevState* st = a.st;
+  if (!st->active || st->omp_mode != OMP_GENERAL) return;
+  __shared__ double scratch[BCX_SCRATCH];
+  const int tid = threadIdx.x, d = a.d;
+  const int k = st->k, slot = st->omp_slot;
+  const int k1 = k + (st->omp_fresh ? 1 : 0);
+  if (!st->hvalid) rebuild_passive(n, k, scratch);
+  for (int j = tid; j < k1; j += blockDim.x) {
+    const bool in = (j == slot) || (a.act_w[j] > 0.0);
+    n.flag[j] = in ? FLAG_INS : 0;
+    if (n.ppos[j] < 0) n.x[j] = 0.0;
+  }
+  __syncthreads();
+  const double eps = 2.220446049250313e-16;
+  const double tolscale = 10.0 * eps * (double)(d > k1 ? d : k1) * st->bnorm;
+  nnls_run(n, k1, tolscale, scratch);
+}
+
+// tmp[j] = sum_{q < np} x[plist[q]] * rows[plist[q]][j]: one workgroup per 64 columns
+__global__ __launch_bounds__(256) void omp_combine_kernel(NnlsArgs n, int ncol_wg) {
+  const ApplyArgs& a = n.a;
+  DevState* st = a.st;
+  if (!st->active) return;
+  if ((int)blockIdx.x >= ncol_wg) { omp_rank1_part(n, blockIdx.x - ncol_wg, gridDim.x - ncol_wg); return; }
+  __shared__ double seg[4][64];
+  const int d = a.d, p = st->np;
+  const int col = blockIdx.x * 64 + (threadIdx.x & 63), w = threadIdx.x >> 6;
+  double acc = 0.0;
+  if (col < d) {
+    int q = w;
+    for (; q + 28 < p; q += 32) {
+      double m[8], xv[8];
+#pragma unroll
+      for (int t = 0; t < 8; ++t) { const int c = n.plist[q + 4 * t]; xv[t] = n.x[c]; m[t] = a.act_rows[(size_t)c * d + col]; }
+#pragma unroll
+      for (int t = 0; t < 8; ++t) acc += xv[t] * m[t];
+    }
+    for (; q < p; q += 4) { const int c = n.plist[q]; acc += n.x[c] * a.act_rows[(size_t)c * d + col]; }
+  }
+  seg[w][threadIdx.x & 63] = acc;
+  __syncthreads();
+  if (w == 0 && col < d) a.tmp[col] = ((seg[0][threadIdx.x] + seg[1][threadIdx.x]) + seg[2][threadIdx.x]) + seg[3][threadIdx.x];
+}
+
+__global__ __launch_bounds__(BCX_APPLY_THREADS) void omp_finish_kernel(NnlsArgs n) {
+  const ApplyArgs& a = n.a;
+  DevState* st = a.st;
+  if (!st->active) return;
+  __shared__ double scratch[BCX_SCRATCH];
+  const int tid = threadIdx.x, d = a.d;
+  const int k = st->k;
+  const int k1 = k + (st->omp_fresh ? 1 : 0);
+  const bool checked = st->omp_checked != 0;
+  const double err0 = st->err;
+  double v[2] = {0.0, 0.0};
+  for (int j = tid; j < d; j += blockDim.x) {
+    const double x = a.tmp[j], rr = x - a.b[j];
+    v[0] += rr * rr; v[1] += x * x;
+  }
+  block_allsum<2>(v, scratch);
+  const double new_err = sqrt(v[0]);
+  int status = BCX_IT_OK;
+  if (checked && new_err > err0) status = BCX_IT_FAIL_MONOTONE;      // snnls.py:58
+  if (status == BCX_IT_OK) {
+    for (int j = tid; j < k1; j += blockDim.x) a.act_w[j] = (n.ppos[j] >= 0) ? n.x[j] : 0.0;
+    for (int j = tid; j < d; j += blockDim.x) a.xw[j] = a.tmp[j];
+    if (tid == 0) {
+      st->k = k1;
+      st->err = new_err;
+      const double nwn = sqrt(v[1]);
+      st->nw = nwn == 0.0 ? 1.0 : nwn;
+      st->since_refresh += 1;
+      if (checked) st->retried = 0;
+    }
+  } else {
+    for (int j = tid; j < k; j += blockDim.x) a.act_w[j] = n.wbak[j];
+    if (tid == 0) st->hvalid = 0;
+  }
+  __syncthreads();
+  if (tid == 0) {
+    const int64_t it = st->it;
+    a.tr_sel[it] = st->omp_f; a.tr_err[it] = st->err; a.tr_status[it] = status;
+    st->it = it + 1;
+    st->exact_mode = 0;
+    st->omp_mode = OMP_IDLE;
+    if (status != BCX_IT_OK) {
+      if (st->retried) { st->limit = 1; st->active = 0; st->halt = HALT_LIMIT; }
+      else st->retried = 1;
+    }
+  }
+  __syncthreads();
+  if (!st->active) return;
+  prepare_next(a, scratch);
+}
+
 static void fill_nnls_args(bcx_solver* s, NnlsArgs& n, const double* recs) {
   fill_apply_args(s, n.a, recs);
   n.a.refresh_every = 0;   // OMP recomputes xw from the passive set on every step
@@ -509,13 +823,30 @@ static void fill_nnls_args(bcx_solver* s, NnlsArgs& n, const double* recs) {
   n.cvec = s->cvec; n.plist = s->plist; n.ppos = s->ppos;
   n.x = s->nn_x; n.z = s->nn_z;
   n.t0 = s->nn_tmp; n.t1 = s->nn_tmp + s->gram_cap; n.t2 = s->nn_tmp + 2 * s->gram_cap;
+  n.t3 = s->nn_tmp + 3 * s->gram_cap;
   n.flag = s->nn_flag; n.wbak = s->nn_wbak;
 }
 
 int bcx_launch_apply_omp(bcx_solver* s, const double* recv_dev) {
   NnlsArgs n;
   fill_nnls_args(s, n, recv_dev);
-  hipLaunchKernelGGL(apply_omp_kernel, dim3(1), dim3(NN_THREADS), 0, s->stream, n);
+  s->k_ub += 1;                               // this step may add one slot
+  const int64_t kub = s->k_ub;
+  if ((kub < 160 && !getenv("BCX_OMP_MULTI")) || getenv("BCX_OMP_SINGLE")) {  // small active sets: one launch is cheaper than eight
+    hipLaunchKernelGGL(apply_omp_kernel, dim3(1), dim3(NN_THREADS), 0, s->stream, n);
+    BCX_HIP(hipGetLastError());
+    return BCX_OK;
+  }
+  const int d = s->cfg.d;
+  hipLaunchKernelGGL(omp_rows_kernel, dim3((unsigned)((kub + 1 + 3) / 4)), dim3(256), 0, s->stream, n);
+  hipLaunchKernelGGL(omp_decide_kernel, dim3(1), dim3(NN_THREADS), 0, s->stream, n);
+  hipLaunchKernelGGL(omp_mv_kernel, dim3((unsigned)((kub + 63) / 64)), dim3(256), 0, s->stream, n);
+  hipLaunchKernelGGL(omp_step_kernel, dim3(1), dim3(NN_THREADS), 0, s->stream, n);
+  hipLaunchKernelGGL(omp_general_kernel, dim3(1), dim3(NN_THREADS), 0, s->stream, n);
+  const int ncol = (d + 63) / 64;
+  const int64_t r1 = std::max<int64_t>(1, std::min<int64_t>((kub * kub + 2047) / 2048, 512));
+  hipLaunchKernelGGL(omp_combine_kernel, dim3((unsigned)(ncol + r1)), dim3(256), 0, s->stream, n, ncol);
+  hipLaunchKernelGGL(omp_finish_kernel, dim3(1), dim3(BCX_APPLY_THREADS), 0, s->stream, n);
   BCX_HIP(hipGetLastError());
   return BCX_OK;
 }
