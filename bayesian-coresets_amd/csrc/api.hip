@@ -116,10 +116,22 @@ extern "C" int bcx_load_rows(bcx_solver* s, const void* src, int32_t src_is_devi
     int rc = bcx_launch_ingest(s, src, src_dtype, ld, row_begin, rows);
     if (rc != BCX_OK) return rc;
   } else if (s->A64 && src_dtype == BCX_F64) {
-    // host fp64 rows go straight to their final place; the ingest kernel then works in place
+    // host fp64 rows go straight to their final place; the ingest kernel then works in place.
+    // Pageable host memory copies at a few GB/s; pinning the caller's buffer for the duration of the
+    // copy (hipHostRegister) lets the DMA engines run at PCIe speed.  Falls back silently if the
+    // registration is refused.
     double* dst = s->A64 + (size_t)row_begin * s->ld64;
-    BCX_HIP(hipMemcpy2DAsync(dst, (size_t)s->ld64 * 8, src, (size_t)ld * 8, (size_t)d * 8, (size_t)rows,
-                             hipMemcpyHostToDevice, s->stream));
+    const size_t span = ((size_t)(rows - 1) * ld + d) * 8;
+    const bool pinned = span >= (size_t)(8u << 20) &&
+                        hipHostRegister(const_cast<void*>(src), span, hipHostRegisterDefault) == hipSuccess;
+    if (!pinned) (void)hipGetLastError();
+    hipError_t ce = hipMemcpy2DAsync(dst, (size_t)s->ld64 * 8, src, (size_t)ld * 8, (size_t)d * 8, (size_t)rows,
+                                     hipMemcpyHostToDevice, s->stream);
+    if (pinned) {
+      (void)hipStreamSynchronize(s->stream);
+      (void)hipHostUnregister(const_cast<void*>(src));
+    }
+    BCX_HIP(ce);
     int rc = bcx_launch_ingest(s, dst, BCX_F64, s->ld64, row_begin, rows);
     if (rc != BCX_OK) return rc;
   } else {
