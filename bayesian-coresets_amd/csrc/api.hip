@@ -420,7 +420,7 @@ extern "C" int bcx_reset(bcx_solver* s) {
   DevState h;
   int rc = read_state(s, &h);
   if (rc != BCX_OK) return rc;
-  h.k = 0; h.np = 0; h.hvalid = 1; h.limit = 0; h.retried = 0; h.active = 0; h.halt = HALT_NONE; h.since_refresh = 0; h.exact_mode = 0;
+  h.k = 0; h.np = 0; h.hvalid = 1; h.omp_ill = 0; h.limit = 0; h.retried = 0; h.active = 0; h.halt = HALT_NONE; h.since_refresh = 0; h.exact_mode = 0;
   h.err = h.bnorm; h.nw = 1.0; h.it = 0; h.itrs = 0;
   BCX_HIP(hipMemcpy(s->st, &h, sizeof h, hipMemcpyHostToDevice));
   BCX_HIP(hipMemset(s->xw, 0, (size_t)s->cfg.d * 8));

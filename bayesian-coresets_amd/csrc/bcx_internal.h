@@ -53,6 +53,8 @@ struct DevState {
   // multi-kernel OMP step (nnls.hip): decisions handed from kernel to kernel
   int32_t omp_mode;    // OMP_* below
   int32_t omp_slot, omp_fresh, omp_checked, omp_p;
+  int32_t omp_ill;     // a Schur complement below 1e-4 of its diagonal was seen: the Gram system is
+                       // ill-conditioned, every step takes the refined general solve from now on
   int64_t omp_f;
   double omp_nf, omp_gff, omp_cf, omp_t, omp_inv;
   double tol;          // bc.util.TOL at build() time

@@ -145,6 +145,8 @@ __global__ __launch_bounds__(256) void finalize_kernel(int d, int have_b, const 
     st->qscale = 1.0;
     st->np = 0;
     st->hvalid = 1;
+    st->omp_ill = 0;
+    st->omp_mode = OMP_IDLE;
   }
 }
 

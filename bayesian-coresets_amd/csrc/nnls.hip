@@ -114,6 +114,7 @@ static __device__ bool border_add(const NnlsArgs& n, int slot, double* scratch) 
   const double gff = n.gram[(size_t)slot * ld + slot];
   const double s = gff - v[0];
   if (!(s > 1e-12 * gff)) return false;
+  if (threadIdx.x == 0 && !(s > 1e-4 * gff)) st->omp_ill = 1;
   const double inv = 1.0 / s;
   for (int idx = threadIdx.x; idx < p * p; idx += blockDim.x) {
     const int r = idx / p, c = idx - r * p;
@@ -167,18 +168,25 @@ static __device__ void border_del(const NnlsArgs& n, int q) {
   __syncthreads();
 }
 
-// z = argmin over the passive set: z = H c_P, then one refinement step z += H (c_P - G_PP z).
-static __device__ void passive_solve(const NnlsArgs& n) {
+// z = argmin over the passive set: z = H c_P, then iterative refinement against the Gram matrix itself,
+// z += H (c_P - G_PP z), until the residual is at rounding level (at most 4 steps; one suffices unless the
+// system is ill-conditioned and the bordered inverse has drifted).
+static __device__ void passive_solve(const NnlsArgs& n, double* scratch) {
   const int p = n.a.st->np;
-  for (int a = threadIdx.x; a < p; a += blockDim.x) n.t0[a] = n.cvec[n.plist[a]];
-  __syncthreads();
+  double cmax = 0.0;
+  for (int a = threadIdx.x; a < p; a += blockDim.x) { const double c = n.cvec[n.plist[a]]; n.t0[a] = c; cmax = fmax(cmax, fabs(c)); }
+  cmax = block_allmax(cmax, scratch);
   mv_sym(n.hinv, n.ldg, p, n.t0, n.z);
-  mv_gram(n, p, n.z, n.t1);
-  for (int a = threadIdx.x; a < p; a += blockDim.x) n.t1[a] = n.t0[a] - n.t1[a];
-  __syncthreads();
-  mv_sym(n.hinv, n.ldg, p, n.t1, n.t2);
-  for (int a = threadIdx.x; a < p; a += blockDim.x) n.z[a] += n.t2[a];
-  __syncthreads();
+  for (int it = 0; it < 4; ++it) {
+    mv_gram(n, p, n.z, n.t1);
+    double rmax = 0.0;
+    for (int a = threadIdx.x; a < p; a += blockDim.x) { const double r = n.t0[a] - n.t1[a]; n.t1[a] = r; rmax = fmax(rmax, fabs(r)); }
+    rmax = block_allmax(rmax, scratch);
+    if (!(rmax > 1e-14 * cmax)) break;
+    mv_sym(n.hinv, n.ldg, p, n.t1, n.t2);
+    for (int a = threadIdx.x; a < p; a += blockDim.x) n.z[a] += n.t2[a];
+    __syncthreads();
+  }
 }
 
 // Lawson-Hanson active-set iteration over the slots flagged FLAG_INS, warm-started from the
@@ -219,7 +227,7 @@ static __device__ void nnls_run(const NnlsArgs& n, int k, double tolscale, doubl
     if (threadIdx.x == 0) n.x[best.i] = 0.0;
     __syncthreads();
     for (int inner = 0; inner < max_outer; ++inner) {
-      passive_solve(n);
+      passive_solve(n, scratch);
       const int pp = st->np;
       // feasibility: all z > 0 ?  else step length alpha = min x/(x - z) over z <= 0
       double amin = INFINITY; int apos = -1;
@@ -411,7 +419,7 @@ __global__ __launch_bounds__(NN_THREADS) void apply_omp_kernel(NnlsArgs n) {
   const double tolscale = 10.0 * eps * (double)(d > k1 ? d : k1) * st->bnorm;
   const int p = st->np;
   bool done = n.ppos[slot] >= 0;          // f already carries weight: the NNLS problem is unchanged
-  if (!done && (st->since_refresh % OMP_RESOLVE_EVERY) != OMP_RESOLVE_EVERY - 1) {
+  if (!done && !st->omp_ill && (st->since_refresh % OMP_RESOLVE_EVERY) != OMP_RESOLVE_EVERY - 1) {
     // closed-form bordered step
     for (int q = tid; q < p; q += blockDim.x) n.t0[q] = n.gram[(size_t)slot * n.ldg + n.plist[q]];
     __syncthreads();
@@ -424,7 +432,9 @@ __global__ __launch_bounds__(NN_THREADS) void apply_omp_kernel(NnlsArgs n) {
     const double wvf = n.cvec[slot] - r[1];
     if (!(wvf > tolscale * a.act_norm[slot])) {
       done = true;                                        // dual not positive: f gets weight 0
-    } else if (sc > 1e-12 * gff) {
+    } else if (!(sc > 1e-4 * gff)) {
+      if (tid == 0) st->omp_ill = 1;                      // nearly dependent column: refined general solve
+    } else {
       const double t = wvf / sc;
       for (int q = tid; q < p; q += blockDim.x)
         if (!(n.x[n.plist[q]] - t * n.t1[q] > 0.0)) s_bad = 1;
@@ -621,7 +631,8 @@ __global__ __launch_bounds__(NN_THREADS) void omp_decide_kernel(NnlsArgs n) {
   const int p = st->np;
   int mode;
   if (!st->hvalid) mode = OMP_GENERAL;
-  else if (n.ppos[slot] >= 0) mode = OMP_DONE;             // f already carries weight: nothing changes
+  else if (n.ppos[slot] >= 0) mode = OMP_DONE;
+  else if (st->omp_ill) mode = OMP_GENERAL;             // f already carries weight: nothing changes
   else if ((st->since_refresh % OMP_RESOLVE_EVERY) == OMP_RESOLVE_EVERY - 1) mode = OMP_GENERAL;
   else {
     mode = OMP_FAST_TRY;
@@ -680,7 +691,9 @@ __global__ __launch_bounds__(NN_THREADS) void omp_step_kernel(NnlsArgs n) {
   int mode = OMP_GENERAL;
   if (!(wvf > tolscale * a.act_norm[slot])) {
     mode = OMP_DONE;                                        // dual not positive: f gets weight 0
-  } else if (sc > 1e-12 * gff) {
+  } else if (!(sc > 1e-4 * gff)) {
+    if (tid == 0) st->omp_ill = 1;                        // nearly dependent column: refined general solve
+  } else {
     const double t = wvf / sc;
     for (int q = tid; q < p; q += blockDim.x)
       if (!(n.x[n.plist[q]] - t * n.t1[q] > 0.0)) s_bad = 1;

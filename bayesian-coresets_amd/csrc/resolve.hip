@@ -112,7 +112,7 @@ static __device__ void resolve_core(const ResolveArgs& a, Winner* win, double* x
     __syncthreads();
     if (tid == 0) cand[0] = minrow;
     nc = 1;
-  } else if (tid < nc) {
+  } else if (!storm && tid < nc) {   // (a storm without exact scores overflows: no candidate list to read)
     const int cp = cand_p[tid];
     cand[tid] = (cp & 1) ? a.pv.i2[cp >> 1] : a.pv.i1[cp >> 1];
   }

@@ -367,3 +367,60 @@ def test_float32_and_torch_inputs(bc):
     s32 = bc.snnls.FrankWolfe(X32.T, X32.astype(np.float64).sum(axis=0))
     s32.build(15)
     assert np.array_equal(s32.last_trace[0], np.array([t[0] for t in o32.trace]))
+
+
+def test_candidate_storm_lowrank_rows(bc):
+    """Effectively 2-dimensional data: hundreds of rows sit inside the fp32 candidate window, the iteration must
+    take the exact fp64 scan (regression test: the overflowing candidate list used to be read out of bounds)."""
+    from oracle.snnls_oracle import SnnlsOracle
+    rs = np.random.RandomState(5)
+    N, d = 120000, 17
+    X = rs.randn(N, 2).dot(rs.randn(2, d)) + 1e-3 * rs.randn(N, d)
+    for alg in ("giga", "fw"):
+        o = SnnlsOracle(X.T, X.sum(axis=0), alg=alg, mode="onepass")
+        o.build(12)
+        s = _run(bc, X, alg, 12)
+        scale = np.sqrt((X.sum(axis=0) ** 2).sum())
+        n = sum(1 for t in o.trace if t[2] == 0 and t[1] > 1e-7 * scale)
+        assert n >= 3
+        assert np.array_equal(s.last_trace[0][:n], np.array([t[0] for t in o.trace[:n]]))
+
+
+@pytest.mark.parametrize("seed", (11, 12, 13))
+def test_randomized_parity_sweep(bc, seed):
+    """Random shapes / algorithms / storage types / data pathologies (duplicates, 11 decades of row scale,
+    bundles of nearly parallel rows, low rank) against the CPU oracle (tools/stress_parity.py, reduced)."""
+    from oracle.snnls_oracle import SnnlsOracle
+    rs = np.random.RandomState(seed)
+    for case in range(14):
+        N = int(rs.choice([700, 5000, 30000]))
+        d = int(rs.choice([3, 17, 64, 100, 256, 300, 512]))
+        alg = str(rs.choice(["giga", "fw", "omp"]))
+        dtype = str(rs.choice(["float32", "float16", "float64"]))
+        kind = str(rs.choice(["plain", "dups", "scaled", "parallel", "lowrank"]))
+        X = rs.randn(N, d)
+        if kind == "dups":
+            src, dst = rs.randint(0, N, size=N // 10), rs.randint(0, N, size=N // 10)
+            X[dst] = X[src]
+        elif kind == "scaled":
+            X *= 10.0 ** rs.uniform(-8, 3, size=(N, 1))
+        elif kind == "parallel":
+            X[: N // 20] = rs.randn(d) * rs.uniform(0.5, 2.0, size=(N // 20, 1)) + 1e-7 * rs.randn(N // 20, d)
+        elif kind == "lowrank":
+            r = max(1, d // 8)
+            X = rs.randn(N, r).dot(rs.randn(r, d)) + 1e-3 * rs.randn(N, d)
+        itrs = int(min(30, d + 5))
+        o = SnnlsOracle(X.T, X.sum(axis=0), alg=alg, mode="onepass")
+        o.build(itrs)
+        s = _run(bc, X, alg, itrs, dtype=dtype)
+        scale = np.sqrt((X.sum(axis=0) ** 2).sum())
+        n = 0
+        for t in o.trace:
+            if t[2] != 0 or t[1] < 1e-7 * scale:
+                break
+            n += 1
+        n = min(n, len(s.last_trace[0]))
+        tag = "case %d: N=%d d=%d %s %s %s" % (case, N, d, alg, dtype, kind)
+        assert np.array_equal(s.last_trace[0][:n], np.array([t[0] for t in o.trace[:n]])), tag
+        np.testing.assert_allclose(s.last_trace[1][:n], np.array([t[1] for t in o.trace[:n]]), rtol=1e-6,
+                                   atol=1e-9 * scale, err_msg=tag)

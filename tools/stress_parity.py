@@ -1,0 +1,48 @@
+"""dev: randomized parity stress -- HIP engine vs CPU oracle over random shapes / algorithms / storage types,
+including duplicated rows (exact ties), wildly scaled rows and nearly parallel rows."""
+import sys, os, time
+import numpy as np
+ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
+sys.path.insert(0, os.path.join(ROOT, "bayesian-coresets_amd")); sys.path.insert(0, ROOT)
+import bayesiancoresets_amd as bc
+from oracle.snnls_oracle import SnnlsOracle
+
+cls = {"giga": bc.snnls.GIGA, "fw": bc.snnls.FrankWolfe, "omp": bc.snnls.OrthoPursuit}
+rs = np.random.RandomState(int(sys.argv[1]) if len(sys.argv) > 1 else 0)
+ncase = int(sys.argv[2]) if len(sys.argv) > 2 else 40
+bad = 0
+t0 = time.time()
+for case in range(ncase):
+    N = int(rs.choice([700, 5000, 30000, 120000]))
+    d = int(rs.choice([3, 17, 64, 100, 256, 300, 512]))
+    alg = str(rs.choice(["giga", "fw", "omp"]))
+    dtype = str(rs.choice(["float32", "float16", "float64"]))
+    kind = str(rs.choice(["plain", "dups", "scaled", "parallel", "lowrank"]))
+    X = rs.randn(N, d)
+    if kind == "dups":
+        src = rs.randint(0, N, size=N // 10); dst = rs.randint(0, N, size=N // 10); X[dst] = X[src]
+    elif kind == "scaled":
+        X *= 10.0 ** rs.uniform(-8, 3, size=(N, 1))
+    elif kind == "parallel":
+        base = rs.randn(d); X[: N // 20] = base * rs.uniform(0.5, 2.0, size=(N // 20, 1)) + 1e-7 * rs.randn(N // 20, d)
+    elif kind == "lowrank":
+        r = max(1, d // 8); X = rs.randn(N, r).dot(rs.randn(r, d)) + 1e-3 * rs.randn(N, d)
+    itrs = int(min(30, d + 5))
+    if os.environ.get('STRESS_VERBOSE'): print('case', case, N, d, alg, dtype, kind, flush=True)
+    o = SnnlsOracle(X.T, X.sum(axis=0), alg=alg, mode="onepass"); o.build(itrs)
+    s = cls[alg](X.T, X.sum(axis=0), dtype=dtype); s.build(itrs)
+    sel = s.last_trace[0]; osel = np.array([t[0] for t in o.trace]); oerr = np.array([t[1] for t in o.trace])
+    scale = np.sqrt((X.sum(axis=0) ** 2).sum())
+    n = 0
+    for t in o.trace:
+        if t[2] != 0 or t[1] < 1e-7 * scale: break
+        n += 1
+    n = min(n, len(sel))
+    ok = np.array_equal(sel[:n], osel[:n])
+    if ok and n:
+        ok = np.allclose(s.last_trace[1][:n], oerr[:n], rtol=1e-6, atol=1e-9 * scale)
+    if not ok:
+        bad += 1
+        k = int(np.argmax(sel[:n] != osel[:n])) if not np.array_equal(sel[:n], osel[:n]) else -1
+        print("MISMATCH case %d: N=%d d=%d %s %s %s first diff at %d (n=%d) gpu %s oracle %s" % (case, N, d, alg, dtype, kind, k, n, sel[max(0,k-1):k+2], osel[max(0,k-1):k+2]), flush=True)
+print("cases %d bad %d in %.1f s" % (ncase, bad, time.time() - t0))
