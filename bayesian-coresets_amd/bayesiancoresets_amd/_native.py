@@ -22,7 +22,7 @@ SYMBOLS = (
     "bcx_finalize", "bcx_build_begin", "bcx_step_scan", "bcx_step_apply", "bcx_build_enqueue", "bcx_build_poll",
     "bcx_step_scan_exact", "bcx_build_trace", "bcx_active_count", "bcx_get_weights", "bcx_error", "bcx_optimize",
     "bcx_reset", "bcx_reached_numeric_limit", "bcx_get_vector", "bcx_get_norms", "bcx_argmax_correlation", "bcx_time_scan",
-    "bcx_profile_scan", "bcx_profile_read", "bcx_version",
+    "bcx_stats", "bcx_profile_scan", "bcx_profile_read", "bcx_version",
     "bcx_project_write", "bcx_project_colsum", "bcx_project_select", "bcx_project_last_error",
 )
 
@@ -79,6 +79,7 @@ def load():
         "bcx_get_norms": [vp, i64, i64, vp],
         "bcx_argmax_correlation": [vp, vp, P(i64), P(dbl)],
         "bcx_time_scan": [vp, i32, i32, P(dbl), P(dbl)],
+        "bcx_stats": [vp, P(i64), P(i64), P(i64)],
         "bcx_profile_scan": [vp, i32],
         "bcx_profile_read": [vp, P(dbl), P(i64)],
     }
@@ -315,6 +316,11 @@ class Engine(object):
         ms, by = ctypes.c_double(), ctypes.c_double()
         self._check(self.lib.bcx_time_scan(self.h, reps, int(exact), ctypes.byref(ms), ctypes.byref(by)))
         return ms.value, by.value
+
+    def stats(self):
+        a, b, c = ctypes.c_int64(), ctypes.c_int64(), ctypes.c_int64()
+        self._check(self.lib.bcx_stats(self.h, ctypes.byref(a), ctypes.byref(b), ctypes.byref(c)))
+        return {"exact_fallbacks": a.value, "candidates": b.value, "resolves": c.value}
 
     def profile(self, on):
         self._check(self.lib.bcx_profile_scan(self.h, int(on)))

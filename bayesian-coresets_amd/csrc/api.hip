@@ -540,6 +540,17 @@ extern "C" int bcx_argmax_correlation(bcx_solver* s, const double* query_host, i
   return BCX_OK;
 }
 
+extern "C" int bcx_stats(bcx_solver* s, int64_t* exact_fallbacks, int64_t* candidates, int64_t* resolves) {
+  if (!s) return BCX_ERR_ARG;
+  DevState h;
+  int rc = read_state(s, &h);
+  if (rc != BCX_OK) return rc;
+  if (exact_fallbacks) *exact_fallbacks = h.n_exact;
+  if (candidates) *candidates = h.n_cand;
+  if (resolves) *resolves = h.n_resolved;
+  return BCX_OK;
+}
+
 extern "C" int bcx_profile_scan(bcx_solver* s, int32_t on) {
   if (!s) return BCX_ERR_ARG;
   s->profile = on != 0;

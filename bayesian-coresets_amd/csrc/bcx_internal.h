@@ -62,6 +62,9 @@ struct DevState {
   double nw;           // ||A w|| (1 when zero, giga.py:23)
   double bnorm;        // ||b||
   double sigma;        // sum of row norms (frankwolfe.py:25)
+  int64_t n_exact;     // diagnostics: iterations that needed the exact fp64 scan (candidate window overflow)
+  int64_t n_cand;      // diagnostics: candidate rows re-scored in fp64, summed over iterations
+  int64_t n_resolved;  // diagnostics: resolve passes
   double qscale;       // norm of the query vector (error bound of the fp32 scan scales with it)
 };
 

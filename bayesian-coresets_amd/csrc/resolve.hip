@@ -126,6 +126,7 @@ static __device__ void resolve_core(const ResolveArgs& a, Winner* win, double* x
     __syncthreads();
     return;
   }
+  if (tid == 0) { a.st->n_cand += nc; a.st->n_resolved += 1; }
   // exact fp64 score of every candidate, one wave per candidate; norm, row and query loads are independent
   const double* q0 = a.q64;
   const double* q1 = a.q64 + a.ld64;
@@ -422,7 +423,7 @@ __global__ __launch_bounds__(BCX_APPLY_THREADS) void begin_kernel(ApplyArgs a, i
 }
 
 __global__ __launch_bounds__(64) void resume_exact_kernel(DevState* st) {
-  if (threadIdx.x == 0 && st->halt == HALT_NEED_EXACT) { st->active = 1; st->halt = HALT_NONE; st->exact_mode = 1; }
+  if (threadIdx.x == 0 && st->halt == HALT_NEED_EXACT) { st->active = 1; st->halt = HALT_NONE; st->exact_mode = 1; st->n_exact += 1; }
 }
 
 // error() outside a build: refresh xw from the slots and recompute err (snnls.py:28-29)

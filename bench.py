@@ -200,7 +200,7 @@ def main():
                 "alg": args.alg, "rows": args.rows, "dim": args.dim, "rows_per_gpu": solver.n_local,
                 "exact_rows_resident": not args.no_exact_rows,
                 "steps_accepted": int((status == 0).sum()), "final_error": float(err[-1]) if len(err) else None,
-                "coreset_points_per_s": float(solver.size()) / elapsed if args.warmup == 0 else None,
+                "rescue": solver.engine.stats(),   # fp64 re-scored candidates / exact-scan fallbacks since construction
             },
             "roofline": {
                 "bound": "hbm", "kernel": "scan_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",

@@ -143,6 +143,9 @@ int bcx_argmax_correlation(bcx_solver* s, const double* query_host, int64_t* idx
 /* Time `reps` launches of the correlation-scan kernel alone with hipEvents on the solver's stream;
  * returns the mean milliseconds per launch and the algorithmic bytes one launch reads. */
 int bcx_time_scan(bcx_solver* s, int32_t reps, int32_t exact, double* ms_per_launch, double* bytes_per_launch);
+/* Diagnostics since construction: iterations that fell back to the exact fp64 scan, candidate rows re-scored
+ * in fp64 (total) and resolve passes (candidates / resolves = mean candidates per iteration). */
+int bcx_stats(bcx_solver* s, int64_t* exact_fallbacks, int64_t* candidates, int64_t* resolves);
 /* Sum of scan-kernel time recorded by hipEvents during bcx_build_enqueue (enable with on=1). */
 int bcx_profile_scan(bcx_solver* s, int32_t on);
 int bcx_profile_read(bcx_solver* s, double* scan_ms_total, int64_t* scan_launches);
