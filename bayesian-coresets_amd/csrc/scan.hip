@@ -130,8 +130,12 @@ template <typename T, int G> __device__ __forceinline__ T group_allsum(T v) {
   if constexpr (sizeof(T) == 4) {
     return group_allsum_f32<G>(v);
   } else {
-#pragma unroll
-    for (int off = G / 2; off >= 1; off >>= 1) v += __shfl_xor(v, off, BCX_WAVE);
+    if (G >= 2) v += bcx_dpp_f64<0xB1>(v);
+    if (G >= 4) v += bcx_dpp_f64<0x4E>(v);
+    if (G >= 8) v += bcx_dpp_f64<0x141>(v);
+    if (G >= 16) v += bcx_dpp_f64<0x140>(v);
+    if (G >= 32) v += bcx_xor16_f64(v);
+    if (G >= 64) v += bcx_xor32_f64(v);
     return v;
   }
 }
@@ -356,11 +360,11 @@ static int pick_group(int nvec) {  // lanes per row
 // with the 8 workgroups per CU one would launch by reflex.  So: grid = 256 CUs x (8 / loads per lane).
 int bcx_scan_grid(const bcx_solver* s) { return BCX_MAX_PARTIALS; }   // capacity of the partial arrays
 
-static int scan_grid_for(int64_t n, int rows_per_block, int loads_per_lane, bool f64) {
+static int scan_grid_for(int64_t n, int rows_per_block, int loads_per_lane, bool heavy) {
   int64_t want = (n + rows_per_block - 1) / rows_per_block;
   if (want < 1) want = 1;
   int64_t cap = 256 * (int64_t)(8 / (loads_per_lane < 1 ? 1 : (loads_per_lane > 8 ? 8 : loads_per_lane)));
-  if (f64) cap = BCX_MAX_PARTIALS;   // the fp64 kernels reduce through LDS permutes and want the occupancy
+  if (heavy) cap = BCX_MAX_PARTIALS;   // fp64 GIGA is VALU-heavy (fp64 sqrt/divide per row): it wants the occupancy
   if (const char* e = getenv("BCX_SCAN_GRID")) { const long v = atol(e); if (v > 0) cap = v; }
   if (cap > BCX_MAX_PARTIALS) cap = BCX_MAX_PARTIALS;
   if (want > cap) want = cap;
@@ -431,7 +435,7 @@ int bcx_launch_scan(bcx_solver* s, int exact) {
   // mirror of the kernel's UR / RPB arithmetic
   const int ur = (CH >= BCX_LOADS_IN_FLIGHT) ? 1 : (BCX_LOADS_IN_FLIGHT / CH > BCX_UR_MAX ? BCX_UR_MAX : BCX_LOADS_IN_FLIGHT / CH);
   const int rpb = (BCX_SCAN_THREADS / 64) * (64 / G) * ur;
-  const int grid = scan_grid_for(a.n, rpb, CH * ur, f64);
+  const int grid = scan_grid_for(a.n, rpb, CH * ur, f64 && dual);
   s->n_partials = grid;                     // resolve reads exactly this launch's partials
   a.out = partial_view(s->partials, grid);
   int rc;
