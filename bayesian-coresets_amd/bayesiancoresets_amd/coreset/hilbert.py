@@ -5,6 +5,7 @@ to ``wts / idcs / pts`` in index order."""
 import numpy as np
 
 from ..snnls.giga import GIGA
+from ..snnls.snnls import SparseNNLS as _DeviceSolver
 from .coreset import Coreset
 
 
@@ -55,12 +56,14 @@ class HilbertCoreset(Coreset):
 
     @staticmethod
     def _make_solver(snnls, vecs):
-        """Solver on A = vecs^T, b = column sums (hilbert.py:24).  Host arrays: b is summed on the host
-        exactly as the reference does; a projection that already lives on the GPU lets the engine form it."""
+        """Solver on A = vecs^T with b = the column sums of vecs (hilbert.py:24).  The device solvers form b
+        themselves during ingest (fp64 chunked column sums, csrc/ingest.hip) when handed ``b=None``; host-only
+        solver classes (the sampling baselines) get the NumPy sum as in the reference."""
+        on_device = isinstance(snnls, type) and issubclass(snnls, _DeviceSolver)
         if _is_torch(vecs):
-            b = None if vecs.device.type == "cuda" else vecs.sum(dim=0).numpy()
+            b = None if (on_device or vecs.device.type == "cuda") else vecs.sum(dim=0).numpy()
             return snnls(vecs.t(), b)
-        return snnls(vecs.T, vecs.sum(axis=0))
+        return snnls(vecs.T, None if on_device else vecs.sum(axis=0))
 
     # ---- Coreset interface ----------------------------------------------------------------
     def reset(self):

@@ -43,7 +43,7 @@ class SparseNNLS(object):
     def __init__(self, A, b, check_error_monotone=True, *, device=0, dtype="float32", keep_exact_rows=True):
         self.alg_name, self.log = object_logger(self)
         self.A = A
-        self.b = b
+        self._b_arg = b
         self.check_error_monotone = check_error_monotone
         self._w_cache = None
         self._eng = None
@@ -75,6 +75,13 @@ class SparseNNLS(object):
             raise nat.EngineError(rc, eng.lib.bcx_last_error(eng.h).decode())
         self.reached_numeric_limit = False
         self.last_trace = None
+
+    @property
+    def b(self):
+        """The target vector (as passed, or the device column sums when constructed with b=None)."""
+        if self._b_arg is None and self._eng is not None:
+            self._b_arg = self._eng.vector(0)
+        return self._b_arg
 
     # ---- state ------------------------------------------------------------
     @property
