@@ -8,10 +8,14 @@
 //
 // Mapping (wave64): a group of G lanes owns one row; lane `sub` of the group loads the 16-byte
 // pieces sub, sub+G, ... of that row (fully coalesced: one wave-wide load covers 1 KiB of
-// contiguous row data), multiplies them with the matching query pieces held in REGISTERS (a lane
-// always touches the same columns), and the G partial sums are combined with a butterfly.  A
-// workgroup of 4 waves walks the rows with a grid stride; UR row-steps are issued back to back so
-// every lane keeps CH*UR independent 16-byte loads in flight.
+// contiguous row data) with the non-temporal hint, multiplies them with the matching query pieces
+// held in REGISTERS (a lane always touches the same columns), and the partial sums are combined
+// without LDS: for G = 64 four rows at a time by a transposed butterfly (v_permlane32_swap,
+// v_permlane16_swap, 4 DPP adds), after which each 16-lane row of the wave tracks one data row.
+// A workgroup of 4 waves walks the rows with a grid stride; UR row-steps are issued back to back
+// (fenced) so every lane keeps CH*UR = 4-8 independent 16-byte loads in flight, and only 1-2
+// workgroups are resident per CU (see scan_grid_for): the stream is fastest with few, deep waves.
+// Rows may be stored as fp32 (default), fp16 (half the bytes; fp32 accumulation) or fp64.
 //
 // The fp32 scan does not decide the arg-max alone: every row gets a rigorous interval
 // [L, U] around its exact score (forward error bound of the fp32 dot product), each workgroup
