@@ -12,6 +12,8 @@ The driver is written against a small engine protocol (``bayesiancoresets_amd._n
 implements it on the GPU); tests inject a CPU stand-in to exercise this orchestration under
 ``gloo`` without a GPU.
 """
+import os
+
 import numpy as np
 
 from . import _native as nat
@@ -117,7 +119,7 @@ class ShardedSolver(object):
             return None
         remaining = itrs
         while True:
-            if self.world == 1 and hasattr(self.engine, "enqueue"):
+            if self.world == 1 and hasattr(self.engine, "enqueue") and not os.environ.get("BCX_SHARDED_GENERIC"):
                 self.engine.enqueue(remaining)       # single shard: scan + merged resolve/apply launches
             else:
                 for _ in range(remaining):

@@ -177,12 +177,19 @@ static __device__ void passive_solve(const NnlsArgs& n, double* scratch) {
   for (int a = threadIdx.x; a < p; a += blockDim.x) { const double c = n.cvec[n.plist[a]]; n.t0[a] = c; cmax = fmax(cmax, fabs(c)); }
   cmax = block_allmax(cmax, scratch);
   mv_sym(n.hinv, n.ldg, p, n.t0, n.z);
-  for (int it = 0; it < 4; ++it) {
+  // well-conditioned systems: one refinement step, no convergence test (3 passes in total);
+  // ill-conditioned ones (omp_ill): refine until the residual is at rounding level
+  const int max_it = n.a.st->omp_ill ? 4 : 1;
+  for (int it = 0; it < max_it; ++it) {
     mv_gram(n, p, n.z, n.t1);
     double rmax = 0.0;
     for (int a = threadIdx.x; a < p; a += blockDim.x) { const double r = n.t0[a] - n.t1[a]; n.t1[a] = r; rmax = fmax(rmax, fabs(r)); }
-    rmax = block_allmax(rmax, scratch);
-    if (!(rmax > 1e-14 * cmax)) break;
+    if (max_it > 1) {
+      rmax = block_allmax(rmax, scratch);
+      if (!(rmax > 1e-14 * cmax)) break;
+    } else {
+      __syncthreads();
+    }
     mv_sym(n.hinv, n.ldg, p, n.t1, n.t2);
     for (int a = threadIdx.x; a < p; a += blockDim.x) n.z[a] += n.t2[a];
     __syncthreads();
