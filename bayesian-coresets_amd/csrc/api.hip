@@ -96,6 +96,8 @@ extern "C" int bcx_set_stream(bcx_solver* s, void* hip_stream) {
   return BCX_OK;
 }
 
+static int read_state(bcx_solver* s, DevState* h);
+
 extern "C" int bcx_load_rows(bcx_solver* s, const void* src, int32_t src_is_device, int32_t src_dtype,
                              int64_t row_begin, int64_t rows, int64_t ld) {
   if (!s || (!src && rows > 0)) return BCX_ERR_ARG;
@@ -111,6 +113,18 @@ extern "C" int bcx_load_rows(bcx_solver* s, const void* src, int32_t src_is_devi
     return BCX_ERR_ARG;
   }
   BCX_HIP(hipSetDevice(s->cfg.device));
+  if (row_begin == 0) {
+    // a (re)load from the first row starts a new matrix: forget the previous one's zero-row flag and state
+    if (s->finalized) {
+      DevState h;
+      int rc0 = read_state(s, &h);
+      if (rc0 != BCX_OK) return rc0;
+      h.zero_row = 0; h.k = 0; h.np = 0; h.hvalid = 1; h.omp_ill = 0; h.limit = 0; h.active = 0; h.halt = HALT_NONE;
+      BCX_HIP(hipMemcpy(s->st, &h, sizeof h, hipMemcpyHostToDevice));
+      s->finalized = false;
+    }
+    s->rows_loaded = 0;
+  }
   const size_t esz = src_dtype == BCX_F64 ? 8 : 4;
   if (src_is_device) {
     int rc = bcx_launch_ingest(s, src, src_dtype, ld, row_begin, rows);
@@ -480,9 +494,14 @@ extern "C" int bcx_time_scan(bcx_solver* s, int32_t reps, int32_t exact, double*
   hipEvent_t e0, e1;
   BCX_HIP(hipEventCreate(&e0));
   BCX_HIP(hipEventCreate(&e1));
-  for (int i = 0; i < 3; ++i) if ((rc = bcx_launch_scan(s, exact))) return rc;
-  BCX_HIP(hipEventRecord(e0, s->stream));
-  for (int i = 0; i < reps; ++i) if ((rc = bcx_launch_scan(s, exact))) return rc;
+  for (int i = 0; i < 3 && rc == BCX_OK; ++i) rc = bcx_launch_scan(s, exact);
+  if (rc == BCX_OK) (void)hipEventRecord(e0, s->stream);
+  for (int i = 0; i < reps && rc == BCX_OK; ++i) rc = bcx_launch_scan(s, exact);
+  if (rc != BCX_OK) {
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    (void)hipMemcpy(s->st, &h, sizeof h, hipMemcpyHostToDevice);
+    return rc;
+  }
   BCX_HIP(hipEventRecord(e1, s->stream));
   BCX_HIP(hipEventSynchronize(e1));
   float ms = 0.f;
