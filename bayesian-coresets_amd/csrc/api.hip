@@ -585,3 +585,12 @@ extern "C" int bcx_profile_read(bcx_solver* s, double* scan_ms_total, int64_t* s
   if (scan_launches) *scan_launches = s->prof_launches;
   return BCX_OK;
 }
+
+// dev builds (-DBCX_TIMING): phase time stamps (100 MHz ticks) of the last merged tail; not in include/bcx.h
+extern "C" int bcx_debug_stamps(bcx_solver* s, long long* out32) {
+  DevState h;
+  int rc = read_state(s, &h);
+  if (rc != BCX_OK) return rc;
+  for (int i = 0; i < 32; ++i) out32[i] = h.dbg_t[i];
+  return BCX_OK;
+}

@@ -66,6 +66,7 @@ struct DevState {
   int64_t n_cand;      // diagnostics: candidate rows re-scored in fp64, summed over iterations
   int64_t n_resolved;  // diagnostics: resolve passes
   double qscale;       // norm of the query vector (error bound of the fp32 scan scales with it)
+  long long dbg_t[32]; // phase time stamps of the last tail (dev builds with -DBCX_TIMING, tools/tail_timing.py)
 };
 
 struct bcx_solver {
@@ -140,6 +141,12 @@ int bcx_launch_resume_exact(bcx_solver* s);
 int bcx_launch_error_refresh(bcx_solver* s);
 int bcx_launch_optimize(bcx_solver* s, double tol);
 int bcx_scan_grid(const bcx_solver* s);
+
+#ifdef BCX_TIMING
+#define BCX_STAMP(st, i) do { if (threadIdx.x == 0) (st)->dbg_t[i] = wall_clock64(); } while (0)
+#else
+#define BCX_STAMP(st, i) do {} while (0)
+#endif
 
 #define BCX_HIP(call)                                                        \
   do {                                                                       \

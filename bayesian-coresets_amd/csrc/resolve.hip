@@ -83,6 +83,7 @@ static __device__ void resolve_core(const ResolveArgs& a, Winner* win, double* x
 #pragma unroll
   for (int t = 0; t < PP_MAX; ++t) lmax = fmax(lmax, exact ? u1[t] : lo[t]);
   const double Lstar = block_allmax(lmax, scratch);   // (exact: the maximum score itself)
+  BCX_STAMP(a.st, 1);
 #pragma unroll
   for (int t = 0; t < PP_MAX; ++t) {
     const int p = tid + t * 256;
@@ -127,6 +128,7 @@ static __device__ void resolve_core(const ResolveArgs& a, Winner* win, double* x
     return;
   }
   if (tid == 0) { a.st->n_cand += nc; a.st->n_resolved += 1; }
+  BCX_STAMP(a.st, 2);
   // exact fp64 score of every candidate, one wave per candidate; norm, row and query loads are independent
   const double* q0 = a.q64;
   const double* q1 = a.q64 + a.ld64;
@@ -148,6 +150,7 @@ static __device__ void resolve_core(const ResolveArgs& a, Winner* win, double* x
     if (lane == 0) cscore[c] = dual ? giga_score64(s0, s1) : s0;
   }
   __syncthreads();
+  BCX_STAMP(a.st, 3);
   if (tid == 0) {
     int best = 0;
     for (int c = 1; c < nc; ++c)
@@ -172,6 +175,7 @@ static __device__ void resolve_core(const ResolveArgs& a, Winner* win, double* x
     if (a.rec) a.rec[BCX_REC_HDR + j] = raw;
   }
   __syncthreads();
+  BCX_STAMP(a.st, 4);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -220,6 +224,7 @@ static __device__ void apply_core(const ApplyArgs& a, const StateVecs& v, int64_
     if (npos) atomicAdd(&s_npos, npos);
   }
   __syncthreads();
+  BCX_STAMP(st, 5);
   const bool checked = s_npos > 0;
   const int slot = s_slot == 0x7fffffff ? -1 : s_slot;
   const double wf_old = slot >= 0 ? a.act_w[slot] : 0.0;
@@ -269,6 +274,7 @@ static __device__ void apply_core(const ApplyArgs& a, const StateVecs& v, int64_
       else { alpha = 1.0 - gnum / gden; beta = sc * gnum / gden; }
     }
   }
+  BCX_STAMP(st, 6);
   double new_err = err0, new_nw = nw, tdot = 0.0, wf_new = 0.0;
   if (status == BCX_IT_OK) {
     // w <- alpha*w ; w[f] <- max(0, w[f] + beta)   giga.py:63-64 / frankwolfe.py:39-40
@@ -290,6 +296,7 @@ static __device__ void apply_core(const ApplyArgs& a, const StateVecs& v, int64_
     tdot = r[2];
     if (checked && new_err > err0) status = BCX_IT_FAIL_MONOTONE;   // snnls.py:58
   }
+  BCX_STAMP(st, 7);
   bool limit = false;
   if (status == BCX_IT_OK) {
     for (int s = tid; s < k; s += blockDim.x)
@@ -318,6 +325,7 @@ static __device__ void apply_core(const ApplyArgs& a, const StateVecs& v, int64_
       else st->retried = 1;
     }
   }
+  BCX_STAMP(st, 8);
   if (limit) return;
   // ---- next query ----
   const bool fast = status == BCX_IT_OK && it + 1 < itrs &&
@@ -326,6 +334,7 @@ static __device__ void apply_core(const ApplyArgs& a, const StateVecs& v, int64_
     if (ALG != BCX_ALG_GIGA) {
       for (int j = tid; j < d; j += blockDim.x) store_query(a, 0, j, v.b[j] - v.xw[j]);   // frankwolfe.py:16
       if (tid == 0) st->qscale = new_err;
+      BCX_STAMP(st, 9);
       return;
     }
     // giga.py:21-30 on the new iterate
@@ -344,6 +353,7 @@ static __device__ void apply_core(const ApplyArgs& a, const StateVecs& v, int64_
         store_query(a, 1, j, v.xw[j] / new_nw);
       }
       if (tid == 0) st->qscale = 1.0;
+      BCX_STAMP(st, 9);
       return;
     }
   }
@@ -402,6 +412,7 @@ __global__ __launch_bounds__(BCX_APPLY_THREADS) void tail_kernel(ResolveArgs r, 
   extern __shared__ double dyn[];
   __shared__ double scratch[BCX_SCRATCH];
   __shared__ Winner win;
+  BCX_STAMP(st, 0);
   const StateVecs v = carve(dyn, a.d);
   stage_state(a, v);
   resolve_core(r, &win, v.xf, scratch);

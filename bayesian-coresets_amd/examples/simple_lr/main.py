@@ -3,7 +3,7 @@
 examples/simple_lr/main.py): synthetic data, Laplace approximation at the MAP, S Monte-Carlo samples,
 log-likelihood projection on the device (DeviceProjector "logistic"), greedy Hilbert coreset.
 
-    python simple_lr.py --rows 1000000 --samples 512 --alg OMP --size 512
+    python main.py --rows 1000000 --samples 512 --alg OMP --size 512
 """
 import argparse
 import os
@@ -13,7 +13,7 @@ import time
 import numpy as np
 from scipy.optimize import minimize
 
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."))
 import bayesiancoresets_amd as bc  # noqa: E402
 
 

@@ -1,6 +1,9 @@
 """GPU parity: the HIP engine (through the C ABI / Python mirror) against the golden vectors
 produced by the reference and against the CPU oracle on the same seeded inputs.
 Indices must be bit-exact; weights within 1e-5 relative (BASELINE.json north_star)."""
+import os
+import sys
+
 import numpy as np
 import pytest
 
@@ -424,3 +427,34 @@ def test_randomized_parity_sweep(bc, seed):
         assert np.array_equal(s.last_trace[0][:n], np.array([t[0] for t in o.trace[:n]])), tag
         np.testing.assert_allclose(s.last_trace[1][:n], np.array([t[1] for t in o.trace[:n]]), rtol=1e-6,
                                    atol=1e-9 * scale, err_msg=tag)
+
+
+# ---- the experiment harness end to end -------------------------------------------------
+@pytest.mark.parametrize("trial", (1, 2))
+def test_harness_cli_writes_reference_results(golden, tmp_path, trial):
+    """`main.py --alg GIGA --trial t run` (examples/synthetic_vectors/run_experiment.sh:7) stores Ms / csize /
+    err columns equal to the reference's stored run for the same arguments; a second call is a no-op."""
+    import subprocess
+    import pandas as pd
+    script = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "bayesian-coresets_amd", "examples",
+                          "synthetic_vectors", "main.py")
+    folder = str(tmp_path / "results") + "/"
+    cmd = [sys.executable, script, "--alg", "GIGA", "--trial", str(trial), "--data_type", "normal",
+           "--results_folder", folder, "run"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    files = [f for f in os.listdir(folder) if f != "manifest.csv"]
+    assert len(files) == 1
+    t = pd.read_csv(os.path.join(folder, files[0]))
+    assert list(t.columns[:10]) == ["alg", "data_num", "data_dim", "data_type", "coreset_size_max",
+                                    "coreset_num_sizes", "coreset_size_spacing", "trial", "results_folder",
+                                    "verbosity"]
+    k = "F3_t%d_giga_" % trial
+    assert np.array_equal(t["Ms"].to_numpy(), golden["F3_Ms"])
+    assert np.array_equal(t["csize"].to_numpy(), golden[k + "csize"])
+    ge = golden[k + "err"]
+    np.testing.assert_allclose(t["err"].to_numpy()[ge > 1e-6], ge[ge > 1e-6], rtol=1e-6)
+    assert (np.diff(t["cput"].to_numpy()) >= 0).all() and (np.diff(t["wall"].to_numpy()) > 0).all()
+    again = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+    assert again.returncode == 0 and "Results already exist" in again.stdout
+    assert len(open(os.path.join(folder, "manifest.csv")).read().splitlines()) == 1
