@@ -24,6 +24,7 @@ SYMBOLS = (
     "bcx_reset", "bcx_reached_numeric_limit", "bcx_get_vector", "bcx_get_norms", "bcx_argmax_correlation", "bcx_time_scan",
     "bcx_stats", "bcx_profile_scan", "bcx_profile_read", "bcx_version",
     "bcx_project_write", "bcx_project_colsum", "bcx_project_select", "bcx_project_last_error",
+    "bcx_build_enqueue_exact", "bcx_exchange_export", "bcx_exchange_attach", "bcx_exchange_probe", "bcx_exchange_disable",
 )
 
 
@@ -82,6 +83,11 @@ def load():
         "bcx_stats": [vp, P(i64), P(i64), P(i64)],
         "bcx_profile_scan": [vp, i32],
         "bcx_profile_read": [vp, P(dbl), P(i64)],
+        "bcx_build_enqueue_exact": [vp],
+        "bcx_exchange_export": [vp, vp, i32],
+        "bcx_exchange_attach": [vp, vp, i32, dbl],
+        "bcx_exchange_probe": [vp, P(i32)],
+        "bcx_exchange_disable": [vp],
     }
     proj_common = [vp, i32, vp, i64, i64, i32, i32, vp, i32, i32, dbl]
     sigs["bcx_project_write"] = proj_common + [vp, i64, vp]
@@ -229,6 +235,30 @@ class Engine(object):
 
     def enqueue(self, itrs):
         self._check(self.lib.bcx_build_enqueue(self.h, itrs))
+
+    def enqueue_exact(self):
+        self._check(self.lib.bcx_build_enqueue_exact(self.h))
+
+    # -- peer mailbox (device-side record exchange between row shards) -------
+    IPC_HANDLE_BYTES = 64
+
+    def exchange_export(self):
+        buf = ctypes.create_string_buffer(self.IPC_HANDLE_BYTES)
+        self._check(self.lib.bcx_exchange_export(self.h, buf, self.IPC_HANDLE_BYTES))
+        return buf.raw
+
+    def exchange_attach(self, handles, timeout_s=0.0):
+        blob = b"".join(handles)
+        assert len(blob) == self.IPC_HANDLE_BYTES * len(handles)
+        self._check(self.lib.bcx_exchange_attach(self.h, blob, self.IPC_HANDLE_BYTES, float(timeout_s)))
+
+    def exchange_probe(self):
+        res = ctypes.c_int32()
+        self._check(self.lib.bcx_exchange_probe(self.h, ctypes.byref(res)))
+        return res.value
+
+    def exchange_disable(self):
+        self._check(self.lib.bcx_exchange_disable(self.h))
 
     def poll(self):
         n, ne, lim = ctypes.c_int64(), ctypes.c_int32(), ctypes.c_int32()

@@ -2,11 +2,22 @@
 greedy iteration.
 
 Every rank scans only its own rows and produces a record {exact score, global index, norm,
-flags, raw row} (d + 4 doubles).  The records are all-gathered (RCCL over xGMI through
-``torch.distributed``; payload world_size * (d + 4) * 8 bytes, i.e. latency-bound) and every
-rank applies the *same* fp64 reweight to its replicated O(d) state, so xw, weights and the
-trace stay bit-identical on all ranks; no residual all-reduce is needed.  Contiguous shards
-plus the (score desc, global index asc) winner rule keep NumPy's lowest-index tie-break.
+flags, raw row} (d + 4 doubles).  The records reach every rank (payload world_size * (d + 4) * 8
+bytes, i.e. latency-bound) and every rank applies the *same* fp64 reweight to its replicated
+O(d) state, so xw, weights and the trace stay bit-identical on all ranks; no residual
+all-reduce is needed.  Contiguous shards plus the (score desc, global index asc) winner rule
+keep NumPy's lowest-index tie-break.
+
+Two exchange modes:
+  * "mailbox" (default when every rank is on this node): the iteration's tail kernel stores its
+    record straight into the peers' mailboxes over xGMI (hipIpc-mapped fine-grained memory) and
+    waits for theirs, so a whole build() is enqueued without a host round trip or a collective
+    launch per iteration (csrc/resolve.hip: mailbox_exchange).  Set up once through
+    torch.distributed (handle all-gather) and verified by a collective probe; any failure falls
+    back, on all ranks together, to
+  * "collective": resolve kernel -> all_gather (RCCL over xGMI via torch.distributed) -> apply
+    kernel, driven from the host every iteration.  BCX_EXCHANGE=collective forces it.
+Either way build() ends with a cross-rank check that every rank recorded the same trace.
 
 The driver is written against a small engine protocol (``bayesiancoresets_amd._native.Engine``
 implements it on the GPU); tests inject a CPU stand-in to exercise this orchestration under
@@ -62,6 +73,54 @@ class ShardedSolver(object):
         self.reached_numeric_limit = False
         self.last_trace = None
         self._flat_gather = True
+        self.exchange = "collective"
+        if self.world > 1 and hasattr(self.engine, "exchange_export") \
+                and os.environ.get("BCX_EXCHANGE", "mailbox") == "mailbox":
+            self._setup_mailbox()
+
+    def _agree(self, ok):
+        """True iff `ok` holds on every rank."""
+        flag = self.torch.tensor([1.0 if ok else 0.0], dtype=self.torch.float64, device=self.tdev)
+        self.dist.all_reduce(flag, op=self.dist.ReduceOp.MIN, group=self.group)
+        return bool(flag.item() > 0.5)
+
+    def _setup_mailbox(self):
+        """Map every rank's mailbox (one node: hipIpc) and prove the path with one probe exchange;
+        all ranks end up in the same mode."""
+        import logging
+        import socket
+        handle, why = None, ""
+        try:
+            handle = self.engine.exchange_export()
+        except nat.EngineError as e:
+            why = str(e)
+        mine = (socket.gethostname(), handle)
+        everyone = [None] * self.world
+        self.dist.all_gather_object(everyone, mine, group=self.group)
+        ok = all(h is not None and host == mine[0] for host, h in everyone)
+        if ok:
+            try:
+                self.engine.exchange_attach([h for _, h in everyone],
+                                            float(os.environ.get("BCX_EXCHANGE_TIMEOUT", "20")))
+            except nat.EngineError as e:
+                ok, why = False, str(e)
+        if self._agree(ok):           # (also a barrier: every mailbox is mapped before the first store)
+            res = self.engine.exchange_probe()
+            ok = res == 1
+            why = why or "probe result %d" % res
+            if self._agree(ok):
+                self.exchange = "mailbox"
+                return
+        self.engine.exchange_disable()
+        if self.rank == 0:
+            logging.getLogger().warning("sharded build: peer mailbox unavailable (%s); using the all-gather exchange",
+                                        why or "a peer failed")
+
+    def fallback_to_collective(self):
+        """Leave mailbox mode (COLLECTIVE call: every rank, e.g. after build() raised on all of them)."""
+        if self.exchange == "mailbox":
+            self.engine.exchange_disable()
+            self.exchange = "collective"
 
     def _all_gather(self, recv, send):
         """all_gather_into_tensor (one RCCL call); backends without it (gloo on device tensors) get the
@@ -119,14 +178,19 @@ class ShardedSolver(object):
             return None
         remaining = itrs
         while True:
-            if self.world == 1 and hasattr(self.engine, "enqueue") and not os.environ.get("BCX_SHARDED_GENERIC"):
-                self.engine.enqueue(remaining)       # single shard: scan + merged resolve/apply launches
+            on_device = self.exchange == "mailbox" or (
+                self.world == 1 and hasattr(self.engine, "enqueue") and not os.environ.get("BCX_SHARDED_GENERIC"))
+            if on_device:
+                self.engine.enqueue(remaining)       # scan + merged resolve / (exchange) / apply launches
             else:
                 for _ in range(remaining):
                     self._one_iteration()
             done, need_exact, limit = self.engine.poll()   # replicated state: same answer on every rank
             if need_exact:
-                self._one_iteration(exact=True)
+                if self.exchange == "mailbox":
+                    self.engine.enqueue_exact()
+                else:
+                    self._one_iteration(exact=True)
                 done, need_exact, limit = self.engine.poll()
                 if need_exact:
                     raise nat.EngineError(nat.ERR_STATE, "exact scan did not resolve the iteration")
@@ -135,7 +199,24 @@ class ShardedSolver(object):
             remaining = itrs - done
         self.reached_numeric_limit = bool(limit)
         self.last_trace = self.engine.trace(itrs)
+        self._check_replicated(self.last_trace)
         return self.last_trace
+
+    def _check_replicated(self, trace):
+        """The design invariant, checked once per build(): every rank recorded the same (selection,
+        error, status) sequence.  One tiny all-reduce; a mismatch means a broken exchange."""
+        if self.world == 1:
+            return
+        sel, err, status = trace
+        digest = np.zeros(3)
+        if len(sel):
+            wgt = 1.0 + (np.arange(len(sel)) % 8191)
+            digest[:] = (float(np.dot(sel % 65521, wgt)), float(np.dot(status, wgt)), float(err[-1]))
+        t = self.torch.tensor(np.concatenate([digest, -digest]), dtype=self.torch.float64, device=self.tdev)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX, group=self.group)
+        t = t.cpu().numpy()
+        if not np.array_equal(t[:3], -t[3:]):
+            raise nat.EngineError(nat.ERR_STATE, "ranks disagree on the build trace (exchange mode %s)" % self.exchange)
 
     # ---- read-out --------------------------------------------------------------
     def sparse_weights(self):

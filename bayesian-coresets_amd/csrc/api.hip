@@ -29,6 +29,11 @@ static void free_all(bcx_solver* s) {
                   s->tr_status};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
+  for (size_t w = 0; w < s->peer_mbox.size(); ++w)
+    if (s->peer_mbox[w] && s->peer_mbox[w] != s->mbox) (void)hipIpcCloseMemHandle(s->peer_mbox[w]);
+  void* xptrs[] = {s->mbox, s->peer_tab, s->xseq, s->xprobe, s->rec_gather};
+  for (void* p : xptrs)
+    if (p) (void)hipFree(p);
   for (auto& ev : s->prof_events) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
 }
 
@@ -332,15 +337,125 @@ extern "C" int bcx_step_apply(bcx_solver* s, const void* recv_dev) {
   return bcx_launch_apply(s, recv_dev ? (const double*)recv_dev : s->rec_local);
 }
 
+// one whole iteration without the host: single shard, or row shards with an attached peer mailbox
+static int enqueue_one(bcx_solver* s, int exact) {
+  if (s->cfg.world_size != 1) {
+    if (!s->exchange_ready) {
+      s->err = "bcx_build_enqueue on a row shard needs bcx_exchange_attach (or drive bcx_step_scan / bcx_step_apply)";
+      return BCX_ERR_ARG;
+    }
+    int rc;
+    if (exact && (rc = bcx_launch_resume_exact(s))) return rc;
+    if ((rc = prof_begin(s))) return rc;
+    if ((rc = bcx_launch_scan(s, exact))) return rc;
+    if ((rc = prof_end(s))) return rc;
+    return bcx_launch_tail_exchange(s, exact);
+  }
+  const bool fuse = s->cfg.alg != BCX_ALG_OMP;
+  int rc = step_scan(s, nullptr, exact, fuse);
+  if (rc != BCX_OK) return rc;
+  return fuse ? BCX_OK : bcx_launch_apply(s, s->rec_local);
+}
+
 extern "C" int bcx_build_enqueue(bcx_solver* s, int64_t itrs) {
   if (!s) return BCX_ERR_ARG;
-  if (s->cfg.world_size != 1) { s->err = "bcx_build_enqueue is single-shard; use bcx_step_scan/apply"; return BCX_ERR_ARG; }
-  const bool fuse = s->cfg.alg != BCX_ALG_OMP;
+  if (!s->finalized) { s->err = "solver not finalized"; return BCX_ERR_STATE; }
   for (int64_t i = 0; i < itrs; ++i) {
-    int rc = step_scan(s, nullptr, 0, fuse);
+    int rc = enqueue_one(s, 0);
     if (rc != BCX_OK) return rc;
-    if (!fuse && (rc = bcx_launch_apply(s, s->rec_local))) return rc;
   }
+  return BCX_OK;
+}
+
+extern "C" int bcx_build_enqueue_exact(bcx_solver* s) {
+  if (!s) return BCX_ERR_ARG;
+  if (!s->finalized) { s->err = "solver not finalized"; return BCX_ERR_STATE; }
+  return enqueue_one(s, 1);
+}
+
+// ---- peer mailbox --------------------------------------------------------------------------------
+static int mailbox_alloc(bcx_solver* s) {
+  if (s->mbox) return BCX_OK;
+  const int world = s->cfg.world_size;
+  const size_t bytes = bcx_mailbox_slot_offset(world) + 2 * (size_t)world * (s->cfg.d + BCX_REC_HDR) * sizeof(double);
+  // fine-grained: stores from peer GPUs become visible to a kernel that is already running here
+  hipError_t e = hipExtMallocWithFlags(&s->mbox, bytes, hipDeviceMallocFinegrained);
+  if (e != hipSuccess) {
+    (void)hipGetLastError();
+    s->mbox = nullptr;
+    s->err = std::string("peer mailbox: fine-grained allocation failed: ") + hipGetErrorString(e);
+    return BCX_ERR_HIP;
+  }
+  s->mbox_bytes = bytes;
+  BCX_HIP(hipMemset(s->mbox, 0, bytes));
+  BCX_HIP(hipDeviceSynchronize());
+  return BCX_OK;
+}
+
+extern "C" int bcx_exchange_export(bcx_solver* s, void* handle_out, int32_t handle_bytes) {
+  if (!s || !handle_out) return BCX_ERR_ARG;
+  if (handle_bytes < (int32_t)sizeof(hipIpcMemHandle_t)) { s->err = "bcx_exchange_export: handle buffer too small"; return BCX_ERR_ARG; }
+  BCX_HIP(hipSetDevice(s->cfg.device));
+  int rc = mailbox_alloc(s);
+  if (rc != BCX_OK) return rc;
+  hipIpcMemHandle_t h;
+  BCX_HIP(hipIpcGetMemHandle(&h, s->mbox));
+  memset(handle_out, 0, handle_bytes);
+  memcpy(handle_out, &h, sizeof(h));
+  return BCX_OK;
+}
+
+extern "C" int bcx_exchange_attach(bcx_solver* s, const void* handles, int32_t handle_bytes, double timeout_s) {
+  if (!s || !handles) return BCX_ERR_ARG;
+  if (s->exchange_ready) return BCX_OK;
+  if (!s->mbox) { s->err = "bcx_exchange_attach: call bcx_exchange_export first"; return BCX_ERR_STATE; }
+  if (handle_bytes < (int32_t)sizeof(hipIpcMemHandle_t)) return BCX_ERR_ARG;
+  BCX_HIP(hipSetDevice(s->cfg.device));
+  const int world = s->cfg.world_size;
+  if (world > BCX_APPLY_THREADS) { s->err = "peer mailbox supports at most 256 shards"; return BCX_ERR_ARG; }
+  s->peer_mbox.assign(world, nullptr);
+  for (int w = 0; w < world; ++w) {
+    if (w == s->cfg.rank) { s->peer_mbox[w] = s->mbox; continue; }
+    hipIpcMemHandle_t h;
+    memcpy(&h, (const char*)handles + (size_t)w * handle_bytes, sizeof(h));
+    hipError_t e = hipIpcOpenMemHandle(&s->peer_mbox[w], h, hipIpcMemLazyEnablePeerAccess);
+    if (e != hipSuccess) {
+      (void)hipGetLastError();
+      s->peer_mbox[w] = nullptr;
+      s->err = "peer mailbox: cannot map shard " + std::to_string(w) + ": " + hipGetErrorString(e);
+      for (int v = 0; v < w; ++v)
+        if (v != s->cfg.rank && s->peer_mbox[v]) { (void)hipIpcCloseMemHandle(s->peer_mbox[v]); s->peer_mbox[v] = nullptr; }
+      s->peer_mbox.clear();
+      return BCX_ERR_HIP;
+    }
+  }
+  hipError_t e;
+  if ((e = dev_alloc(&s->peer_tab, (size_t)world)) != hipSuccess || (e = dev_alloc(&s->xseq, 1)) != hipSuccess ||
+      (e = dev_alloc(&s->xprobe, 1)) != hipSuccess ||
+      (e = dev_alloc(&s->rec_gather, (size_t)world * (s->cfg.d + BCX_REC_HDR))) != hipSuccess) {
+    s->err = std::string("peer mailbox: ") + hipGetErrorString(e);
+    return BCX_ERR_NOMEM;
+  }
+  BCX_HIP(hipMemcpy(s->peer_tab, s->peer_mbox.data(), (size_t)world * sizeof(void*), hipMemcpyHostToDevice));
+  if (timeout_s > 0.0) s->exchange_timeout_s = timeout_s;
+  s->exchange_ready = true;
+  return BCX_OK;
+}
+
+extern "C" int bcx_exchange_probe(bcx_solver* s, int32_t* result) {
+  if (!s || !result) return BCX_ERR_ARG;
+  if (!s->exchange_ready) { s->err = "bcx_exchange_probe: no peer mailbox attached"; return BCX_ERR_STATE; }
+  BCX_HIP(hipSetDevice(s->cfg.device));
+  int rc = bcx_launch_exchange_probe(s);
+  if (rc != BCX_OK) return rc;
+  BCX_HIP(hipStreamSynchronize(s->stream));
+  BCX_HIP(hipMemcpy(result, s->xprobe, sizeof(int32_t), hipMemcpyDeviceToHost));
+  return BCX_OK;
+}
+
+extern "C" int bcx_exchange_disable(bcx_solver* s) {
+  if (!s) return BCX_ERR_ARG;
+  s->exchange_ready = false;   // mappings stay until bcx_destroy; the host-driven step_scan / step_apply path is used again
   return BCX_OK;
 }
 
@@ -349,6 +464,10 @@ extern "C" int bcx_build_poll(bcx_solver* s, int64_t* n_done, int32_t* need_exac
   DevState h;
   int rc = read_state(s, &h);
   if (rc != BCX_OK) return rc;
+  if (h.halt == HALT_EXCHANGE_TIMEOUT) {
+    s->err = "peer mailbox: a shard did not deliver its record within " + std::to_string(s->exchange_timeout_s) + " s";
+    return BCX_ERR_EXCHANGE;
+  }
   if (n_done) *n_done = h.it;
   if (need_exact) *need_exact = (h.halt == HALT_NEED_EXACT);
   if (limit) *limit = h.limit;

@@ -17,7 +17,7 @@
 #define BCX_SCAN_THREADS 256
 #define BCX_APPLY_THREADS 256
 
-enum { HALT_NONE = 0, HALT_DONE = 1, HALT_LIMIT = 2, HALT_NEED_EXACT = 3 };
+enum { HALT_NONE = 0, HALT_DONE = 1, HALT_LIMIT = 2, HALT_NEED_EXACT = 3, HALT_EXCHANGE_TIMEOUT = 4 };
 enum { OMP_IDLE = 0, OMP_DONE = 1, OMP_FAST_TRY = 2, OMP_FAST_ACCEPT = 3, OMP_GENERAL = 4 };
 
 // Per-workgroup result of the correlation scan, stored as separate arrays (coalesced reads in the
@@ -35,6 +35,25 @@ static inline __host__ __device__ PartialView partial_view(void* base, int n) {
   v.i1 = (int32_t*)(v.L + n); v.i2 = v.i1 + n;
   return v;
 }
+
+// Peer mailbox: the per-iteration record exchange of a row-sharded build without a host-side collective.
+// Every shard owns one fine-grained device allocation, mapped by all peers (hipIpc):
+//   flags [2][world] u64  -- sequence number of the record in slot [parity][source shard]
+//   slots [2][world][d+4] doubles, starting at off_slots
+// Exchange number `seq` uses parity seq & 1: a shard stores its record into slot [parity][rank] of every
+// mailbox, fences, stores seq into the matching flags, then waits until its own flags [parity][*] reach
+// seq.  A peer can be at most one exchange ahead (it needs this shard's next record to go further), so two
+// parities suffice.  Sequence numbers never restart during the life of the solver.
+struct Mailbox {
+  void* const* peers;          // world mailbox base addresses (device array; [rank] is this shard's own)
+  unsigned long long* seq;     // exchanges completed so far (device word; identical on every shard)
+  int32_t* probe;              // result of bcx_exchange_probe: 1 ok, -1 timeout, -2 payload mismatch
+  int world, rank, recw;
+  unsigned off_slots;
+  long long timeout_ticks;     // wall_clock64 ticks (100 MHz) before a wait gives up
+};
+
+static inline unsigned bcx_mailbox_slot_offset(int world) { return (unsigned)((2u * world * 8u + 255u) / 256u * 256u); }
 
 // Replicated solver state (device resident; every shard holds an identical copy).
 struct DevState {
@@ -94,6 +113,16 @@ struct bcx_solver {
   void* partials = nullptr;     // PartialView storage
   int n_partials = 0;
   double* rec_local = nullptr;   // (d+4) record produced by this shard when world_size == 1
+  // peer mailbox (bcx_exchange_*): device-side record exchange for world_size > 1
+  void* mbox = nullptr;          // this shard's mailbox (fine-grained device memory, exported over hipIpc)
+  size_t mbox_bytes = 0;
+  std::vector<void*> peer_mbox;  // mapped mailboxes by rank ([rank] == mbox)
+  void** peer_tab = nullptr;     // device copy of peer_mbox
+  unsigned long long* xseq = nullptr;
+  int32_t* xprobe = nullptr;
+  double* rec_gather = nullptr;  // world x (d+4): records of the last exchange (input of the OMP apply kernels)
+  bool exchange_ready = false;
+  double exchange_timeout_s = 20.0;
   // sparse weight list (selection order), grown on demand
   int64_t cap = 0;
   int64_t* act_idx = nullptr;    // global row index per slot
@@ -137,6 +166,9 @@ int bcx_launch_resolve(bcx_solver* s, double* send_dev, int exact);
 int bcx_launch_begin(bcx_solver* s, int64_t itrs, double tol);
 int bcx_launch_apply(bcx_solver* s, const double* recv_dev);
 int bcx_launch_tail(bcx_solver* s, int exact);
+int bcx_launch_tail_exchange(bcx_solver* s, int exact);   // resolve + mailbox exchange + apply (world_size > 1)
+int bcx_launch_exchange_probe(bcx_solver* s);
+Mailbox bcx_mailbox(const bcx_solver* s);
 int bcx_launch_resume_exact(bcx_solver* s);
 int bcx_launch_error_refresh(bcx_solver* s);
 int bcx_launch_optimize(bcx_solver* s, double tol);

@@ -421,6 +421,137 @@ __global__ __launch_bounds__(BCX_APPLY_THREADS) void tail_kernel(ResolveArgs r, 
   apply_core<ALG>(a, v, win.gidx, win.norm, scratch);
 }
 
+// ---- peer mailbox exchange (row-sharded builds, no host-side collective) --------------------------
+// System-scope accesses: the mailboxes are fine-grained memory written by other GPUs over xGMI while
+// this kernel runs, so neither the stores nor the loads may linger in this GPU's caches.
+static __device__ __forceinline__ void st_sys(double* p, double v) {
+  __hip_atomic_store((unsigned long long*)p, (unsigned long long)__double_as_longlong(v), __ATOMIC_RELAXED,
+                     __HIP_MEMORY_SCOPE_SYSTEM);
+}
+static __device__ __forceinline__ double ld_sys(const double* p) {
+  return __longlong_as_double((long long)__hip_atomic_load((const unsigned long long*)p, __ATOMIC_RELAXED,
+                                                           __HIP_MEMORY_SCOPE_SYSTEM));
+}
+
+// Publish this shard's record (hdr[4] + row[recw-4], both in LDS) to every mailbox and wait for the
+// records of all shards.  Returns this shard's slots of the exchange (world records; read them with
+// ld_sys) or nullptr after a timeout.  All threads of the workgroup; *s_flag is LDS scratch.
+static __device__ const double* mailbox_exchange(const Mailbox& m, const double* hdr, const double* row, int* s_flag) {
+  const int tid = threadIdx.x;
+  const unsigned long long seq = *m.seq + 1;
+  const int par = (int)(seq & 1ull);
+  const size_t my_slot = m.off_slots + ((size_t)par * m.world + m.rank) * m.recw * sizeof(double);
+  for (int w = 0; w < m.world; ++w) {
+    double* dst = (double*)((char*)m.peers[w] + my_slot);
+    for (int j = tid; j < m.recw; j += blockDim.x) st_sys(dst + j, j < BCX_REC_HDR ? hdr[j] : row[j - BCX_REC_HDR]);
+  }
+  __threadfence_system();          // every thread's record stores are performed before the flags below
+  if (tid == 0) *s_flag = 0;
+  __syncthreads();
+  if (tid < m.world) {
+    unsigned long long* out = (unsigned long long*)m.peers[tid] + (par * m.world + m.rank);
+    __hip_atomic_store(out, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    const unsigned long long* in = (const unsigned long long*)m.peers[m.rank] + (par * m.world + tid);
+    const long long t0 = wall_clock64();
+    while (__hip_atomic_load(in, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) < seq) {
+      __builtin_amdgcn_s_sleep(2);
+      if (wall_clock64() - t0 > m.timeout_ticks) { atomicOr(s_flag, 1); break; }
+    }
+  }
+  __syncthreads();
+  __threadfence_system();
+  if (*s_flag) return nullptr;
+  if (tid == 0) *m.seq = seq;
+  return (const double*)((const char*)m.peers[m.rank] + m.off_slots + (size_t)par * m.world * m.recw * sizeof(double));
+}
+
+// (max score, lowest global index) over the valid records; -1 if none.  One thread.
+static __device__ int pick_record(const double* recs, int world, int recw, int* overflow) {
+  int win = -1;
+  double bs = 0.0, bi = 0.0;
+  *overflow = 0;
+  for (int r = 0; r < world; ++r) {
+    const double* rec = recs + (size_t)r * recw;
+    const double fl = ld_sys(rec + 3);
+    if (fl == BCX_REC_OVERFLOW) *overflow = 1;
+    if (fl != BCX_REC_VALID) continue;
+    const double sc = ld_sys(rec), gi = ld_sys(rec + 1);
+    if (win < 0 || sc > bs || (sc == bs && gi < bi)) { win = r; bs = sc; bi = gi; }
+  }
+  return win;
+}
+
+// row-sharded GIGA / FW iteration tail in one launch: resolve, exchange records with the peers, apply
+template <int ALG>
+__global__ __launch_bounds__(BCX_APPLY_THREADS) void tail_exchange_kernel(ResolveArgs r, ApplyArgs a, Mailbox m) {
+  DevState* st = a.st;
+  if (!st->active) return;
+  extern __shared__ double dyn[];
+  __shared__ double scratch[BCX_SCRATCH];
+  __shared__ Winner win;
+  __shared__ double s_hdr[BCX_REC_HDR];
+  __shared__ int s_flag, s_win, s_overflow;
+  const int tid = threadIdx.x;
+  const StateVecs v = carve(dyn, a.d);
+  stage_state(a, v);
+  resolve_core(r, &win, v.xf, scratch);
+  if (tid == 0) { s_hdr[0] = win.score; s_hdr[1] = (double)win.gidx; s_hdr[2] = win.norm; s_hdr[3] = win.flags; }
+  __syncthreads();
+  const double* recs = mailbox_exchange(m, s_hdr, v.xf, &s_flag);
+  if (!recs) { if (tid == 0) { st->active = 0; st->halt = HALT_EXCHANGE_TIMEOUT; } return; }
+  if (tid == 0) { int ovf; s_win = pick_record(recs, m.world, m.recw, &ovf); s_overflow = ovf; }
+  __syncthreads();
+  if (s_overflow) { if (tid == 0) { st->active = 0; st->halt = HALT_NEED_EXACT; } return; }
+  if (s_win < 0) { if (tid == 0) { st->active = 0; st->halt = HALT_DONE; } return; }
+  const double* rec = recs + (size_t)s_win * m.recw;
+  if (s_win != m.rank)
+    for (int j = tid; j < a.d; j += blockDim.x) v.xf[j] = ld_sys(rec + BCX_REC_HDR + j);
+  const int64_t f = (int64_t)ld_sys(rec + 1);
+  const double nf = ld_sys(rec + 2);
+  __syncthreads();
+  apply_core<ALG>(a, v, f, nf, scratch);
+}
+
+// OMP: resolve + exchange; the gathered records go to `gather` for the apply kernels of nnls.hip
+__global__ __launch_bounds__(BCX_APPLY_THREADS) void resolve_exchange_kernel(ResolveArgs r, Mailbox m, double* gather) {
+  DevState* st = r.st;
+  if (!st->active) return;
+  extern __shared__ double dyn[];   // d doubles: the local winner's row
+  __shared__ double scratch[BCX_SCRATCH];
+  __shared__ Winner win;
+  __shared__ double s_hdr[BCX_REC_HDR];
+  __shared__ int s_flag;
+  const int tid = threadIdx.x;
+  resolve_core(r, &win, dyn, scratch);
+  if (tid == 0) { s_hdr[0] = win.score; s_hdr[1] = (double)win.gidx; s_hdr[2] = win.norm; s_hdr[3] = win.flags; }
+  __syncthreads();
+  const double* recs = mailbox_exchange(m, s_hdr, dyn, &s_flag);
+  if (!recs) { if (tid == 0) { st->active = 0; st->halt = HALT_EXCHANGE_TIMEOUT; } return; }
+  for (int j = tid; j < m.world * m.recw; j += blockDim.x) gather[j] = ld_sys(recs + j);
+}
+
+// one exchange with a known payload: checks mapping, ordering and visibility between all shards
+__global__ __launch_bounds__(BCX_APPLY_THREADS) void exchange_probe_kernel(Mailbox m) {
+  extern __shared__ double dyn[];   // recw - 4 payload doubles
+  __shared__ double s_hdr[BCX_REC_HDR];
+  __shared__ int s_flag, s_bad;
+  const int tid = threadIdx.x, nrow = m.recw - BCX_REC_HDR;
+  const double seq = (double)(*m.seq + 1);
+  for (int j = tid; j < nrow; j += blockDim.x) dyn[j] = seq * 4096.0 + m.rank * 8192.0 * 4096.0 + j;
+  if (tid == 0) { s_hdr[0] = seq; s_hdr[1] = (double)m.rank; s_hdr[2] = 0.5; s_hdr[3] = -3.0; s_bad = 0; }
+  __syncthreads();
+  const double* recs = mailbox_exchange(m, s_hdr, dyn, &s_flag);
+  if (!recs) { if (tid == 0) *m.probe = -1; return; }
+  for (int w = 0; w < m.world; ++w) {
+    const double* rec = recs + (size_t)w * m.recw;
+    if (tid == 0 && (ld_sys(rec) != seq || ld_sys(rec + 1) != (double)w || ld_sys(rec + 3) != -3.0)) s_bad = 1;
+    for (int j = tid; j < nrow; j += blockDim.x)
+      if (ld_sys(rec + BCX_REC_HDR + j) != seq * 4096.0 + w * 8192.0 * 4096.0 + j) s_bad = 1;
+  }
+  __syncthreads();
+  if (tid == 0) *m.probe = s_bad ? -2 : 1;
+}
+
 __global__ __launch_bounds__(BCX_APPLY_THREADS) void begin_kernel(ApplyArgs a, int64_t itrs, double tol) {
   __shared__ double scratch[BCX_SCRATCH];
   DevState* st = a.st;
@@ -528,6 +659,52 @@ int bcx_launch_tail(bcx_solver* s, int exact) {
     if ((rc = allow_lds(s, tail_kernel<BCX_ALG_FW>, lds))) return rc;
     hipLaunchKernelGGL((tail_kernel<BCX_ALG_FW>), dim3(1), dim3(BCX_APPLY_THREADS), lds, s->stream, r, a);
   }
+  BCX_HIP(hipGetLastError());
+  return BCX_OK;
+}
+
+Mailbox bcx_mailbox(const bcx_solver* s) {
+  Mailbox m;
+  m.peers = s->peer_tab;
+  m.seq = s->xseq;
+  m.probe = s->xprobe;
+  m.world = s->cfg.world_size;
+  m.rank = s->cfg.rank;
+  m.recw = s->cfg.d + BCX_REC_HDR;
+  m.off_slots = bcx_mailbox_slot_offset(s->cfg.world_size);
+  m.timeout_ticks = (long long)(s->exchange_timeout_s * 1e8);
+  return m;
+}
+
+// row shards with a peer mailbox: resolve + exchange + apply (GIGA / FW: one launch; OMP: + the NNLS kernels)
+int bcx_launch_tail_exchange(bcx_solver* s, int exact) {
+  ResolveArgs r;
+  fill_resolve_args(s, r, nullptr, exact);
+  const Mailbox m = bcx_mailbox(s);
+  int rc;
+  if (s->cfg.alg == BCX_ALG_OMP) {
+    const size_t lds = (size_t)s->cfg.d * sizeof(double);
+    hipLaunchKernelGGL(resolve_exchange_kernel, dim3(1), dim3(BCX_APPLY_THREADS), lds, s->stream, r, m, s->rec_gather);
+    BCX_HIP(hipGetLastError());
+    return bcx_launch_apply_omp(s, s->rec_gather);
+  }
+  ApplyArgs a;
+  fill_apply_args(s, a, nullptr);
+  const size_t lds = vec_lds_bytes(s);
+  if (s->cfg.alg == BCX_ALG_GIGA) {
+    if ((rc = allow_lds(s, tail_exchange_kernel<BCX_ALG_GIGA>, lds))) return rc;
+    hipLaunchKernelGGL((tail_exchange_kernel<BCX_ALG_GIGA>), dim3(1), dim3(BCX_APPLY_THREADS), lds, s->stream, r, a, m);
+  } else {
+    if ((rc = allow_lds(s, tail_exchange_kernel<BCX_ALG_FW>, lds))) return rc;
+    hipLaunchKernelGGL((tail_exchange_kernel<BCX_ALG_FW>), dim3(1), dim3(BCX_APPLY_THREADS), lds, s->stream, r, a, m);
+  }
+  BCX_HIP(hipGetLastError());
+  return BCX_OK;
+}
+
+int bcx_launch_exchange_probe(bcx_solver* s) {
+  const Mailbox m = bcx_mailbox(s);
+  hipLaunchKernelGGL(exchange_probe_kernel, dim3(1), dim3(BCX_APPLY_THREADS), (size_t)s->cfg.d * sizeof(double), s->stream, m);
   BCX_HIP(hipGetLastError());
   return BCX_OK;
 }

@@ -148,13 +148,27 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
+    def build(n):
+        """solver.build with the safety net of the sharded path: if the device-side record exchange fails
+        (it raises on every rank: timeout or trace mismatch), redo the work over the RCCL all-gather."""
+        try:
+            return solver.build(n)
+        except nat.EngineError as e:
+            if solver.exchange != "mailbox":
+                raise
+            if rank == 0:
+                print("bench: peer mailbox exchange failed (%s); falling back to the all-gather" % e, file=sys.stderr)
+            solver.fallback_to_collective()
+            solver.engine.reset()
+            return solver.build(n)
+
     # ---- warm-up, then time exactly K greedy iterations --------------------------------------
     if args.warmup > 0:
-        solver.build(args.warmup)
+        build(args.warmup)
     solver.engine.profile(True)
     sync()
     t0 = time.perf_counter()
-    tr = solver.build(args.steps)
+    tr = build(args.steps)
     sync()
     t1 = time.perf_counter()
     elapsed = t1 - t0
@@ -198,6 +212,7 @@ def main():
                             % (args.rows, args.dim, {"fw": "Frank-Wolfe", "giga": "GIGA", "omp": "OMP"}[args.alg],
                                world, args.steps),
                 "alg": args.alg, "rows": args.rows, "dim": args.dim, "rows_per_gpu": solver.n_local,
+                "exchange": solver.exchange if world > 1 else None,   # mailbox = device-side P2P stores; collective = all-gather
                 "exact_rows_resident": not args.no_exact_rows,
                 "steps_accepted": int((status == 0).sum()), "final_error": float(err[-1]) if len(err) else None,
                 "rescue": solver.engine.stats(),   # fp64 re-scored candidates / exact-scan fallbacks since construction

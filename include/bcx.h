@@ -38,7 +38,8 @@ enum {
   BCX_ERR_ZERO_ROW = -3,   /* a data row has zero norm: reference raises ValueError (giga.py:11-12) */
   BCX_ERR_ZERO_B = -4,     /* ||b|| == 0 for GIGA: reference raises NumericalPrecisionError (giga.py:16-17) */
   BCX_ERR_NOMEM = -5,
-  BCX_ERR_STATE = -6       /* solver not initialised / already latched where not allowed */
+  BCX_ERR_STATE = -6,      /* solver not initialised / already latched where not allowed */
+  BCX_ERR_EXCHANGE = -7    /* peer mailbox: a shard's record did not arrive in time (see bcx_exchange_attach) */
 };
 
 /* per-iteration status written to the trace (snnls.py:41-74 outcome of one loop iteration) */
@@ -109,9 +110,28 @@ int bcx_step_scan(bcx_solver* s, void* send_dev);
  * (giga.py:40-64 / frankwolfe.py:19-40 / orthopursuit.py:37-42), monotone check / revert / retry /
  * latch (snnls.py:56-74), and the next query vector.  Asynchronous on the stream. */
 int bcx_step_apply(bcx_solver* s, const void* recv_dev);
-/* Single-shard convenience: enqueue up to `itrs` whole iterations (scan + apply) without host
- * round trips. */
+/* Enqueue up to `itrs` whole iterations (scan + resolve + apply) without host round trips: single
+ * shard, or row shards after bcx_exchange_attach (the record exchange then happens on the device).
+ * bcx_build_enqueue_exact enqueues one iteration with the exact fp64 scan (after *need_exact). */
 int bcx_build_enqueue(bcx_solver* s, int64_t itrs);
+int bcx_build_enqueue_exact(bcx_solver* s);
+/* ---- peer mailbox: device-side record exchange between row shards ------------
+ * Replaces the per-iteration all-gather of bcx_step_scan / bcx_step_apply by direct stores into the
+ * peers' mailboxes over xGMI, issued by the iteration's own tail kernel, so a sharded build needs no
+ * host-side collective and no host round trip per iteration.  One process per GPU on one node:
+ *   bcx_exchange_export  allocate this shard's mailbox and return its hipIpc handle (64 bytes);
+ *   (the caller all-gathers the handles, e.g. torch.distributed.all_gather_object)
+ *   bcx_exchange_attach  map the mailboxes of all shards (handles in rank order, handle_bytes apart);
+ *                        timeout_s bounds every wait for a peer (<= 0: default 20 s), after which the
+ *                        build stops and bcx_build_poll returns BCX_ERR_EXCHANGE instead of hanging;
+ *   bcx_exchange_probe   COLLECTIVE: one exchange with a known payload; *result = 1 if every shard's
+ *                        record arrived intact, -1 timeout, -2 payload mismatch;
+ *   bcx_exchange_disable go back to the host-driven exchange (e.g. after a failed probe).
+ * All shards must issue the same sequence of exchanges (they do: the solver state is replicated). */
+int bcx_exchange_export(bcx_solver* s, void* handle_out, int32_t handle_bytes);
+int bcx_exchange_attach(bcx_solver* s, const void* handles, int32_t handle_bytes, double timeout_s);
+int bcx_exchange_probe(bcx_solver* s, int32_t* result);
+int bcx_exchange_disable(bcx_solver* s);
 /* Synchronise and report.  *n_done = loop iterations consumed so far in this build() call;
  * *need_exact = 1 if the engine stopped before an iteration because the fp32 candidate window
  * overflowed (tie-heavy data) -- call bcx_step_scan_exact for that iteration and continue;

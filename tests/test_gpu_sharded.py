@@ -25,7 +25,8 @@ def _data(N, d):
     return np.random.RandomState(21).randn(N, d)
 
 
-def _worker(rank, world, port, alg, itrs, N, d, out_dir):
+def _worker(rank, world, port, alg, itrs, N, d, out_dir, exchange="collective", tag=""):
+    os.environ["BCX_EXCHANGE"] = exchange
     for p in (ROOT, os.path.join(ROOT, "bayesian-coresets_amd")):
         if p not in sys.path:
             sys.path.insert(0, p)
@@ -44,7 +45,8 @@ def _worker(rank, world, port, alg, itrs, N, d, out_dir):
     tr = s.build(itrs)
     idx, w = s.sparse_weights()
     b = s.engine.vector(0)
-    np.savez(os.path.join(out_dir, "w%d_r%d.npz" % (world, rank)), sel=tr[0], err=tr[1], status=tr[2], idx=idx, w=w, b=b)
+    assert s.exchange == (exchange if world > 1 else "collective"), s.exchange
+    np.savez(os.path.join(out_dir, "%sw%d_r%d.npz" % (tag, world, rank)), sel=tr[0], err=tr[1], status=tr[2], idx=idx, w=w, b=b)
     dist.barrier()
     dist.destroy_process_group()
 
@@ -72,6 +74,64 @@ def test_two_shards_on_one_gpu_match_one_shard(tmp_path, alg, name):
     ow = o.weights()
     assert np.array_equal(np.flatnonzero(w > 0), np.flatnonzero(ow > 0))
     np.testing.assert_allclose(w[w > 0], ow[ow > 0], rtol=1e-5)
+
+
+@pytest.mark.parametrize("alg,name", ((0, "giga"), (1, "fw"), (2, "omp")))
+def test_peer_mailbox_exchange_matches_one_shard(tmp_path, alg, name):
+    """The device-side record exchange (hipIpc-mapped mailboxes, csrc/resolve.hip mailbox_exchange): ranks
+    sharing cuda:0 map each other's mailbox exactly as ranks on different GPUs would; world sizes 2 and 3
+    must reproduce the single-shard run bit for bit, with the whole build enqueued at once."""
+    import torch.multiprocessing as mp
+    N, d, itrs = 9000, 40, 60
+    mp.spawn(_worker, args=(1, _free_port(), alg, itrs, N, d, str(tmp_path)), nprocs=1, join=True)
+    ref = np.load(tmp_path / "w1_r0.npz")
+    for world in (2, 3):
+        mp.spawn(_worker, args=(world, _free_port(), alg, itrs, N, d, str(tmp_path), "mailbox", "mb_"),
+                 nprocs=world, join=True)
+        for rank in range(world):
+            r = np.load(tmp_path / ("mb_w%d_r%d.npz" % (world, rank)))
+            for k in ("sel", "err", "status", "idx", "w", "b"):
+                assert np.array_equal(ref[k], r[k]), (world, rank, k)
+
+
+def _mailbox_storm_worker(rank, world, port, out_dir):
+    """tie-heavy rows: the candidate window overflows on a shard, every rank takes the exact-scan fallback"""
+    for p in (ROOT, os.path.join(ROOT, "bayesian-coresets_amd")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    import torch
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ["BCX_EXCHANGE"] = "mailbox" if world > 1 else "collective"
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from bayesiancoresets_amd.sharded import ShardedSolver
+    rs = np.random.RandomState(5)
+    base = rs.randn(8, 17)
+    X = base[rs.randint(0, 8, size=40000)] * (1.0 + rs.randint(0, 3, size=40000)[:, None])   # heavily duplicated directions
+    s = ShardedSolver(0, X.shape[0], X.shape[1], device=0)
+    s.load_local(torch.from_numpy(X[s.row_begin:s.row_end]).cuda())
+    torch.cuda.synchronize()
+    assert s.finalize(None) == 0
+    tr = s.build(12)
+    idx, w = s.sparse_weights()
+    ex = s.engine.stats()["exact_fallbacks"]
+    np.savez(os.path.join(out_dir, "storm_w%d_r%d.npz" % (world, rank)), sel=tr[0], err=tr[1], status=tr[2], idx=idx, w=w, ex=ex)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_peer_mailbox_exact_fallback(tmp_path):
+    import torch.multiprocessing as mp
+    for world in (1, 2):
+        mp.spawn(_mailbox_storm_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    ref = np.load(tmp_path / "storm_w1_r0.npz")
+    for rank in range(2):
+        r = np.load(tmp_path / ("storm_w2_r%d.npz" % rank))
+        for k in ("sel", "err", "status", "idx", "w"):
+            assert np.array_equal(ref[k], r[k]), (rank, k)
+    assert int(np.load(tmp_path / "storm_w2_r0.npz")["ex"]) > 0   # the fallback really ran
 
 
 def _svi_worker(rank, world, port, out_dir):
