@@ -31,7 +31,7 @@ static void free_all(bcx_solver* s) {
     if (p) (void)hipFree(p);
   for (size_t w = 0; w < s->peer_mbox.size(); ++w)
     if (s->peer_mbox[w] && s->peer_mbox[w] != s->mbox) (void)hipIpcCloseMemHandle(s->peer_mbox[w]);
-  void* xptrs[] = {s->mbox, s->peer_tab, s->xseq, s->xprobe, s->rec_gather};
+  void* xptrs[] = {s->mbox, s->peer_tab, s->xseq, s->xprobe, s->rec_gather, s->grid_counter};
   for (void* p : xptrs)
     if (p) (void)hipFree(p);
   for (auto& ev : s->prof_events) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
@@ -294,7 +294,12 @@ extern "C" int bcx_build_begin(bcx_solver* s, int64_t itrs, double tol, int32_t*
   if (h.limit || s->cfg.n_global == 0 || itrs <= 0) { *skip = 1; return BCX_OK; }   // snnls.py:32-38
   s->k_ub = h.k;
   if ((rc = ensure_slots(s, (int64_t)h.k + itrs))) return rc;
-  if (s->cfg.alg == BCX_ALG_OMP && (rc = bcx_ensure_gram(s, (int64_t)h.k + itrs))) return rc;
+  if (s->cfg.alg == BCX_ALG_OMP) {
+    if ((rc = bcx_ensure_gram(s, (int64_t)h.k + itrs))) return rc;
+    if (!s->grid_counter && dev_alloc(&s->grid_counter, 1) != hipSuccess) { s->err = "grid counter allocation failed"; return BCX_ERR_NOMEM; }
+    BCX_HIP(hipMemsetAsync(s->grid_counter, 0, sizeof(unsigned long long), s->stream));
+    s->grid_epoch = 0;
+  }
   if ((rc = ensure_trace(s, itrs))) return rc;
   return bcx_launch_begin(s, itrs, tol);
 }
@@ -464,6 +469,7 @@ extern "C" int bcx_build_poll(bcx_solver* s, int64_t* n_done, int32_t* need_exac
   DevState h;
   int rc = read_state(s, &h);
   if (rc != BCX_OK) return rc;
+  if (h.halt == HALT_GRID_TIMEOUT) { s->err = "OMP step: grid barrier timed out"; return BCX_ERR_STATE; }
   if (h.halt == HALT_EXCHANGE_TIMEOUT) {
     s->err = "peer mailbox: a shard did not deliver its record within " + std::to_string(s->exchange_timeout_s) + " s";
     return BCX_ERR_EXCHANGE;

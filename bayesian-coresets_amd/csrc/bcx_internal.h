@@ -17,7 +17,7 @@
 #define BCX_SCAN_THREADS 256
 #define BCX_APPLY_THREADS 256
 
-enum { HALT_NONE = 0, HALT_DONE = 1, HALT_LIMIT = 2, HALT_NEED_EXACT = 3, HALT_EXCHANGE_TIMEOUT = 4 };
+enum { HALT_NONE = 0, HALT_DONE = 1, HALT_LIMIT = 2, HALT_NEED_EXACT = 3, HALT_EXCHANGE_TIMEOUT = 4, HALT_GRID_TIMEOUT = 5 };
 enum { OMP_IDLE = 0, OMP_DONE = 1, OMP_FAST_TRY = 2, OMP_FAST_ACCEPT = 3, OMP_GENERAL = 4 };
 
 // Per-workgroup result of the correlation scan, stored as separate arrays (coalesced reads in the
@@ -143,6 +143,9 @@ struct bcx_solver {
   double* nn_wbak = nullptr;     // cap: weights before the step (revert on monotone failure)
   int64_t gram_cap = 0;
   int64_t k_ub = 0;              // host upper bound of the slot count (grid sizing of the multi-kernel OMP step)
+  unsigned long long* grid_counter = nullptr;   // arrival counter of the fused OMP step's grid barriers
+  uint64_t grid_epoch = 0;       // fused OMP launches since the counter was reset (bcx_build_begin)
+  size_t omp_lds_allowed = 0;
   // trace of the current build() call
   int64_t trace_cap = 0;
   int64_t* tr_sel = nullptr;

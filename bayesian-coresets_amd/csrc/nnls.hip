@@ -836,6 +836,321 @@ __global__ __launch_bounds__(BCX_APPLY_THREADS) void omp_finish_kernel(NnlsArgs 
   prepare_next(a, scratch);
 }
 
+// ---- OMP apply, fused multi-workgroup form ----------------------------------------------------------
+// The phases of the multi-kernel form above in ONE launch of OMPF_WGS co-resident workgroups, separated by
+// grid barriers (an arrival counter in device memory) instead of kernel boundaries.  The single-workgroup
+// phases (decide, step) are computed REDUNDANTLY by every workgroup from the same data in the same order,
+// so each one knows the decision without another barrier; only workgroup 0 writes the shared state.
+// Fast path: 3 barriers
+//   rows | B1 | decide, u = H g | B2 | step, xw' = sum x_j row_j, bordered update of H | B4 | finish (WG 0)
+// (B3 only when the general active-set solve runs on WG 0).  Every workgroup arrives exactly
+// OMPF_NBAR times per launch whatever path it takes, so barrier `i` of launch `e` is "counter >=
+// (e * OMPF_NBAR + i) * OMPF_WGS"; the host resets the counter at build_begin.
+#define OMPF_WGS 16
+#define OMPF_NBAR 4
+#define OMPF_MAX_K 8192      // t0 / t1 copies in LDS: 16 bytes per position
+#define OMPF_MIN_K 0
+
+struct GridSync {
+  unsigned long long* counter;
+  unsigned long long base;
+  long long timeout_ticks;
+};
+
+static __device__ __forceinline__ void grid_arrive(const GridSync& g, int times) {
+  __threadfence();
+  __hip_atomic_fetch_add(g.counter, (unsigned long long)times, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+}
+// all threads; false after a timeout (the build is then stopped instead of hanging the GPU)
+static __device__ bool grid_barrier(const GridSync& g, int index, int* s_flag) {
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    grid_arrive(g, 1);
+    const unsigned long long target = g.base + (unsigned long long)index * gridDim.x;
+    const long long t0 = wall_clock64();
+    int ok = 1;
+    while (__hip_atomic_load(g.counter, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < target) {
+      __builtin_amdgcn_s_sleep(1);
+      if (wall_clock64() - t0 > g.timeout_ticks) { ok = 0; break; }
+    }
+    __threadfence();
+    *s_flag = ok;
+  }
+  __syncthreads();
+  return *s_flag != 0;
+}
+
+#define OMPF_STAMP(i) do { if (blockIdx.x == 0) BCX_STAMP(st, i); } while (0)
+
+__global__ __launch_bounds__(NN_THREADS) void omp_fused_kernel(NnlsArgs n, GridSync gs, int kcap) {
+  const ApplyArgs& a = n.a;
+  DevState* st = a.st;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = blockDim.x >> 6, d = a.d;
+  const int wg = blockIdx.x, nwg = gridDim.x;
+  if (!st->active) { if (tid == 0) grid_arrive(gs, OMPF_NBAR); return; }
+  extern __shared__ double dyn[];
+  double* t0s = dyn;             // g = G[slot, P] by position
+  double* t1s = dyn + kcap;      // u = H g
+  __shared__ double scratch[BCX_SCRATCH];
+  __shared__ double seg[NN_THREADS / 64][64];
+  __shared__ int s_win, s_ovf, s_slot, s_npos, s_bad, s_flag;
+  __shared__ unsigned long long s_minidx;
+  OMPF_STAMP(0);
+  if (tid == 0) {
+    int o; s_win = omp_pick_record(a, &o); s_ovf = o;
+    s_slot = 0x7fffffff; s_npos = 0; s_bad = 0; s_minidx = 0x7fffffffffffffffULL;
+  }
+  __syncthreads();
+  if (s_ovf || s_win < 0) {
+    if (tid == 0) {
+      grid_arrive(gs, OMPF_NBAR);
+      if (wg == 0) { st->active = 0; st->halt = s_ovf ? HALT_NEED_EXACT : HALT_DONE; }
+    }
+    return;
+  }
+  const double* rec = a.recs + (size_t)s_win * (d + BCX_REC_HDR);
+  const double* xf = rec + BCX_REC_HDR;
+  const int k = st->k, p = st->np;
+  const double err0 = st->err;
+  // ---- phase 1: -An[j].r for the active rows, row_j . xf for all slots, xf.xf, xf.b ------------------
+  for (int j = wg * nw + wave; j <= k; j += nwg * nw) {
+    const double* row = (j < k) ? a.act_rows + (size_t)j * d : xf;
+    const double* other = (j < k) ? a.q64 : a.b;
+    double a0 = 0.0, a1 = 0.0;
+    for (int i = lane; i < d; i += 64) {
+      const double rv = row[i];
+      a0 += rv * xf[i];
+      a1 += rv * other[i];
+    }
+    a0 = wave_allsum(a0);
+    a1 = wave_allsum(a1);
+    if (lane == 0) {
+      if (j < k) { n.t3[j] = a0; n.t2[j] = -(a1 / a.act_norm[j]); }
+      else { st->omp_gff = a0; st->omp_cf = a1; }
+    }
+  }
+  OMPF_STAMP(1);
+  if (!grid_barrier(gs, 1, &s_flag)) { if (wg == 0 && tid == 0) { st->active = 0; st->halt = HALT_GRID_TIMEOUT; } return; }
+  OMPF_STAMP(2);
+  // ---- phase 2: decide (every workgroup; workgroup 0 writes) -----------------------------------------
+  int npos = 0;
+  for (int s = tid; s < k; s += blockDim.x) if (a.act_w[s] > 0.0) ++npos;
+  if (npos) atomicAdd(&s_npos, npos);
+  __syncthreads();
+  const bool checked = s_npos > 0;
+  int64_t f = (int64_t)rec[1];
+  const double nf = rec[2];
+  if (checked) {
+    double bv = -INFINITY; int bi = -1; int64_t bidx = 0;
+    for (int j = tid; j < k; j += blockDim.x) {
+      if (!(a.act_w[j] > 0.0)) continue;
+      const double vv = n.t2[j];
+      if (bi < 0 || vv > bv || (vv == bv && a.act_idx[j] < bidx)) { bv = vv; bi = j; bidx = a.act_idx[j]; }
+    }
+    const double vmax = block_allmax(bi >= 0 ? bv : -INFINITY, scratch);
+    if (bi >= 0 && bv == vmax) atomicMin(&s_minidx, (unsigned long long)bidx);
+    __syncthreads();
+    if (!(rec[0] >= vmax)) f = (int64_t)s_minidx;          // orthopursuit.py:32-35
+  }
+  for (int s = tid; s < k; s += blockDim.x) if (a.act_idx[s] == f) atomicMin(&s_slot, s);
+  __syncthreads();
+  int slot = s_slot == 0x7fffffff ? -1 : s_slot;
+  const bool fresh = slot < 0;
+  if (fresh) slot = k;
+  const int k1 = fresh ? k + 1 : k;
+  const double gff = fresh ? st->omp_gff : n.gram[(size_t)slot * n.ldg + slot];
+  const double cf = fresh ? st->omp_cf : n.cvec[slot];
+  const double nslot = fresh ? nf : a.act_norm[slot];
+  if (wg == 0) {
+    for (int j = tid; j < k; j += blockDim.x) n.wbak[j] = a.act_w[j];
+    if (fresh) {
+      for (int i = tid; i < d; i += blockDim.x) a.act_rows[(size_t)slot * d + i] = xf[i];
+      for (int j = tid; j < k; j += blockDim.x) {
+        const double g = n.t3[j];
+        n.gram[(size_t)slot * n.ldg + j] = g;
+        n.gram[(size_t)j * n.ldg + slot] = g;
+      }
+      if (tid == 0) {
+        a.act_idx[slot] = f; a.act_norm[slot] = nf; a.act_w[slot] = 0.0; n.ppos[slot] = -1; n.x[slot] = 0.0;
+        n.gram[(size_t)slot * n.ldg + slot] = gff;
+        n.cvec[slot] = cf;
+      }
+    }
+  }
+  const int pos_slot = fresh ? -1 : n.ppos[slot];
+  int mode;
+  if (!st->hvalid) mode = OMP_GENERAL;
+  else if (pos_slot >= 0) mode = OMP_DONE;                // f already carries weight: nothing changes
+  else if (st->omp_ill) mode = OMP_GENERAL;
+  else if ((st->since_refresh % OMP_RESOLVE_EVERY) == OMP_RESOLVE_EVERY - 1) mode = OMP_GENERAL;
+  else mode = OMP_FAST_TRY;
+  OMPF_STAMP(3);
+  // ---- phase 3: u = H g on this workgroup's 64-column blocks ------------------------------------------
+  if (mode == OMP_FAST_TRY) {
+    for (int q = tid; q < p; q += blockDim.x)
+      t0s[q] = fresh ? n.t3[n.plist[q]] : n.gram[(size_t)slot * n.ldg + n.plist[q]];
+    __syncthreads();
+    for (int cb = wg; cb * 64 < p; cb += nwg) {
+      const int col = cb * 64 + lane;
+      double acc = 0.0;
+      if (col < p) {
+        int b = wave;
+        for (; b + 7 * nw < p; b += 8 * nw) {
+          double m[8];
+#pragma unroll
+          for (int t = 0; t < 8; ++t) m[t] = n.hinv[(size_t)(b + t * nw) * n.ldg + col];
+#pragma unroll
+          for (int t = 0; t < 8; ++t) acc += m[t] * t0s[b + t * nw];
+        }
+        for (; b < p; b += nw) acc += n.hinv[(size_t)b * n.ldg + col] * t0s[b];
+      }
+      seg[wave][lane] = acc;
+      __syncthreads();
+      if (wave == 0 && col < p) {
+        double t = seg[0][lane];
+        for (int w = 1; w < nw; ++w) t += seg[w][lane];
+        n.t1[col] = t;
+      }
+      __syncthreads();
+    }
+  }
+  OMPF_STAMP(4);
+  if (!grid_barrier(gs, 2, &s_flag)) { if (wg == 0 && tid == 0) { st->active = 0; st->halt = HALT_GRID_TIMEOUT; } return; }
+  OMPF_STAMP(5);
+  // ---- phase 4: step (every workgroup) -------------------------------------------------------------------
+  const double eps = 2.220446049250313e-16;
+  const double tolscale = 10.0 * eps * (double)(d > k1 ? d : k1) * st->bnorm;
+  double tstep = 0.0, inv = 0.0;
+  if (mode == OMP_FAST_TRY) {
+    for (int q = tid; q < p; q += blockDim.x) t1s[q] = n.t1[q];
+    __syncthreads();
+    double r[2] = {0.0, 0.0};
+    for (int q = tid; q < p; q += blockDim.x) { r[0] += t0s[q] * t1s[q]; r[1] += t0s[q] * n.x[n.plist[q]]; }
+    block_allsum<2>(r, scratch);
+    const double sc = gff - r[0];
+    const double wvf = cf - r[1];
+    mode = OMP_GENERAL;
+    if (!(wvf > tolscale * nslot)) {
+      mode = OMP_DONE;                                      // dual not positive: f gets weight 0
+    } else if (!(sc > 1e-4 * gff)) {
+      if (wg == 0 && tid == 0) st->omp_ill = 1;             // nearly dependent column: refined general solve
+    } else {
+      tstep = wvf / sc;
+      for (int q = tid; q < p; q += blockDim.x)
+        if (!(n.x[n.plist[q]] - tstep * t1s[q] > 0.0)) s_bad = 1;
+      __syncthreads();
+      if (!s_bad && tstep > 0.0) { mode = OMP_FAST_ACCEPT; inv = 1.0 / sc; }
+    }
+    __syncthreads();
+  }
+  OMPF_STAMP(6);
+  // ---- general active-set solve (rare): workgroup 0 alone, the others wait at barrier 3 -------------------
+  if (mode == OMP_GENERAL) {
+    if (wg == 0) {
+      if (!st->hvalid) rebuild_passive(n, k, scratch);
+      for (int j = tid; j < k1; j += blockDim.x) {
+        const bool in = (j == slot) || (a.act_w[j] > 0.0);
+        n.flag[j] = in ? FLAG_INS : 0;
+        if (n.ppos[j] < 0) n.x[j] = 0.0;
+      }
+      __syncthreads();
+      nnls_run(n, k1, tolscale, scratch);
+    }
+    if (!grid_barrier(gs, 3, &s_flag)) { if (wg == 0 && tid == 0) { st->active = 0; st->halt = HALT_GRID_TIMEOUT; } return; }
+  } else if (tid == 0) {
+    grid_arrive(gs, 1);
+  }
+  // ---- phase 5: xw' = sum_P x_j row_j on 64-column blocks; bordered update of H ---------------------------
+  const bool acc_fast = mode == OMP_FAST_ACCEPT;
+  const int pn = (mode == OMP_GENERAL) ? st->np : (acc_fast ? p + 1 : p);
+  for (int cb = wg; cb * 64 < d; cb += nwg) {
+    const int col = cb * 64 + lane;
+    double acc = 0.0;
+    if (col < d) {
+      for (int q = wave; q < pn; q += nw) {
+        const bool fnew = acc_fast && q == p;
+        const int c = fnew ? slot : n.plist[q];
+        const double xq = fnew ? tstep : (acc_fast ? n.x[c] - tstep * t1s[q] : n.x[c]);
+        acc += xq * a.act_rows[(size_t)c * d + col];
+      }
+    }
+    seg[wave][lane] = acc;
+    __syncthreads();
+    if (wave == 0 && col < d) {
+      double t = seg[0][lane];
+      for (int w = 1; w < nw; ++w) t += seg[w][lane];
+      a.tmp[col] = t;
+    }
+    __syncthreads();
+  }
+  OMPF_STAMP(7);
+  if (acc_fast) {
+    // H <- [[H + u u^T / s, -u/s], [-u^T/s, 1/s]]
+    const int64_t total = (int64_t)p * p;
+    for (int64_t idx = (int64_t)wg * blockDim.x + tid; idx < total; idx += (int64_t)nwg * blockDim.x) {
+      const int rr = (int)(idx / p), cc = (int)(idx - (int64_t)rr * p);
+      n.hinv[(size_t)rr * n.ldg + cc] += t1s[rr] * t1s[cc] * inv;
+    }
+    for (int q = wg * blockDim.x + tid; q < p; q += nwg * blockDim.x) {
+      const double e = -t1s[q] * inv;
+      n.hinv[(size_t)p * n.ldg + q] = e;
+      n.hinv[(size_t)q * n.ldg + p] = e;
+    }
+    if (wg == 0 && tid == 0) n.hinv[(size_t)p * n.ldg + p] = inv;
+  }
+  OMPF_STAMP(8);
+  if (wg != 0) { __syncthreads(); if (tid == 0) grid_arrive(gs, 1); return; }
+  if (!grid_barrier(gs, 4, &s_flag)) { if (tid == 0) { st->active = 0; st->halt = HALT_GRID_TIMEOUT; } return; }
+  OMPF_STAMP(9);
+  // ---- phase 6 (workgroup 0): commit the step's x, error, monotone check, trace, next query ------------------
+  if (acc_fast) {
+    for (int q = tid; q < p; q += blockDim.x) n.x[n.plist[q]] -= tstep * t1s[q];
+    if (tid == 0) { n.plist[p] = slot; n.ppos[slot] = p; n.x[slot] = tstep; st->np = p + 1; }
+    __syncthreads();
+  }
+  double v[2] = {0.0, 0.0};
+  for (int j = tid; j < d; j += blockDim.x) {
+    const double x = a.tmp[j], rr = x - a.b[j];
+    v[0] += rr * rr; v[1] += x * x;
+  }
+  block_allsum<2>(v, scratch);
+  const double new_err = sqrt(v[0]);
+  int status = BCX_IT_OK;
+  if (checked && new_err > err0) status = BCX_IT_FAIL_MONOTONE;      // snnls.py:58
+  if (status == BCX_IT_OK) {
+    for (int j = tid; j < k1; j += blockDim.x) a.act_w[j] = (n.ppos[j] >= 0) ? n.x[j] : 0.0;
+    for (int j = tid; j < d; j += blockDim.x) a.xw[j] = a.tmp[j];
+    if (tid == 0) {
+      st->k = k1;
+      st->err = new_err;
+      const double nwn = sqrt(v[1]);
+      st->nw = nwn == 0.0 ? 1.0 : nwn;
+      st->since_refresh += 1;
+      if (checked) st->retried = 0;
+    }
+  } else {
+    for (int j = tid; j < k; j += blockDim.x) a.act_w[j] = n.wbak[j];
+    if (tid == 0) st->hvalid = 0;
+  }
+  __syncthreads();
+  if (tid == 0) {
+    const int64_t it = st->it;
+    a.tr_sel[it] = f; a.tr_err[it] = st->err; a.tr_status[it] = status;
+    st->it = it + 1;
+    st->exact_mode = 0;
+    st->omp_mode = OMP_IDLE;
+    if (status != BCX_IT_OK) {
+      if (st->retried) { st->limit = 1; st->active = 0; st->halt = HALT_LIMIT; }
+      else st->retried = 1;
+    }
+  }
+  __syncthreads();
+  OMPF_STAMP(10);
+  if (!st->active) return;
+  prepare_next(a, scratch);
+  OMPF_STAMP(11);
+}
+
 static void fill_nnls_args(bcx_solver* s, NnlsArgs& n, const double* recs) {
   fill_apply_args(s, n.a, recs);
   n.a.refresh_every = 0;   // OMP recomputes xw from the passive set on every step
@@ -852,7 +1167,24 @@ int bcx_launch_apply_omp(bcx_solver* s, const double* recv_dev) {
   fill_nnls_args(s, n, recv_dev);
   s->k_ub += 1;                               // this step may add one slot
   const int64_t kub = s->k_ub;
-  if ((kub < 160 && !getenv("BCX_OMP_MULTI")) || getenv("BCX_OMP_SINGLE")) {  // small active sets: one launch is cheaper than eight
+  static const int omp_path = getenv("BCX_OMP_PATH") ? atoi(getenv("BCX_OMP_PATH")) : 0;   // dev: 1 = single WG, 2 = multi-kernel
+  if (omp_path == 0 && s->grid_counter && kub >= OMPF_MIN_K && kub <= OMPF_MAX_K) {
+    const int kcap = (int)((kub + 63) / 64 * 64);
+    const size_t lds = 2 * (size_t)kcap * sizeof(double);
+    if (lds > s->omp_lds_allowed) {
+      BCX_HIP(hipFuncSetAttribute((const void*)omp_fused_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(2 * (size_t)OMPF_MAX_K * sizeof(double))));
+      s->omp_lds_allowed = 2 * (size_t)OMPF_MAX_K * sizeof(double);
+    }
+    GridSync gs;
+    gs.counter = s->grid_counter;
+    gs.base = (unsigned long long)s->grid_epoch * OMPF_NBAR * OMPF_WGS;
+    gs.timeout_ticks = 1000000000LL;   // 10 s
+    s->grid_epoch += 1;
+    hipLaunchKernelGGL(omp_fused_kernel, dim3(OMPF_WGS), dim3(NN_THREADS), lds, s->stream, n, gs, kcap);
+    BCX_HIP(hipGetLastError());
+    return BCX_OK;
+  }
+  if ((kub < 160 && omp_path != 2) || omp_path == 1) {  // small active sets: one launch is cheaper than eight
     hipLaunchKernelGGL(apply_omp_kernel, dim3(1), dim3(NN_THREADS), 0, s->stream, n);
     BCX_HIP(hipGetLastError());
     return BCX_OK;
