@@ -332,200 +332,10 @@ static __device__ void rebuild_passive(const NnlsArgs& n, int k, double* scratch
 // Anything else (a weight would turn non-positive, dependent column, stale inverse, periodic
 // re-solve) goes through nnls_run, which gives the same unique solution.
 #define OMP_RESOLVE_EVERY 32
-__global__ __launch_bounds__(NN_THREADS) void apply_omp_kernel(NnlsArgs n) {
-  const ApplyArgs& a = n.a;
-  DevState* st = a.st;
-  if (!st->active) return;
-  __shared__ double scratch[BCX_SCRATCH];
-  __shared__ int s_win, s_overflow, s_slot, s_npos, s_bad;
-  __shared__ unsigned long long s_minidx;
-  __shared__ double s_gff, s_cf;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = blockDim.x >> 6, d = a.d;
-  const int recw = d + BCX_REC_HDR;
-  if (tid == 0) {
-    int win = -1, ovf = 0;
-    for (int r = 0; r < a.world; ++r) {
-      const double* rec = a.recs + (size_t)r * recw;
-      if (rec[3] == BCX_REC_OVERFLOW) ovf = 1;
-      if (rec[3] != BCX_REC_VALID) continue;
-      if (win < 0) { win = r; continue; }
-      const double* best = a.recs + (size_t)win * recw;
-      if (rec[0] > best[0] || (rec[0] == best[0] && rec[1] < best[1])) win = r;
-    }
-    s_win = win; s_overflow = ovf; s_slot = 0x7fffffff; s_npos = 0; s_bad = 0;
-    s_minidx = 0x7fffffffffffffffULL;
-  }
-  __syncthreads();
-  if (s_overflow) { if (tid == 0) { st->active = 0; st->halt = HALT_NEED_EXACT; } return; }
-  if (s_win < 0) { if (tid == 0) { st->active = 0; st->halt = HALT_DONE; } return; }
-  const double* rec = a.recs + (size_t)s_win * recw;
-  const double* xf = rec + BCX_REC_HDR;
-  const int k = st->k;
-  const double err0 = st->err;
-  // one pass over the replicated rows: -An[j].residual for the active ones (orthopursuit.py:27-31)
-  // and row_j . xf (the Gram row of the positive-direction candidate); the extra "row k" is xf itself
-  for (int j = wave; j <= k; j += nw) {
-    const double* row = (j < k) ? a.act_rows + (size_t)j * d : xf;
-    double a0 = 0.0, a1 = 0.0;
-    for (int i = lane; i < d; i += 64) {
-      const double rv = row[i];
-      a0 += rv * xf[i];
-      a1 += rv * ((j < k) ? a.q64[i] : a.b[i]);
-    }
-    a0 = wave_allsum(a0);
-    a1 = wave_allsum(a1);
-    if (lane == 0) {
-      if (j < k) { n.t0[j] = a0; n.t2[j] = -(a1 / a.act_norm[j]); }
-      else { s_gff = a0; s_cf = a1; }
-    }
-  }
-  int npos = 0;
-  for (int s = tid; s < k; s += blockDim.x) if (a.act_w[s] > 0.0) ++npos;
-  if (npos) atomicAdd(&s_npos, npos);
-  __syncthreads();
-  const bool checked = s_npos > 0;
-  int64_t f = (int64_t)rec[1];
-  const double nf = rec[2];
-  if (checked) {
-    // first maximum of -dots over the active indices in index order == (value desc, global index asc)
-    double bv = -INFINITY; int bi = -1; int64_t bidx = 0;
-    for (int j = tid; j < k; j += blockDim.x) {
-      if (!(a.act_w[j] > 0.0)) continue;
-      const double vv = n.t2[j];
-      if (bi < 0 || vv > bv || (vv == bv && a.act_idx[j] < bidx)) { bv = vv; bi = j; bidx = a.act_idx[j]; }
-    }
-    const double vmax = block_allmax(bi >= 0 ? bv : -INFINITY, scratch);
-    if (bi >= 0 && bv == vmax) atomicMin(&s_minidx, (unsigned long long)bidx);
-    __syncthreads();
-    if (!(rec[0] >= vmax)) f = (int64_t)s_minidx;          // orthopursuit.py:32-35
-  }
-  for (int s = tid; s < k; s += blockDim.x) if (a.act_idx[s] == f) atomicMin(&s_slot, s);
-  __syncthreads();
-  int slot = s_slot == 0x7fffffff ? -1 : s_slot;
-  const bool fresh = slot < 0;
-  if (fresh) slot = k;
-  const int k1 = fresh ? k + 1 : k;
-  for (int j = tid; j < k; j += blockDim.x) n.wbak[j] = a.act_w[j];
-  if (fresh) {
-    // new slot: row, Gram row (from the pass above), c = row . b
-    for (int i = tid; i < d; i += blockDim.x) a.act_rows[(size_t)slot * d + i] = xf[i];
-    for (int j = tid; j < k; j += blockDim.x) {
-      const double g = n.t0[j];
-      n.gram[(size_t)slot * n.ldg + j] = g;
-      n.gram[(size_t)j * n.ldg + slot] = g;
-    }
-    if (tid == 0) {
-      a.act_idx[slot] = f; a.act_norm[slot] = nf; a.act_w[slot] = 0.0; n.ppos[slot] = -1; n.x[slot] = 0.0;
-      n.gram[(size_t)slot * n.ldg + slot] = s_gff;
-      n.cvec[slot] = s_cf;
-    }
-  }
-  __syncthreads();
-  if (!st->hvalid) rebuild_passive(n, k, scratch);
-  const double eps = 2.220446049250313e-16;
-  const double tolscale = 10.0 * eps * (double)(d > k1 ? d : k1) * st->bnorm;
-  const int p = st->np;
-  bool done = n.ppos[slot] >= 0;          // f already carries weight: the NNLS problem is unchanged
-  if (!done && !st->omp_ill && (st->since_refresh % OMP_RESOLVE_EVERY) != OMP_RESOLVE_EVERY - 1) {
-    // closed-form bordered step
-    for (int q = tid; q < p; q += blockDim.x) n.t0[q] = n.gram[(size_t)slot * n.ldg + n.plist[q]];
-    __syncthreads();
-    mv_sym(n.hinv, n.ldg, p, n.t0, n.t1);                 // u = H g
-    double r[2] = {0.0, 0.0};
-    for (int q = tid; q < p; q += blockDim.x) { r[0] += n.t0[q] * n.t1[q]; r[1] += n.t0[q] * n.x[n.plist[q]]; }
-    block_allsum<2>(r, scratch);
-    const double gff = n.gram[(size_t)slot * n.ldg + slot];
-    const double sc = gff - r[0];
-    const double wvf = n.cvec[slot] - r[1];
-    if (!(wvf > tolscale * a.act_norm[slot])) {
-      done = true;                                        // dual not positive: f gets weight 0
-    } else if (!(sc > 1e-4 * gff)) {
-      if (tid == 0) st->omp_ill = 1;                      // nearly dependent column: refined general solve
-    } else {
-      const double t = wvf / sc;
-      for (int q = tid; q < p; q += blockDim.x)
-        if (!(n.x[n.plist[q]] - t * n.t1[q] > 0.0)) s_bad = 1;
-      __syncthreads();
-      if (!s_bad && t > 0.0) {
-        const double inv = 1.0 / sc;
-        for (int q = tid; q < p; q += blockDim.x) n.x[n.plist[q]] -= t * n.t1[q];
-        for (int idx = tid; idx < p * p; idx += blockDim.x) {
-          const int rr = idx / p, cc = idx - rr * p;
-          n.hinv[(size_t)rr * n.ldg + cc] += n.t1[rr] * n.t1[cc] * inv;
-        }
-        for (int q = tid; q < p; q += blockDim.x) {
-          const double e = -n.t1[q] * inv;
-          n.hinv[(size_t)p * n.ldg + q] = e;
-          n.hinv[(size_t)q * n.ldg + p] = e;
-        }
-        if (tid == 0) {
-          n.hinv[(size_t)p * n.ldg + p] = inv;
-          n.plist[p] = slot; n.ppos[slot] = p; n.x[slot] = t;
-          st->np = p + 1;
-        }
-        done = true;
-      }
-    }
-    __syncthreads();
-  }
-  if (!done) {
-    // general active-set solve on S = support U {f}   (w[f] = 1 then active = w > 0: orthopursuit.py:38-39)
-    for (int j = tid; j < k1; j += blockDim.x) {
-      const bool in = (j == slot) || (a.act_w[j] > 0.0);
-      n.flag[j] = in ? FLAG_INS : 0;
-      if (n.ppos[j] < 0) n.x[j] = 0.0;
-    }
-    __syncthreads();
-    nnls_run(n, k1, tolscale, scratch);
-  }
-  __syncthreads();
-  // candidate state: xw' and its error
-  passive_combination(n, a.tmp, a.tmp + 4 * (size_t)d);
-  double v[2] = {0.0, 0.0};
-  for (int j = tid; j < d; j += blockDim.x) {
-    const double x = a.tmp[j], rr = x - a.b[j];
-    v[0] += rr * rr; v[1] += x * x;
-  }
-  block_allsum<2>(v, scratch);
-  const double new_err = sqrt(v[0]);
-  int status = BCX_IT_OK;
-  if (checked && new_err > err0) status = BCX_IT_FAIL_MONOTONE;      // snnls.py:58
-  if (status == BCX_IT_OK) {
-    for (int j = tid; j < k1; j += blockDim.x) a.act_w[j] = (n.ppos[j] >= 0) ? n.x[j] : 0.0;
-    for (int j = tid; j < d; j += blockDim.x) a.xw[j] = a.tmp[j];
-    if (tid == 0) {
-      st->k = k1;
-      st->err = new_err;
-      const double nwn = sqrt(v[1]);
-      st->nw = nwn == 0.0 ? 1.0 : nwn;
-      st->since_refresh += 1;
-      if (checked) st->retried = 0;
-    }
-  } else {
-    // revert: weights as before (snnls.py:60), a freshly added slot is dropped, passive data rebuilt lazily
-    for (int j = tid; j < k; j += blockDim.x) a.act_w[j] = n.wbak[j];
-    if (tid == 0) st->hvalid = 0;
-  }
-  __syncthreads();
-  if (tid == 0) {
-    const int64_t it = st->it;
-    a.tr_sel[it] = f; a.tr_err[it] = st->err; a.tr_status[it] = status;
-    st->it = it + 1;
-    st->exact_mode = 0;
-    if (status != BCX_IT_OK) {
-      if (st->retried) { st->limit = 1; st->active = 0; st->halt = HALT_LIMIT; }
-      else st->retried = 1;
-    }
-  }
-  __syncthreads();
-  if (!st->active) return;
-  prepare_next(a, scratch);
-}
 
 // ---- OMP apply, multi-kernel form ----------------------------------------------------------------
-// The single-workgroup kernel above reads the k replicated rows three times and the inverse twice with
-// one CU; its time grows ~0.5 us per active point.  For larger active sets the same step is split into
-// phases that use the whole chip, chained by ordinary kernel boundaries (decisions travel in DevState):
+// The step split into phases that use many CUs, chained by ordinary kernel boundaries (decisions travel in
+// DevState).  Fallback of the fused form below for active sets beyond its LDS budget (k >= OMPF_MAX_K):
 //   rows    (grid)  -An[j].r for the active rows and row_j . xf for all slots (+ xf.xf, xf.b)
 //   decide  (1 WG)  f, slot, new-slot data, g = G[slot, P]; chooses DONE / FAST_TRY / GENERAL
 //   matvec  (grid)  u = H g
@@ -846,10 +656,11 @@ __global__ __launch_bounds__(BCX_APPLY_THREADS) void omp_finish_kernel(NnlsArgs 
 // (B3 only when the general active-set solve runs on WG 0).  Every workgroup arrives exactly
 // OMPF_NBAR times per launch whatever path it takes, so barrier `i` of launch `e` is "counter >=
 // (e * OMPF_NBAR + i) * OMPF_WGS"; the host resets the counter at build_begin.
+#ifndef OMPF_WGS
 #define OMPF_WGS 16
+#endif
 #define OMPF_NBAR 4
-#define OMPF_MAX_K 8192      // t0 / t1 copies in LDS: 16 bytes per position
-#define OMPF_MIN_K 0
+#define OMPF_MAX_K 4096      // LDS per position: g / x (8) + u (8) + slot (4) bytes, next to 3 d-vectors
 
 struct GridSync {
   unsigned long long* counter;
@@ -882,24 +693,51 @@ static __device__ bool grid_barrier(const GridSync& g, int index, int* s_flag) {
 
 #define OMPF_STAMP(i) do { if (blockIdx.x == 0) BCX_STAMP(st, i); } while (0)
 
-__global__ __launch_bounds__(NN_THREADS) void omp_fused_kernel(NnlsArgs n, GridSync gs, int kcap) {
+// (value desc, global index asc) arg-max over the workgroup; carries the slot of the winner.  idx < 0: no entry.
+struct NegBest { double v; long long idx; int slot; };
+static __device__ __forceinline__ bool negbest_better(double v, long long i, double ov, long long oi) {
+  return oi >= 0 && (i < 0 || ov > v || (ov == v && oi < i));
+}
+
+// data of a newly selected slot: row, Gram row / column (from the rows phase), c = row . b.  One workgroup.
+static __device__ void omp_store_new_slot(const NnlsArgs& n, int slot, int k, const double* xfs, int64_t f, double nf,
+                                          double gff, double cf) {
+  const ApplyArgs& a = n.a;
+  const int tid = threadIdx.x, d = a.d;
+  for (int i = tid; i < d; i += blockDim.x) a.act_rows[(size_t)slot * d + i] = xfs[i];
+  for (int j = tid; j < k; j += blockDim.x) {
+    const double g = n.t3[j];
+    n.gram[(size_t)slot * n.ldg + j] = g;
+    n.gram[(size_t)j * n.ldg + slot] = g;
+  }
+  if (tid == 0) {
+    a.act_idx[slot] = f; a.act_norm[slot] = nf; a.act_w[slot] = 0.0; n.ppos[slot] = -1; n.x[slot] = 0.0;
+    n.gram[(size_t)slot * n.ldg + slot] = gff;
+    n.cvec[slot] = cf;
+  }
+}
+
+__global__ __launch_bounds__(NN_THREADS) void omp_fused_kernel(NnlsArgs n, GridSync gs, int kcap, int dpad) {
   const ApplyArgs& a = n.a;
   DevState* st = a.st;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = blockDim.x >> 6, d = a.d;
   const int wg = blockIdx.x, nwg = gridDim.x;
   if (!st->active) { if (tid == 0) grid_arrive(gs, OMPF_NBAR); return; }
   extern __shared__ double dyn[];
-  double* t0s = dyn;             // g = G[slot, P] by position
-  double* t1s = dyn + kcap;      // u = H g
+  double* t0s = dyn;                     // g = G[slot, P] by position; later the new x by position
+  double* t1s = dyn + kcap;              // u = H g
+  double* xfs = dyn + 2 * (size_t)kcap;  // the winner's row
+  double* qs = xfs + dpad;               // current residual query
+  double* bs = qs + dpad;                // b
+  int* cs = (int*)(bs + dpad);           // passive list: slot by position
   __shared__ double scratch[BCX_SCRATCH];
   __shared__ double seg[NN_THREADS / 64][64];
-  __shared__ int s_win, s_ovf, s_slot, s_npos, s_bad, s_flag;
-  __shared__ unsigned long long s_minidx;
+  __shared__ double w_v[NN_THREADS / 64];
+  __shared__ long long w_i[NN_THREADS / 64];
+  __shared__ int w_s[NN_THREADS / 64], w_np[NN_THREADS / 64], w_m[NN_THREADS / 64];
+  __shared__ int s_win, s_ovf, s_bad, s_flag;
   OMPF_STAMP(0);
-  if (tid == 0) {
-    int o; s_win = omp_pick_record(a, &o); s_ovf = o;
-    s_slot = 0x7fffffff; s_npos = 0; s_bad = 0; s_minidx = 0x7fffffffffffffffULL;
-  }
+  if (tid == 0) { int o; s_win = omp_pick_record(a, &o); s_ovf = o; s_bad = 0; }
   __syncthreads();
   if (s_ovf || s_win < 0) {
     if (tid == 0) {
@@ -912,71 +750,77 @@ __global__ __launch_bounds__(NN_THREADS) void omp_fused_kernel(NnlsArgs n, GridS
   const double* xf = rec + BCX_REC_HDR;
   const int k = st->k, p = st->np;
   const double err0 = st->err;
-  // ---- phase 1: -An[j].r for the active rows, row_j . xf for all slots, xf.xf, xf.b ------------------
-  for (int j = wg * nw + wave; j <= k; j += nwg * nw) {
-    const double* row = (j < k) ? a.act_rows + (size_t)j * d : xf;
-    const double* other = (j < k) ? a.q64 : a.b;
+  for (int i = tid; i < d; i += blockDim.x) { xfs[i] = xf[i]; qs[i] = a.q64[i]; bs[i] = a.b[i]; }
+  for (int q = tid; q < p; q += blockDim.x) cs[q] = n.plist[q];
+  __syncthreads();
+  // ---- phase 1: -An[j].r for the active rows and row_j . xf for all slots; one wave per row, all loads of a
+  // 512-element stretch in flight together ------------------------------------------------------------------
+  for (int j = wg * nw + wave; j < k; j += nwg * nw) {
+    const double* row = a.act_rows + (size_t)j * d;
     double a0 = 0.0, a1 = 0.0;
-    for (int i = lane; i < d; i += 64) {
-      const double rv = row[i];
-      a0 += rv * xf[i];
-      a1 += rv * other[i];
+    for (int i0 = 0; i0 < d; i0 += 512) {
+      double rv[8];
+#pragma unroll
+      for (int t = 0; t < 8; ++t) { const int i = i0 + t * 64 + lane; rv[t] = i < d ? row[i] : 0.0; }
+#pragma unroll
+      for (int t = 0; t < 8; ++t) { const int i = i0 + t * 64 + lane; if (i < d) { a0 += rv[t] * xfs[i]; a1 += rv[t] * qs[i]; } }
     }
     a0 = wave_allsum(a0);
     a1 = wave_allsum(a1);
-    if (lane == 0) {
-      if (j < k) { n.t3[j] = a0; n.t2[j] = -(a1 / a.act_norm[j]); }
-      else { st->omp_gff = a0; st->omp_cf = a1; }
-    }
+    if (lane == 0) { n.t3[j] = a0; n.t2[j] = -(a1 / a.act_norm[j]); }
   }
   OMPF_STAMP(1);
   if (!grid_barrier(gs, 1, &s_flag)) { if (wg == 0 && tid == 0) { st->active = 0; st->halt = HALT_GRID_TIMEOUT; } return; }
   OMPF_STAMP(2);
-  // ---- phase 2: decide (every workgroup; workgroup 0 writes) -----------------------------------------
-  int npos = 0;
-  for (int s = tid; s < k; s += blockDim.x) if (a.act_w[s] > 0.0) ++npos;
-  if (npos) atomicAdd(&s_npos, npos);
-  __syncthreads();
-  const bool checked = s_npos > 0;
-  int64_t f = (int64_t)rec[1];
+  // ---- phase 2: decide (every workgroup, one pass over the slots; workgroup 0 writes) --------------------------
+  const int64_t fpos = (int64_t)rec[1];
   const double nf = rec[2];
-  if (checked) {
-    double bv = -INFINITY; int bi = -1; int64_t bidx = 0;
-    for (int j = tid; j < k; j += blockDim.x) {
-      if (!(a.act_w[j] > 0.0)) continue;
+  int npos = 0, match = 0x7fffffff;
+  double bv = -INFINITY; long long bidx = -1; int bslot = -1;
+  for (int j = tid; j < k; j += blockDim.x) {
+    const double wj = a.act_w[j];
+    const long long gj = a.act_idx[j];
+    if (gj == fpos && j < match) match = j;
+    if (wj > 0.0) {
+      ++npos;
       const double vv = n.t2[j];
-      if (bi < 0 || vv > bv || (vv == bv && a.act_idx[j] < bidx)) { bv = vv; bi = j; bidx = a.act_idx[j]; }
+      if (negbest_better(bv, bidx, vv, gj)) { bv = vv; bidx = gj; bslot = j; }
     }
-    const double vmax = block_allmax(bi >= 0 ? bv : -INFINITY, scratch);
-    if (bi >= 0 && bv == vmax) atomicMin(&s_minidx, (unsigned long long)bidx);
-    __syncthreads();
-    if (!(rec[0] >= vmax)) f = (int64_t)s_minidx;          // orthopursuit.py:32-35
   }
-  for (int s = tid; s < k; s += blockDim.x) if (a.act_idx[s] == f) atomicMin(&s_slot, s);
+  double g2[2] = {0.0, 0.0};                                   // xf . xf, xf . b
+  for (int i = tid; i < d; i += blockDim.x) { g2[0] += xfs[i] * xfs[i]; g2[1] += xfs[i] * bs[i]; }
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) {
+    const double ov = __shfl_xor(bv, off, BCX_WAVE);
+    const long long oi = __shfl_xor(bidx, off, BCX_WAVE);
+    const int os = __shfl_xor(bslot, off, BCX_WAVE);
+    if (negbest_better(bv, bidx, ov, oi)) { bv = ov; bidx = oi; bslot = os; }
+    npos += __shfl_xor(npos, off, BCX_WAVE);
+    match = min(match, __shfl_xor(match, off, BCX_WAVE));
+  }
+  g2[0] = wave_allsum(g2[0]);
+  g2[1] = wave_allsum(g2[1]);
+  if (lane == 0) { w_v[wave] = bv; w_i[wave] = bidx; w_s[wave] = bslot; w_np[wave] = npos; w_m[wave] = match; seg[0][wave] = g2[0]; seg[1][wave] = g2[1]; }
   __syncthreads();
-  int slot = s_slot == 0x7fffffff ? -1 : s_slot;
+  bv = w_v[0]; bidx = w_i[0]; bslot = w_s[0]; npos = w_np[0]; match = w_m[0];
+  double xfxf = seg[0][0], xfb = seg[1][0];
+  for (int w = 1; w < nw; ++w) {
+    if (negbest_better(bv, bidx, w_v[w], w_i[w])) { bv = w_v[w]; bidx = w_i[w]; bslot = w_s[w]; }
+    npos += w_np[w];
+    match = min(match, w_m[w]);
+    xfxf += seg[0][w]; xfb += seg[1][w];
+  }
+  __syncthreads();
+  const bool checked = npos > 0;
+  int64_t f = fpos;
+  int slot = match == 0x7fffffff ? -1 : match;
+  if (checked && !(rec[0] >= bv)) { f = bidx; slot = bslot; }   // orthopursuit.py:32-35
   const bool fresh = slot < 0;
   if (fresh) slot = k;
   const int k1 = fresh ? k + 1 : k;
-  const double gff = fresh ? st->omp_gff : n.gram[(size_t)slot * n.ldg + slot];
-  const double cf = fresh ? st->omp_cf : n.cvec[slot];
+  const double gff = fresh ? xfxf : n.gram[(size_t)slot * n.ldg + slot];
+  const double cf = fresh ? xfb : n.cvec[slot];
   const double nslot = fresh ? nf : a.act_norm[slot];
-  if (wg == 0) {
-    for (int j = tid; j < k; j += blockDim.x) n.wbak[j] = a.act_w[j];
-    if (fresh) {
-      for (int i = tid; i < d; i += blockDim.x) a.act_rows[(size_t)slot * d + i] = xf[i];
-      for (int j = tid; j < k; j += blockDim.x) {
-        const double g = n.t3[j];
-        n.gram[(size_t)slot * n.ldg + j] = g;
-        n.gram[(size_t)j * n.ldg + slot] = g;
-      }
-      if (tid == 0) {
-        a.act_idx[slot] = f; a.act_norm[slot] = nf; a.act_w[slot] = 0.0; n.ppos[slot] = -1; n.x[slot] = 0.0;
-        n.gram[(size_t)slot * n.ldg + slot] = gff;
-        n.cvec[slot] = cf;
-      }
-    }
-  }
   const int pos_slot = fresh ? -1 : n.ppos[slot];
   int mode;
   if (!st->hvalid) mode = OMP_GENERAL;
@@ -988,7 +832,7 @@ __global__ __launch_bounds__(NN_THREADS) void omp_fused_kernel(NnlsArgs n, GridS
   // ---- phase 3: u = H g on this workgroup's 64-column blocks ------------------------------------------
   if (mode == OMP_FAST_TRY) {
     for (int q = tid; q < p; q += blockDim.x)
-      t0s[q] = fresh ? n.t3[n.plist[q]] : n.gram[(size_t)slot * n.ldg + n.plist[q]];
+      t0s[q] = fresh ? n.t3[cs[q]] : n.gram[(size_t)slot * n.ldg + cs[q]];
     __syncthreads();
     for (int cb = wg; cb * 64 < p; cb += nwg) {
       const int col = cb * 64 + lane;
@@ -1022,10 +866,19 @@ __global__ __launch_bounds__(NN_THREADS) void omp_fused_kernel(NnlsArgs n, GridS
   const double tolscale = 10.0 * eps * (double)(d > k1 ? d : k1) * st->bnorm;
   double tstep = 0.0, inv = 0.0;
   if (mode == OMP_FAST_TRY) {
-    for (int q = tid; q < p; q += blockDim.x) t1s[q] = n.t1[q];
-    __syncthreads();
     double r[2] = {0.0, 0.0};
-    for (int q = tid; q < p; q += blockDim.x) { r[0] += t0s[q] * t1s[q]; r[1] += t0s[q] * n.x[n.plist[q]]; }
+    double xo[OMPF_MAX_K / NN_THREADS];
+#pragma unroll
+    for (int t = 0; t < OMPF_MAX_K / NN_THREADS; ++t) {
+      const int q = tid + t * NN_THREADS;
+      xo[t] = 0.0;
+      if (q < p) {
+        const double u = n.t1[q];
+        xo[t] = n.x[cs[q]];
+        t1s[q] = u;
+        r[0] += t0s[q] * u; r[1] += t0s[q] * xo[t];
+      }
+    }
     block_allsum<2>(r, scratch);
     const double sc = gff - r[0];
     const double wvf = cf - r[1];
@@ -1036,8 +889,17 @@ __global__ __launch_bounds__(NN_THREADS) void omp_fused_kernel(NnlsArgs n, GridS
       if (wg == 0 && tid == 0) st->omp_ill = 1;             // nearly dependent column: refined general solve
     } else {
       tstep = wvf / sc;
-      for (int q = tid; q < p; q += blockDim.x)
-        if (!(n.x[n.plist[q]] - tstep * t1s[q] > 0.0)) s_bad = 1;
+      int bad = 0;
+#pragma unroll
+      for (int t = 0; t < OMPF_MAX_K / NN_THREADS; ++t) {
+        const int q = tid + t * NN_THREADS;
+        if (q < p) {
+          const double xn = xo[t] - tstep * t1s[q];
+          t0s[q] = xn;                                      // candidate x by position (g is no longer needed)
+          if (!(xn > 0.0)) bad = 1;
+        }
+      }
+      if (bad) s_bad = 1;
       __syncthreads();
       if (!s_bad && tstep > 0.0) { mode = OMP_FAST_ACCEPT; inv = 1.0 / sc; }
     }
@@ -1047,6 +909,7 @@ __global__ __launch_bounds__(NN_THREADS) void omp_fused_kernel(NnlsArgs n, GridS
   // ---- general active-set solve (rare): workgroup 0 alone, the others wait at barrier 3 -------------------
   if (mode == OMP_GENERAL) {
     if (wg == 0) {
+      if (fresh) { omp_store_new_slot(n, slot, k, xfs, f, nf, gff, cf); __syncthreads(); }
       if (!st->hvalid) rebuild_passive(n, k, scratch);
       for (int j = tid; j < k1; j += blockDim.x) {
         const bool in = (j == slot) || (a.act_w[j] > 0.0);
@@ -1063,16 +926,30 @@ __global__ __launch_bounds__(NN_THREADS) void omp_fused_kernel(NnlsArgs n, GridS
   // ---- phase 5: xw' = sum_P x_j row_j on 64-column blocks; bordered update of H ---------------------------
   const bool acc_fast = mode == OMP_FAST_ACCEPT;
   const int pn = (mode == OMP_GENERAL) ? st->np : (acc_fast ? p + 1 : p);
+  if (mode == OMP_GENERAL) {
+    for (int q = tid; q < pn; q += blockDim.x) { const int c = n.plist[q]; cs[q] = c; t0s[q] = n.x[c]; }
+  } else if (acc_fast) {
+    if (tid == 0) { cs[p] = slot; t0s[p] = tstep; }
+  } else {
+    for (int q = tid; q < pn; q += blockDim.x) t0s[q] = n.x[cs[q]];
+  }
+  __syncthreads();
+  const bool new_in_lds = acc_fast && fresh;          // the new slot's row is not in act_rows yet
+  const int pg = new_in_lds ? p : pn;
   for (int cb = wg; cb * 64 < d; cb += nwg) {
     const int col = cb * 64 + lane;
     double acc = 0.0;
     if (col < d) {
-      for (int q = wave; q < pn; q += nw) {
-        const bool fnew = acc_fast && q == p;
-        const int c = fnew ? slot : n.plist[q];
-        const double xq = fnew ? tstep : (acc_fast ? n.x[c] - tstep * t1s[q] : n.x[c]);
-        acc += xq * a.act_rows[(size_t)c * d + col];
+      int q = wave;
+      for (; q + 7 * nw < pg; q += 8 * nw) {
+        double m[8];
+#pragma unroll
+        for (int t = 0; t < 8; ++t) m[t] = a.act_rows[(size_t)cs[q + t * nw] * d + col];
+#pragma unroll
+        for (int t = 0; t < 8; ++t) acc += t0s[q + t * nw] * m[t];
       }
+      for (; q < pg; q += nw) acc += t0s[q] * a.act_rows[(size_t)cs[q] * d + col];
+      if (new_in_lds && wave == (p % nw)) acc += tstep * xfs[col];
     }
     seg[wave][lane] = acc;
     __syncthreads();
@@ -1085,11 +962,14 @@ __global__ __launch_bounds__(NN_THREADS) void omp_fused_kernel(NnlsArgs n, GridS
   }
   OMPF_STAMP(7);
   if (acc_fast) {
-    // H <- [[H + u u^T / s, -u/s], [-u^T/s, 1/s]]
-    const int64_t total = (int64_t)p * p;
-    for (int64_t idx = (int64_t)wg * blockDim.x + tid; idx < total; idx += (int64_t)nwg * blockDim.x) {
-      const int rr = (int)(idx / p), cc = (int)(idx - (int64_t)rr * p);
-      n.hinv[(size_t)rr * n.ldg + cc] += t1s[rr] * t1s[cc] * inv;
+    // H <- [[H + u u^T / s, -u/s], [-u^T/s, 1/s]]; the workgroups without a column block start first
+    const int ncb = (d + 63) / 64;
+    const int shift = ncb < nwg ? ncb : 0;
+    const int vwg = (wg + nwg - shift) % nwg;
+    for (int rr = vwg * nw + wave; rr < p; rr += nwg * nw) {
+      const double ur = t1s[rr] * inv;
+      double* hrow = n.hinv + (size_t)rr * n.ldg;
+      for (int cc = lane; cc < p; cc += 64) hrow[cc] += ur * t1s[cc];
     }
     for (int q = wg * blockDim.x + tid; q < p; q += nwg * blockDim.x) {
       const double e = -t1s[q] * inv;
@@ -1099,18 +979,19 @@ __global__ __launch_bounds__(NN_THREADS) void omp_fused_kernel(NnlsArgs n, GridS
     if (wg == 0 && tid == 0) n.hinv[(size_t)p * n.ldg + p] = inv;
   }
   OMPF_STAMP(8);
+  if (fresh && mode != OMP_GENERAL && wg == nwg - 1) omp_store_new_slot(n, slot, k, xfs, f, nf, gff, cf);
   if (wg != 0) { __syncthreads(); if (tid == 0) grid_arrive(gs, 1); return; }
   if (!grid_barrier(gs, 4, &s_flag)) { if (tid == 0) { st->active = 0; st->halt = HALT_GRID_TIMEOUT; } return; }
   OMPF_STAMP(9);
   // ---- phase 6 (workgroup 0): commit the step's x, error, monotone check, trace, next query ------------------
   if (acc_fast) {
-    for (int q = tid; q < p; q += blockDim.x) n.x[n.plist[q]] -= tstep * t1s[q];
-    if (tid == 0) { n.plist[p] = slot; n.ppos[slot] = p; n.x[slot] = tstep; st->np = p + 1; }
+    for (int q = tid; q <= p; q += blockDim.x) n.x[cs[q]] = t0s[q];
+    if (tid == 0) { n.plist[p] = slot; n.ppos[slot] = p; st->np = p + 1; }
     __syncthreads();
   }
   double v[2] = {0.0, 0.0};
   for (int j = tid; j < d; j += blockDim.x) {
-    const double x = a.tmp[j], rr = x - a.b[j];
+    const double x = a.tmp[j], rr = x - bs[j];
     v[0] += rr * rr; v[1] += x * x;
   }
   block_allsum<2>(v, scratch);
@@ -1128,9 +1009,8 @@ __global__ __launch_bounds__(NN_THREADS) void omp_fused_kernel(NnlsArgs n, GridS
       st->since_refresh += 1;
       if (checked) st->retried = 0;
     }
-  } else {
-    for (int j = tid; j < k; j += blockDim.x) a.act_w[j] = n.wbak[j];
-    if (tid == 0) st->hvalid = 0;
+  } else if (tid == 0) {
+    st->hvalid = 0;        // weights were not touched; passive data is rebuilt lazily
   }
   __syncthreads();
   if (tid == 0) {
@@ -1167,25 +1047,22 @@ int bcx_launch_apply_omp(bcx_solver* s, const double* recv_dev) {
   fill_nnls_args(s, n, recv_dev);
   s->k_ub += 1;                               // this step may add one slot
   const int64_t kub = s->k_ub;
-  static const int omp_path = getenv("BCX_OMP_PATH") ? atoi(getenv("BCX_OMP_PATH")) : 0;   // dev: 1 = single WG, 2 = multi-kernel
-  if (omp_path == 0 && s->grid_counter && kub >= OMPF_MIN_K && kub <= OMPF_MAX_K) {
-    const int kcap = (int)((kub + 63) / 64 * 64);
-    const size_t lds = 2 * (size_t)kcap * sizeof(double);
+  static const bool legacy = getenv("BCX_OMP_MULTI") != nullptr;   // dev: force the multi-kernel form
+  if (!legacy && s->grid_counter && kub < OMPF_MAX_K) {
+    const int kcap = (int)((kub + 1 + 63) / 64 * 64);
+    const int dpad = (s->cfg.d + 63) / 64 * 64;
+    const size_t lds = (2 * (size_t)kcap + 3 * (size_t)dpad) * sizeof(double) + (size_t)kcap * sizeof(int);
     if (lds > s->omp_lds_allowed) {
-      BCX_HIP(hipFuncSetAttribute((const void*)omp_fused_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(2 * (size_t)OMPF_MAX_K * sizeof(double))));
-      s->omp_lds_allowed = 2 * (size_t)OMPF_MAX_K * sizeof(double);
+      const size_t mx = (2 * (size_t)OMPF_MAX_K + 3 * (size_t)BCX_MAX_D) * sizeof(double) + (size_t)OMPF_MAX_K * sizeof(int);
+      BCX_HIP(hipFuncSetAttribute((const void*)omp_fused_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)mx));
+      s->omp_lds_allowed = mx;
     }
     GridSync gs;
     gs.counter = s->grid_counter;
     gs.base = (unsigned long long)s->grid_epoch * OMPF_NBAR * OMPF_WGS;
     gs.timeout_ticks = 1000000000LL;   // 10 s
     s->grid_epoch += 1;
-    hipLaunchKernelGGL(omp_fused_kernel, dim3(OMPF_WGS), dim3(NN_THREADS), lds, s->stream, n, gs, kcap);
-    BCX_HIP(hipGetLastError());
-    return BCX_OK;
-  }
-  if ((kub < 160 && omp_path != 2) || omp_path == 1) {  // small active sets: one launch is cheaper than eight
-    hipLaunchKernelGGL(apply_omp_kernel, dim3(1), dim3(NN_THREADS), 0, s->stream, n);
+    hipLaunchKernelGGL(omp_fused_kernel, dim3(OMPF_WGS), dim3(NN_THREADS), lds, s->stream, n, gs, kcap, dpad);
     BCX_HIP(hipGetLastError());
     return BCX_OK;
   }

@@ -38,6 +38,15 @@ for case in range(ncase):
         if t[2] != 0 or t[1] < 1e-7 * scale: break
         n += 1
     n = min(n, len(sel))
+    # bit-identical duplicate rows tie exactly; which of them NumPy's arg-max names depends on the BLAS kernel of
+    # the host CPU (observed: same input, different pick on two hosts), the engine takes the lowest index.
+    # Compare up to that relabelling: every row is represented by the first row with the same bytes.
+    if kind == "dups":
+        _, first = np.unique(X, axis=0, return_index=True)
+        canon = {}
+        for i in np.sort(first): canon.setdefault(X[i].tobytes(), i)
+        cmap = lambda v: np.array([canon[X[i].tobytes()] if i >= 0 else i for i in v])
+        sel, osel = cmap(sel), cmap(osel)
     ok = np.array_equal(sel[:n], osel[:n])
     if ok and n:
         ok = np.allclose(s.last_trace[1][:n], oerr[:n], rtol=1e-6, atol=1e-9 * scale)
