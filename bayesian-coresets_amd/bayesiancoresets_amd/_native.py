@@ -24,7 +24,7 @@ SYMBOLS = (
     "bcx_reset", "bcx_reached_numeric_limit", "bcx_get_vector", "bcx_get_norms", "bcx_argmax_correlation", "bcx_time_scan",
     "bcx_stats", "bcx_profile_scan", "bcx_profile_read", "bcx_version",
     "bcx_project_write", "bcx_project_colsum", "bcx_project_select", "bcx_project_last_error",
-    "bcx_build_enqueue_exact", "bcx_exchange_export", "bcx_exchange_attach", "bcx_exchange_probe", "bcx_exchange_disable",
+    "bcx_build_enqueue_exact", "bcx_exchange_export", "bcx_exchange_attach", "bcx_exchange_probe", "bcx_exchange_disable", "bcx_exchange_set_timeout",
 )
 
 
@@ -88,6 +88,7 @@ def load():
         "bcx_exchange_attach": [vp, vp, i32, dbl],
         "bcx_exchange_probe": [vp, P(i32)],
         "bcx_exchange_disable": [vp],
+        "bcx_exchange_set_timeout": [vp, dbl],
     }
     proj_common = [vp, i32, vp, i64, i64, i32, i32, vp, i32, i32, dbl]
     sigs["bcx_project_write"] = proj_common + [vp, i64, vp]
@@ -256,6 +257,9 @@ class Engine(object):
         res = ctypes.c_int32()
         self._check(self.lib.bcx_exchange_probe(self.h, ctypes.byref(res)))
         return res.value
+
+    def exchange_set_timeout(self, timeout_s):
+        self._check(self.lib.bcx_exchange_set_timeout(self.h, float(timeout_s)))
 
     def exchange_disable(self):
         self._check(self.lib.bcx_exchange_disable(self.h))

@@ -106,6 +106,8 @@ class ShardedSolver(object):
                 ok, why = False, str(e)
         if self._agree(ok):           # (also a barrier: every mailbox is mapped before the first store)
             res = self.engine.exchange_probe()
+            if os.environ.get("BCX_TEST_FAIL_PROBE"):      # tests: exercise the fall-back
+                res = -2
             ok = res == 1
             why = why or "probe result %d" % res
             if self._agree(ok):

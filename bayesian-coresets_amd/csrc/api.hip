@@ -458,6 +458,12 @@ extern "C" int bcx_exchange_probe(bcx_solver* s, int32_t* result) {
   return BCX_OK;
 }
 
+extern "C" int bcx_exchange_set_timeout(bcx_solver* s, double timeout_s) {
+  if (!s || !(timeout_s > 0.0)) return BCX_ERR_ARG;
+  s->exchange_timeout_s = timeout_s;
+  return BCX_OK;
+}
+
 extern "C" int bcx_exchange_disable(bcx_solver* s) {
   if (!s) return BCX_ERR_ARG;
   s->exchange_ready = false;   // mappings stay until bcx_destroy; the host-driven step_scan / step_apply path is used again

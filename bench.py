@@ -165,6 +165,8 @@ def main():
     # ---- warm-up, then time exactly K greedy iterations --------------------------------------
     if args.warmup > 0:
         build(args.warmup)
+    if os.environ.get("BENCH_TEST_EXPIRE_MAILBOX") and solver.exchange == "mailbox":
+        solver.engine.exchange_set_timeout(1e-7)      # tests: every later wait expires -> the fall-back below runs
     solver.engine.profile(True)
     sync()
     t0 = time.perf_counter()

@@ -126,11 +126,13 @@ int bcx_build_enqueue_exact(bcx_solver* s);
  *                        build stops and bcx_build_poll returns BCX_ERR_EXCHANGE instead of hanging;
  *   bcx_exchange_probe   COLLECTIVE: one exchange with a known payload; *result = 1 if every shard's
  *                        record arrived intact, -1 timeout, -2 payload mismatch;
+ *   bcx_exchange_set_timeout  change the bound on every later wait;
  *   bcx_exchange_disable go back to the host-driven exchange (e.g. after a failed probe).
  * All shards must issue the same sequence of exchanges (they do: the solver state is replicated). */
 int bcx_exchange_export(bcx_solver* s, void* handle_out, int32_t handle_bytes);
 int bcx_exchange_attach(bcx_solver* s, const void* handles, int32_t handle_bytes, double timeout_s);
 int bcx_exchange_probe(bcx_solver* s, int32_t* result);
+int bcx_exchange_set_timeout(bcx_solver* s, double timeout_s);
 int bcx_exchange_disable(bcx_solver* s);
 /* Synchronise and report.  *n_done = loop iterations consumed so far in this build() call;
  * *need_exact = 1 if the engine stopped before an iteration because the fp32 candidate window

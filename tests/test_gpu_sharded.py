@@ -173,3 +173,42 @@ def test_sparsevi_two_shards_match_reference(tmp_path):
         assert np.array_equal(r0[k], r1[k]), k
     assert np.array_equal(r0["idcs"], g["step2_idcs"])
     np.testing.assert_allclose(r0["wts"], g["step2_wts"], rtol=1e-5, atol=1e-8)
+
+
+# ---- bench.py contract, single process and under torchrun (two ranks sharing the GPU) -------------------
+def _run_bench(extra_env, nproc, args):
+    import json
+    import subprocess
+    env = dict(os.environ)
+    env.update(extra_env)
+    bench = os.path.join(ROOT, "bench.py")
+    if nproc == 1:
+        cmd = [sys.executable, bench] + args
+    else:
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nproc),
+               "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), bench, "--gpus", str(nproc)] + args
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]          # exactly ONE JSON line, from rank 0
+    return json.loads(lines[0]), out.stderr
+
+
+def test_bench_contract_one_and_two_ranks():
+    args = ["--rows", "300000", "--dim", "64", "--steps", "40", "--warmup", "5", "--no-cpu-baseline"]
+    one, _ = _run_bench({}, 1, args)
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                "vs_baseline", "dtype", "data", "config", "roofline"):
+        assert key in one, key
+    assert one["n_gpus"] == 1 and one["steps"] == 40 and one["roofline"]["bound"] == "hbm" and "workload" in one["config"]
+    two, _ = _run_bench({"BENCH_SHARE_GPU": "1"}, 2, args)
+    assert two["n_gpus"] == 2 and two["config"]["exchange"] == "mailbox"
+    assert two["config"]["final_error"] == one["config"]["final_error"]          # same bits for any shard count
+    assert two["config"]["steps_accepted"] == one["config"]["steps_accepted"]
+    # a probe that fails at construction: every rank uses the all-gather from the start
+    three, err = _run_bench({"BENCH_SHARE_GPU": "1", "BCX_TEST_FAIL_PROBE": "1"}, 2, args)
+    assert three["config"]["exchange"] == "collective" and three["config"]["final_error"] == one["config"]["final_error"]
+    # an exchange that stops delivering mid-run: the build raises on every rank, bench.py redoes it over the all-gather
+    four, err = _run_bench({"BENCH_SHARE_GPU": "1", "BENCH_TEST_EXPIRE_MAILBOX": "1", "BCX_EXCHANGE_TIMEOUT": "5"}, 2, args)
+    assert four["config"]["exchange"] == "collective" and "falling back" in err
+    assert four["config"]["final_error"] is not None
