@@ -584,6 +584,7 @@ extern "C" int bcx_optimize(bcx_solver* s, double tol, int32_t* accepted) {
   if ((rc = bcx_launch_optimize(s, tol))) return rc;
   DevState h2;
   if ((rc = read_state(s, &h2))) return rc;
+  if (h2.halt == HALT_GRID_TIMEOUT) { s->err = "optimize: grid barrier timed out"; return BCX_ERR_STATE; }
   *accepted = h2.limit ? 0 : 1;
   return BCX_OK;
 }
