@@ -1,8 +1,8 @@
-"""dev: randomized parity stress -- HIP engine vs CPU oracle over random shapes / algorithms / storage types,
+"""test infrastructure (run by hand on the GPU box: python tests/stress_parity.py SEED CASES): randomized parity stress -- HIP engine vs CPU oracle over random shapes / algorithms / storage types,
 including duplicated rows (exact ties), wildly scaled rows and nearly parallel rows."""
 import sys, os, time
 import numpy as np
-ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
+ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")  # tests/ -> repo root
 sys.path.insert(0, os.path.join(ROOT, "bayesian-coresets_amd")); sys.path.insert(0, ROOT)
 import bayesiancoresets_amd as bc
 from oracle.snnls_oracle import SnnlsOracle

@@ -392,7 +392,7 @@ def test_candidate_storm_lowrank_rows(bc):
 @pytest.mark.parametrize("seed", (11, 12, 13))
 def test_randomized_parity_sweep(bc, seed):
     """Random shapes / algorithms / storage types / data pathologies (duplicates, 11 decades of row scale,
-    bundles of nearly parallel rows, low rank) against the CPU oracle (tools/stress_parity.py, reduced)."""
+    bundles of nearly parallel rows, low rank) against the CPU oracle (tests/stress_parity.py, reduced)."""
     from oracle.snnls_oracle import SnnlsOracle
     rs = np.random.RandomState(seed)
     for case in range(14):
