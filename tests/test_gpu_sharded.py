@@ -212,3 +212,18 @@ def test_bench_contract_one_and_two_ranks():
     four, err = _run_bench({"BENCH_SHARE_GPU": "1", "BENCH_TEST_EXPIRE_MAILBOX": "1", "BCX_EXCHANGE_TIMEOUT": "5"}, 2, args)
     assert four["config"]["exchange"] == "collective" and "falling back" in err
     assert four["config"]["final_error"] is not None
+
+
+@pytest.mark.parametrize("exchange", ("collective", "mailbox"))
+def test_empty_shard(tmp_path, exchange):
+    """N = 1500 rows are two 1024-row chunks: with three ranks the last shard owns no rows at all and still
+    has to take part in every exchange (and must never win one)."""
+    import torch.multiprocessing as mp
+    N, d, itrs = 1500, 8, 12
+    mp.spawn(_worker, args=(1, _free_port(), 1, itrs, N, d, str(tmp_path)), nprocs=1, join=True)
+    mp.spawn(_worker, args=(3, _free_port(), 1, itrs, N, d, str(tmp_path), exchange, "e_"), nprocs=3, join=True)
+    ref = np.load(tmp_path / "w1_r0.npz")
+    for rank in range(3):
+        r = np.load(tmp_path / ("e_w3_r%d.npz" % rank))
+        for k in ("sel", "err", "status", "idx", "w", "b"):
+            assert np.array_equal(ref[k], r[k]), (rank, k)
