@@ -6,7 +6,7 @@
 
 Namespace mirrors bayesiancoresets/__init__.py:1-2 for the components on that path
 (SURVEY.md section 8); the batch pseudocoreset (BPSVI) is out of scope of this engine."""
-from .coreset import Coreset, HilbertCoreset, UniformSamplingCoreset, SparseVICoreset
+from .coreset import Coreset, HilbertCoreset, UniformSamplingCoreset, SparseVICoreset, ShardedHilbertCoreset
 from .projector import BlackBoxProjector, Projector, DeviceProjector
 from . import snnls
 from . import util

@@ -37,6 +37,16 @@ def _as_row_matrix(A):
     return ("numpy", rows)
 
 
+def warn_failed_steps(log, status):
+    """One WARNING per failed loop iteration, as the reference logs the caught NumericalPrecisionError
+    (snnls.py:63-65)."""
+    for i in np.flatnonzero(status != nat.IT_OK):
+        what = {nat.IT_FAIL_SELECT: "select failed (cdirnrm < TOL)",
+                nat.IT_FAIL_REWEIGHT: "reweight step lost precision",
+                nat.IT_FAIL_MONOTONE: "Error not monotone"}[int(status[i])]
+        log.warning("numerical precision error: " + what + " at loop iteration " + str(int(i)))
+
+
 class SparseNNLS(object):
     _ALG = None  # set by subclasses
 
@@ -125,11 +135,7 @@ class SparseNNLS(object):
             return
         self.last_trace = tr
         sel, err, status = tr
-        for i in np.flatnonzero(status != nat.IT_OK):
-            what = {nat.IT_FAIL_SELECT: "select failed (cdirnrm < TOL)",
-                    nat.IT_FAIL_REWEIGHT: "reweight step lost precision",
-                    nat.IT_FAIL_MONOTONE: "Error not monotone"}[int(status[i])]
-            self.log.warning("numerical precision error: " + what + " at loop iteration " + str(int(i)))
+        warn_failed_steps(self.log, status)
         if self._eng.reached_numeric_limit():
             self.log.warning("iterative step failed a second time. Assuming numeric limit reached.")
             self.reached_numeric_limit = True

@@ -123,3 +123,13 @@ class FakeEngine(object):
 
     def error(self):
         return self.oracle.error()
+
+    def optimize(self, tol):
+        before = self.oracle.error()
+        self.oracle.optimize()
+        return not self.oracle.reached_numeric_limit and self.oracle.error() <= before * (1.0 + tol)
+
+    def reset(self):
+        self.oracle.reset()
+        self._trace = []
+        self.done = 0

@@ -227,3 +227,61 @@ def test_empty_shard(tmp_path, exchange):
         r = np.load(tmp_path / ("e_w3_r%d.npz" % rank))
         for k in ("sel", "err", "status", "idx", "w", "b"):
             assert np.array_equal(ref[k], r[k]), (rank, k)
+
+
+def _hilbert_worker(rank, world, port, out_dir):
+    for p in (ROOT, os.path.join(ROOT, "bayesian-coresets_amd")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    import torch
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import bayesiancoresets_amd as bc
+
+    class IDProjector(bc.Projector):
+        def update(self, wts, pts):
+            pass
+
+        def project(self, pts, grad=False):
+            return pts
+
+    N, d = 7000, 32
+    data = _data(N, d)
+    if world == 1:
+        cs = bc.HilbertCoreset(data, IDProjector(), snnls=bc.snnls.GIGA)
+    else:
+        lo, hi = bc.ShardedHilbertCoreset.local_rows(N)
+        cs = bc.ShardedHilbertCoreset(data[lo:hi], IDProjector(), N, snnls=bc.snnls.GIGA)
+        assert cs.snnls.exchange == "mailbox"
+    cs.build(10)
+    cs.build(15)
+    w1, p1, i1 = cs.get()
+    e1 = cs.error()
+    cs.optimize()
+    w2, p2, i2 = cs.get()
+    e2 = cs.error()
+    cs.reset()
+    assert cs.size() == 0
+    cs.build(5)
+    w3, p3, i3 = cs.get()
+    np.savez(os.path.join(out_dir, "hc_w%d_r%d.npz" % (world, rank)), w1=w1, p1=p1, i1=i1, e1=e1, w2=w2, p2=p2, i2=i2, e2=e2,
+             w3=w3, i3=i3)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_sharded_hilbert_coreset_equals_hilbert_coreset(tmp_path):
+    """bc.ShardedHilbertCoreset on two ranks (mailbox exchange) == bc.HilbertCoreset on the whole data: build in
+    two calls, get(), error(), optimize(), reset() -- same values on both ranks."""
+    import torch.multiprocessing as mp
+    for world in (1, 2):
+        mp.spawn(_hilbert_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    ref = np.load(tmp_path / "hc_w1_r0.npz")
+    for rank in range(2):
+        r = np.load(tmp_path / ("hc_w2_r%d.npz" % rank))
+        for k in ref.files:
+            assert np.array_equal(ref[k], r[k]), (rank, k)
+    assert float(ref["e2"]) <= float(ref["e1"])

@@ -87,3 +87,58 @@ def test_shard_bounds_properties():
             sizes = [hi - lo for lo, hi in bounds]
             nonempty = [s for s in sizes if s > 0]
             assert all(s == per * 1024 for s in nonempty[:-1])
+
+
+def _hilbert_worker(rank, world, port, N, d, out_dir):
+    for p in (ROOT, os.path.join(ROOT, "bayesian-coresets_amd"), os.path.join(ROOT, "tests")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from fake_engine import FakeEngine
+    import bayesiancoresets_amd as bc
+
+    class Scaled(bc.Projector):           # any row-wise map will do: vecs = 2 * data
+        def update(self, wts, pts):
+            pass
+
+        def project(self, pts, grad=False):
+            return 2.0 * pts
+
+    data = np.random.RandomState(17).randn(N, d)
+    FakeEngine.FULL = 2.0 * data
+    lo, hi = bc.ShardedHilbertCoreset.local_rows(N)
+    cs = bc.ShardedHilbertCoreset(data[lo:hi], Scaled(), N, snnls=bc.snnls.FrankWolfe, engine_factory=FakeEngine)
+    assert cs.get()[0].shape == (0,)                       # nothing built yet: empty triple (coreset.py:25-28)
+    cs.build(7)
+    cs.build(8)                                            # incremental builds continue (coreset.py:33-38)
+    wts, pts, idcs = cs.get()
+    err = cs.error()
+    with pytest.raises(ValueError):
+        bc.ShardedHilbertCoreset(data[lo:hi - 1] if hi > lo else data[:1], Scaled(), N, snnls=bc.snnls.FrankWolfe,
+                                 engine_factory=FakeEngine)
+    np.savez(os.path.join(out_dir, "h%d.npz" % rank), wts=wts, pts=pts, idcs=idcs, err=err, size=cs.size())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_sharded_hilbert_coreset_matches_single_process(tmp_path):
+    """ShardedHilbertCoreset on two ranks == the reference HilbertCoreset semantics on the whole data
+    (index-sorted wts / idcs, pts = data rows gathered from their owners)."""
+    from oracle.snnls_oracle import SnnlsOracle, hilbert_readout
+    N, d, world = 3000, 12, 2
+    mp.spawn(_hilbert_worker, args=(world, _free_port(), N, d, str(tmp_path)), nprocs=world, join=True)
+    h0, h1 = np.load(tmp_path / "h0.npz"), np.load(tmp_path / "h1.npz")
+    for k in ("wts", "pts", "idcs", "err", "size"):
+        assert np.array_equal(h0[k], h1[k]), k
+    data = np.random.RandomState(17).randn(N, d)
+    vecs = 2.0 * data
+    o = SnnlsOracle(vecs.T, vecs.sum(axis=0), alg="fw", mode="onepass")
+    o.build(15)
+    wts, idcs = hilbert_readout(o.weights())
+    assert np.array_equal(h0["idcs"], idcs)
+    np.testing.assert_allclose(h0["wts"], wts, rtol=1e-12)
+    assert np.array_equal(h0["pts"], data[idcs])
+    np.testing.assert_allclose(float(h0["err"]), o.error(), rtol=1e-12)
+    assert int(h0["size"]) == len(idcs)
