@@ -35,6 +35,7 @@ static __device__ __forceinline__ void gsync(Grid& g) {
 
 struct Rep {             // replicated solver state in LDS
   double *t0, *t1, *x, *z;   // t0/t1/z by position, x by slot
+  double* rv;                // d doubles: residual b - A z of the refinement step
   int *cs, *pos, *fl;        // position -> slot, slot -> position (-1), flags by slot
 };
 
@@ -165,27 +166,66 @@ static __device__ void g_passive_solve(const NnlsArgs& n, const Rep& r, int p, i
                                        double* scratch) {
   const int tid = threadIdx.x;
   double cmax = 0.0;
-  for (int a = tid; a < p; a += blockDim.x) { const double c = n.cvec[r.cs[a]]; r.t0[a] = c; cmax = fmax(cmax, fabs(c)); }
+  for (int q = tid; q < p; q += blockDim.x) { const double c = n.cvec[r.cs[q]]; r.t0[q] = c; cmax = fmax(cmax, fabs(c)); }
   cmax = block_allmax(cmax, scratch);
   g_mv_hinv(n, p, r.t0, n.z, seg);
   gsync(g);
-  for (int a = tid; a < p; a += blockDim.x) r.z[a] = n.z[a];
+  for (int q = tid; q < p; q += blockDim.x) r.z[q] = n.z[q];
   __syncthreads();
-  const int max_it = ill ? 4 : 1;
+  // Refinement with the residual formed in DATA space, t1 = V_P (b - V_P^T z) (corrected semi-normal
+  // equations): the Gram form c - G z loses cond(G) = cond(V)^2 digits, which shows as soon as the support
+  // approaches d columns and the true residual is tiny; this form keeps the reference's (QR-based) accuracy.
+  const ApplyArgs& a = n.a;
+  const int d = a.d, lane = tid & 63, wave = tid >> 6, nw = blockDim.x >> 6;
+  const int max_it = ill ? 4 : 2;
   for (int it = 0; it < max_it; ++it) {
-    g_mv_gram(n, p, r.cs, r.z, n.t1, seg);
-    gsync(g);
-    double rmax = 0.0;
-    for (int a = tid; a < p; a += blockDim.x) { const double rv = r.t0[a] - n.t1[a]; r.t1[a] = rv; rmax = fmax(rmax, fabs(rv)); }
-    if (max_it > 1) {
-      rmax = block_allmax(rmax, scratch);
-      if (!(rmax > 1e-14 * cmax)) break;
-    } else {
+    for (int cb = blockIdx.x; cb * 64 < d; cb += gridDim.x) {      // A z on this workgroup's column blocks
+      const int col = cb * 64 + lane;
+      double acc = 0.0;
+      if (col < d) {
+        int q = wave;
+        for (; q + 7 * nw < p; q += 8 * nw) {
+          double m[8];
+#pragma unroll
+          for (int t = 0; t < 8; ++t) m[t] = a.act_rows[(size_t)r.cs[q + t * nw] * d + col];
+#pragma unroll
+          for (int t = 0; t < 8; ++t) acc += r.z[q + t * nw] * m[t];
+        }
+        for (; q < p; q += nw) acc += r.z[q] * a.act_rows[(size_t)r.cs[q] * d + col];
+      }
+      seg[wave][lane] = acc;
+      __syncthreads();
+      if (wave == 0 && col < d) {
+        double t = seg[0][lane];
+        for (int w = 1; w < nw; ++w) t += seg[w][lane];
+        a.tmp[col] = t;
+      }
       __syncthreads();
     }
+    gsync(g);
+    for (int j = tid; j < d; j += blockDim.x) r.rv[j] = a.b[j] - a.tmp[j];
+    __syncthreads();
+    for (int q = blockIdx.x * nw + wave; q < p; q += gridDim.x * nw) {   // V_P (b - A z): one wave per row
+      const double* row = a.act_rows + (size_t)r.cs[q] * d;
+      double acc = 0.0;
+      for (int i0 = 0; i0 < d; i0 += 512) {
+        double m[8];
+#pragma unroll
+        for (int t = 0; t < 8; ++t) { const int i = i0 + t * 64 + lane; m[t] = i < d ? row[i] : 0.0; }
+#pragma unroll
+        for (int t = 0; t < 8; ++t) { const int i = i0 + t * 64 + lane; if (i < d) acc += m[t] * r.rv[i]; }
+      }
+      acc = wave_allsum(acc);
+      if (lane == 0) n.t1[q] = acc;
+    }
+    gsync(g);
+    double rmax = 0.0;
+    for (int q = tid; q < p; q += blockDim.x) { const double rvv = n.t1[q]; r.t1[q] = rvv; rmax = fmax(rmax, fabs(rvv)); }
+    rmax = block_allmax(rmax, scratch);
+    if (!(rmax > 1e-14 * cmax)) break;
     g_mv_hinv(n, p, r.t1, n.t2, seg);
     gsync(g);
-    for (int a = tid; a < p; a += blockDim.x) r.z[a] += n.t2[a];
+    for (int q = tid; q < p; q += blockDim.x) r.z[q] += n.t2[q];
     __syncthreads();
   }
 }
@@ -286,13 +326,14 @@ static __device__ void g_nnls(const NnlsArgs& n, const Rep& r, int& p, int& ill,
   }
 }
 
-__global__ __launch_bounds__(NN_THREADS) void optimize_grid_kernel(NnlsArgs n, GridSync gs, double tol, int kcap) {
+__global__ __launch_bounds__(NN_THREADS) void optimize_grid_kernel(NnlsArgs n, GridSync gs, double tol, int kcap, int dpad) {
   const ApplyArgs& a = n.a;
   DevState* st = a.st;
   extern __shared__ double dyn[];
   Rep r;
   r.t0 = dyn; r.t1 = dyn + kcap; r.x = dyn + 2 * (size_t)kcap; r.z = dyn + 3 * (size_t)kcap;
-  r.cs = (int*)(dyn + 4 * (size_t)kcap); r.pos = r.cs + kcap; r.fl = r.pos + kcap;
+  r.rv = dyn + 4 * (size_t)kcap;
+  r.cs = (int*)(r.rv + dpad); r.pos = r.cs + kcap; r.fl = r.pos + kcap;
   __shared__ double scratch[BCX_SCRATCH];
   __shared__ double seg[NN_THREADS / 64][64];
   __shared__ int s_flag;
@@ -385,18 +426,19 @@ int bcx_launch_optimize_grid(bcx_solver* s, double tol, int k) {
   NnlsArgs n;
   fill_nnls_args(s, n, nullptr);
   const int kcap = (k + 1 + 63) / 64 * 64;
-  const size_t lds = (size_t)kcap * (4 * sizeof(double) + 3 * sizeof(int));
+  const int dpad = (s->cfg.d + 63) / 64 * 64;
+  const size_t lds = (size_t)kcap * (4 * sizeof(double) + 3 * sizeof(int)) + (size_t)dpad * sizeof(double);
   static bool allowed = false;
   if (!allowed) {
     BCX_HIP(hipFuncSetAttribute((const void*)optimize_grid_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                (int)((size_t)OPT_MAX_K * (4 * sizeof(double) + 3 * sizeof(int)))));
+                                (int)((size_t)OPT_MAX_K * (4 * sizeof(double) + 3 * sizeof(int)) + (size_t)BCX_MAX_D * sizeof(double))));
     allowed = true;
   }
   GridSync gs;
   gs.counter = s->grid_counter;
   gs.base = 0;
   gs.timeout_ticks = 1000000000LL;   // 10 s
-  hipLaunchKernelGGL(optimize_grid_kernel, dim3(OPT_WGS), dim3(NN_THREADS), lds, s->stream, n, gs, tol, kcap);
+  hipLaunchKernelGGL(optimize_grid_kernel, dim3(OPT_WGS), dim3(NN_THREADS), lds, s->stream, n, gs, tol, kcap, dpad);
   BCX_HIP(hipGetLastError());
   return BCX_OK;
 }
