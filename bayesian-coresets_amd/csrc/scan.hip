@@ -130,6 +130,58 @@ __device__ __forceinline__ float reduce4_rows(float p0, float p1, float p2, floa
   return m;
 }
 
+// xor-4 exchange inside a row of 16 lanes: reverse the quads, then mirror the halves (i -> 7-i -> i^4)
+__device__ __forceinline__ float xor4_mov(float v) { return dpp_mov<0x141>(dpp_mov<0x1B>(v)); }
+
+// The same transposed reduction for rows shorter than a wave (G lanes per row, 64/G rows per wave-wide load):
+// four row steps p0..p3 are folded into ONE register in which every group of G/4 lanes holds the total of a
+// different (step, row) pair -- at each of the first two butterfly levels a lane keeps the half it is going to
+// own and hands the other half to its partner, so two registers become one; the remaining levels are plain
+// DPP adds.  One interval + one arg-max update per FOUR row steps instead of one per step.
+//   lane -> (step u, row-in-load rsub): pack_map<G>
+template <int G> __device__ __forceinline__ float reduce4_pack(float p0, float p1, float p2, float p3) {
+  const int lane = __lane_id();
+  if constexpr (G == 64) {
+    return reduce4_rows(p0, p1, p2, p3);
+  } else if constexpr (G == 32) {
+    const float m01 = swap16_add(p0, p1), m23 = swap16_add(p2, p3);
+    const bool h8 = (lane & 8) != 0;
+    float m = (h8 ? m23 : m01) + dpp_mov<0x128>(h8 ? m01 : m23);   // row_ror:8 == xor 8 inside a 16-lane row
+    m += dpp_mov<0xB1>(m);
+    m += dpp_mov<0x4E>(m);
+    m += dpp_mov<0x141>(m);
+    return m;
+  } else if constexpr (G == 16) {
+    const bool h8 = (lane & 8) != 0, h4 = (lane & 4) != 0;
+    const float b0 = (h8 ? p1 : p0) + dpp_mov<0x128>(h8 ? p0 : p1);
+    const float b1 = (h8 ? p3 : p2) + dpp_mov<0x128>(h8 ? p2 : p3);
+    float m = (h4 ? b1 : b0) + xor4_mov(h4 ? b0 : b1);
+    m += dpp_mov<0xB1>(m);
+    m += dpp_mov<0x4E>(m);
+    return m;
+  } else if constexpr (G == 8) {
+    const bool h4 = (lane & 4) != 0, h2 = (lane & 2) != 0;
+    const float b0 = (h4 ? p1 : p0) + xor4_mov(h4 ? p0 : p1);
+    const float b1 = (h4 ? p3 : p2) + xor4_mov(h4 ? p2 : p3);
+    float m = (h2 ? b1 : b0) + dpp_mov<0x4E>(h2 ? b0 : b1);
+    m += dpp_mov<0xB1>(m);
+    return m;
+  } else {   // G == 4
+    const bool h2 = (lane & 2) != 0, h1 = (lane & 1) != 0;
+    const float b0 = (h2 ? p1 : p0) + dpp_mov<0x4E>(h2 ? p0 : p1);
+    const float b1 = (h2 ? p3 : p2) + dpp_mov<0x4E>(h2 ? p2 : p3);
+    return (h1 ? b1 : b0) + dpp_mov<0xB1>(h1 ? b0 : b1);
+  }
+}
+template <int G> __device__ __forceinline__ void pack_map(int lane, int& u, int& rsub) {
+  const int r = lane >> 4;
+  if constexpr (G == 64) { u = (r & 1) * 2 + (r >> 1); rsub = 0; }
+  else if constexpr (G == 32) { u = (r & 1) + 2 * ((lane >> 3) & 1); rsub = r >> 1; }
+  else if constexpr (G == 16) { u = ((lane >> 3) & 1) + 2 * ((lane >> 2) & 1); rsub = r; }
+  else if constexpr (G == 8) { u = ((lane >> 2) & 1) + 2 * ((lane >> 1) & 1); rsub = lane >> 3; }
+  else { u = ((lane >> 1) & 1) + 2 * (lane & 1); rsub = lane >> 2; }
+}
+
 template <typename T, int G> __device__ __forceinline__ T group_allsum(T v) {
   if constexpr (sizeof(T) == 4) {
     return group_allsum_f32<G>(v);
@@ -227,20 +279,21 @@ template <typename T> __device__ __forceinline__ void track_update(Track<T>& tr,
   tr.L = L > tr.L ? L : tr.L;
 }
 
-template <typename ST, bool DUAL, int G, int CH>
+template <typename ST, bool DUAL, int G, int CH, int UR>
 __global__ __launch_bounds__(BCX_SCAN_THREADS) void scan_kernel(ScanArgs a) {
   if (!a.st->active) return;
   typedef typename Stor<ST>::V V;
   typedef typename Stor<ST>::Q Q;
   typedef typename Stor<ST>::T T;
   constexpr int RPW = 64 / G;                       // rows per wave per step
-  constexpr int UR = (CH >= BCX_LOADS_IN_FLIGHT) ? 1 : (BCX_LOADS_IN_FLIGHT / CH > BCX_UR_MAX ? BCX_UR_MAX : BCX_LOADS_IN_FLIGHT / CH);  // row steps in flight
   constexpr int WAVES = BCX_SCAN_THREADS / 64;
   constexpr int RPB = WAVES * RPW * UR;             // rows per workgroup per trip
-  constexpr bool PACK4 = (sizeof(T) == 4) && G == 64 && (UR % 4 == 0);
+  constexpr bool PACK4 = (sizeof(T) == 4) && G >= 4 && (UR % 4 == 0);
+  constexpr int GSZ = PACK4 ? G / 4 : G;          // lanes that end up tracking the same row
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int sub = lane % G, rsub = lane / G;
-  const int myu = ((lane >> 4) & 1) * 2 + (lane >> 5);   // PACK4: which of the 4 rows this 16-lane row tracks
+  int myu = 0, myrs = 0;                            // PACK4: the (row step, row-in-load) pair this lane tracks
+  if constexpr (PACK4) pack_map<G>(lane, myu, myrs);
 
   // query pieces for this lane's columns -> registers
   Q q0[CH], q1[CH];
@@ -283,7 +336,7 @@ __global__ __launch_bounds__(BCX_SCAN_THREADS) void scan_kernel(ScanArgs a) {
     // through one register quad to save VGPRs, which serialises the HBM round trips of a wave
     __builtin_amdgcn_sched_barrier(0);
     if constexpr (PACK4) {
-      // four rows at a time: transposed reduction, then every 16-lane row of the wave tracks one row
+      // four row steps at a time: transposed reduction, then every group of G/4 lanes tracks one row
 #pragma unroll
       for (int g4 = 0; g4 < UR / 4; ++g4) {
         float a0[4], a1[4];
@@ -297,9 +350,9 @@ __global__ __launch_bounds__(BCX_SCAN_THREADS) void scan_kernel(ScanArgs a) {
           }
           a0[u] = t0; a1[u] = t1;
         }
-        const float s0 = reduce4_rows(a0[0], a0[1], a0[2], a0[3]);
-        const float s1 = DUAL ? reduce4_rows(a1[0], a1[1], a1[2], a1[3]) : 0.f;
-        const int64_t myrow = r0 + (int64_t)((g4 * 4 + myu) * WAVES + wave);
+        const float s0 = reduce4_pack<G>(a0[0], a0[1], a0[2], a0[3]);
+        const float s1 = DUAL ? reduce4_pack<G>(a1[0], a1[1], a1[2], a1[3]) : 0.f;
+        const int64_t myrow = r0 + (int64_t)((g4 * 4 + myu) * WAVES + wave) * RPW + myrs;
         float U, L;
         if (DUAL) giga_interval(s0, s1, (float)e, U, L);
         else { const float ee = (float)e + fabsf(s0) * 2e-7f; U = s0 + ee; L = s0 - ee; }
@@ -337,7 +390,7 @@ __global__ __launch_bounds__(BCX_SCAN_THREADS) void scan_kernel(ScanArgs a) {
   }
   // combine the row groups of a wave (lanes with equal `sub` hold distinct row groups)
 #pragma unroll
-  for (int off = PACK4 ? 16 : G; off < 64; off <<= 1) tr = merge<T>(tr, shfl_track<T>(tr, off));
+  for (int off = GSZ; off < 64; off <<= 1) tr = merge<T>(tr, shfl_track<T>(tr, off));
   __shared__ Track<T> wtr[WAVES];
   if (lane == 0) wtr[wave] = tr;
   __syncthreads();
@@ -364,10 +417,14 @@ static int pick_group(int nvec) {  // lanes per row
 // with the 8 workgroups per CU one would launch by reflex.  So: grid = 256 CUs x (8 / loads per lane).
 int bcx_scan_grid(const bcx_solver* s) { return BCX_MAX_PARTIALS; }   // capacity of the partial arrays
 
-static int scan_grid_for(int64_t n, int rows_per_block, int loads_per_lane, bool heavy) {
+static int scan_grid_for(int64_t n, int rows_per_block, double loads_per_lane, bool heavy) {
   int64_t want = (n + rows_per_block - 1) / rows_per_block;
   if (want < 1) want = 1;
-  int64_t cap = 256 * (int64_t)(8 / (loads_per_lane < 1 ? 1 : (loads_per_lane > 8 ? 8 : loads_per_lane)));
+  // 256 CUs x (8 / useful loads per lane), in steps of one workgroup per CU
+  if (loads_per_lane < 1.0) loads_per_lane = 1.0;
+  if (loads_per_lane > 8.0) loads_per_lane = 8.0;
+  int64_t cap = (int64_t)floor(2048.0 / loads_per_lane / 256.0 + 0.5) * 256;
+  if (cap < 256) cap = 256;
   if (heavy) cap = BCX_MAX_PARTIALS;   // fp64 GIGA is VALU-heavy (fp64 sqrt/divide per row): it wants the occupancy
   if (const char* e = getenv("BCX_SCAN_GRID")) { const long v = atol(e); if (v > 0) cap = v; }
   if (cap > BCX_MAX_PARTIALS) cap = BCX_MAX_PARTIALS;
@@ -375,15 +432,19 @@ static int scan_grid_for(int64_t n, int rows_per_block, int loads_per_lane, bool
   return (int)want;
 }
 
+// (G, CH, UR) menu.  UR row steps are in flight per lane; the default keeps CH * UR = BCX_LOADS_IN_FLIGHT
+// 16-byte loads per lane, the "deep" variant doubles UR for row lengths that leave many lanes of the last
+// chunk idle (d = 300: 75 pieces in 128 slots), so the USEFUL bytes in flight stay the same.
 template <typename T, bool DUAL>
-static int launch_t(bcx_solver* s, const ScanArgs& a, int G, int CH, int grid) {
+static int launch_t(bcx_solver* s, const ScanArgs& a, int G, int CH, int UR, int grid) {
   dim3 g(grid), b(BCX_SCAN_THREADS);
-#define L(GG, CC)                                                                                    \
-  if (G == GG && CH == CC) {                                                                         \
-    hipLaunchKernelGGL((scan_kernel<T, DUAL, GG, CC>), g, b, 0, s->stream, a);                       \
+#define L(GG, CC, UU)                                                                                \
+  if (G == GG && CH == CC && UR == UU) {                                                             \
+    hipLaunchKernelGGL((scan_kernel<T, DUAL, GG, CC, UU>), g, b, 0, s->stream, a);                   \
     return BCX_OK;                                                                                   \
   }
-  L(1, 1) L(2, 1) L(4, 1) L(8, 1) L(16, 1) L(32, 1) L(64, 1) L(64, 2) L(64, 4) L(64, 8) L(64, 16)   // d <= 2048
+  L(1, 1, 4) L(2, 1, 4) L(4, 1, 4) L(8, 1, 4) L(16, 1, 4) L(32, 1, 4) L(64, 1, 4) L(64, 2, 4) L(64, 4, 2) L(64, 8, 1) L(64, 16, 1)
+  L(1, 1, 8) L(2, 1, 8) L(4, 1, 8) L(8, 1, 8) L(16, 1, 8) L(32, 1, 8) L(64, 1, 8) L(64, 2, 8) L(64, 4, 4) L(64, 8, 2)
 #undef L
   s->err = "scan: unsupported row length";
   return BCX_ERR_ARG;
@@ -436,16 +497,21 @@ int bcx_launch_scan(bcx_solver* s, int exact) {
   if (f16) coef += 1.02 * (4.8828125e-4 + 2.9802322387695312e-08 * sqrt((double)d));
   a.err_coef = f64 ? 0.0f : (float)coef;
   const bool dual = s->cfg.alg == BCX_ALG_GIGA;
-  // mirror of the kernel's UR / RPB arithmetic
-  const int ur = (CH >= BCX_LOADS_IN_FLIGHT) ? 1 : (BCX_LOADS_IN_FLIGHT / CH > BCX_UR_MAX ? BCX_UR_MAX : BCX_LOADS_IN_FLIGHT / CH);
+  // row steps in flight: CH * UR = BCX_LOADS_IN_FLIGHT slots per lane, twice that when fewer than ~70 % of the
+  // slots carry data (idle lanes in the last chunk / in the row group)
+  int ur = (CH >= BCX_LOADS_IN_FLIGHT) ? 1 : (BCX_LOADS_IN_FLIGHT / CH > BCX_UR_MAX ? BCX_UR_MAX : BCX_LOADS_IN_FLIGHT / CH);
+  const double util = (double)nvec / ((double)G * CH);
+  static const int deep_env = getenv("BCX_SCAN_DEEP") ? atoi(getenv("BCX_SCAN_DEEP")) : -1;   // dev: force 0 / 1
+  const bool deep = CH < 16 && (deep_env >= 0 ? deep_env == 1 : (G == 64 && CH >= 2 && util < 0.80));
+  if (deep) ur *= 2;
   const int rpb = (BCX_SCAN_THREADS / 64) * (64 / G) * ur;
-  const int grid = scan_grid_for(a.n, rpb, CH * ur, f64 && dual);
+  const int grid = scan_grid_for(a.n, rpb, CH * ur * util, f64 && dual);   // idle lanes do not count as loads in flight
   s->n_partials = grid;                     // resolve reads exactly this launch's partials
   a.out = partial_view(s->partials, grid);
   int rc;
-  if (f64) rc = dual ? launch_t<double, true>(s, a, G, CH, grid) : launch_t<double, false>(s, a, G, CH, grid);
-  else if (f16) rc = dual ? launch_t<half_t, true>(s, a, G, CH, grid) : launch_t<half_t, false>(s, a, G, CH, grid);
-  else rc = dual ? launch_t<float, true>(s, a, G, CH, grid) : launch_t<float, false>(s, a, G, CH, grid);
+  if (f64) rc = dual ? launch_t<double, true>(s, a, G, CH, ur, grid) : launch_t<double, false>(s, a, G, CH, ur, grid);
+  else if (f16) rc = dual ? launch_t<half_t, true>(s, a, G, CH, ur, grid) : launch_t<half_t, false>(s, a, G, CH, ur, grid);
+  else rc = dual ? launch_t<float, true>(s, a, G, CH, ur, grid) : launch_t<float, false>(s, a, G, CH, ur, grid);
   if (rc != BCX_OK) return rc;
   BCX_HIP(hipGetLastError());
   return BCX_OK;
