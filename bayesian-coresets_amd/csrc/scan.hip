@@ -108,6 +108,24 @@ __device__ __forceinline__ float swap16_add(float a, float b) {
   const unsigned x = r.x, y = r.y;   // (indexing r[0]/r[1] through a bit_cast is miscompiled by ROCm 7.2: both read element 0)
   return __uint_as_float(x) + __uint_as_float(y);
 }
+// the same exchanges on doubles: low and high words travel separately
+template <int CTRL> __device__ __forceinline__ double dpp_mov(double v) { return bcx_dpp_f64<CTRL>(v); }
+__device__ __forceinline__ double swap32_add(double a, double b) {
+  const unsigned long long ua = (unsigned long long)__double_as_longlong(a), ub = (unsigned long long)__double_as_longlong(b);
+  const v2u lo = __builtin_amdgcn_permlane32_swap((unsigned)ua, (unsigned)ub, false, false);
+  const v2u hi = __builtin_amdgcn_permlane32_swap((unsigned)(ua >> 32), (unsigned)(ub >> 32), false, false);
+  const unsigned xl = lo.x, yl = lo.y, xh = hi.x, yh = hi.y;
+  return __longlong_as_double((long long)(((unsigned long long)xh << 32) | xl)) +
+         __longlong_as_double((long long)(((unsigned long long)yh << 32) | yl));
+}
+__device__ __forceinline__ double swap16_add(double a, double b) {
+  const unsigned long long ua = (unsigned long long)__double_as_longlong(a), ub = (unsigned long long)__double_as_longlong(b);
+  const v2u lo = __builtin_amdgcn_permlane16_swap((unsigned)ua, (unsigned)ub, false, false);
+  const v2u hi = __builtin_amdgcn_permlane16_swap((unsigned)(ua >> 32), (unsigned)(ub >> 32), false, false);
+  const unsigned xl = lo.x, yl = lo.y, xh = hi.x, yh = hi.y;
+  return __longlong_as_double((long long)(((unsigned long long)xh << 32) | xl)) +
+         __longlong_as_double((long long)(((unsigned long long)yh << 32) | yl));
+}
 template <int G> __device__ __forceinline__ float group_allsum_f32(float v) {
   if (G >= 2) v += dpp_mov<0xB1>(v);    // quad_perm [1,0,3,2]
   if (G >= 4) v += dpp_mov<0x4E>(v);    // quad_perm [2,3,0,1]
@@ -119,10 +137,13 @@ template <int G> __device__ __forceinline__ float group_allsum_f32(float v) {
 }
 // Four wave-wide partial sums -> one register: the 16-lane row r of the result holds, in every lane,
 // the total of input {0, 2, 1, 3}[r].  10 VALU instructions for four 64-lane reductions.
-__device__ __forceinline__ float reduce4_rows(float p0, float p1, float p2, float p3) {
-  const float m01 = swap32_add(p0, p1);
-  const float m23 = swap32_add(p2, p3);
-  float m = swap16_add(m01, m23);
+// (generic in T: the float and double overloads of the exchanges above must both be declared before this point --
+// a later double overload would silently route doubles through the float versions)
+template <typename T> __device__ __forceinline__ T reduce4_rows(T p0, T p1, T p2, T p3) {
+  static_assert(sizeof(decltype(swap32_add(p0, p1))) == sizeof(T), "exchange overload narrows");
+  const T m01 = swap32_add(p0, p1);
+  const T m23 = swap32_add(p2, p3);
+  T m = swap16_add(m01, m23);
   m += dpp_mov<0xB1>(m);
   m += dpp_mov<0x4E>(m);
   m += dpp_mov<0x141>(m);
@@ -131,7 +152,7 @@ __device__ __forceinline__ float reduce4_rows(float p0, float p1, float p2, floa
 }
 
 // xor-4 exchange inside a row of 16 lanes: reverse the quads, then mirror the halves (i -> 7-i -> i^4)
-__device__ __forceinline__ float xor4_mov(float v) { return dpp_mov<0x141>(dpp_mov<0x1B>(v)); }
+template <typename T> __device__ __forceinline__ T xor4_mov(T v) { return dpp_mov<0x141>(dpp_mov<0x1B>(v)); }
 
 // The same transposed reduction for rows shorter than a wave (G lanes per row, 64/G rows per wave-wide load):
 // four row steps p0..p3 are folded into ONE register in which every group of G/4 lanes holds the total of a
@@ -139,37 +160,37 @@ __device__ __forceinline__ float xor4_mov(float v) { return dpp_mov<0x141>(dpp_m
 // own and hands the other half to its partner, so two registers become one; the remaining levels are plain
 // DPP adds.  One interval + one arg-max update per FOUR row steps instead of one per step.
 //   lane -> (step u, row-in-load rsub): pack_map<G>
-template <int G> __device__ __forceinline__ float reduce4_pack(float p0, float p1, float p2, float p3) {
+template <int G, typename T> __device__ __forceinline__ T reduce4_pack(T p0, T p1, T p2, T p3) {
   const int lane = __lane_id();
   if constexpr (G == 64) {
     return reduce4_rows(p0, p1, p2, p3);
   } else if constexpr (G == 32) {
-    const float m01 = swap16_add(p0, p1), m23 = swap16_add(p2, p3);
+    const T m01 = swap16_add(p0, p1), m23 = swap16_add(p2, p3);
     const bool h8 = (lane & 8) != 0;
-    float m = (h8 ? m23 : m01) + dpp_mov<0x128>(h8 ? m01 : m23);   // row_ror:8 == xor 8 inside a 16-lane row
+    T m = (h8 ? m23 : m01) + dpp_mov<0x128>(h8 ? m01 : m23);   // row_ror:8 == xor 8 inside a 16-lane row
     m += dpp_mov<0xB1>(m);
     m += dpp_mov<0x4E>(m);
     m += dpp_mov<0x141>(m);
     return m;
   } else if constexpr (G == 16) {
     const bool h8 = (lane & 8) != 0, h4 = (lane & 4) != 0;
-    const float b0 = (h8 ? p1 : p0) + dpp_mov<0x128>(h8 ? p0 : p1);
-    const float b1 = (h8 ? p3 : p2) + dpp_mov<0x128>(h8 ? p2 : p3);
-    float m = (h4 ? b1 : b0) + xor4_mov(h4 ? b0 : b1);
+    const T b0 = (h8 ? p1 : p0) + dpp_mov<0x128>(h8 ? p0 : p1);
+    const T b1 = (h8 ? p3 : p2) + dpp_mov<0x128>(h8 ? p2 : p3);
+    T m = (h4 ? b1 : b0) + xor4_mov(h4 ? b0 : b1);
     m += dpp_mov<0xB1>(m);
     m += dpp_mov<0x4E>(m);
     return m;
   } else if constexpr (G == 8) {
     const bool h4 = (lane & 4) != 0, h2 = (lane & 2) != 0;
-    const float b0 = (h4 ? p1 : p0) + xor4_mov(h4 ? p0 : p1);
-    const float b1 = (h4 ? p3 : p2) + xor4_mov(h4 ? p2 : p3);
-    float m = (h2 ? b1 : b0) + dpp_mov<0x4E>(h2 ? b0 : b1);
+    const T b0 = (h4 ? p1 : p0) + xor4_mov(h4 ? p0 : p1);
+    const T b1 = (h4 ? p3 : p2) + xor4_mov(h4 ? p2 : p3);
+    T m = (h2 ? b1 : b0) + dpp_mov<0x4E>(h2 ? b0 : b1);
     m += dpp_mov<0xB1>(m);
     return m;
   } else {   // G == 4
     const bool h2 = (lane & 2) != 0, h1 = (lane & 1) != 0;
-    const float b0 = (h2 ? p1 : p0) + dpp_mov<0x4E>(h2 ? p0 : p1);
-    const float b1 = (h2 ? p3 : p2) + dpp_mov<0x4E>(h2 ? p2 : p3);
+    const T b0 = (h2 ? p1 : p0) + dpp_mov<0x4E>(h2 ? p0 : p1);
+    const T b1 = (h2 ? p3 : p2) + dpp_mov<0x4E>(h2 ? p2 : p3);
     return (h1 ? b1 : b0) + dpp_mov<0xB1>(h1 ? b0 : b1);
   }
 }
@@ -288,7 +309,7 @@ __global__ __launch_bounds__(BCX_SCAN_THREADS) void scan_kernel(ScanArgs a) {
   constexpr int RPW = 64 / G;                       // rows per wave per step
   constexpr int WAVES = BCX_SCAN_THREADS / 64;
   constexpr int RPB = WAVES * RPW * UR;             // rows per workgroup per trip
-  constexpr bool PACK4 = (sizeof(T) == 4) && G >= 4 && (UR % 4 == 0);
+  constexpr bool PACK4 = G >= 4 && (UR % 4 == 0);
   constexpr int GSZ = PACK4 ? G / 4 : G;          // lanes that end up tracking the same row
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int sub = lane % G, rsub = lane / G;
@@ -339,10 +360,10 @@ __global__ __launch_bounds__(BCX_SCAN_THREADS) void scan_kernel(ScanArgs a) {
       // four row steps at a time: transposed reduction, then every group of G/4 lanes tracks one row
 #pragma unroll
       for (int g4 = 0; g4 < UR / 4; ++g4) {
-        float a0[4], a1[4];
+        T a0[4], a1[4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-          float t0 = 0.f, t1 = 0.f;
+          T t0 = 0, t1 = 0;
 #pragma unroll
           for (int c = 0; c < CH; ++c) {
             t0 = vdot(x[g4 * 4 + u][c], q0[c], t0);
@@ -350,14 +371,20 @@ __global__ __launch_bounds__(BCX_SCAN_THREADS) void scan_kernel(ScanArgs a) {
           }
           a0[u] = t0; a1[u] = t1;
         }
-        const float s0 = reduce4_pack<G>(a0[0], a0[1], a0[2], a0[3]);
-        const float s1 = DUAL ? reduce4_pack<G>(a1[0], a1[1], a1[2], a1[3]) : 0.f;
+        const T s0 = reduce4_pack<G, T>(a0[0], a0[1], a0[2], a0[3]);
+        const T s1 = DUAL ? reduce4_pack<G, T>(a1[0], a1[1], a1[2], a1[3]) : (T)0;
         const int64_t myrow = r0 + (int64_t)((g4 * 4 + myu) * WAVES + wave) * RPW + myrs;
-        float U, L;
-        if (DUAL) giga_interval(s0, s1, (float)e, U, L);
-        else { const float ee = (float)e + fabsf(s0) * 2e-7f; U = s0 + ee; L = s0 - ee; }
+        T U, L;
+        if constexpr (sizeof(T) == 4) {
+          float Uf, Lf;
+          if (DUAL) giga_interval((float)s0, (float)s1, (float)e, Uf, Lf);
+          else { const float ee = (float)e + fabsf((float)s0) * 2e-7f; Uf = (float)s0 + ee; Lf = (float)s0 - ee; }
+          U = Uf; L = Lf;
+        } else {
+          U = L = DUAL ? (T)giga_score((double)s0, (double)s1) : s0;   // exact mode: the score itself
+        }
         if (!(myrow < n)) { U = -INFINITY; L = -INFINITY; }
-        track_update<T>(tr, (T)U, (T)L, (int)myrow);
+        track_update<T>(tr, U, L, (int)myrow);
       }
     } else {
 #pragma unroll

@@ -58,17 +58,20 @@ for case in range(ncase):
     # the numeric limit): same support afterwards, weights to 1e-5, cost to 1e-7
     if ok and kind in ("plain", "scaled") and n == len(osel) == len(sel) and oerr[-1] > 1e-6 * scale:
         o_ok = o.optimize(); s.optimize()
-        if not o_ok and not s.reached_numeric_limit and s.error() < o.error():
-            continue   # SciPy's solve came back worse than its start (rows scaled over 11 decades, k > d) and the reference
-                       # latched; the engine found the optimum -- a difference in the reference's favour is not claimed
+        ge, oe = s.error(), o.error()
+        tol_e = 1e-7 * oe + 1e-9 * scale
+        if ge < oe - tol_e and not s.reached_numeric_limit:
+            continue   # the engine's optimum is strictly better than SciPy's answer (rows scaled over 11 decades: SciPy's
+                       # dual tolerance 10 max(m,n) eps ||A||_1 leaves tiny columns out / stops early; with k >= d it may
+                       # even come back worse than its start and the reference latches) -- not claimed as a mismatch
         ow, gw = o.weights(), s.weights()
-        same = np.array_equal(np.flatnonzero(ow > 0), np.flatnonzero(gw > 0))
-        if same and (ow > 0).any():
-            same = np.allclose(gw[ow > 0], ow[ow > 0], rtol=1e-5, atol=1e-10 * ow.max()) and \
-                   np.isclose(s.error(), o.error(), rtol=1e-7, atol=1e-9 * scale)
-        if not same or bool(s.reached_numeric_limit) != (not o_ok):
+        same = ge <= oe + tol_e and bool(s.reached_numeric_limit) == (not o_ok)
+        if same and (ow > 0).sum() < d:       # unique minimiser only for independent columns
+            same = np.array_equal(np.flatnonzero(ow > 0), np.flatnonzero(gw > 0)) and \
+                   np.allclose(gw[ow > 0], ow[ow > 0], rtol=1e-5, atol=1e-10 * ow.max())
+        if not same:
             bad += 1
             print("OPTIMIZE MISMATCH case %d: N=%d d=%d %s %s %s err gpu %.12g oracle %.12g support %d / %d accepted %s / %s"
-                  % (case, N, d, alg, dtype, kind, s.error(), o.error(), (gw > 0).sum(), (ow > 0).sum(),
+                  % (case, N, d, alg, dtype, kind, ge, oe, (gw > 0).sum(), (ow > 0).sum(),
                      not s.reached_numeric_limit, o_ok), flush=True)
 print("cases %d bad %d in %.1f s" % (ncase, bad, time.time() - t0))
