@@ -32,6 +32,7 @@ struct ResolveArgs {
   int64_t n_local;
   int64_t row_offset;
   int exact;      // take the arg-max of the partials as is (fp64 scan, or fallback without raw rows)
+  int need_score; // 0: a single candidate wins unscored (single shard, GIGA / FW: nobody reads its exact score)
   double* rec;    // out: d + 4 doubles (may be null inside tail_kernel)
 };
 
@@ -60,7 +61,6 @@ static __device__ __forceinline__ double raw_elem(const ResolveArgs& a, int64_t 
 // Partials -> candidates -> exact scores -> winner (LDS `win`); raw winner row to xf_lds (optional)
 // and the record to a.rec (optional).  All 256 threads.
 static __device__ void resolve_core(const ResolveArgs& a, Winner* win, double* xf_lds, double* scratch) {
-  __shared__ int cand_p[BCX_MAX_CAND];      // partial id * 2 + which
   __shared__ int cand[BCX_MAX_CAND];        // local row
   __shared__ double cscore[BCX_MAX_CAND];
   __shared__ int ncand, overflow, minrow;
@@ -69,6 +69,7 @@ static __device__ void resolve_core(const ResolveArgs& a, Winner* win, double* x
   const bool exact = a.exact || a.st->exact_mode;
   // one round trip: this thread's partial bounds
   double u1[PP_MAX], u2[PP_MAX], u3[PP_MAX], lo[PP_MAX];
+  int r1[PP_MAX], r2[PP_MAX];               // the rows behind U1 / U2 come along: no second round trip
 #pragma unroll
   for (int t = 0; t < PP_MAX; ++t) {
     const int p = tid + t * 256;
@@ -77,6 +78,8 @@ static __device__ void resolve_core(const ResolveArgs& a, Winner* win, double* x
     u2[t] = ok ? a.pv.U2[p] : -INFINITY;
     u3[t] = ok ? a.pv.U3[p] : -INFINITY;
     lo[t] = ok ? a.pv.L[p] : -INFINITY;
+    r1[t] = ok ? a.pv.i1[p] : 0;
+    r2[t] = ok ? a.pv.i2[p] : 0;
   }
   if (tid == 0) { ncand = 0; overflow = 0; minrow = 0x7fffffff; }
   double lmax = -INFINITY;
@@ -86,15 +89,14 @@ static __device__ void resolve_core(const ResolveArgs& a, Winner* win, double* x
   BCX_STAMP(a.st, 1);
 #pragma unroll
   for (int t = 0; t < PP_MAX; ++t) {
-    const int p = tid + t * 256;
     if (u1[t] > -INFINITY && u1[t] >= Lstar) {
       const int slot = atomicAdd(&ncand, 1);
-      if (slot < BCX_MAX_CAND) cand_p[slot] = p * 2;
+      if (slot < BCX_MAX_CAND) cand[slot] = r1[t];
     }
     if (!exact) {
       if (u2[t] > -INFINITY && u2[t] >= Lstar) {
         const int slot = atomicAdd(&ncand, 1);
-        if (slot < BCX_MAX_CAND) cand_p[slot] = p * 2 + 1;
+        if (slot < BCX_MAX_CAND) cand[slot] = r2[t];
       }
       if (u3[t] > -INFINITY && u3[t] >= Lstar) overflow = 1;
     }
@@ -107,17 +109,13 @@ static __device__ void resolve_core(const ResolveArgs& a, Winner* win, double* x
     // exact scores tie across more than 64 workgroups: the lowest row among the maxima wins
 #pragma unroll
     for (int t = 0; t < PP_MAX; ++t) {
-      const int p = tid + t * 256;
-      if (p < np && u1[t] == Lstar) atomicMin(&minrow, a.pv.i1[p]);
+      if (u1[t] > -INFINITY && u1[t] == Lstar) atomicMin(&minrow, r1[t]);
     }
     __syncthreads();
     if (tid == 0) cand[0] = minrow;
     nc = 1;
-  } else if (!storm && tid < nc) {   // (a storm without exact scores overflows: no candidate list to read)
-    const int cp = cand_p[tid];
-    cand[tid] = (cp & 1) ? a.pv.i2[cp >> 1] : a.pv.i1[cp >> 1];
-  }
-  __syncthreads();
+    __syncthreads();
+  }   // (a storm without exact scores overflows: the candidate list is not read)
   if (overflow || nc == 0) {
     if (tid == 0) {
       win->score = -INFINITY; win->gidx = -1; win->norm = 0.0; win->lrow = -1;
@@ -127,13 +125,18 @@ static __device__ void resolve_core(const ResolveArgs& a, Winner* win, double* x
     __syncthreads();
     return;
   }
-  if (tid == 0) { a.st->n_cand += nc; a.st->n_resolved += 1; }
+  if (tid == 0) {   // diagnostics: fire-and-forget atomics (a read-modify-write would stall wave 0 for a memory round trip)
+    atomicAdd((unsigned long long*)&a.st->n_cand, (unsigned long long)nc);
+    atomicAdd((unsigned long long*)&a.st->n_resolved, 1ull);
+  }
   BCX_STAMP(a.st, 2);
   // exact fp64 score of every candidate, one wave per candidate; norm, row and query loads are independent
   const double* q0 = a.q64;
   const double* q1 = a.q64 + a.ld64;
   const bool dual = a.alg == BCX_ALG_GIGA;
-  for (int c = wave; c < nc; c += nwaves) {
+  const bool unscored = !a.need_score && nc == 1;       // (the usual case: 1.00-1.01 candidates per iteration)
+  if (unscored && tid == 0) cscore[0] = 0.0;
+  for (int c = wave; c < nc && !unscored; c += nwaves) {
     const int64_t i = cand[c];
     const double nrm = a.norms[i];
     double s0 = 0.0, s1 = 0.0;
@@ -200,34 +203,76 @@ static __device__ __forceinline__ void stage_state(const ApplyArgs& a, const Sta
 }
 
 // Reweight with the winner (f, nf, xf in LDS), commit or fail, trace, next query.
+// The sparse weight list (slot -> global row, weight) does not depend on the scan: the kernels fetch it into
+// registers at entry, so the look-up of the winner's slot costs no memory round trip after the winner is known.
+#define SLOT_PRE 4
+struct SlotPre {
+  long long id[SLOT_PRE];
+  double w[SLOT_PRE];
+  int k;
+  // the scalars of the replicated state the step needs, fetched in the same early round trip
+  double nw, err0, bnorm, sigma, tol;
+  int64_t it, itrs;
+  int retried, since;
+};
+static __device__ __forceinline__ SlotPre slot_prefetch(const ApplyArgs& a) {
+  SlotPre p;
+  const DevState* st = a.st;
+  p.k = st->k;
+  p.nw = st->nw; p.err0 = st->err; p.bnorm = st->bnorm; p.sigma = st->sigma; p.tol = st->tol;
+  p.it = st->it; p.itrs = st->itrs; p.retried = st->retried; p.since = st->since_refresh;
+#pragma unroll
+  for (int t = 0; t < SLOT_PRE; ++t) {
+    const int s = threadIdx.x + t * blockDim.x;
+    const bool ok = s < p.k;
+    p.id[t] = ok ? a.act_idx[s] : -1;
+    p.w[t] = ok ? a.act_w[s] : 0.0;
+  }
+  return p;
+}
+
 template <int ALG>
-static __device__ void apply_core(const ApplyArgs& a, const StateVecs& v, int64_t f, double nf, double* scratch) {
+static __device__ void apply_core(const ApplyArgs& a, const StateVecs& v, int64_t f, double nf, double* scratch,
+                                  const SlotPre& pre) {
   DevState* st = a.st;
   __shared__ int s_slot, s_npos;
+  __shared__ double s_wf;
   const int tid = threadIdx.x, d = a.d;
-  const int k = st->k;
-  const double nw = st->nw, err0 = st->err, bnorm = st->bnorm, sigma = st->sigma, tol = st->tol;
-  const int64_t it = st->it, itrs = st->itrs;
-  const int retried = st->retried, since = st->since_refresh;
+  const int k = pre.k;
+  const double nw = pre.nw, err0 = pre.err0, bnorm = pre.bnorm, sigma = pre.sigma, tol = pre.tol;
+  const int64_t it = pre.it, itrs = pre.itrs;
+  const int retried = pre.retried, since = pre.since;
   if (tid == 0) { s_slot = 0x7fffffff; s_npos = 0; }
   __syncthreads();
   // slot of f in the sparse weight list, and size() > 0  (snnls.py:44)
   {
     int npos = 0, slot = 0x7fffffff;
-    for (int s = tid; s < k; s += blockDim.x) {
-      const int64_t id = a.act_idx[s];
-      const double w = a.act_w[s];
-      if (id == f) slot = s;
-      if (w > 0.0) ++npos;
+    double wf = 0.0;
+    if (k <= SLOT_PRE * (int)blockDim.x) {
+#pragma unroll
+      for (int t = 0; t < SLOT_PRE; ++t) {
+        if (pre.id[t] == f && pre.id[t] >= 0) { slot = tid + t * blockDim.x; wf = pre.w[t]; }
+        if (pre.w[t] > 0.0) ++npos;
+      }
+    } else {
+      for (int s = tid; s < k; s += blockDim.x) {
+        const int64_t id = a.act_idx[s];
+        const double w = a.act_w[s];
+        if (id == f) { slot = s; wf = w; }
+        if (w > 0.0) ++npos;
+      }
     }
-    if (slot != 0x7fffffff) atomicMin(&s_slot, slot);
-    if (npos) atomicAdd(&s_npos, npos);
+    if (slot != 0x7fffffff) { atomicMin(&s_slot, slot); s_wf = wf; }   // global rows are unique among the slots
+    // (one LDS atomic per wave: 256 same-address atomics serialise for ~1 us)
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) npos += __shfl_xor(npos, off, BCX_WAVE);
+    if ((tid & 63) == 0 && npos) atomicAdd(&s_npos, npos);
   }
   __syncthreads();
   BCX_STAMP(st, 5);
   const bool checked = s_npos > 0;
   const int slot = s_slot == 0x7fffffff ? -1 : s_slot;
-  const double wf_old = slot >= 0 ? a.act_w[slot] : 0.0;
+  const double wf_old = slot >= 0 ? s_wf : 0.0;
   int status = BCX_IT_OK;
   double alpha = 0.0, beta = 0.0;
   if (ALG == BCX_ALG_GIGA) {
@@ -378,6 +423,7 @@ __global__ __launch_bounds__(BCX_APPLY_THREADS) void apply_kernel(ApplyArgs a) {
   __shared__ double scratch[BCX_SCRATCH];
   __shared__ int s_win, s_overflow;
   const StateVecs v = carve(dyn, a.d);
+  const SlotPre pre = slot_prefetch(a);
   stage_state(a, v);
   const int tid = threadIdx.x, d = a.d;
   const int recw = d + BCX_REC_HDR;
@@ -401,7 +447,7 @@ __global__ __launch_bounds__(BCX_APPLY_THREADS) void apply_kernel(ApplyArgs a) {
   const int64_t f = (int64_t)rec[1];
   const double nf = rec[2];
   __syncthreads();
-  apply_core<ALG>(a, v, f, nf, scratch);
+  apply_core<ALG>(a, v, f, nf, scratch, pre);
 }
 
 // single shard: resolve + apply in one launch
@@ -414,11 +460,12 @@ __global__ __launch_bounds__(BCX_APPLY_THREADS) void tail_kernel(ResolveArgs r, 
   __shared__ Winner win;
   BCX_STAMP(st, 0);
   const StateVecs v = carve(dyn, a.d);
+  const SlotPre pre = slot_prefetch(a);
   stage_state(a, v);
   resolve_core(r, &win, v.xf, scratch);
   if (win.flags == BCX_REC_OVERFLOW) { if (threadIdx.x == 0) { st->active = 0; st->halt = HALT_NEED_EXACT; } return; }
   if (win.flags != BCX_REC_VALID) { if (threadIdx.x == 0) { st->active = 0; st->halt = HALT_DONE; } return; }
-  apply_core<ALG>(a, v, win.gidx, win.norm, scratch);
+  apply_core<ALG>(a, v, win.gidx, win.norm, scratch, pre);
 }
 
 // ---- peer mailbox exchange (row-sharded builds, no host-side collective) --------------------------
@@ -493,6 +540,7 @@ __global__ __launch_bounds__(BCX_APPLY_THREADS) void tail_exchange_kernel(Resolv
   __shared__ int s_flag, s_win, s_overflow;
   const int tid = threadIdx.x;
   const StateVecs v = carve(dyn, a.d);
+  const SlotPre pre = slot_prefetch(a);
   stage_state(a, v);
   resolve_core(r, &win, v.xf, scratch);
   if (tid == 0) { s_hdr[0] = win.score; s_hdr[1] = (double)win.gidx; s_hdr[2] = win.norm; s_hdr[3] = win.flags; }
@@ -509,7 +557,7 @@ __global__ __launch_bounds__(BCX_APPLY_THREADS) void tail_exchange_kernel(Resolv
   const int64_t f = (int64_t)ld_sys(rec + 1);
   const double nf = ld_sys(rec + 2);
   __syncthreads();
-  apply_core<ALG>(a, v, f, nf, scratch);
+  apply_core<ALG>(a, v, f, nf, scratch, pre);
 }
 
 // OMP: resolve + exchange; the gathered records go to `gather` for the apply kernels of nnls.hip
@@ -593,6 +641,7 @@ static void fill_resolve_args(bcx_solver* s, ResolveArgs& a, double* send_dev, i
   a.row_offset = s->cfg.row_offset;
   // the raw fp64 scan already produced exact scores; without raw rows the fp32 arg-max is taken as is
   a.exact = exact || a.store_f64;
+  a.need_score = 1;
   a.rec = send_dev;
 }
 
@@ -648,6 +697,7 @@ int bcx_launch_apply(bcx_solver* s, const double* recv_dev) {
 int bcx_launch_tail(bcx_solver* s, int exact) {
   ResolveArgs r;
   fill_resolve_args(s, r, nullptr, exact);
+  r.need_score = 0;
   ApplyArgs a;
   fill_apply_args(s, a, nullptr);
   const size_t lds = vec_lds_bytes(s);
