@@ -675,7 +675,8 @@ __global__ __launch_bounds__(NN_THREADS) void omp_fused_kernel(NnlsArgs n, GridS
   const double* rec = a.recs + (size_t)s_win * (d + BCX_REC_HDR);
   const double* xf = rec + BCX_REC_HDR;
   const int k = st->k, p = st->np;
-  const double err0 = st->err;
+  const double err0 = st->err, bnorm0 = st->bnorm;
+  const int hvalid0 = st->hvalid, ill0 = st->omp_ill, since0 = st->since_refresh;   // fetched with the first round trip
   for (int i = tid; i < d; i += blockDim.x) { xfs[i] = xf[i]; qs[i] = a.q64[i]; bs[i] = a.b[i]; }
   for (int q = tid; q < p; q += blockDim.x) cs[q] = n.plist[q];
   __syncthreads();
@@ -749,10 +750,10 @@ __global__ __launch_bounds__(NN_THREADS) void omp_fused_kernel(NnlsArgs n, GridS
   const double nslot = fresh ? nf : a.act_norm[slot];
   const int pos_slot = fresh ? -1 : n.ppos[slot];
   int mode;
-  if (!st->hvalid) mode = OMP_GENERAL;
+  if (!hvalid0) mode = OMP_GENERAL;
   else if (pos_slot >= 0) mode = OMP_DONE;                // f already carries weight: nothing changes
-  else if (st->omp_ill) mode = OMP_GENERAL;
-  else if ((st->since_refresh % OMP_RESOLVE_EVERY) == OMP_RESOLVE_EVERY - 1) mode = OMP_GENERAL;
+  else if (ill0) mode = OMP_GENERAL;
+  else if ((since0 % OMP_RESOLVE_EVERY) == OMP_RESOLVE_EVERY - 1) mode = OMP_GENERAL;
   else mode = OMP_FAST_TRY;
   OMPF_STAMP(3);
   // ---- phase 3: u = H g on this workgroup's 64-column blocks ------------------------------------------
@@ -789,7 +790,7 @@ __global__ __launch_bounds__(NN_THREADS) void omp_fused_kernel(NnlsArgs n, GridS
   OMPF_STAMP(5);
   // ---- phase 4: step (every workgroup) -------------------------------------------------------------------
   const double eps = 2.220446049250313e-16;
-  const double tolscale = 10.0 * eps * (double)(d > k1 ? d : k1) * st->bnorm;
+  const double tolscale = 10.0 * eps * (double)(d > k1 ? d : k1) * bnorm0;
   double tstep = 0.0, inv = 0.0;
   if (mode == OMP_FAST_TRY) {
     double r[2] = {0.0, 0.0};
@@ -836,7 +837,7 @@ __global__ __launch_bounds__(NN_THREADS) void omp_fused_kernel(NnlsArgs n, GridS
   if (mode == OMP_GENERAL) {
     if (wg == 0) {
       if (fresh) { omp_store_new_slot(n, slot, k, xfs, f, nf, gff, cf); __syncthreads(); }
-      if (!st->hvalid) rebuild_passive(n, k, scratch);
+      if (!hvalid0) rebuild_passive(n, k, scratch);
       for (int j = tid; j < k1; j += blockDim.x) {
         const bool in = (j == slot) || (a.act_w[j] > 0.0);
         n.flag[j] = in ? FLAG_INS : 0;
