@@ -66,35 +66,6 @@ static __device__ void g_mv_hinv(const NnlsArgs& n, int p, const double* v, doub
     __syncthreads();
   }
 }
-// out[col] = sum_b G[cs[b]][cs[col]] v[b]
-static __device__ void g_mv_gram(const NnlsArgs& n, int p, const int* cs, const double* v, double* out, double (*seg)[64]) {
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
-  for (int cb = blockIdx.x; cb * 64 < p; cb += gridDim.x) {
-    const int col = cb * 64 + lane;
-    double acc = 0.0;
-    if (col < p) {
-      const int cc = cs[col];
-      int b = wave;
-      for (; b + 7 * nw < p; b += 8 * nw) {
-        double m[8];
-#pragma unroll
-        for (int t = 0; t < 8; ++t) m[t] = n.gram[(size_t)cs[b + t * nw] * n.ldg + cc];
-#pragma unroll
-        for (int t = 0; t < 8; ++t) acc += m[t] * v[b + t * nw];
-      }
-      for (; b < p; b += nw) acc += n.gram[(size_t)cs[b] * n.ldg + cc] * v[b];
-    }
-    seg[wave][lane] = acc;
-    __syncthreads();
-    if (wave == 0 && col < p) {
-      double t = seg[0][lane];
-      for (int w = 1; w < nw; ++w) t += seg[w][lane];
-      out[col] = t;
-    }
-    __syncthreads();
-  }
-}
-
 // Add `slot` to the passive set (bordered inverse).  False: numerically dependent on P.  2 barriers.
 static __device__ bool g_border_add(const NnlsArgs& n, const Rep& r, int& p, int& ill, int slot, Grid& g,
                                     double (*seg)[64], double* scratch) {
