@@ -29,3 +29,7 @@ if __name__ == "__main__":
     run("logistic", 1000000, 10, 512)
     run("poisson", 1000000, 16, 256)
     run("linreg", 1000000, 32, 64)
+    run("linreg", 625000, 301, 256)     # BASELINE configs[4] per-GPU shard: N=5M/8, D=301 (300 bases + const), S=256
+    run("linreg", 1000000, 304, 256)
+    run("linreg", 1000000, 512, 512)
+    run("logistic", 1000000, 100, 500)
