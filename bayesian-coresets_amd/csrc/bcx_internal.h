@@ -113,6 +113,8 @@ struct bcx_solver {
   void* partials = nullptr;     // PartialView storage
   int n_partials = 0;
   double* rec_local = nullptr;   // (d+4) record produced by this shard when world_size == 1
+  double* fin_part = nullptr;    // finalize: sums of groups of chunk sums
+  int64_t fin_cap = 0;
   // peer mailbox (bcx_exchange_*): device-side record exchange for world_size > 1
   void* mbox = nullptr;          // this shard's mailbox (fine-grained device memory, exported over hipIpc)
   size_t mbox_bytes = 0;

@@ -110,6 +110,28 @@ int bcx_launch_ingest(bcx_solver* s, const void* src, int src_dtype, int64_t ld_
 // Finish construction: b and sum(Anorms) from the chunk sums in global chunk order
 // (or b from the caller), ||b||, bn = b/||b|| (giga.py:15-18), and the zero state
 // xw = 0, err = ||b|| (snnls.py:15,29).
+// Column sums of the chunk sums, level 1: workgroup g adds chunks [g*FIN_GROUP, (g+1)*FIN_GROUP) in order.
+// The grouping depends only on the GLOBAL chunk index, so b stays bit-identical for any shard count.
+#define FIN_GROUP 128
+__global__ __launch_bounds__(256) void finalize_partial_kernel(int d, const double* __restrict__ sums, int64_t n_sums,
+                                                               double* __restrict__ part) {
+  const int64_t j0 = (int64_t)blockIdx.x * FIN_GROUP;
+  const int64_t j1 = j0 + FIN_GROUP < n_sums ? j0 + FIN_GROUP : n_sums;
+  for (int c = threadIdx.x; c <= d; c += blockDim.x) {
+    double acc = 0.0;
+    int64_t j = j0;
+    for (; j + 8 <= j1; j += 8) {
+      double m[8];
+#pragma unroll
+      for (int t = 0; t < 8; ++t) m[t] = sums[(j + t) * (int64_t)(d + 1) + c];
+#pragma unroll
+      for (int t = 0; t < 8; ++t) acc += m[t];
+    }
+    for (; j < j1; ++j) acc += sums[j * (int64_t)(d + 1) + c];
+    part[(int64_t)blockIdx.x * (d + 1) + c] = acc;
+  }
+}
+
 __global__ __launch_bounds__(256) void finalize_kernel(int d, int have_b, const double* __restrict__ sums,
                                                        int64_t n_sums, double* __restrict__ b, double* __restrict__ bn,
                                                        double* __restrict__ xw, DevState* st) {
@@ -152,9 +174,22 @@ __global__ __launch_bounds__(256) void finalize_kernel(int d, int have_b, const 
 
 int bcx_launch_finalize(bcx_solver* s, int have_b, const double* gathered, int64_t n_gathered) {
   const double* sums = gathered ? gathered : s->chunk_sums;
-  const int64_t n = gathered ? n_gathered : s->n_chunks;
-  hipLaunchKernelGGL(finalize_kernel, dim3(1), dim3(256), 0, s->stream, s->cfg.d, have_b, sums, n, s->b, s->bn, s->xw,
-                     s->st);
+  int64_t n = gathered ? n_gathered : s->n_chunks;
+  const int d = s->cfg.d;
+  if (n > 2 * FIN_GROUP) {
+    // two levels: groups of FIN_GROUP chunks in parallel, then the (few) group sums in order
+    const int64_t ng = (n + FIN_GROUP - 1) / FIN_GROUP;
+    if (s->fin_cap < ng) {
+      if (s->fin_part) (void)hipFree(s->fin_part);
+      s->fin_part = nullptr;
+      BCX_HIP(hipMalloc((void**)&s->fin_part, (size_t)ng * (d + 1) * sizeof(double)));
+      s->fin_cap = ng;
+    }
+    hipLaunchKernelGGL(finalize_partial_kernel, dim3((unsigned)ng), dim3(256), 0, s->stream, d, sums, n, s->fin_part);
+    sums = s->fin_part;
+    n = ng;
+  }
+  hipLaunchKernelGGL(finalize_kernel, dim3(1), dim3(256), 0, s->stream, d, have_b, sums, n, s->b, s->bn, s->xw, s->st);
   BCX_HIP(hipGetLastError());
   return BCX_OK;
 }

@@ -285,3 +285,20 @@ def test_sharded_hilbert_coreset_equals_hilbert_coreset(tmp_path):
         for k in ref.files:
             assert np.array_equal(ref[k], r[k]), (rank, k)
     assert float(ref["e2"]) <= float(ref["e1"])
+
+
+def test_two_level_column_sums_are_shard_count_independent(tmp_path):
+    """N = 300k rows = 293 chunk sums: b is formed by the two-level reduction (groups of 128 chunks by GLOBAL
+    chunk index, csrc/ingest.hip) and must still be bit-identical for 1, 2 and 3 shards."""
+    import torch.multiprocessing as mp
+    N, d, itrs = 300000, 8, 6
+    for world in (1, 2, 3):
+        mp.spawn(_worker, args=(world, _free_port(), 1, itrs, N, d, str(tmp_path), "mailbox" if world > 1 else "collective",
+                                "b2_"), nprocs=world, join=True)
+    ref = np.load(tmp_path / "b2_w1_r0.npz")
+    np.testing.assert_allclose(ref["b"], _data(N, d).sum(axis=0), rtol=1e-12, atol=1e-9)
+    for world in (2, 3):
+        for rank in range(world):
+            r = np.load(tmp_path / ("b2_w%d_r%d.npz" % (world, rank)))
+            for k in ("sel", "err", "status", "idx", "w", "b"):
+                assert np.array_equal(ref[k], r[k]), (world, rank, k)
