@@ -29,10 +29,15 @@ __global__ __launch_bounds__(1024) void ingest_kernel(const TS* src, int64_t ld_
   const int64_t r1 = (r0 + BCX_CHUNK_ROWS < rows) ? r0 + BCX_CHUNK_ROWS : rows;
   for (int64_t r = r0 + wave; r < r1; r += nw) {
     const TS* x = src + r * ld_src;
+    // squares are summed in the order of the vectorised kernel below (a lane owns the 16-byte pieces
+    // lane, lane + 64, ... of the row), so both kernels give the same norm bit for bit
+    constexpr int EPS = 16 / (int)sizeof(TS);
     double ss = 0.0;
-    for (int c = lane; c < d; c += 64) {
-      double v = (double)x[c];
-      ss += v * v;
+    for (int c0 = lane * EPS; c0 < d; c0 += 64 * EPS) {
+#pragma unroll
+      for (int e = 0; e < EPS; ++e) {
+        if (c0 + e < d) { const double v = (double)x[c0 + e]; ss = fma(v, v, ss); }   // (explicit: both kernels contract alike)
+      }
     }
     ss = wave_allsum(ss);
     const double nrm = sqrt(ss);
@@ -80,6 +85,124 @@ __global__ __launch_bounds__(1024) void ingest_kernel(const TS* src, int64_t ld_
   }
 }
 
+// ---- vectorised form: 16-byte pieces, the row stays in registers between the norm and the store, column sums
+// accumulate in registers (a lane always owns the same columns) and meet in LDS once per chunk.  Same row ->
+// wave assignment and the same wave 0..nw-1 combination as the scalar kernel above, so the chunk sums (hence
+// b) are bit-identical between the two.  Needs d % EPS == 0 and 16-byte aligned source rows.
+template <typename TS> struct SrcVec;
+template <> struct SrcVec<double> { typedef double2 V; static constexpr int EPS = 2; };
+template <> struct SrcVec<float>  { typedef float4 V;  static constexpr int EPS = 4; };
+__device__ __forceinline__ void unpack(const double2& v, double* o) { o[0] = v.x; o[1] = v.y; }
+__device__ __forceinline__ void unpack(const float4& v, double* o) { o[0] = v.x; o[1] = v.y; o[2] = v.z; o[3] = v.w; }
+template <typename TD, int EPS> __device__ __forceinline__ void store_piece(TD* dst, const double* v) {
+  if constexpr (sizeof(TD) == 8) {
+#pragma unroll
+    for (int e = 0; e < EPS; e += 2) *(double2*)(dst + e) = make_double2(v[e], v[e + 1]);
+  } else if constexpr (sizeof(TD) == 4) {
+    if constexpr (EPS == 2) *(float2*)dst = make_float2((float)v[0], (float)v[1]);
+    else *(float4*)dst = make_float4((float)v[0], (float)v[1], (float)v[2], (float)v[3]);
+  } else {
+#pragma unroll
+    for (int e = 0; e < EPS; e += 2)
+      *(__half2*)(dst + e) = __halves2half2(__float2half_rn((float)v[e]), __float2half_rn((float)v[e + 1]));
+  }
+}
+
+template <typename TS, typename TD, int CHI>
+__global__ __launch_bounds__(1024) void ingest_vec_kernel(const TS* src, int64_t ld_src, int64_t row_begin,
+                                                          int64_t rows, int d, TD* __restrict__ An, int ld, int ld64,
+                                                          double* A64, double* __restrict__ norms,
+                                                          double* __restrict__ chunk_sums, DevState* st) {
+  typedef typename SrcVec<TS>::V V;
+  constexpr int EPS = SrcVec<TS>::EPS;
+  extern __shared__ double lds[];  // nw * d column sums + nw norm sums
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  const int npieces = d / EPS;
+  double ca[CHI][EPS];
+#pragma unroll
+  for (int t = 0; t < CHI; ++t)
+#pragma unroll
+    for (int e = 0; e < EPS; ++e) ca[t][e] = 0.0;
+  double normacc = 0.0;
+  const int64_t chunk = blockIdx.x;
+  const int64_t r0 = chunk * BCX_CHUNK_ROWS;
+  const int64_t r1 = (r0 + BCX_CHUNK_ROWS < rows) ? r0 + BCX_CHUNK_ROWS : rows;
+  for (int64_t r = r0 + wave; r < r1; r += nw) {
+    const V* x = (const V*)(src + r * ld_src);
+    V xv[CHI];
+#pragma unroll
+    for (int t = 0; t < CHI; ++t) {
+      const int pc = lane + 64 * t;
+      xv[t] = x[pc < npieces ? pc : 0];
+    }
+    double v[CHI][EPS];
+    double ss = 0.0;
+#pragma unroll
+    for (int t = 0; t < CHI; ++t) {
+      unpack(xv[t], v[t]);
+      if (lane + 64 * t < npieces) {
+#pragma unroll
+        for (int e = 0; e < EPS; ++e) ss = fma(v[t][e], v[t][e], ss);
+      }
+    }
+    ss = wave_allsum(ss);
+    const double nrm = sqrt(ss);
+    const int64_t lr = row_begin + r;
+    if (lane == 0) {
+      norms[lr] = nrm;
+      if (!(nrm > 0.0)) {
+        const int32_t want = (int32_t)(lr + 1);
+        int32_t cur = atomicCAS(&st->zero_row, 0, want);
+        while (cur != 0 && cur > want) {
+          const int32_t prev = atomicCAS(&st->zero_row, cur, want);
+          if (prev == cur) break;
+          cur = prev;
+        }
+      }
+    }
+    normacc += nrm;
+    TD* y = An + lr * (int64_t)ld;
+    double* raw = A64 ? A64 + lr * (int64_t)ld64 : nullptr;
+    const bool copy_raw = raw && (const void*)raw != (const void*)x;
+#pragma unroll
+    for (int t = 0; t < CHI; ++t) {
+      const int pc = lane + 64 * t;
+      if (pc < npieces) {
+        double q[EPS];
+#pragma unroll
+        for (int e = 0; e < EPS; ++e) { ca[t][e] += v[t][e]; q[e] = v[t][e] / nrm; }
+        store_piece<TD, EPS>(y + pc * EPS, q);
+        if (copy_raw) store_piece<double, EPS>(raw + pc * EPS, v[t]);
+      }
+    }
+  }
+#pragma unroll
+  for (int t = 0; t < CHI; ++t) {
+    const int pc = lane + 64 * t;
+    if (pc < npieces) {
+#pragma unroll
+      for (int e = 0; e < EPS; ++e) lds[(size_t)wave * d + pc * EPS + e] = ca[t][e];
+    }
+  }
+  __syncthreads();
+  const int64_t gchunk = row_begin / BCX_CHUNK_ROWS + chunk;
+  double* out = chunk_sums + gchunk * (int64_t)(d + 1);
+  for (int c = threadIdx.x; c < d; c += blockDim.x) {
+    double acc = lds[c];
+    for (int w = 1; w < nw; ++w) acc += lds[(size_t)w * d + c];
+    out[c] = acc;
+  }
+  double* nacc = lds + (size_t)nw * d;
+  __syncthreads();
+  if (lane == 0) nacc[wave] = normacc;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double acc = nacc[0];
+    for (int w = 1; w < nw; ++w) acc += nacc[w];
+    out[d] = acc;
+  }
+}
+
 int bcx_launch_ingest(bcx_solver* s, const void* src, int src_dtype, int64_t ld_src, int64_t row_begin, int64_t rows) {
   const int d = s->cfg.d;
   const int64_t nblk = (rows + BCX_CHUNK_ROWS - 1) / BCX_CHUNK_ROWS;
@@ -88,13 +211,28 @@ int bcx_launch_ingest(bcx_solver* s, const void* src, int src_dtype, int64_t ld_
   if (nw < 1) nw = 1;
   const size_t shmem = ((size_t)nw * d + nw) * sizeof(double);
   dim3 grid((unsigned)nblk), block(64 * nw);
-#define LAUNCH(TS, TD)                                                                                        \
+  const int esz = src_dtype == BCX_F64 ? 8 : 4, eps = 16 / esz;
+  const bool vec_ok = d % eps == 0 && ld_src % eps == 0 && ((uintptr_t)src % 16 == 0) && d / eps <= 64 * 16 &&
+                      !getenv("BCX_INGEST_SCALAR");
+  int chi = 1;
+  while (vec_ok && chi * 64 < d / eps) chi <<= 1;
+#define LAUNCH_K(KFN)                                                                                         \
   do {                                                                                                        \
-    auto kfn = ingest_kernel<TS, TD>;                                                                         \
+    auto kfn = KFN;                                                                                           \
     if (shmem > 48 * 1024)                                                                                    \
       BCX_HIP(hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));  \
-    hipLaunchKernelGGL(kfn, grid, block, shmem, s->stream, (const TS*)src, ld_src, row_begin, rows, d,        \
-                       (TD*)s->An, s->ld, s->ld64, s->A64, s->norms, s->chunk_sums, s->st);                   \
+    hipLaunchKernelGGL(kfn, grid, block, shmem, s->stream, (const TS_*)src, ld_src, row_begin, rows, d,       \
+                       (TD_*)s->An, s->ld, s->ld64, s->A64, s->norms, s->chunk_sums, s->st);                  \
+  } while (0)
+#define LAUNCH(TS, TD)                                                                                        \
+  do {                                                                                                        \
+    typedef TS TS_; typedef TD TD_;                                                                           \
+    if (!vec_ok) LAUNCH_K((ingest_kernel<TS, TD>));                                                           \
+    else if (chi == 1) LAUNCH_K((ingest_vec_kernel<TS, TD, 1>));                                              \
+    else if (chi == 2) LAUNCH_K((ingest_vec_kernel<TS, TD, 2>));                                              \
+    else if (chi == 4) LAUNCH_K((ingest_vec_kernel<TS, TD, 4>));                                              \
+    else if (chi == 8) LAUNCH_K((ingest_vec_kernel<TS, TD, 8>));                                              \
+    else LAUNCH_K((ingest_vec_kernel<TS, TD, 16>));                                                           \
   } while (0)
   const int sd = s->cfg.store_dtype;
   if (src_dtype == BCX_F64) {
@@ -103,6 +241,7 @@ int bcx_launch_ingest(bcx_solver* s, const void* src, int src_dtype, int64_t ld_
     if (sd == BCX_F32) LAUNCH(float, float); else if (sd == BCX_F16) LAUNCH(float, __half); else LAUNCH(float, double);
   }
 #undef LAUNCH
+#undef LAUNCH_K
   BCX_HIP(hipGetLastError());
   return BCX_OK;
 }

@@ -458,3 +458,27 @@ def test_harness_cli_writes_reference_results(golden, tmp_path, trial):
     again = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
     assert again.returncode == 0 and "Results already exist" in again.stdout
     assert len(open(os.path.join(folder, "manifest.csv")).read().splitlines()) == 1
+
+
+# ---- constructor kernels: vectorised ingest == scalar ingest ---------------------------------------------
+@pytest.mark.parametrize("d", (8, 64, 100, 512, 1030, 2048))
+@pytest.mark.parametrize("src", ("float64", "float32"))
+def test_vectorised_ingest_matches_scalar(bc, d, src, monkeypatch):
+    """csrc/ingest.hip: the 16-byte-piece kernel and the scalar kernel (odd d / unaligned rows) must produce the
+    same norms, the same column sums b (bit for bit: same summation tree) and the same stored rows (same trace)."""
+    N = 3000
+    X = np.random.RandomState(d).randn(N, d).astype(src)
+    X[7] *= 1e-30          # tiny and huge rows
+    X[11] *= 1e20
+    out = []
+    for scalar in (False, True):
+        if scalar:
+            monkeypatch.setenv("BCX_INGEST_SCALAR", "1")
+        else:
+            monkeypatch.delenv("BCX_INGEST_SCALAR", raising=False)
+        s = bc.snnls.FrankWolfe(X.T, None)
+        s.build(8)
+        out.append((s.Anorms.copy(), np.array(s.b), s.last_trace[0].copy(), s.last_trace[1].copy()))
+    for a, b in zip(out[0], out[1]):
+        assert np.array_equal(a, b)
+    np.testing.assert_allclose(out[0][0], np.sqrt((X.astype(np.float64) ** 2).sum(axis=1)), rtol=1e-14)
