@@ -726,3 +726,11 @@ extern "C" int bcx_debug_stamps(bcx_solver* s, long long* out32) {
   for (int i = 0; i < 32; ++i) out32[i] = h.dbg_t[i];
   return BCX_OK;
 }
+
+// dev builds: raw copy of the weight back-up buffer (debug digests of nnls_grid.hip with -DBCX_DEBUG_GRID)
+extern "C" int bcx_debug_wbak(bcx_solver* s, double* out, int32_t count) {
+  if (!s || !s->nn_wbak || count > s->gram_cap) return BCX_ERR_ARG;
+  BCX_HIP(hipDeviceSynchronize());
+  BCX_HIP(hipMemcpy(out, s->nn_wbak, (size_t)count * sizeof(double), hipMemcpyDeviceToHost));
+  return BCX_OK;
+}

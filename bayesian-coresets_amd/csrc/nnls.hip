@@ -607,14 +607,15 @@ __global__ __launch_bounds__(BCX_APPLY_THREADS) void omp_finish_kernel(NnlsArgs 
 // phases (decide, step) are computed REDUNDANTLY by every workgroup from the same data in the same order,
 // so each one knows the decision without another barrier; only workgroup 0 writes the shared state.
 // Fast path: 3 barriers
-//   rows | B1 | decide, u = H g | B2 | step, xw' = sum x_j row_j, bordered update of H | B4 | finish (WG 0)
-// (B3 only when the general active-set solve runs on WG 0).  Every workgroup arrives exactly
+//   rows | B1 | decide, u = H g | B2 | step, xw' = sum x_j row_j, bordered update of H | B5 | finish (WG 0)
+// (B3 / B4 only around the general active-set solve on WG 0: everybody done with the fast step's data | solve |
+// result visible).  Every workgroup arrives exactly
 // OMPF_NBAR times per launch whatever path it takes, so barrier `i` of launch `e` is "counter >=
 // (e * OMPF_NBAR + i) * OMPF_WGS"; the host resets the counter at build_begin.
 #ifndef OMPF_WGS
 #define OMPF_WGS 16
 #endif
-#define OMPF_NBAR 4
+#define OMPF_NBAR 5
 #define OMPF_MAX_K 4096      // LDS per position: g / x (8) + u (8) + slot (4) bytes, next to 3 d-vectors
 
 #define OMPF_STAMP(i) do { if (blockIdx.x == 0) BCX_STAMP(st, i); } while (0)
@@ -648,7 +649,7 @@ __global__ __launch_bounds__(NN_THREADS) void omp_fused_kernel(NnlsArgs n, GridS
   DevState* st = a.st;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = blockDim.x >> 6, d = a.d;
   const int wg = blockIdx.x, nwg = gridDim.x;
-  if (!st->active) { if (tid == 0) grid_arrive(gs, OMPF_NBAR); return; }
+  if (!st->active) { grid_arrive(gs, OMPF_NBAR); return; }
   extern __shared__ double dyn[];
   double* t0s = dyn;                     // g = G[slot, P] by position; later the new x by position
   double* t1s = dyn + kcap;              // u = H g
@@ -666,10 +667,8 @@ __global__ __launch_bounds__(NN_THREADS) void omp_fused_kernel(NnlsArgs n, GridS
   if (tid == 0) { int o; s_win = omp_pick_record(a, &o); s_ovf = o; s_bad = 0; }
   __syncthreads();
   if (s_ovf || s_win < 0) {
-    if (tid == 0) {
-      grid_arrive(gs, OMPF_NBAR);
-      if (wg == 0) { st->active = 0; st->halt = s_ovf ? HALT_NEED_EXACT : HALT_DONE; }
-    }
+    grid_arrive(gs, OMPF_NBAR);
+    if (wg == 0 && tid == 0) { st->active = 0; st->halt = s_ovf ? HALT_NEED_EXACT : HALT_DONE; }
     return;
   }
   const double* rec = a.recs + (size_t)s_win * (d + BCX_REC_HDR);
@@ -835,6 +834,8 @@ __global__ __launch_bounds__(NN_THREADS) void omp_fused_kernel(NnlsArgs n, GridS
   OMPF_STAMP(6);
   // ---- general active-set solve (rare): workgroup 0 alone, the others wait at barrier 3 -------------------
   if (mode == OMP_GENERAL) {
+    // every workgroup must be done with x / u of the failed fast step before workgroup 0 starts rewriting them
+    if (!grid_barrier(gs, 3, &s_flag)) { if (wg == 0 && tid == 0) { st->active = 0; st->halt = HALT_GRID_TIMEOUT; } return; }
     if (wg == 0) {
       if (fresh) { omp_store_new_slot(n, slot, k, xfs, f, nf, gff, cf); __syncthreads(); }
       if (!hvalid0) rebuild_passive(n, k, scratch);
@@ -845,16 +846,26 @@ __global__ __launch_bounds__(NN_THREADS) void omp_fused_kernel(NnlsArgs n, GridS
       }
       __syncthreads();
       nnls_run(n, k1, tolscale, scratch);
+      // Publish the result for the other workgroups in buffers none of them has loaded in this launch, with
+      // write-through stores: their XCD's L2 may still hold the x / passive-list / np lines they read in the
+      // earlier phases, and an acquire fence does not drop stale L2 lines.
+      const int npub = st->np;
+      for (int q = tid; q < npub; q += blockDim.x) {
+        const int c = n.plist[q];
+        coh_store(&n.z[q], n.x[c]);
+        coh_store(&n.wbak[q], (double)c);
+      }
+      if (tid == 0) coh_store(&n.wbak[n.ldg - 1], (double)npub);
     }
-    if (!grid_barrier(gs, 3, &s_flag)) { if (wg == 0 && tid == 0) { st->active = 0; st->halt = HALT_GRID_TIMEOUT; } return; }
-  } else if (tid == 0) {
-    grid_arrive(gs, 1);
+    if (!grid_barrier(gs, 4, &s_flag)) { if (wg == 0 && tid == 0) { st->active = 0; st->halt = HALT_GRID_TIMEOUT; } return; }
+  } else {
+    grid_arrive(gs, 2);
   }
   // ---- phase 5: xw' = sum_P x_j row_j on 64-column blocks; bordered update of H ---------------------------
   const bool acc_fast = mode == OMP_FAST_ACCEPT;
-  const int pn = (mode == OMP_GENERAL) ? st->np : (acc_fast ? p + 1 : p);
+  const int pn = (mode == OMP_GENERAL) ? (int)coh_load(&n.wbak[n.ldg - 1]) : (acc_fast ? p + 1 : p);
   if (mode == OMP_GENERAL) {
-    for (int q = tid; q < pn; q += blockDim.x) { const int c = n.plist[q]; cs[q] = c; t0s[q] = n.x[c]; }
+    for (int q = tid; q < pn; q += blockDim.x) { cs[q] = (int)coh_load(&n.wbak[q]); t0s[q] = coh_load(&n.z[q]); }
   } else if (acc_fast) {
     if (tid == 0) { cs[p] = slot; t0s[p] = tstep; }
   } else {
@@ -907,8 +918,8 @@ __global__ __launch_bounds__(NN_THREADS) void omp_fused_kernel(NnlsArgs n, GridS
   }
   OMPF_STAMP(8);
   if (fresh && mode != OMP_GENERAL && wg == nwg - 1) omp_store_new_slot(n, slot, k, xfs, f, nf, gff, cf);
-  if (wg != 0) { __syncthreads(); if (tid == 0) grid_arrive(gs, 1); return; }
-  if (!grid_barrier(gs, 4, &s_flag)) { if (tid == 0) { st->active = 0; st->halt = HALT_GRID_TIMEOUT; } return; }
+  if (wg != 0) { grid_arrive(gs, 1); return; }
+  if (!grid_barrier(gs, 5, &s_flag)) { if (tid == 0) { st->active = 0; st->halt = HALT_GRID_TIMEOUT; } return; }
   OMPF_STAMP(9);
   // ---- phase 6 (workgroup 0): commit the step's x, error, monotone check, trace, next query ------------------
   if (acc_fast) {

@@ -60,23 +60,49 @@ struct GridSync {
   long long timeout_ticks;
 };
 
+// write-through (sc1) store / sc1 load of one double: the pair that is coherent across XCDs without relying on
+// what the reader's L2 happens to hold
+static __device__ __forceinline__ double coh_load(const double* p) {
+  return __longlong_as_double((long long)__hip_atomic_load((const unsigned long long*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+}
+static __device__ __forceinline__ void coh_store(double* p, double v) {
+  __hip_atomic_store((unsigned long long*)p, (unsigned long long)__double_as_longlong(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// The hand-off recipe of the CDNA programming guide (section 6, guideline 16), counter form:
+//   producer  every wave drains its stores (s_waitcnt vmcnt(0)) -> __syncthreads() -> lane 0: agent RELEASE fence
+//             (writes this XCD's dirty L2 lines back) -> explicit s_waitcnt again (ROCm 7.2 may drop the wait that
+//             belongs to the fence, and the counter would overtake the write-back) -> relaxed agent fetch_add
+//   consumer  lane 0 polls with RELAXED loads -> ONE agent ACQUIRE fence -> __syncthreads() -> loads
+// A workgroup-scope barrier alone publishes nothing to other CUs, and a fence by lane 0 does not wait for the
+// stores of the other waves -- both showed up as rare wrong results of optimize() (tests/race_hunt.py).
+static __device__ __forceinline__ void grid_publish() {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+}
+static __device__ __forceinline__ void grid_signal(const GridSync& g, unsigned long long times) {   // lane 0 only
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __hip_atomic_fetch_add(g.counter, times, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// arrive `times` times without waiting (paths that skip barriers).  All threads.
 static __device__ __forceinline__ void grid_arrive(const GridSync& g, int times) {
-  __threadfence();
-  __hip_atomic_fetch_add(g.counter, (unsigned long long)times, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+  grid_publish();
+  if (threadIdx.x == 0) grid_signal(g, (unsigned long long)times);
 }
 // all threads; false after a timeout (the build is then stopped instead of hanging the GPU)
 static __device__ bool grid_barrier(const GridSync& g, int index, int* s_flag) {
-  __syncthreads();
+  grid_publish();
   if (threadIdx.x == 0) {
-    grid_arrive(g, 1);
+    grid_signal(g, 1ull);
     const unsigned long long target = g.base + (unsigned long long)index * gridDim.x;
     const long long t0 = wall_clock64();
     int ok = 1;
-    while (__hip_atomic_load(g.counter, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < target) {
+    while (__hip_atomic_load(g.counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
       __builtin_amdgcn_s_sleep(1);
       if (wall_clock64() - t0 > g.timeout_ticks) { ok = 0; break; }
     }
-    __threadfence();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     *s_flag = ok;
   }
   __syncthreads();

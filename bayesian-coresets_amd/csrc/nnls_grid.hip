@@ -21,9 +21,23 @@
 #define OPT_WGS 16
 #define OPT_MAX_K 2048     // LDS per slot: 4 doubles + 3 ints = 44 bytes
 
+// Cross-XCD rule of this kernel (per-XCD L2s are not coherent with each other, and an acquire fence drops the
+// reader's L1 but not a stale line in its XCD's L2):
+//   * H is OWNER-COMPUTES: row rr of the inverse is read and written only by wave (rr mod 16*G) -- the mat-vec
+//     y = H v takes whole rows (H is symmetric), the rank-1 up/down-dates touch own rows, a new or moved row /
+//     column entry is written by the row's owner.  No line of H is ever shared between workgroups.
+//   * everything that does cross workgroups is a small EXCHANGE vector, written with write-through (sc1) stores
+//     and read with sc1 loads after a grid barrier; consecutive exchanges rotate through four buffers, so a
+//     buffer is rewritten only three barriers after it was read and no trailing barrier is needed.
+// (A first version shared H between workgroups with plain accesses and fences only: 0.3 % of the runs of one
+//  test problem re-read a stale line and took a different path; tests/race_hunt.py.)
+static __device__ __forceinline__ double xld(const double* p) { return coh_load(p); }
+static __device__ __forceinline__ void xst(double* p, double v) { coh_store(p, v); }
+
 struct Grid {
   GridSync gs;
   int bi;        // barriers passed so far in this launch (identical in every workgroup)
+  int xi;        // exchanges so far (ring position)
   int* s_flag;
   bool ok;       // false after a barrier timed out: everything below becomes a no-op
 };
@@ -32,6 +46,10 @@ static __device__ __forceinline__ void gsync(Grid& g) {
   g.bi += 1;
   if (!grid_barrier(g.gs, g.bi, g.s_flag)) g.ok = false;
 }
+static __device__ __forceinline__ double* xbuf(const NnlsArgs& n, Grid& g) {   // next exchange buffer (gram_cap doubles)
+  double* ring[4] = {n.t0, n.t1, n.t2, n.t3};
+  return ring[(g.xi++) & 3];
+}
 
 struct Rep {             // replicated solver state in LDS
   double *t0, *t1, *x, *z;   // t0/t1/z by position, x by slot
@@ -39,73 +57,78 @@ struct Rep {             // replicated solver state in LDS
   int *cs, *pos, *fl;        // position -> slot, slot -> position (-1), flags by slot
 };
 
-// out[col] = sum_b H[b][col] v[b]  on this workgroup's 64-column blocks (H symmetric)
-static __device__ void g_mv_hinv(const NnlsArgs& n, int p, const double* v, double* out, double (*seg)[64]) {
+static __device__ __forceinline__ bool owns_row(int rr) {
+  const int nw = blockDim.x >> 6, wave = threadIdx.x >> 6;
+  return rr % ((int)gridDim.x * nw) == (int)blockIdx.x * nw + wave;
+}
+
+// out[rr] = sum_cc H[rr][cc] v[cc] for the rows this wave owns (v in LDS); out is an exchange buffer
+static __device__ void g_mv_rows(const NnlsArgs& n, int p, const double* v, double* out) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
-  for (int cb = blockIdx.x; cb * 64 < p; cb += gridDim.x) {
-    const int col = cb * 64 + lane;
+  for (int rr = blockIdx.x * nw + wave; rr < p; rr += gridDim.x * nw) {
+    const double* hrow = n.hinv + (size_t)rr * n.ldg;
     double acc = 0.0;
-    if (col < p) {
-      int b = wave;
-      for (; b + 7 * nw < p; b += 8 * nw) {
-        double m[8];
+    for (int c0 = 0; c0 < p; c0 += 512) {
+      double m[8];
 #pragma unroll
-        for (int t = 0; t < 8; ++t) m[t] = n.hinv[(size_t)(b + t * nw) * n.ldg + col];
+      for (int t = 0; t < 8; ++t) { const int c = c0 + t * 64 + lane; m[t] = c < p ? hrow[c] : 0.0; }
 #pragma unroll
-        for (int t = 0; t < 8; ++t) acc += m[t] * v[b + t * nw];
-      }
-      for (; b < p; b += nw) acc += n.hinv[(size_t)b * n.ldg + col] * v[b];
+      for (int t = 0; t < 8; ++t) { const int c = c0 + t * 64 + lane; if (c < p) acc += m[t] * v[c]; }
     }
-    seg[wave][lane] = acc;
-    __syncthreads();
-    if (wave == 0 && col < p) {
-      double t = seg[0][lane];
-      for (int w = 1; w < nw; ++w) t += seg[w][lane];
-      out[col] = t;
-    }
-    __syncthreads();
+    acc = wave_allsum(acc);
+    if (lane == 0) xst(&out[rr], acc);
   }
 }
-// Add `slot` to the passive set (bordered inverse).  False: numerically dependent on P.  2 barriers.
+
+// Add `slot` to the passive set (bordered inverse).  False: numerically dependent on P.  1 barrier.
 static __device__ bool g_border_add(const NnlsArgs& n, const Rep& r, int& p, int& ill, int slot, Grid& g,
-                                    double (*seg)[64], double* scratch) {
+                                    double* scratch) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = blockDim.x >> 6;
   const int64_t ld = n.ldg;
   for (int a = tid; a < p; a += blockDim.x) r.t0[a] = n.gram[(size_t)slot * ld + r.cs[a]];
   __syncthreads();
-  g_mv_hinv(n, p, r.t0, n.t1, seg);                 // u = H g
+  double* X = xbuf(n, g);
+  g_mv_rows(n, p, r.t0, X);                          // u = H g
   gsync(g);
   double v[1] = {0.0};
-  for (int a = tid; a < p; a += blockDim.x) { const double u = n.t1[a]; r.t1[a] = u; v[0] += r.t0[a] * u; }
+  for (int a = tid; a < p; a += blockDim.x) { const double u = xld(&X[a]); r.t1[a] = u; v[0] += r.t0[a] * u; }
   block_allsum<1>(v, scratch);
   const double gff = n.gram[(size_t)slot * ld + slot];
   const double s = gff - v[0];
   if (!(s > 1e-12 * gff)) return false;
   if (!(s > 1e-4 * gff)) ill = 1;
   const double inv = 1.0 / s;
+  // H <- [[H + u u^T / s, -u/s], [-u^T/s, 1/s]]: every wave updates the rows it owns, incl. their new column p
   for (int rr = blockIdx.x * nw + wave; rr < p; rr += gridDim.x * nw) {
     const double ur = r.t1[rr] * inv;
     double* hrow = n.hinv + (size_t)rr * ld;
     for (int cc = lane; cc < p; cc += 64) hrow[cc] += ur * r.t1[cc];
+    if (lane == 0) hrow[p] = -ur;
   }
-  for (int a = blockIdx.x * blockDim.x + tid; a < p; a += gridDim.x * blockDim.x) {
-    const double e = -r.t1[a] * inv;
-    n.hinv[(size_t)p * ld + a] = e;
-    n.hinv[(size_t)a * ld + p] = e;
+  if (owns_row(p)) {
+    double* hrow = n.hinv + (size_t)p * ld;
+    for (int cc = lane; cc < p; cc += 64) hrow[cc] = -r.t1[cc] * inv;
+    if (lane == 0) hrow[p] = inv;
   }
-  if (blockIdx.x == 0 && tid == 0) n.hinv[(size_t)p * ld + p] = inv;
+  __syncthreads();
   if (tid == 0) { r.cs[p] = slot; r.pos[slot] = p; }
   p += 1;
-  gsync(g);
+  __syncthreads();
   return true;
 }
 
-// Remove position q (rank-1 downdate, then the last position moves into q).  2 barriers.
+// Remove position q (rank-1 downdate, then the last position moves into q).  1-2 barriers.
 static __device__ void g_border_del(const NnlsArgs& n, const Rep& r, int& p, int q, Grid& g) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = blockDim.x >> 6;
   const int64_t ld = n.ldg;
   const int last = p - 1;
-  for (int a = tid; a < p; a += blockDim.x) r.t0[a] = n.hinv[(size_t)a * ld + q];
+  double* X = xbuf(n, g);
+  if (owns_row(q)) {                                // row q == column q (symmetric): its owner publishes it
+    const double* hrow = n.hinv + (size_t)q * ld;
+    for (int cc = lane; cc < p; cc += 64) xst(&X[cc], hrow[cc]);
+  }
+  gsync(g);
+  for (int a = tid; a < p; a += blockDim.x) r.t0[a] = xld(&X[a]);
   __syncthreads();
   const double hqq = r.t0[q];
   for (int rr = blockIdx.x * nw + wave; rr < p; rr += gridDim.x * nw) {
@@ -113,35 +136,44 @@ static __device__ void g_border_del(const NnlsArgs& n, const Rep& r, int& p, int
     double* hrow = n.hinv + (size_t)rr * ld;
     for (int cc = lane; cc < p; cc += 64) hrow[cc] -= tr * r.t0[cc] / hqq;
   }
-  gsync(g);
   const int gone = r.cs[q];
   if (q != last) {
-    for (int a = tid; a < p; a += blockDim.x) r.t1[a] = n.hinv[(size_t)last * ld + a];
-    __syncthreads();
-    for (int a = blockIdx.x * blockDim.x + tid; a < last; a += gridDim.x * blockDim.x) {
-      if (a == q) continue;
-      n.hinv[(size_t)q * ld + a] = r.t1[a];
-      n.hinv[(size_t)a * ld + q] = r.t1[a];
+    double* Y = xbuf(n, g);
+    if (owns_row(last)) {                           // (same wave just finished the downdate of this row)
+      const double* hrow = n.hinv + (size_t)last * ld;
+      for (int cc = lane; cc < p; cc += 64) xst(&Y[cc], hrow[cc]);
     }
-    if (blockIdx.x == 0 && tid == 0) n.hinv[(size_t)q * ld + q] = r.t1[last];
+    gsync(g);
+    for (int a = tid; a < p; a += blockDim.x) r.t1[a] = xld(&Y[a]);
+    __syncthreads();
+    for (int rr = blockIdx.x * nw + wave; rr < last; rr += gridDim.x * nw) {   // column q of the rows I own
+      if (rr != q && lane == 0) n.hinv[(size_t)rr * ld + q] = r.t1[rr];
+    }
+    if (owns_row(q)) {
+      double* hrow = n.hinv + (size_t)q * ld;
+      for (int cc = lane; cc < last; cc += 64) if (cc != q) hrow[cc] = r.t1[cc];
+      if (lane == 0) hrow[q] = r.t1[last];
+    }
+    __syncthreads();
     if (tid == 0) { const int moved = r.cs[last]; r.cs[q] = moved; r.pos[moved] = q; }
   }
   __syncthreads();
   if (tid == 0) r.pos[gone] = -1;
   p = last;
-  gsync(g);
+  __syncthreads();
 }
 
-// z = argmin on the passive set: z = H c_P + refinement against G (as passive_solve in nnls.hip).  3+ barriers.
+// z = argmin on the passive set: z = H c_P, then refinement (as passive_solve in nnls.hip).  3+ barriers.
 static __device__ void g_passive_solve(const NnlsArgs& n, const Rep& r, int p, int ill, Grid& g, double (*seg)[64],
                                        double* scratch) {
   const int tid = threadIdx.x;
   double cmax = 0.0;
-  for (int q = tid; q < p; q += blockDim.x) { const double c = n.cvec[r.cs[q]]; r.t0[q] = c; cmax = fmax(cmax, fabs(c)); }
+  for (int q = tid; q < p; q += blockDim.x) { const double c = xld(&n.cvec[r.cs[q]]); r.t0[q] = c; cmax = fmax(cmax, fabs(c)); }
   cmax = block_allmax(cmax, scratch);
-  g_mv_hinv(n, p, r.t0, n.z, seg);
+  double* X = xbuf(n, g);
+  g_mv_rows(n, p, r.t0, X);
   gsync(g);
-  for (int q = tid; q < p; q += blockDim.x) r.z[q] = n.z[q];
+  for (int q = tid; q < p; q += blockDim.x) r.z[q] = xld(&X[q]);
   __syncthreads();
   // Refinement with the residual formed in DATA space, t1 = V_P (b - V_P^T z) (corrected semi-normal
   // equations): the Gram form c - G z loses cond(G) = cond(V)^2 digits, which shows as soon as the support
@@ -169,13 +201,14 @@ static __device__ void g_passive_solve(const NnlsArgs& n, const Rep& r, int p, i
       if (wave == 0 && col < d) {
         double t = seg[0][lane];
         for (int w = 1; w < nw; ++w) t += seg[w][lane];
-        a.tmp[col] = t;
+        xst(&a.tmp[col], t);
       }
       __syncthreads();
     }
     gsync(g);
-    for (int j = tid; j < d; j += blockDim.x) r.rv[j] = a.b[j] - a.tmp[j];
+    for (int j = tid; j < d; j += blockDim.x) r.rv[j] = a.b[j] - xld(&a.tmp[j]);
     __syncthreads();
+    double* Y = xbuf(n, g);
     for (int q = blockIdx.x * nw + wave; q < p; q += gridDim.x * nw) {   // V_P (b - A z): one wave per row
       const double* row = a.act_rows + (size_t)r.cs[q] * d;
       double acc = 0.0;
@@ -187,16 +220,17 @@ static __device__ void g_passive_solve(const NnlsArgs& n, const Rep& r, int p, i
         for (int t = 0; t < 8; ++t) { const int i = i0 + t * 64 + lane; if (i < d) acc += m[t] * r.rv[i]; }
       }
       acc = wave_allsum(acc);
-      if (lane == 0) n.t1[q] = acc;
+      if (lane == 0) xst(&Y[q], acc);
     }
     gsync(g);
     double rmax = 0.0;
-    for (int q = tid; q < p; q += blockDim.x) { const double rvv = n.t1[q]; r.t1[q] = rvv; rmax = fmax(rmax, fabs(rvv)); }
+    for (int q = tid; q < p; q += blockDim.x) { const double rvv = xld(&Y[q]); r.t1[q] = rvv; rmax = fmax(rmax, fabs(rvv)); }
     rmax = block_allmax(rmax, scratch);
     if (!(rmax > 1e-14 * cmax)) break;
-    g_mv_hinv(n, p, r.t1, n.t2, seg);
+    double* W = xbuf(n, g);
+    g_mv_rows(n, p, r.t1, W);
     gsync(g);
-    for (int q = tid; q < p; q += blockDim.x) r.z[q] += n.t2[q];
+    for (int q = tid; q < p; q += blockDim.x) r.z[q] += xld(&W[q]);
     __syncthreads();
   }
 }
@@ -219,6 +253,7 @@ static __device__ void g_nnls(const NnlsArgs& n, const Rep& r, int& p, int& ill,
       double cnt[1] = {(double)nc};
       block_allsum<1>(cnt, scratch);
       if (cnt[0] == 0.0) break;
+      double* D = xbuf(n, g);
       for (int j = blockIdx.x * nw + wave; j < k; j += gridDim.x * nw) {
         const int fl = r.fl[j];
         if (!(fl & FLAG_INS) || (fl & FLAG_REJ) || r.pos[j] >= 0) continue;
@@ -228,20 +263,20 @@ static __device__ void g_nnls(const NnlsArgs& n, const Rep& r, int& p, int& ill,
           acc += n.gram[(size_t)j * n.ldg + ca] * r.x[ca];
         }
         acc = wave_allsum(acc);
-        if (lane == 0) n.t2[j] = n.cvec[j] - acc;
+        if (lane == 0) xst(&D[j], xld(&n.cvec[j]) - acc);
       }
       gsync(g);
       double bv = -INFINITY; int bi = -1;
       for (int j = tid; j < k; j += blockDim.x) {
         const int fl = r.fl[j];
         if (!(fl & FLAG_INS) || (fl & FLAG_REJ) || r.pos[j] >= 0) continue;
-        const double wv = n.t2[j];
+        const double wv = xld(&D[j]);
         if (wv > tolscale * n.a.act_norm[j] && (bi < 0 || wv > bv)) { bv = wv; bi = j; }
       }
       const ArgBest pick = block_argbest(bv, bi, scratch);
       if (pick.i < 0) break;
       best = pick.i;
-      if (!g_border_add(n, r, p, ill, best, g, seg, scratch)) {
+      if (!g_border_add(n, r, p, ill, best, g, scratch)) {
         if (tid == 0) r.fl[best] |= FLAG_REJ;
         __syncthreads();
         continue;
@@ -310,7 +345,7 @@ __global__ __launch_bounds__(NN_THREADS) void optimize_grid_kernel(NnlsArgs n, G
   __shared__ int s_flag;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = blockDim.x >> 6, d = a.d;
   const int wg = blockIdx.x, nwg = gridDim.x;
-  Grid g; g.gs = gs; g.bi = 0; g.s_flag = &s_flag; g.ok = true;
+  Grid g; g.gs = gs; g.bi = 0; g.xi = 0; g.s_flag = &s_flag; g.ok = true;
   const int k = st->k;
   double prev_cost = 0.0;
   if (wg == 0) {
@@ -323,7 +358,7 @@ __global__ __launch_bounds__(NN_THREADS) void optimize_grid_kernel(NnlsArgs n, G
     double acc = 0.0;
     for (int i = lane; i < d; i += 64) acc += a.act_rows[(size_t)j * d + i] * a.b[i];
     acc = wave_allsum(acc);
-    if (lane == 0) n.cvec[j] = acc;
+    if (lane == 0) xst(&n.cvec[j], acc);
   }
   for (int j = tid; j < k; j += blockDim.x) {
     r.pos[j] = -1; r.x[j] = 0.0;
@@ -335,7 +370,7 @@ __global__ __launch_bounds__(NN_THREADS) void optimize_grid_kernel(NnlsArgs n, G
   int p = 0, ill = st->omp_ill;
   bool refused = false;
   for (int j = 0; j < k && g.ok && !refused; ++j)
-    if (r.fl[j] & FLAG_INS) refused = !g_border_add(n, r, p, ill, j, g, seg, scratch);
+    if (r.fl[j] & FLAG_INS) refused = !g_border_add(n, r, p, ill, j, g, scratch);
   if (refused) {
     // dependent columns (k > d): an arbitrary maximal independent subset is a poor starting basis, so fall
     // back to Lawson-Hanson's own order -- empty passive set, columns enter by largest dual
@@ -348,6 +383,15 @@ __global__ __launch_bounds__(NN_THREADS) void optimize_grid_kernel(NnlsArgs n, G
     __syncthreads();
   }
   g_nnls(n, r, p, ill, k, tolscale, p > 0, g, seg, scratch);
+#ifdef BCX_DEBUG_GRID
+  {
+    // per-workgroup digest of the replicated state: all workgroups must agree
+    double hx = 0.0; long long hc = 0;
+    for (int j = 0; j < k; ++j) { hx += r.x[j] * (j + 1); }
+    for (int q = 0; q < p; ++q) hc = hc * 31 + r.cs[q];
+    if (tid == 0) { n.wbak[k + 8 + 4 * wg] = hx; n.wbak[k + 8 + 4 * wg + 1] = (double)hc; n.wbak[k + 8 + 4 * wg + 2] = (double)p; n.wbak[k + 8 + 4 * wg + 3] = (double)g.bi; }
+  }
+#endif
   if (wg != 0) return;
   // ---- workgroup 0: publish the passive data, new weights, accept / revert (snnls.py:88-97) ----------
   if (!g.ok) { if (tid == 0) { st->hvalid = 0; st->halt = HALT_GRID_TIMEOUT; } return; }

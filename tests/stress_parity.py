@@ -71,7 +71,9 @@ for case in range(ncase):
                    np.allclose(gw[ow > 0], ow[ow > 0], rtol=1e-5, atol=1e-10 * ow.max())
         if not same:
             bad += 1
-            print("OPTIMIZE MISMATCH case %d: N=%d d=%d %s %s %s err gpu %.12g oracle %.12g support %d / %d accepted %s / %s"
-                  % (case, N, d, alg, dtype, kind, ge, oe, (gw > 0).sum(), (ow > 0).sum(),
-                     not s.reached_numeric_limit, o_ok), flush=True)
+            sup = ow > 0
+            rel = np.max(np.abs(gw[sup] - ow[sup]) / ow[sup]) if sup.any() and np.array_equal(gw > 0, sup) else float("nan")
+            print("OPTIMIZE MISMATCH case %d: N=%d d=%d %s %s %s err gpu %.15g oracle %.15g support %d / %d (equal %s) accepted %s / %s max rel dw %.3e"
+                  % (case, N, d, alg, dtype, kind, ge, oe, (gw > 0).sum(), (ow > 0).sum(), np.array_equal(gw > 0, sup),
+                     not s.reached_numeric_limit, o_ok, rel), flush=True)
 print("cases %d bad %d in %.1f s" % (ncase, bad, time.time() - t0))
