@@ -157,6 +157,9 @@ struct bcx_solver {
   int64_t rows_loaded = 0;
   // measurement
   bool profile = false;
+  bool prof_now = false;
+  int prof_every = 1;
+  int64_t prof_tick = 0;
   double prof_ms = 0.0;
   int64_t prof_launches = 0;
   std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_events;

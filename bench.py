@@ -27,6 +27,9 @@ HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICR
 GEN_BLOCK = 8192        # rows per seeded generation block (multiple of the 1024-row engine chunk)
 
 
+PROFILE_EVERY = 8   # hipEvent pairs around every 8th scan launch of the timed region (a pair costs 7-12 us of stream time)
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -167,7 +170,8 @@ def main():
         build(args.warmup)
     if os.environ.get("BENCH_TEST_EXPIRE_MAILBOX") and solver.exchange == "mailbox":
         solver.engine.exchange_set_timeout(1e-7)      # tests: every later wait expires -> the fall-back below runs
-    solver.engine.profile(True)
+    if not os.environ.get("BENCH_NO_EVENTS"):      # dev: what do the per-launch hipEvents cost?
+        solver.engine.profile(PROFILE_EVERY)
     sync()
     t0 = time.perf_counter()
     tr = build(args.steps)
@@ -222,7 +226,7 @@ def main():
             "roofline": {
                 "bound": "hbm", "kernel": "scan_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                "avg_launch_ms": avg_ms, "launches": int(scan_launches),
+                "avg_launch_ms": avg_ms, "launches": int(scan_launches), "timed_every": PROFILE_EVERY,
                 "algorithmic_bytes_per_launch": bytes_per_launch,
             },
         }

@@ -168,7 +168,8 @@ int bcx_time_scan(bcx_solver* s, int32_t reps, int32_t exact, double* ms_per_lau
 /* Diagnostics since construction: iterations that fell back to the exact fp64 scan, candidate rows re-scored
  * in fp64 (total) and resolve passes (candidates / resolves = mean candidates per iteration). */
 int bcx_stats(bcx_solver* s, int64_t* exact_fallbacks, int64_t* candidates, int64_t* resolves);
-/* Sum of scan-kernel time recorded by hipEvents during bcx_build_enqueue (enable with on=1). */
+/* Sum of scan-kernel time recorded by hipEvents during bcx_build_enqueue: on = 1 times every scan launch,
+ * on = N > 1 every N-th one (an event pair costs several microseconds of stream time), on = 0 stops. */
 int bcx_profile_scan(bcx_solver* s, int32_t on);
 int bcx_profile_read(bcx_solver* s, double* scan_ms_total, int64_t* scan_launches);
 /* ---- device-native projection (projector.py:19-21 with the example likelihoods) --------------------
