@@ -493,6 +493,7 @@ static __device__ const double* mailbox_exchange(const Mailbox& m, const double*
     for (int j = tid; j < m.recw; j += blockDim.x) st_sys(dst + j, j < BCX_REC_HDR ? hdr[j] : row[j - BCX_REC_HDR]);
   }
   __threadfence_system();          // every thread's record stores are performed before the flags below
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (explicit: ROCm 7.2 can drop the wait that belongs to a fence)
   if (tid == 0) *s_flag = 0;
   __syncthreads();
   if (tid < m.world) {
