@@ -133,3 +133,40 @@ class FakeEngine(object):
         self.oracle.reset()
         self._trace = []
         self.done = 0
+
+
+class FakeMailboxEngine(FakeEngine):
+    """Adds the peer-mailbox protocol of the real engine (exchange_export / attach / probe / enqueue): the
+    "device-side" exchange is an all-gather inside enqueue(), which is all the host logic can observe."""
+    PROBE_RESULT = 1
+
+    def exchange_export(self):
+        return bytes([self.rank]) * 64
+
+    def exchange_attach(self, handles, timeout_s=0.0):
+        assert len(handles) == self.world and all(len(h) == 64 for h in handles)
+        assert [h[0] for h in handles] == list(range(self.world))      # handles arrive in rank order
+        self.attached = True
+
+    def exchange_probe(self):
+        return self.PROBE_RESULT
+
+    def exchange_disable(self):
+        self.attached = False
+
+    def _exchange_step(self, exact=False):
+        import torch.distributed as dist
+        rec = self.d + REC_HDR
+        send = torch.zeros(rec, dtype=torch.float64)
+        recv = torch.zeros(self.world * rec, dtype=torch.float64)
+        self.step_scan_tensor(send, exact)
+        dist.all_gather(list(recv.view(self.world, -1).unbind(0)), send)
+        self.step_apply_tensor(recv)
+
+    def enqueue(self, n):
+        assert getattr(self, "attached", False), "enqueue on a row shard needs an attached mailbox"
+        for _ in range(n):
+            self._exchange_step()
+
+    def enqueue_exact(self):
+        self._exchange_step(exact=True)
