@@ -121,8 +121,20 @@ class DeviceProjector(Projector):
 
     # -- Projector interface ---------------------------------------------------
     def update(self, wts, pts):
-        self.samples = np.atleast_2d(np.asarray(self.sampler(self.projection_dimension, wts, pts), dtype=np.float64))
-        self.theta = self._torch.from_numpy(np.ascontiguousarray(self.samples)).to(self.device)
+        """``samples = sampler(S, wts, pts)`` (projector.py:23-24).  A sampler may return a torch tensor that is
+        already on the GPU (S x D): it is then used in place -- no host round trip on the per-ADAM-step path of
+        SparseVI, where a host sampler otherwise dominates (examples/common/model_linreg.py)."""
+        torch = self._torch
+        drawn = self.sampler(self.projection_dimension, wts, pts)
+        if isinstance(drawn, torch.Tensor):
+            t = drawn.to(self.device, dtype=torch.float64)
+            if t.dim() == 1:
+                t = t[None, :]
+            self.theta = t if t.is_contiguous() else t.contiguous()
+            self.samples = self.theta
+        else:
+            self.samples = np.atleast_2d(np.asarray(drawn, dtype=np.float64))
+            self.theta = torch.from_numpy(np.ascontiguousarray(self.samples)).to(self.device)
 
     def project(self, pts, grad=False):
         if grad:

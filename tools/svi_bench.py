@@ -15,6 +15,7 @@ def main():
     ap.add_argument("--samples", type=int, default=256)
     ap.add_argument("--opt-itrs", type=int, default=20)
     ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--device-sampler", action="store_true", help="draw the posterior samples on the GPU (examples/common/model_linreg.py)")
     a = ap.parse_args()
     import torch
     import bayesiancoresets_amd as bc
@@ -27,7 +28,13 @@ def main():
     Zd = torch.cat((X, y[:, None]), dim=1).contiguous()
     del X
     np.random.seed(2)
-    prj = bc.DeviceProjector("linreg", linreg_sampler(np.zeros(D), np.eye(D), 1.0), S, sigsq=1.0)
+    if a.device_sampler:
+        sys.path.insert(0, os.path.join(ROOT, "bayesian-coresets_amd", "examples", "common"))
+        from model_linreg import posterior_sampler
+        smp = posterior_sampler(np.zeros(D), np.eye(D), 1.0, device="cuda", seed=2)
+    else:
+        smp = linreg_sampler(np.zeros(D), np.eye(D), 1.0)
+    prj = bc.DeviceProjector("linreg", smp, S, sigsq=1.0)
 
     class DevData(object):      # device-resident data set with ndarray-style row access for the coreset points
         shape = (N, D + 1)
@@ -56,7 +63,7 @@ def main():
         "metric": "SparseVI greedy steps/sec (N=%d, D=%d, S=%d, opt_itrs=%d)" % (N, D, S, a.opt_itrs),
         "value": a.steps / dt, "unit": "steps/s", "n_gpus": 1, "steps": a.steps, "s_per_step": dt / a.steps,
         "full_data_projections_per_step": 1 + a.opt_itrs, "ms_per_projection_end_to_end": dt / nproj * 1e3,
-        "dtype": "f64", "data": "synthetic",
+        "dtype": "f64", "data": "synthetic", "sampler": "device (torch)" if a.device_sampler else "host (NumPy/SciPy)",
         "roofline": {"bound": "mfma", "kernel": "proj_kernel<linreg, colsum>", "achieved": flops / (ms * 1e-3) / 1e12,
                      "peak": 78.6, "unit": "TFLOP/s", "frac": flops / (ms * 1e-3) / 1e12 / 78.6,
                      "avg_launch_ms": ms, "flops_per_launch": flops},
