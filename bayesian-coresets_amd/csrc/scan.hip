@@ -335,27 +335,30 @@ __global__ __launch_bounds__(BCX_SCAN_THREADS) void scan_kernel(ScanArgs a) {
 
   const V* base = (const V*)a.An;
   const int64_t n = a.n;
-  for (int64_t r0 = (int64_t)blockIdx.x * RPB; r0 < n; r0 += (int64_t)gridDim.x * RPB) {
-    V x[UR][CH];
-    int64_t row[UR];
+  auto row_of = [&](int64_t r0, int u) { return r0 + (int64_t)(u * WAVES + wave) * RPW + rsub; };
+  auto load_trip = [&](V (&x)[UR][CH], int64_t r0) {
 #pragma unroll
     for (int u = 0; u < UR; ++u) {
-      row[u] = r0 + (int64_t)(u * WAVES + wave) * RPW + rsub;
-      const int64_t rc = row[u] < n ? row[u] : n - 1;
+      const int64_t rw = row_of(r0, u);
+      const int64_t rc = rw < n ? rw : n - 1;
       const V* p = base + rc * a.ldv;
 #pragma unroll
       for (int c = 0; c < CH; ++c) x[u][c] = stream_load(p + voff[c]);
+    }
+  };
+  auto compute_trip = [&](V (&x)[UR][CH], int64_t r0) {
+    int64_t row[UR];
+#pragma unroll
+    for (int u = 0; u < UR; ++u) {
+      row[u] = row_of(r0, u);
       if constexpr (sizeof(T) == 8) {
         if (a.norms) {   // raw fp64 rows: An = A / Anorms element by element (giga.py:13)
-          const double nr = a.norms[rc];
+          const double nr = a.norms[row[u] < n ? row[u] : n - 1];
 #pragma unroll
           for (int c = 0; c < CH; ++c) { x[u][c].x /= nr; x[u][c].y /= nr; }
         }
       }
     }
-    // keep all CH*UR loads of the trip in flight: without this fence hipcc interleaves load/wait/FMA
-    // through one register quad to save VGPRs, which serialises the HBM round trips of a wave
-    __builtin_amdgcn_sched_barrier(0);
     if constexpr (PACK4) {
       // four row steps at a time: transposed reduction, then every group of G/4 lanes tracks one row
 #pragma unroll
@@ -414,6 +417,17 @@ __global__ __launch_bounds__(BCX_SCAN_THREADS) void scan_kernel(ScanArgs a) {
         track_update<T>(tr, U, L, (int)row[u]);
       }
     }
+  };
+  const int64_t stride = (int64_t)gridDim.x * RPB;
+  // (Two trips in flight per wave -- the loads of trip t+1 issued before trip t is reduced -- measured 3-5 points
+  //  slower at every row length: this stream wants ~32 KiB in flight per CU, not more.)
+  for (int64_t r0 = (int64_t)blockIdx.x * RPB; r0 < n; r0 += stride) {
+    V x[UR][CH];
+    load_trip(x, r0);
+    // keep all CH*UR loads of the trip in flight: without this fence hipcc interleaves load/wait/FMA
+    // through one register quad to save VGPRs, which serialises the HBM round trips of a wave
+    __builtin_amdgcn_sched_barrier(0);
+    compute_trip(x, r0);
   }
   // combine the row groups of a wave (lanes with equal `sub` hold distinct row groups)
 #pragma unroll
