@@ -124,3 +124,27 @@ def test_device_sampler_feeds_projector_in_place(bc):
     # draws have the posterior's first two moments
     big = dev_sampler(20000, wts, pts).cpu().numpy()
     np.testing.assert_allclose(big.mean(axis=0), mu_h, atol=6 * np.sqrt(np.diag(U_h.dot(U_h.T)).max() / 20000))
+
+
+@pytest.mark.parametrize("family", ("logistic", "poisson"))
+def test_project_extreme_arguments(bc, family):
+    """The piecewise branches of the example likelihoods (model_lr.py:29-31: linear tail for -m >= 100;
+    model_poiss.py:25-30: softplus passthrough below -100): features scaled so that z.theta spans +-400."""
+    rs = np.random.RandomState(17)
+    D, S, N = 6, 48, 3001
+    if family == "logistic":
+        Z = rs.randn(N, D) * rs.choice([0.1, 5.0, 60.0], size=(N, 1))
+        ll = logistic_log_likelihood
+    else:
+        X = rs.randn(N, D) * rs.choice([0.1, 5.0, 60.0], size=(N, 1))
+        Z = np.hstack((X, rs.poisson(2.0, size=(N, 1)).astype(np.float64)))
+        ll = poisson_log_likelihood
+    theta = rs.randn(S, D)
+    m = Z[:, :D].dot(theta.T)
+    assert m.min() < -150 and m.max() > 150
+    prj = bc.DeviceProjector(family, lambda n, w, p: theta, S)
+    ref = bc.BlackBoxProjector(lambda n, w, p: theta, S, ll)
+    want = ref.project(Z)
+    got = prj.project(Z).cpu().numpy()
+    assert np.isfinite(want).all() and np.isfinite(got).all()
+    np.testing.assert_allclose(got, want, rtol=1e-10, atol=1e-12 * np.abs(want).max())
