@@ -5,7 +5,7 @@ to ``wts / idcs / pts`` in index order."""
 import numpy as np
 
 from ..snnls.giga import GIGA
-from ..snnls.snnls import SparseNNLS as _DeviceSolver
+from ..snnls.snnls import DeviceSparseNNLS as _DeviceSolver
 from .coreset import Coreset
 
 
@@ -60,10 +60,11 @@ class HilbertCoreset(Coreset):
         themselves during ingest (fp64 chunked column sums, csrc/ingest.hip) when handed ``b=None``; host-only
         solver classes (the sampling baselines) get the NumPy sum as in the reference."""
         on_device = isinstance(snnls, type) and issubclass(snnls, _DeviceSolver)
+        if on_device:
+            return snnls(vecs.t() if _is_torch(vecs) else vecs.T, None)
         if _is_torch(vecs):
-            b = None if (on_device or vecs.device.type == "cuda") else vecs.sum(dim=0).numpy()
-            return snnls(vecs.t(), b)
-        return snnls(vecs.T, None if on_device else vecs.sum(axis=0))
+            vecs = vecs.detach().cpu().numpy()      # a device projector's output, for a host-side solver class
+        return snnls(vecs.T, vecs.sum(axis=0))
 
     # ---- Coreset interface ----------------------------------------------------------------
     def reset(self):

@@ -20,7 +20,7 @@ from .. import util
 from .. import _native as nat
 from ..sharded import ShardedSolver, shard_bounds
 from ..snnls.giga import GIGA
-from ..snnls.snnls import SparseNNLS as _DeviceSolver, warn_failed_steps
+from ..snnls.snnls import DeviceSparseNNLS as _DeviceSolver, warn_failed_steps
 from ..util.errors import NumericalPrecisionError
 from .coreset import Coreset
 

@@ -145,7 +145,9 @@ class ShardedSolver(object):
     def finalize(self, b=None):
         torch, dist = self.torch, self.dist
         gathered_ptr, n_gathered, keep = None, 0, None
-        if b is None and self.world > 1:
+        if self.world > 1:
+            # always: even with a caller-supplied b the sum of row norms (Frank-Wolfe's sigma, frankwolfe.py:25) is
+            # a sum over ALL shards' chunk sums -- local sums alone would give every rank a different, too small sigma
             per = self.chunks_per_rank
             mine = torch.zeros(per * (self.d + 1), dtype=torch.float64, device=self.tdev)
             self.engine.export_chunk_sums_tensor(mine, per)

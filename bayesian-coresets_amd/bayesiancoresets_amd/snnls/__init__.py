@@ -7,6 +7,7 @@ from . import orthopursuit as _omp
 from . import sampling as _sampling
 
 SparseNNLS = _core.SparseNNLS
+DeviceSparseNNLS = _core.DeviceSparseNNLS
 GIGA = _giga.GIGA
 FrankWolfe = _fw.FrankWolfe
 OrthoPursuit = _omp.OrthoPursuit

@@ -1,7 +1,7 @@
 """Frank-Wolfe on the norm-weighted simplex (reference: bayesiancoresets/snnls/frankwolfe.py)."""
-from .snnls import SparseNNLS
+from .snnls import DeviceSparseNNLS
 from .. import _native as nat
 
 
-class FrankWolfe(SparseNNLS):
+class FrankWolfe(DeviceSparseNNLS):
     _ALG = nat.ALG_FW

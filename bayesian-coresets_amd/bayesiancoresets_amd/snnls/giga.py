@@ -1,11 +1,11 @@
 """GIGA: greedy iterative geodesic ascent (reference: bayesiancoresets/snnls/giga.py)."""
 import numpy as np
 
-from .snnls import SparseNNLS
+from .snnls import DeviceSparseNNLS
 from .. import _native as nat
 
 
-class GIGA(SparseNNLS):
+class GIGA(DeviceSparseNNLS):
     _ALG = nat.ALG_GIGA
 
     def __init__(self, A, b, **kw):

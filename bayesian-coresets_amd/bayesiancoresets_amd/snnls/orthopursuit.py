@@ -1,7 +1,7 @@
 """Non-negative orthogonal matching pursuit (reference: bayesiancoresets/snnls/orthopursuit.py)."""
-from .snnls import SparseNNLS
+from .snnls import DeviceSparseNNLS
 from .. import _native as nat
 
 
-class OrthoPursuit(SparseNNLS):
+class OrthoPursuit(DeviceSparseNNLS):
     _ALG = nat.ALG_OMP

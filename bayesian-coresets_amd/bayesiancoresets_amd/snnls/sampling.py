@@ -1,62 +1,46 @@
-"""Sampling baselines (reference: bayesiancoresets/snnls/sampling.py:6-37).  O(1) work per
-iteration, so they stay host NumPy; kept for API parity --
+"""Sampling baselines (reference: bayesiancoresets/snnls/sampling.py:6-37): subclasses of the package's
+``SparseNNLS`` surface that supply ``_select`` / ``_reweight`` on the host (O(1) work per iteration, SURVEY.md
+section 8f #4), driven by the base class's build loop with the monotone check switched off (sampling.py:16) --
+so the latch early-out, the "no data" early-out and the log lines are the reference's.
 examples/synthetic_vectors/main.py:49 uses UniformSampling."""
 import numpy as np
 
-from ..util.log import object_logger
+from .snnls import SparseNNLS
 
 
-class ImportanceSampling(object):
+def _host(x):
+    """ndarray view of a projector's output (a device tensor is brought to the host: these solvers are host-side)."""
+    return x.detach().cpu().numpy() if hasattr(x, "detach") else np.asarray(x)
+
+
+class ImportanceSampling(SparseNNLS):
     def __init__(self, A, b):
-        self.alg_name, self.log = object_logger(self)
-        self.A, self.b = A, b
-        self.reached_numeric_limit = False
-        self.check_error_monotone = False
-        n = A.shape[1]
-        self.w = np.zeros(n)
+        A = _host(A)
+        super().__init__(A, A.sum(axis=1) if b is None else _host(b), check_error_monotone=False)
+        n = self.w.shape[0]
         self.cts = np.zeros(n)
-        self.ps = self._probabilities()
+        self.ps = self._column_norm_probabilities()
 
-    def _probabilities(self):
-        ps = np.sqrt((self.A ** 2).sum(axis=0))
-        if np.any(ps > 0):
-            return ps / ps.sum()
-        return np.ones(self.A.shape[1]) / float(self.A.shape[1])
+    def _column_norm_probabilities(self):
+        # proportional to the column norms; uniform when every column is zero (sampling.py:10-14)
+        norms = np.sqrt((self.A ** 2).sum(axis=0))
+        n = self.w.shape[0]
+        return norms / norms.sum() if np.any(norms > 0) else np.ones(n) / float(n)
 
     def reset(self):
-        self.w = np.zeros(self.A.shape[1])
-        self.cts = np.zeros(self.A.shape[1])
-        self.reached_numeric_limit = False
+        super().reset()
+        self.cts = np.zeros(self.w.shape[0])
 
-    def size(self):
-        return (self.w > 0).sum()
+    def _select(self):
+        return np.random.choice(self.ps.shape[0], p=self.ps)
 
-    def weights(self):
-        return self.w.copy()
-
-    def error(self):
-        return np.sqrt(((self.A.dot(self.w) - self.b) ** 2).sum())
-
-    def build(self, itrs):
-        if self.A.size == 0:
-            self.log.warning("there are no data, returning.")
-            return
-        for _ in range(itrs):
-            f = np.random.choice(self.ps.shape[0], p=self.ps)
-            self.cts[f] += 1
-            self.w = (self.cts / self.cts.sum()) / self.ps
-
-    def optimize(self):
-        from scipy.optimize import nnls
-        prev_cost, prev_w = self.error(), self.w.copy()
-        nz = self.w > 0
-        self.w[nz] = nnls(self.A[:, nz], self.b, maxiter=100 * self.A.shape[1])[0]
-        from .. import util
-        if self.error() > prev_cost * (1.0 + util.TOL):
-            self.w = prev_w
-            self.reached_numeric_limit = True
+    def _reweight(self, f):
+        self.cts[f] += 1
+        self.w = (self.cts / self.cts.sum()) / self.ps
 
 
 class UniformSampling(ImportanceSampling):
-    def _probabilities(self):
-        return np.ones(self.A.shape[1]) / float(self.A.shape[1])
+    def __init__(self, A, b):
+        super().__init__(A, b)
+        n = self.w.shape[0]
+        self.ps = np.ones(n) / float(n)

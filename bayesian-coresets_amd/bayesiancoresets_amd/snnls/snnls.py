@@ -23,6 +23,8 @@ def _as_row_matrix(A):
         import torch
         if isinstance(A, torch.Tensor):
             rows = A.t()
+            if rows.dtype not in (torch.float32, torch.float64):
+                rows = rows.to(torch.float64)      # the ingest kernels read fp32 or fp64 (half / integer tensors are converted)
             if not rows.is_contiguous():
                 rows = rows.contiguous()
             return ("torch", rows)
@@ -48,6 +50,100 @@ def warn_failed_steps(log, status):
 
 
 class SparseNNLS(object):
+    """The reference's solver surface (snnls.py:8-106).  ``isinstance(x, bc.snnls.SparseNNLS)`` holds for every
+    solver of this package.  The loop in ``build`` below drives *host-side* subclasses that supply ``_select`` /
+    ``_reweight`` themselves (the sampling baselines, user subclasses); the greedy solvers (``DeviceSparseNNLS``)
+    override every method and run the same state machine on the GPU."""
+
+    def __init__(self, A, b, check_error_monotone=True):
+        self.alg_name, self.log = object_logger(self)
+        self.A, self.b = A, b
+        self.check_error_monotone = check_error_monotone
+        self.reached_numeric_limit = False
+        self.w = np.zeros(A.shape[1])
+
+    def reset(self):
+        self.w = np.zeros(self.A.shape[1])
+        self.reached_numeric_limit = False
+
+    def size(self):
+        return (self.w > 0).sum()
+
+    def weights(self):
+        return self.w.copy()
+
+    def error(self):
+        return np.sqrt(((self.A.dot(self.w) - self.b) ** 2).sum())
+
+    def _state_suffix(self):
+        return "size = " + str(self.size()) + ", error = " + str(self.error())
+
+    def _guarded_step(self):
+        """One _select + _reweight.  Returns True when the step passed the monotone check (the only outcome that
+        clears the retry flag, snnls.py:56-62), False when it was accepted unchecked; raises
+        NumericalPrecisionError after restoring the weights when the error grew."""
+        checked = bool(self.check_error_monotone) and self.size() > 0   # sampled before _reweight changes it (:44)
+        if checked:
+            err_before, w_before = self.error(), self.w.copy()
+        self._reweight(self._select())
+        if checked:
+            err_after = self.error()
+            if err_after > err_before:
+                self.w = w_before
+                raise NumericalPrecisionError("Error not monotone: curr error = " + str(err_after)
+                                              + " prev error = " + str(err_before))
+        return checked
+
+    def build(self, itrs):
+        if self.reached_numeric_limit:                                    # snnls.py:32-34
+            self.log.warning("the numeric limit was already reached; returning. " + self._state_suffix())
+            return
+        if self.A.size == 0:                                              # snnls.py:36-38
+            self.log.warning("there are no data, returning.")
+            return
+        strikes = 0           # failed steps since the last checked success; the second one latches (:63-72)
+        for _ in range(itrs):
+            try:
+                if self._guarded_step():
+                    strikes = 0
+            except NumericalPrecisionError as e:
+                self.log.warning("numerical precision error: " + str(e))
+                strikes += 1
+                if strikes > 1:
+                    self.log.warning("iterative step failed a second time. Assuming numeric limit reached.")
+                    self.reached_numeric_limit = True
+                    break
+                self.log.warning("iterative step failed. Stabilizing and retrying...")
+                self._stabilize()
+        if self.reached_numeric_limit:                                    # snnls.py:77-78
+            self.log.warning("the numeric limit has been reached. No more points will be added. " + self._state_suffix())
+
+    def optimize(self):
+        """Host re-solve of the weights on the current support (snnls.py:82-97) for host-side subclasses."""
+        from scipy.optimize import nnls
+        cost_before, w_before = self.error(), self.w.copy()
+        support = self.w > 0
+        self.w[support] = nnls(self.A[:, support], self.b, maxiter=100 * self.A.shape[1])[0]
+        cost_after = self.error()
+        if cost_after > cost_before * (1.0 + util.TOL):
+            self.log.warning("self.optimize() returned a solution with increasing error. Numeric limit possibly "
+                             "reached: preverr = " + str(cost_before) + " err = " + str(cost_after) + ".")
+            self.w = w_before
+            self.reached_numeric_limit = True
+
+    def _stabilize(self):
+        pass
+
+    def _select(self):
+        raise NotImplementedError
+
+    def _reweight(self, f):
+        raise NotImplementedError
+
+
+class DeviceSparseNNLS(SparseNNLS):
+    """Engine-backed solver: GIGA / FrankWolfe / OrthoPursuit derive from this.  Nothing of the host loop above is
+    used -- build(), error(), optimize(), reset() and the weights all live in libbcx.so."""
     _ALG = None  # set by subclasses
 
     def __init__(self, A, b, check_error_monotone=True, *, device=0, dtype="float32", keep_exact_rows=True):
@@ -58,7 +154,7 @@ class SparseNNLS(object):
         self._w_cache = None
         self._eng = None
         if self._ALG is None:
-            raise NotImplementedError("SparseNNLS is abstract; use GIGA, FrankWolfe or OrthoPursuit")
+            raise NotImplementedError("DeviceSparseNNLS is abstract; use GIGA, FrankWolfe or OrthoPursuit")
         kind, rows = _as_row_matrix(A)
         self._N, self._d = int(rows.shape[0]), int(rows.shape[1])
         dt = str(dtype)

@@ -119,8 +119,10 @@ extern "C" int bcx_load_rows(bcx_solver* s, const void* src, int32_t src_is_devi
   }
   BCX_HIP(hipSetDevice(s->cfg.device));
   if (row_begin == 0) {
-    // a (re)load from the first row starts a new matrix: forget the previous one's zero-row flag and state
-    if (s->finalized) {
+    // a (re)load from the first row starts a new matrix: forget the previous one's zero-row flag and state.
+    // Unconditionally -- a matrix whose bcx_finalize reported BCX_ERR_ZERO_ROW never became `finalized`, and its
+    // flag must not outlive it (SparseVI reloads one engine with a fresh projection every step).
+    if (s->finalized || s->rows_loaded > 0) {
       DevState h;
       int rc0 = read_state(s, &h);
       if (rc0 != BCX_OK) return rc0;

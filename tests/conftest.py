@@ -1,5 +1,12 @@
+import faulthandler
 import os
 import sys
+import time
+
+# RCCL / cross-process device-memory sharing needs dmabuf IPC on this host driver; set before torch loads.
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+if not os.environ.get("BCX_NO_FAULTHANDLER"):   # (crash hunts preload tools/probe/abort_trace.so instead)
+    faulthandler.enable(all_threads=True)
 
 import numpy as np
 import pytest
@@ -9,6 +16,32 @@ PKG_DIR = os.path.join(ROOT, "bayesian-coresets_amd")
 for p in (ROOT, PKG_DIR):
     if p not in sys.path:
         sys.path.insert(0, p)
+
+
+_MARK_DIR = os.path.join(ROOT, "gpurun_out")
+_MARK_FILE = os.path.join(_MARK_DIR, "current_test.txt")
+
+
+def _mark(line):
+    """Crash attribution: the nodeid is on disk (fsync'd) before the test body runs, so a HIP
+    runtime abort that kills the interpreter still leaves the name of the test it died in."""
+    try:
+        os.makedirs(_MARK_DIR, exist_ok=True)
+        with open(_MARK_FILE, "a") as f:
+            f.write(line + "\n")
+            f.flush()
+            os.fsync(f.fileno())
+    except OSError:
+        pass
+
+
+def pytest_runtest_logstart(nodeid, location):
+    _mark("%.3f START %s" % (time.time(), nodeid))
+
+
+def pytest_runtest_logreport(report):
+    if report.when == "call" or (report.when == "setup" and report.outcome != "passed"):
+        _mark("%.3f %s %s (%.2fs)" % (time.time(), report.outcome.upper(), report.nodeid, report.duration))
 
 
 def pytest_configure(config):

@@ -37,6 +37,7 @@ class FakeEngine(object):
             out[c, self.d] = float(np.sqrt((blk ** 2).sum(axis=1)).sum())
 
     def finalize_any(self, b, gathered, n_gathered):
+        self.saw_gathered = gathered is not None      # (sum of row norms needs every shard's chunk sums, also with an explicit b)
         if b is None:
             if gathered is not None:
                 g = gathered.view(-1, self.d + 1)[:n_gathered].numpy()

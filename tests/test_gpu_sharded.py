@@ -25,7 +25,7 @@ def _data(N, d):
     return np.random.RandomState(21).randn(N, d)
 
 
-def _worker(rank, world, port, alg, itrs, N, d, out_dir, exchange="collective", tag=""):
+def _worker(rank, world, port, alg, itrs, N, d, out_dir, exchange="collective", tag="", explicit_b=False):
     os.environ["BCX_EXCHANGE"] = exchange
     for p in (ROOT, os.path.join(ROOT, "bayesian-coresets_amd")):
         if p not in sys.path:
@@ -41,7 +41,7 @@ def _worker(rank, world, port, alg, itrs, N, d, out_dir, exchange="collective", 
     s = ShardedSolver(alg, N, d, device=0)
     s.load_local(torch.from_numpy(X[s.row_begin:s.row_end]).cuda())
     torch.cuda.synchronize()
-    assert s.finalize(None) == 0
+    assert s.finalize(2.0 * X.sum(axis=0) if explicit_b else None) == 0
     tr = s.build(itrs)
     idx, w = s.sparse_weights()
     b = s.engine.vector(0)
@@ -92,6 +92,32 @@ def test_peer_mailbox_exchange_matches_one_shard(tmp_path, alg, name):
             r = np.load(tmp_path / ("mb_w%d_r%d.npz" % (world, rank)))
             for k in ("sel", "err", "status", "idx", "w", "b"):
                 assert np.array_equal(ref[k], r[k]), (world, rank, k)
+
+
+@pytest.mark.parametrize("exchange", ("collective", "mailbox"))
+def test_explicit_b_frank_wolfe_shards_share_sigma(tmp_path, exchange):
+    """SparseNNLS(A, b) with a caller-supplied b on row shards: Frank-Wolfe's sigma = sum of ALL row norms
+    (frankwolfe.py:22,25) must come from every shard's chunk sums -- two and three shards equal one shard bit for
+    bit, and the weights equal the oracle's (b = 2 * column sums, so the trace differs from the b = None cases)."""
+    import torch.multiprocessing as mp
+    from oracle.snnls_oracle import SnnlsOracle
+    N, d, itrs = 9000, 40, 25
+    mp.spawn(_worker, args=(1, _free_port(), 1, itrs, N, d, str(tmp_path), "collective", "xb_", True), nprocs=1, join=True)
+    ref = np.load(tmp_path / "xb_w1_r0.npz")
+    for world in (2, 3):
+        mp.spawn(_worker, args=(world, _free_port(), 1, itrs, N, d, str(tmp_path), exchange, "xb_", True), nprocs=world, join=True)
+        for rank in range(world):
+            r = np.load(tmp_path / ("xb_w%d_r%d.npz" % (world, rank)))
+            for k in ("sel", "err", "status", "idx", "w", "b"):
+                assert np.array_equal(ref[k], r[k]), (world, rank, k)
+    X = _data(N, d)
+    o = SnnlsOracle(X.T, 2.0 * X.sum(axis=0), alg="fw")
+    o.build(itrs)
+    assert np.array_equal(ref["sel"], np.array([t[0] for t in o.trace]))
+    w = np.zeros(N)
+    w[ref["idx"]] = ref["w"]
+    ow = o.weights()
+    np.testing.assert_allclose(w[ow > 0], ow[ow > 0], rtol=1e-5)
 
 
 def _mailbox_storm_worker(rank, world, port, out_dir):

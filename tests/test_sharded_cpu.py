@@ -23,7 +23,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, alg, itrs, N, d, out_dir):
+def _worker(rank, world, port, alg, itrs, N, d, out_dir, explicit_b=False):
     for p in (ROOT, os.path.join(ROOT, "bayesian-coresets_amd"), os.path.join(ROOT, "tests")):
         if p not in sys.path:
             sys.path.insert(0, p)
@@ -36,8 +36,9 @@ def _worker(rank, world, port, alg, itrs, N, d, out_dir):
     FakeEngine.FULL = X
     s = ShardedSolver(alg, N, d, engine_factory=FakeEngine)
     s.load_local(X[s.row_begin:s.row_end])
-    rc = s.finalize(None)
+    rc = s.finalize(X.sum(axis=0) if explicit_b else None)
     assert rc == 0
+    assert s.engine.saw_gathered        # every shard's chunk sums reach every rank, with or without a caller-supplied b
     tr = s.build(itrs)
     idx, w = s.sparse_weights()
     np.savez(os.path.join(out_dir, "r%d.npz" % rank), sel=tr[0], err=tr[1], idx=idx, w=w, b=s.engine.b,
@@ -46,12 +47,12 @@ def _worker(rank, world, port, alg, itrs, N, d, out_dir):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("alg,name", ((0, "giga"), (1, "fw"), (2, "omp")))
-def test_two_shards_match_single_process(tmp_path, alg, name):
+@pytest.mark.parametrize("alg,name,explicit_b", ((0, "giga", False), (1, "fw", False), (2, "omp", False), (1, "fw", True)))
+def test_two_shards_match_single_process(tmp_path, alg, name, explicit_b):
     from oracle.snnls_oracle import SnnlsOracle
     N, d, itrs, world = 5000, 24, 15, 2
     port = _free_port()
-    mp.spawn(_worker, args=(world, port, alg, itrs, N, d, str(tmp_path)), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, port, alg, itrs, N, d, str(tmp_path), explicit_b), nprocs=world, join=True)
     r0, r1 = np.load(tmp_path / "r0.npz"), np.load(tmp_path / "r1.npz")
     # replicated state is identical on both ranks
     for k in ("sel", "err", "idx", "w", "b"):
