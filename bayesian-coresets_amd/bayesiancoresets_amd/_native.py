@@ -25,6 +25,7 @@ SYMBOLS = (
     "bcx_stats", "bcx_profile_scan", "bcx_profile_read", "bcx_version",
     "bcx_project_write", "bcx_project_colsum", "bcx_project_select", "bcx_project_last_error",
     "bcx_build_enqueue_exact", "bcx_exchange_export", "bcx_exchange_attach", "bcx_exchange_probe", "bcx_exchange_disable", "bcx_exchange_set_timeout",
+    "bcx_set_check_monotone",
 )
 
 
@@ -49,6 +50,9 @@ def load():
         raise RuntimeError(
             "libbcx.so not found at %s -- build it with `make -C bayesian-coresets_amd` "
             "(or python -c 'import __graft_entry__ as g; g.build()'). There is no CPU fallback." % LIB_PATH)
+    # the HSA runtime reads this when the first HIP call initialises it; default to the dmabuf IPC mode the peer
+    # mailbox (hipIpcGetMemHandle) and RCCL need unless the user chose otherwise
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     lib = ctypes.CDLL(LIB_PATH)
     vp, i32, i64, dbl = ctypes.c_void_p, ctypes.c_int32, ctypes.c_int64, ctypes.c_double
     P = ctypes.POINTER
@@ -75,6 +79,7 @@ def load():
         "bcx_error": [vp, P(dbl)],
         "bcx_optimize": [vp, dbl, P(i32)],
         "bcx_reset": [vp],
+        "bcx_set_check_monotone": [vp, i32],
         "bcx_reached_numeric_limit": [vp, P(i32)],
         "bcx_get_vector": [vp, i32, vp],
         "bcx_get_norms": [vp, i64, i64, vp],
@@ -319,6 +324,9 @@ class Engine(object):
 
     def reset(self):
         self._check(self.lib.bcx_reset(self.h))
+
+    def set_check_monotone(self, on):
+        self._check(self.lib.bcx_set_check_monotone(self.h, int(bool(on))))
 
     def reached_numeric_limit(self):
         v = ctypes.c_int32()

@@ -12,7 +12,12 @@ whole data.  COLLECTIVE: construct and call on every rank of ``group``.
     cs.build(1000); wts, pts, idcs = cs.get()                       # identical on all ranks
 
 ``idcs`` are global row numbers; ``pts`` are the data rows of the selected points, supplied by the ranks
-that own them.  The subsampling branch of the reference (``n_subsample``) is not offered here.
+that own them.
+
+``n_subsample`` (hilbert.py:13-22): every rank draws the SAME ``unique(randint(n_global, size=n_subsample))`` -- seed
+NumPy identically on all ranks, as for any replicated random decision -- projects the drawn rows it owns, drops
+zero vectors, and the surviving vectors are dealt to 1024-row aligned solver shards (one padded all-gather of
+n_subsample x d values; a subsample is small by intent).  ``sub_idcs`` is replicated.
 """
 import numpy as np
 
@@ -34,15 +39,31 @@ class ShardedHilbertCoreset(Coreset):
         world = dist.get_world_size(group) if dist.is_initialized() else 1
         return shard_bounds(int(n_global), world)[0][rank]
 
-    def __init__(self, local_data, ll_projector, n_global, snnls=GIGA, group=None, engine_factory=None, **kw):
+    def __init__(self, local_data, ll_projector, n_global, n_subsample=None, snnls=GIGA, group=None,
+                 engine_factory=None, **kw):
         if not (isinstance(snnls, type) and issubclass(snnls, _DeviceSolver) and snnls._ALG is not None):
             raise ValueError("ShardedHilbertCoreset needs a device solver class (GIGA, FrankWolfe, OrthoPursuit)")
-        vecs = ll_projector.project(local_data)
-        d = int(vecs.shape[1])
-        self.snnls = ShardedSolver(snnls._ALG, int(n_global), d, group=group, engine_factory=engine_factory)
-        if int(vecs.shape[0]) != self.snnls.n_local:
+        import torch.distributed as dist
+        n_global = int(n_global)
+        world = dist.get_world_size(group) if dist.is_initialized() else 1
+        rank = dist.get_rank(group) if dist.is_initialized() else 0
+        lo, hi = shard_bounds(n_global, world)[0][rank]
+        if int(local_data.shape[0]) != hi - lo:
             raise ValueError("this rank must hold global rows [%d, %d) (ShardedHilbertCoreset.local_rows); got %d rows"
-                             % (self.snnls.row_begin, self.snnls.row_end, int(vecs.shape[0])))
+                             % (lo, hi, int(local_data.shape[0])))
+        self.data, self.group = local_data, group
+        self.row_begin, self.row_end = lo, hi
+        if n_subsample is None:
+            vecs = ll_projector.project(local_data)
+            n_rows, self.sub_idcs = n_global, None
+        else:
+            drawn = np.unique(np.random.randint(n_global, size=n_subsample))      # hilbert.py:16, same on every rank
+            mine = drawn[(drawn >= lo) & (drawn < hi)]
+            vecs, self.sub_idcs = self._deal_subsample(ll_projector.project(local_data[mine - lo]), mine, world, rank)
+            n_rows = int(self.sub_idcs.shape[0])
+        d = int(vecs.shape[1])
+        self.snnls = ShardedSolver(snnls._ALG, n_rows, d, group=group, engine_factory=engine_factory)
+        assert int(vecs.shape[0]) == self.snnls.n_local
         if self.snnls.n_local:
             self.snnls.load_local(vecs)
         rc = self.snnls.finalize(None)                     # b = column sums over all shards (hilbert.py:24)
@@ -52,10 +73,35 @@ class ShardedHilbertCoreset(Coreset):
             raise NumericalPrecisionError("norm of b must be > 0")                                 # giga.py:16-17
         if rc != nat.OK:
             raise nat.EngineError(rc, "finalize failed")
-        self.data = local_data
-        self.group = group
-        self.row_begin, self.row_end = self.snnls.row_begin, self.snnls.row_end
         super().__init__(**kw)
+
+    def _deal_subsample(self, vecs, mine, world, rank):
+        """Drop zero vectors (hilbert.py:19-22), then move the surviving projected rows from the ranks that OWN the
+        data rows to the ranks that hold the matching 1024-row aligned solver shards.  Returns (this rank's solver
+        rows, the global data indices of all surviving rows in solver-row order)."""
+        import torch
+        import torch.distributed as dist
+        is_t = isinstance(vecs, torch.Tensor)
+        v = vecs if is_t else torch.from_numpy(np.ascontiguousarray(vecs, dtype=np.float64))
+        keep = (v * v).sum(dim=1) > 0.0
+        v, mine = v[keep], mine[keep.cpu().numpy()]
+        if world == 1:
+            return (v if is_t else v.numpy()), mine
+        everyone = [None] * world
+        dist.all_gather_object(everyone, (mine, int(v.shape[1])), group=self.group)
+        d = max(dd for _, dd in everyone)
+        counts = [len(m) for m, _ in everyone]
+        sub_idcs = np.concatenate([m for m, _ in everyone]).astype(np.int64)       # owners are in row order already
+        cap = max(max(counts), 1)
+        block = torch.zeros((cap, d), dtype=torch.float64, device=v.device)
+        if len(mine):
+            block[:len(mine)] = v.to(torch.float64)
+        gathered = [torch.zeros_like(block) for _ in range(world)]
+        dist.all_gather(gathered, block, group=self.group)
+        rows = torch.cat([g[:c] for g, c in zip(gathered, counts)], dim=0)
+        slo, shi = shard_bounds(int(sub_idcs.shape[0]), world)[0][rank]
+        out = rows[slo:shi].contiguous()
+        return (out if is_t else out.cpu().numpy()), sub_idcs
 
     # ---- Coreset interface ----------------------------------------------------------------
     def reset(self):
@@ -84,12 +130,14 @@ class ShardedHilbertCoreset(Coreset):
         idx, w = idx[keep], w[keep]
         order = np.argsort(idx, kind="stable")              # the reference reports in index order (w > 0 mask)
         self.idcs, self.wts = idx[order], w[order]
+        if self.sub_idcs is not None:
+            self.idcs = self.sub_idcs[self.idcs]            # solver rows -> data rows (hilbert.py:37)
         self.pts = self._owned_points(self.idcs)
 
     def _build(self, itrs):
         tr = self.snnls.build(itrs, float(util.TOL))
         if tr is not None:
-            warn_failed_steps(self.log, tr[2])
+            warn_failed_steps(self.log, tr[2], self.snnls.reached_numeric_limit)
         # (as in the reference, the solver's latch is not copied to the coreset: hilbert.py:40-42, coreset.py:34)
         self._read_solver()
 

@@ -30,13 +30,19 @@ class SparseVICoreset(Coreset):
         ``row_offset``, and every rank must seed NumPy identically (the sampler is replicated)."""
         self.row_offset, self.group = int(row_offset), group
         self._sharded = group is not None
-        if self._sharded and (n_subsample_select is not None or n_subsample_opt is not None):
-            raise ValueError("random subsampling is not supported in row-sharded mode")
         if self._sharded and not isinstance(ll_projector, DeviceProjector):
             raise ValueError("row-sharded SparseVI needs a DeviceProjector")
         self.data = data
         self.ll_projector = ll_projector
         n = data.shape[0]
+        if self._sharded:
+            # the subsample sizes are capped by the GLOBAL row count (sparsevi.py:12-13), known to every rank
+            import torch
+            import torch.distributed as dist
+            t = torch.tensor([float(n)], dtype=torch.float64, device=ll_projector.device)
+            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+            n = int(t.item())
+        self.n_global = n
         self.n_subsample_select = None if n_subsample_select is None else min(n, n_subsample_select)
         self.n_subsample_opt = None if n_subsample_opt is None else min(n, n_subsample_opt)
         self.step_sched = step_sched
@@ -56,10 +62,18 @@ class SparseVICoreset(Coreset):
 
     # ---- N-sized pieces ------------------------------------------------------------
     def _subsample(self, n_subsample):
+        """(positions-or-None, drawn global rows-or-None, local points, scaling).  Row-sharded: every rank draws the
+        same indices (replicated NumPy stream) and keeps the drawn rows it owns, in draw order; ``positions`` are
+        their places in the drawn array (the identity that decides arg-max ties, sparsevi.py:55-57)."""
         if n_subsample is None:
-            return None, self.data, 1.0
-        sub = np.random.randint(self.data.shape[0], size=n_subsample)           # sparsevi.py:33
-        return sub, self.data[sub], self.data.shape[0] / n_subsample
+            return None, None, self.data, 1.0
+        sub = np.random.randint(self.n_global, size=n_subsample)                 # sparsevi.py:33
+        scaling = self.n_global / n_subsample
+        if not self._sharded:
+            return None, sub, self.data[sub], scaling
+        lo = self.row_offset
+        pos = np.flatnonzero((sub >= lo) & (sub < lo + self.data.shape[0]))
+        return pos, sub, self.data[sub[pos] - lo], scaling
 
     def _engine_for(self, vecs):
         """Hand host-resident projected vectors to the device engine: norms + column sums in one pass."""
@@ -75,6 +89,9 @@ class SparseVICoreset(Coreset):
         rc = eng.finalize(None)
         if rc not in (nat.OK, nat.ERR_ZERO_ROW):
             raise nat.EngineError(rc, eng.lib.bcx_last_error(eng.h).decode())
+        # a zero projected vector: norms and column sums are valid, the correlation scan is not (the row's
+        # correlation is 0/0); _select treats it as the reference's arithmetic does
+        eng.has_zero_row = rc == nat.ERR_ZERO_ROW
         return eng
 
     def _corevecs(self):
@@ -86,7 +103,7 @@ class SparseVICoreset(Coreset):
     def _residual(self, n_subsample, w):
         """(resid, sub_idcs, points, engine-or-None, corevecs) after updating the projector at (w, pts)."""
         self.ll_projector.update(w, self.pts)                                     # sparsevi.py:25
-        sub, pts, scaling = self._subsample(n_subsample)
+        pos, sub, pts, scaling = self._subsample(n_subsample)
         eng = None
         if isinstance(self.ll_projector, DeviceProjector):
             colsum = self.ll_projector.project_colsum(pts)
@@ -99,14 +116,18 @@ class SparseVICoreset(Coreset):
         if corevecs is None:
             corevecs = np.zeros((0, S))
         resid = scaling * colsum - w.dot(corevecs)                                # sparsevi.py:47 / :72
-        return resid, sub, pts, eng, corevecs
+        return resid, (pos, sub), pts, eng, corevecs
 
     # ---- sparsevi.py:44-67 ------------------------------------------------------------
     def _select(self):
-        resid, sub, pts, eng, corevecs = self._residual(self.n_subsample_select, self.wts)
+        resid, (pos, sub), pts, eng, corevecs = self._residual(self.n_subsample_select, self.wts)
         S = resid.shape[0]
         if eng is None:
-            best, row = self.ll_projector.project_select(pts, resid)
+            best, row = self.ll_projector.project_select(pts, resid, row_ids=pos)
+        elif eng.has_zero_row:
+            # corrs = vecs.dot(resid) / ||vecs|| / S is NaN at a zero row and NumPy's argmax returns the first NaN
+            # (sparsevi.py:49-56): that row is the pick, and NaN > x is False, so it only enters an EMPTY coreset
+            row, best = int(np.flatnonzero(eng.norms() == 0.0)[0]), float("nan")
         else:
             row, score = eng.argmax_correlation(resid)                            # An . resid
             best = score / S

@@ -78,7 +78,7 @@ class DeviceProjector(Projector):
         self._world = 1
         if group is not None or (torch.distributed.is_available() and torch.distributed.is_initialized()):
             self._world = torch.distributed.get_world_size(group)
-        self._cache_key, self._cache_val = None, None
+        self._cache_val, self._cache_ref = None, None
         self._work = None
         self.update(np.array([]), np.array([]))
 
@@ -91,20 +91,25 @@ class DeviceProjector(Projector):
             raise self._nat.EngineError(rc, self._lib.bcx_project_last_error().decode())
 
     def _dev(self, pts):
-        """Device copy of a host array, cached by identity (SparseVI projects the same ``data`` at
-        every step); device tensors pass through."""
+        """Device copy of a host array.  The copy of the LAST large array is kept and reused only when the very same
+        ndarray object comes back (SparseVI projects ``self.data`` 1 + opt_itrs times per step) -- the projector
+        holds a reference to it, so the identity cannot be recycled.  A caller that edits that array in place must
+        call ``invalidate_cache()``; device tensors pass through uncached."""
         torch = self._torch
         if isinstance(pts, torch.Tensor):
             t = pts.to(self.device, dtype=torch.float64)
             return t if t.is_contiguous() else t.contiguous()
         arr = np.atleast_2d(np.asarray(pts, dtype=np.float64))
-        key = (id(pts), arr.shape)
-        if arr.shape[0] >= 4096 and self._cache_key == key:
+        big = arr.shape[0] >= 4096
+        if big and self._cache_ref is pts and self._cache_val.shape == arr.shape:
             return self._cache_val
         t = torch.from_numpy(np.ascontiguousarray(arr)).to(self.device)
-        if arr.shape[0] >= 4096:
-            self._cache_key, self._cache_val, self._cache_ref = key, t, pts
+        if big:
+            self._cache_val, self._cache_ref = t, pts
         return t
+
+    def invalidate_cache(self):
+        self._cache_val, self._cache_ref = None, None
 
     def _dims(self, Z):
         cols = Z.shape[1]
@@ -171,8 +176,11 @@ class DeviceProjector(Projector):
             torch.distributed.all_reduce(col, op=torch.distributed.ReduceOp.SUM, group=self.group)
         return col.cpu().numpy()
 
-    def project_select(self, pts, resid):
-        """(max_n corr_n, arg-max row) with corr_n = vecs[n].resid / ||vecs[n]|| / S (first maximum)."""
+    def project_select(self, pts, resid, row_ids=None):
+        """(max_n corr_n, arg-max row) with corr_n = vecs[n].resid / ||vecs[n]|| / S (first maximum).
+        ``row_ids`` (ascending, one per local row): the identity under which a local row competes -- its global row
+        number (default: ``row_offset`` + local row) or, for a random subsample, its position in the drawn index
+        array -- so that the first-maximum rule of ``corrs.argmax()`` (sparsevi.py:55) holds across shards."""
         torch = self._torch
         Z = self._dev(pts)
         S = self.theta.shape[0]
@@ -182,7 +190,8 @@ class DeviceProjector(Projector):
             self._check(self._lib.bcx_project_select(*self._common(Z), r.data_ptr(), float(np.sum(resid)), res.data_ptr(),
                                                      self._workspace(S).data_ptr()))
             h = res.cpu()
-            best, row = float(h[0]), int(h[1:2].view(torch.int64)[0]) + self.row_offset
+            best, row = float(h[0]), int(h[1:2].view(torch.int64)[0])
+            row = int(row_ids[row]) if row_ids is not None else row + self.row_offset
         else:
             best, row = -np.inf, -1
         if self._world > 1:
@@ -195,6 +204,8 @@ class DeviceProjector(Projector):
             recs = allr.cpu().numpy().reshape(self._world, 2)
             best, row = -np.inf, -1
             for v, i in recs:
-                if i >= 0 and (v > best or (v == best and i < row) or row < 0):
+                # NaN (a zero vector's 0/0) is NumPy's maximum: the first NaN position wins outright
+                if i >= 0 and (row < 0 or (np.isnan(v) and not np.isnan(best)) or (np.isnan(v) and i < row)
+                               or (not np.isnan(best) and (v > best or (v == best and i < row)))):
                     best, row = float(v), int(i)
         return best, row

@@ -39,14 +39,20 @@ def _as_row_matrix(A):
     return ("numpy", rows)
 
 
-def warn_failed_steps(log, status):
-    """One WARNING per failed loop iteration, as the reference logs the caught NumericalPrecisionError
-    (snnls.py:63-65)."""
-    for i in np.flatnonzero(status != nat.IT_OK):
+def warn_failed_steps(log, status, latched=False):
+    """The WARNING lines of the reference's except-branch (snnls.py:63-72), one group per failed loop iteration:
+    the caught NumericalPrecisionError, then either the retry notice or -- for the failure that set the latch,
+    which is the last one of a build() that ended latched -- the numeric-limit notice."""
+    failed = np.flatnonzero(status != nat.IT_OK)
+    for n, i in enumerate(failed):
         what = {nat.IT_FAIL_SELECT: "select failed (cdirnrm < TOL)",
                 nat.IT_FAIL_REWEIGHT: "reweight step lost precision",
                 nat.IT_FAIL_MONOTONE: "Error not monotone"}[int(status[i])]
         log.warning("numerical precision error: " + what + " at loop iteration " + str(int(i)))
+        if latched and n == len(failed) - 1:
+            log.warning("iterative step failed a second time. Assuming numeric limit reached.")
+        else:
+            log.warning("iterative step failed. Stabilizing and retrying...")
 
 
 class SparseNNLS(object):
@@ -162,6 +168,8 @@ class DeviceSparseNNLS(SparseNNLS):
         eng = nat.Engine(self._ALG, self._N, self._d, device=device, store_dtype=store,
                          keep_exact_rows=keep_exact_rows)
         self._eng = eng
+        if not check_error_monotone:
+            eng.set_check_monotone(False)      # snnls.py:9,45,56: no error comparison / revert in the device state machine
         if self._N:
             if kind == "torch":
                 if rows.device.type != "cuda":
@@ -231,9 +239,9 @@ class DeviceSparseNNLS(SparseNNLS):
             return
         self.last_trace = tr
         sel, err, status = tr
-        warn_failed_steps(self.log, status)
-        if self._eng.reached_numeric_limit():
-            self.log.warning("iterative step failed a second time. Assuming numeric limit reached.")
+        latched = self._eng.reached_numeric_limit()
+        warn_failed_steps(self.log, status, latched)
+        if latched:
             self.reached_numeric_limit = True
             self.log.warning("the numeric limit has been reached. No more points will be added. size = "
                              + str(self.size()) + ", error = " + str(self.error()))

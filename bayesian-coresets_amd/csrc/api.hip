@@ -103,6 +103,79 @@ extern "C" int bcx_set_stream(bcx_solver* s, void* hip_stream) {
 
 static int read_state(bcx_solver* s, DevState* h);
 
+// ---- host -> device upload --------------------------------------------------------------------------
+// The GPU never touches the caller's memory: rows are copied by host threads into two pinned bounce buffers that
+// the library owns (hipHostMalloc, allocated once per process) and DMA'd from there, the memcpy of one buffer
+// overlapping the DMA of the other.  (Round 1 pinned the caller's ndarray with hipHostRegister for the duration
+// of the copy; on a fresh box that path died intermittently with "Memory access fault by GPU ... Reason: Unknown"
+// at an address inside the registered heap range -- a user-pointer mapping of glibc heap pages is only as stable
+// as the heap is -- and took the whole GPU test run with it.)  On return the caller's buffer is no longer in use.
+#include <mutex>
+#include <thread>
+namespace {
+constexpr size_t kBounceBytes = (size_t)32 << 20;
+struct Bounce {
+  std::mutex mu;
+  void* buf[2] = {nullptr, nullptr};
+};
+Bounce g_bounce;
+
+void copy_rows_mt(char* dst, size_t dpitch, const char* src, size_t spitch, size_t width, int64_t rows) {
+  const size_t bytes = (size_t)rows * width;
+  int nt = (int)std::min<size_t>(8, bytes / ((size_t)2 << 20));      // one thread per 2 MiB, at most 8
+  const unsigned hw = std::thread::hardware_concurrency();
+  if (hw && (unsigned)nt > hw) nt = (int)hw;
+  auto work = [=](int64_t r0, int64_t r1) {
+    if (dpitch == width && spitch == width) { memcpy(dst + (size_t)r0 * width, src + (size_t)r0 * width, (size_t)(r1 - r0) * width); return; }
+    for (int64_t r = r0; r < r1; ++r) memcpy(dst + (size_t)r * dpitch, src + (size_t)r * spitch, width);
+  };
+  if (nt <= 1) { work(0, rows); return; }
+  std::vector<std::thread> th;
+  const int64_t per = (rows + nt - 1) / nt;
+  for (int t = 1; t < nt; ++t) {
+    const int64_t r0 = std::min<int64_t>(rows, t * per), r1 = std::min<int64_t>(rows, (t + 1) * per);
+    if (r0 < r1) th.emplace_back(work, r0, r1);
+  }
+  work(0, std::min<int64_t>(rows, per));
+  for (auto& t : th) t.join();
+}
+}  // namespace
+
+static int upload_host_rows(bcx_solver* s, void* dst_dev, size_t dpitch, const void* src, size_t spitch, size_t width,
+                            int64_t rows) {
+  if (rows <= 0) return BCX_OK;
+  std::lock_guard<std::mutex> lock(g_bounce.mu);
+  for (int i = 0; i < 2; ++i)
+    if (!g_bounce.buf[i]) BCX_HIP(hipHostMalloc(&g_bounce.buf[i], kBounceBytes, hipHostMallocPortable));
+  if (width > kBounceBytes) { s->err = "bcx_load_rows: a row exceeds the upload buffer"; return BCX_ERR_ARG; }
+  hipEvent_t done[2] = {nullptr, nullptr};     // (per call: events belong to the device that is current now)
+  bool busy[2] = {false, false};
+  for (int i = 0; i < 2; ++i) BCX_HIP(hipEventCreateWithFlags(&done[i], hipEventDisableTiming));
+  const int64_t rows_per = std::max<int64_t>(1, (int64_t)(kBounceBytes / width));
+  int which = 0;
+  int rc = BCX_OK;
+  for (int64_t r = 0; r < rows && rc == BCX_OK; r += rows_per, which ^= 1) {
+    const int64_t m = std::min(rows_per, rows - r);
+    if (busy[which]) {
+      if (hipEventSynchronize(done[which]) != hipSuccess) { s->err = "upload: event wait failed"; rc = BCX_ERR_HIP; break; }
+      busy[which] = false;
+    }
+    copy_rows_mt((char*)g_bounce.buf[which], width, (const char*)src + (size_t)r * spitch, spitch, width, m);
+    hipError_t e = hipMemcpy2DAsync((char*)dst_dev + (size_t)r * dpitch, dpitch, g_bounce.buf[which], width, width, (size_t)m,
+                                    hipMemcpyHostToDevice, s->stream);
+    if (e == hipSuccess) e = hipEventRecord(done[which], s->stream);
+    if (e != hipSuccess) { s->err = std::string("upload: ") + hipGetErrorString(e); rc = BCX_ERR_HIP; break; }
+    busy[which] = true;
+  }
+  // the bounce buffers are shared by every solver of the process: leave them idle
+  for (int i = 0; i < 2; ++i) {
+    if (busy[i]) (void)hipEventSynchronize(done[i]);
+    (void)hipEventDestroy(done[i]);
+  }
+  return rc;
+}
+
+
 extern "C" int bcx_load_rows(bcx_solver* s, const void* src, int32_t src_is_device, int32_t src_dtype,
                              int64_t row_begin, int64_t rows, int64_t ld) {
   if (!s || (!src && rows > 0)) return BCX_ERR_ARG;
@@ -137,23 +210,11 @@ extern "C" int bcx_load_rows(bcx_solver* s, const void* src, int32_t src_is_devi
     int rc = bcx_launch_ingest(s, src, src_dtype, ld, row_begin, rows);
     if (rc != BCX_OK) return rc;
   } else if (s->A64 && src_dtype == BCX_F64) {
-    // host fp64 rows go straight to their final place; the ingest kernel then works in place.
-    // Pageable host memory copies at a few GB/s; pinning the caller's buffer for the duration of the
-    // copy (hipHostRegister) lets the DMA engines run at PCIe speed.  Falls back silently if the
-    // registration is refused.
+    // host fp64 rows go straight to their final place; the ingest kernel then works in place
     double* dst = s->A64 + (size_t)row_begin * s->ld64;
-    const size_t span = ((size_t)(rows - 1) * ld + d) * 8;
-    const bool pinned = span >= (size_t)(8u << 20) &&
-                        hipHostRegister(const_cast<void*>(src), span, hipHostRegisterDefault) == hipSuccess;
-    if (!pinned) (void)hipGetLastError();
-    hipError_t ce = hipMemcpy2DAsync(dst, (size_t)s->ld64 * 8, src, (size_t)ld * 8, (size_t)d * 8, (size_t)rows,
-                                     hipMemcpyHostToDevice, s->stream);
-    if (pinned) {
-      (void)hipStreamSynchronize(s->stream);
-      (void)hipHostUnregister(const_cast<void*>(src));
-    }
-    BCX_HIP(ce);
-    int rc = bcx_launch_ingest(s, dst, BCX_F64, s->ld64, row_begin, rows);
+    int rc = upload_host_rows(s, dst, (size_t)s->ld64 * 8, src, (size_t)ld * 8, (size_t)d * 8, rows);
+    if (rc != BCX_OK) return rc;
+    rc = bcx_launch_ingest(s, dst, BCX_F64, s->ld64, row_begin, rows);
     if (rc != BCX_OK) return rc;
   } else {
     // stage through a device buffer in pieces of <= 256 MiB
@@ -168,9 +229,10 @@ extern "C" int bcx_load_rows(bcx_solver* s, const void* src, int32_t src_is_devi
     }
     for (int64_t r = 0; r < rows; r += piece) {
       const int64_t m = std::min(piece, rows - r);
-      BCX_HIP(hipMemcpy2DAsync(s->staging, (size_t)d * esz, (const char*)src + (size_t)r * ld * esz, (size_t)ld * esz,
-                               (size_t)d * esz, (size_t)m, hipMemcpyHostToDevice, s->stream));
-      int rc = bcx_launch_ingest(s, s->staging, src_dtype, d, row_begin + r, m);
+      int rc = upload_host_rows(s, s->staging, (size_t)d * esz, (const char*)src + (size_t)r * ld * esz, (size_t)ld * esz,
+                                (size_t)d * esz, m);
+      if (rc != BCX_OK) return rc;
+      rc = bcx_launch_ingest(s, s->staging, src_dtype, d, row_begin + r, m);
       if (rc != BCX_OK) return rc;
       BCX_HIP(hipStreamSynchronize(s->stream));  // staging buffer is reused
     }
@@ -577,6 +639,17 @@ extern "C" int bcx_reset(bcx_solver* s) {
   BCX_HIP(hipMemset(s->xw, 0, (size_t)s->cfg.d * 8));
   // error() with an empty list must give ||b|| computed the same way as after finalize
   return bcx_launch_error_refresh(s);
+}
+
+extern "C" int bcx_set_check_monotone(bcx_solver* s, int32_t on) {
+  if (!s) return BCX_ERR_ARG;
+  BCX_HIP(hipSetDevice(s->cfg.device));
+  DevState h;
+  int rc = read_state(s, &h);
+  if (rc != BCX_OK) return rc;
+  h.no_monotone = on ? 0 : 1;
+  BCX_HIP(hipMemcpy(s->st, &h, sizeof h, hipMemcpyHostToDevice));
+  return BCX_OK;
 }
 
 extern "C" int bcx_optimize(bcx_solver* s, double tol, int32_t* accepted) {

@@ -67,6 +67,7 @@ struct DevState {
   int32_t since_refresh;
   int32_t exact_mode;  // current iteration's scan was exact (no candidate window)
   int32_t zero_row;    // first zero-norm local row + 1 (0 = none)
+  int32_t no_monotone; // check_error_monotone=False (snnls.py:9,45,56): no error comparison, no revert, retry flag never cleared
   int32_t np;          // size of the passive set P (OMP / optimize)
   int32_t hvalid;      // hinv == inverse of gram[P,P] and P == {slots with weight > 0}
   // multi-kernel OMP step (nnls.hip): decisions handed from kernel to kernel

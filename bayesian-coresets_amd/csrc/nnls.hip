@@ -568,7 +568,7 @@ __global__ __launch_bounds__(BCX_APPLY_THREADS) void omp_finish_kernel(NnlsArgs 
   block_allsum<2>(v, scratch);
   const double new_err = sqrt(v[0]);
   int status = BCX_IT_OK;
-  if (checked && new_err > err0) status = BCX_IT_FAIL_MONOTONE;      // snnls.py:58
+  if (checked && !st->no_monotone && new_err > err0) status = BCX_IT_FAIL_MONOTONE;      // snnls.py:56-58
   if (status == BCX_IT_OK) {
     for (int j = tid; j < k1; j += blockDim.x) a.act_w[j] = (n.ppos[j] >= 0) ? n.x[j] : 0.0;
     for (int j = tid; j < d; j += blockDim.x) a.xw[j] = a.tmp[j];
@@ -578,7 +578,7 @@ __global__ __launch_bounds__(BCX_APPLY_THREADS) void omp_finish_kernel(NnlsArgs 
       const double nwn = sqrt(v[1]);
       st->nw = nwn == 0.0 ? 1.0 : nwn;
       st->since_refresh += 1;
-      if (checked) st->retried = 0;
+      if (checked && !st->no_monotone) st->retried = 0;
     }
   } else {
     for (int j = tid; j < k; j += blockDim.x) a.act_w[j] = n.wbak[j];
@@ -935,7 +935,7 @@ __global__ __launch_bounds__(NN_THREADS) void omp_fused_kernel(NnlsArgs n, GridS
   block_allsum<2>(v, scratch);
   const double new_err = sqrt(v[0]);
   int status = BCX_IT_OK;
-  if (checked && new_err > err0) status = BCX_IT_FAIL_MONOTONE;      // snnls.py:58
+  if (checked && !st->no_monotone && new_err > err0) status = BCX_IT_FAIL_MONOTONE;      // snnls.py:56-58
   if (status == BCX_IT_OK) {
     for (int j = tid; j < k1; j += blockDim.x) a.act_w[j] = (n.ppos[j] >= 0) ? n.x[j] : 0.0;
     for (int j = tid; j < d; j += blockDim.x) a.xw[j] = a.tmp[j];
@@ -945,7 +945,7 @@ __global__ __launch_bounds__(NN_THREADS) void omp_fused_kernel(NnlsArgs n, GridS
       const double nwn = sqrt(v[1]);
       st->nw = nwn == 0.0 ? 1.0 : nwn;
       st->since_refresh += 1;
-      if (checked) st->retried = 0;
+      if (checked && !st->no_monotone) st->retried = 0;
     }
   } else if (tid == 0) {
     st->hvalid = 0;        // weights were not touched; passive data is rebuilt lazily

@@ -339,7 +339,7 @@ static __device__ void apply_core(const ApplyArgs& a, const StateVecs& v, int64_
     const double n2 = sqrt(r[1]);
     new_nw = n2 == 0.0 ? 1.0 : n2;
     tdot = r[2];
-    if (checked && new_err > err0) status = BCX_IT_FAIL_MONOTONE;   // snnls.py:58
+    if (checked && !st->no_monotone && new_err > err0) status = BCX_IT_FAIL_MONOTONE;   // snnls.py:56-58
   }
   BCX_STAMP(st, 7);
   bool limit = false;
@@ -356,7 +356,7 @@ static __device__ void apply_core(const ApplyArgs& a, const StateVecs& v, int64_
       st->err = new_err;
       st->nw = new_nw;
       st->since_refresh = since + 1;
-      if (checked) st->retried = 0;                        // snnls.py:62
+      if (checked && !st->no_monotone) st->retried = 0;    // snnls.py:62 (inside the monotone-check branch)
     }
   } else {
     limit = retried != 0;                                  // snnls.py:63-72

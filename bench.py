@@ -20,8 +20,8 @@ import time
 import numpy as np
 
 # multi-process GPU work on this platform needs dmabuf IPC (RCCL and the peer mailbox share device memory across
-# processes); the launch environment exports it, keep it if somebody cleaned the environment
-os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+# processes: hipIpcGetMemHandle fails in legacy mode on this host driver) -- set it whatever the launcher exported
+os.environ["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(ROOT, "bayesian-coresets_amd"))

@@ -151,6 +151,10 @@ int bcx_get_weights(bcx_solver* s, int64_t* idx, double* w, int64_t cap, int64_t
 int bcx_error(bcx_solver* s, double* err);
 int bcx_optimize(bcx_solver* s, double tol, int32_t* accepted);
 int bcx_reset(bcx_solver* s);
+/* SparseNNLS(A, b, check_error_monotone) (snnls.py:9,16): on = 0 switches the per-iteration error comparison and the
+ * revert off (snnls.py:45-47,56-62); the retry flag is then never refreshed, exactly as in the reference where the
+ * refresh sits inside the monotone branch.  Default on.  Survives bcx_reset; call between build() calls only. */
+int bcx_set_check_monotone(bcx_solver* s, int32_t on);
 int bcx_reached_numeric_limit(bcx_solver* s, int32_t* limit);
 
 /* ---- introspection / measurement ------------------------------------------------------------ */

@@ -3,8 +3,12 @@ import os
 import sys
 import time
 
-# RCCL / cross-process device-memory sharing needs dmabuf IPC on this host driver; set before torch loads.
-os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+# RCCL / cross-process device-memory sharing needs dmabuf IPC on this host driver (hipIpcGetMemHandle fails in legacy
+# mode): force it before torch / HIP load, whatever the launching environment exported.  The round-1 driver run had
+# legacy mode and died in it (profiles/README.md, "round-1 GPUTEST abort"); BCX_KEEP_IPC_MODE=1 keeps the caller's
+# value for crash hunts.
+if not os.environ.get("BCX_KEEP_IPC_MODE"):
+    os.environ["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
 if not os.environ.get("BCX_NO_FAULTHANDLER"):   # (crash hunts preload tools/probe/abort_trace.so instead)
     faulthandler.enable(all_threads=True)
 

@@ -145,6 +145,62 @@ def test_sharded_hilbert_coreset_matches_single_process(tmp_path):
     assert int(h0["size"]) == len(idcs)
 
 
+def _subsample_worker(rank, world, port, N, d, n_sub, out_dir):
+    for p in (ROOT, os.path.join(ROOT, "bayesian-coresets_amd"), os.path.join(ROOT, "tests")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from fake_engine import FakeEngine
+    import bayesiancoresets_amd as bc
+
+    class Scaled(bc.Projector):
+        def update(self, wts, pts):
+            pass
+
+        def project(self, pts, grad=False):
+            return 2.0 * pts
+
+    data = np.random.RandomState(29).randn(N, d)
+    data[5::7] = 0.0                                       # zero vectors: dropped in the subsample branch (hilbert.py:19-22)
+    np.random.seed(41)
+    drawn = np.unique(np.random.randint(N, size=n_sub))
+    kept = drawn[np.abs(data[drawn]).sum(axis=1) > 0]
+    FakeEngine.FULL = 2.0 * data[kept]                     # what the replicated reweight of the stand-in engine reads
+    np.random.seed(41)                                     # every rank seeds alike: the same draw everywhere
+    lo, hi = bc.ShardedHilbertCoreset.local_rows(N)
+    cs = bc.ShardedHilbertCoreset(data[lo:hi], Scaled(), N, n_subsample=n_sub, snnls=bc.snnls.GIGA, engine_factory=FakeEngine)
+    assert np.array_equal(cs.sub_idcs, kept)
+    cs.build(12)
+    wts, pts, idcs = cs.get()
+    np.savez(os.path.join(out_dir, "ss%d.npz" % rank), wts=wts, pts=pts, idcs=idcs, err=cs.error(), kept=kept)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_sharded_hilbert_subsample_matches_single_process(tmp_path):
+    """n_subsample on row shards (hilbert.py:13-22): same draw on every rank, zero vectors dropped, surviving
+    vectors dealt to aligned solver shards; result == the oracle on the subsampled matrix, idcs are DATA rows."""
+    from oracle.snnls_oracle import SnnlsOracle, hilbert_readout
+    N, d, n_sub, world = 6000, 10, 2500, 2
+    mp.spawn(_subsample_worker, args=(world, _free_port(), N, d, n_sub, str(tmp_path)), nprocs=world, join=True)
+    h0, h1 = np.load(tmp_path / "ss0.npz"), np.load(tmp_path / "ss1.npz")
+    for k in ("wts", "pts", "idcs", "err"):
+        assert np.array_equal(h0[k], h1[k]), k
+    data = np.random.RandomState(29).randn(N, d)
+    data[5::7] = 0.0
+    kept = h0["kept"]
+    assert len(kept) > 1024                                 # the subsample really spans two solver shards
+    vecs = 2.0 * data[kept]
+    o = SnnlsOracle(vecs.T, vecs.sum(axis=0), alg="giga", mode="onepass")
+    o.build(12)
+    wts, sub_rows = hilbert_readout(o.weights())
+    assert np.array_equal(h0["idcs"], kept[sub_rows])
+    np.testing.assert_allclose(h0["wts"], wts, rtol=1e-12)
+    assert np.array_equal(h0["pts"], data[kept[sub_rows]])
+
+
 def _mailbox_worker(rank, world, port, fail_probe, out_dir):
     for p in (ROOT, os.path.join(ROOT, "bayesian-coresets_amd"), os.path.join(ROOT, "tests")):
         if p not in sys.path:

@@ -32,7 +32,7 @@ class NumpyFusedProjector(DeviceProjector):
     def project_colsum(self, pts):
         return self._vecs(pts).sum(axis=0)
 
-    def project_select(self, pts, resid):
+    def project_select(self, pts, resid, row_ids=None):
         v = self._vecs(pts)
         corrs = v.dot(resid) / np.sqrt((v ** 2).sum(axis=1)) / v.shape[1]
         i = int(np.argmax(corrs))
