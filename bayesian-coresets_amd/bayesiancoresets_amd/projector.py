@@ -135,11 +135,16 @@ class DeviceProjector(Projector):
             t = drawn.to(self.device, dtype=torch.float64)
             if t.dim() == 1:
                 t = t[None, :]
-            self.theta = t if t.is_contiguous() else t.contiguous()
-            self.samples = self.theta
+            self.samples = t
         else:
             self.samples = np.atleast_2d(np.asarray(drawn, dtype=np.float64))
-            self.theta = torch.from_numpy(np.ascontiguousarray(self.samples)).to(self.device)
+            t = torch.from_numpy(np.ascontiguousarray(self.samples)).to(self.device)
+        # the kernel reads 16-byte pieces of a parameter row: keep the rows 16-byte aligned (even leading dimension)
+        if t.shape[1] % 2 or not t.is_contiguous():
+            buf = torch.zeros((t.shape[0], t.shape[1] + (t.shape[1] % 2)), dtype=torch.float64, device=self.device)
+            buf[:, :t.shape[1]] = t
+            t = buf[:, :t.shape[1]]
+        self.theta = t
 
     def project(self, pts, grad=False):
         if grad:

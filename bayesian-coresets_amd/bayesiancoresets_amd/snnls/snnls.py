@@ -156,9 +156,9 @@ class DeviceSparseNNLS(SparseNNLS):
         self.alg_name, self.log = object_logger(self)
         self.A = A
         self._b_arg = b
-        self.check_error_monotone = check_error_monotone
         self._w_cache = None
         self._eng = None
+        self._check_monotone = bool(check_error_monotone)
         if self._ALG is None:
             raise NotImplementedError("DeviceSparseNNLS is abstract; use GIGA, FrankWolfe or OrthoPursuit")
         kind, rows = _as_row_matrix(A)
@@ -168,7 +168,7 @@ class DeviceSparseNNLS(SparseNNLS):
         eng = nat.Engine(self._ALG, self._N, self._d, device=device, store_dtype=store,
                          keep_exact_rows=keep_exact_rows)
         self._eng = eng
-        if not check_error_monotone:
+        if not self._check_monotone:
             eng.set_check_monotone(False)      # snnls.py:9,45,56: no error comparison / revert in the device state machine
         if self._N:
             if kind == "torch":
@@ -189,6 +189,18 @@ class DeviceSparseNNLS(SparseNNLS):
             raise nat.EngineError(rc, eng.lib.bcx_last_error(eng.h).decode())
         self.reached_numeric_limit = False
         self.last_trace = None
+
+    @property
+    def check_error_monotone(self):
+        return self._check_monotone
+
+    @check_error_monotone.setter
+    def check_error_monotone(self, on):
+        """The reference's greedy constructors take no such argument; callers switch the check off by assigning the
+        attribute (snnls.py:16) -- forwarded to the device state machine."""
+        self._check_monotone = bool(on)
+        if self._eng is not None:
+            self._eng.set_check_monotone(self._check_monotone)
 
     @property
     def b(self):

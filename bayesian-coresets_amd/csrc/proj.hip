@@ -60,165 +60,298 @@ __device__ __forceinline__ double row16_sum(double v) {
   return v;
 }
 
-struct __attribute__((aligned(8))) pd2 { double x, y; };   // two consecutive k values, 8-byte aligned
+// ---- geometry of the LDS-staged kernel ---------------------------------------------------------------------
+// A workgroup (4 waves) owns 128 rows x 64 columns of the product at a time; wave w computes rows 32w..32w+31 of
+// it as 2 x 4 MFMA tiles (64 accumulator VGPRs).  The k (feature) dimension advances in stages of 16 values.  Per
+// stage the workgroup brings 128 x 16 values of Z and 64 x 16 values of Theta from global memory -- one 16-byte
+// piece per thread and load, eight consecutive threads reading one 128-byte line of a row -- into registers WHILE
+// the MFMAs of the previous stage run, then parks them in the other half of a double-buffered LDS region; every
+// operand is fetched from L2 once per workgroup (Theta used to be fetched once per WAVE, straight into the MFMA
+// operand registers, with the load latency exposed to the matrix pipe) and one barrier separates two stages.
+// The stage sequence runs across tile boundaries (next column group / next row block), so the first loads of a new
+// tile are in flight during the epilogue of the previous one.
+// LDS layout: one block per (16-row operand tile, 8-k step), holding the 64 lanes' 16-byte operand pieces
+// {X[row li][k0 + 2 lk], X[row li][k0 + 2 lk + 1]} in lane order -- lane (li, lk) feeds k-slot lk of two
+// consecutive MFMA steps from one ds_read_b128 -- with the four lk groups 288 bytes apart instead of 256, which
+// makes both the stores (lanes vary k fastest) and the reads (lanes vary li fastest) bank-conflict free.
+#define PJ_KC 16
+#define PJ_ROWS 128
+#define PJ_COLS 64
+#define PJ_LK_STRIDE 288
+#define PJ_BLK (4 * PJ_LK_STRIDE)
+#define PJ_ZBLKS (PJ_ROWS / 16 * (PJ_KC / 8))
+#define PJ_TBLKS (PJ_COLS / 16 * (PJ_KC / 8))
+#define PJ_STAGE_BYTES ((PJ_ZBLKS + PJ_TBLKS) * PJ_BLK)
+#define PJ_STAGING_BYTES (2 * PJ_STAGE_BYTES)
 
-// Register-blocked: a wave owns 32 rows x 64 columns of the product at a time (2 x 4 MFMA tiles).  The four
-// k-slots of an MFMA step are fed from a permuted k order -- lane group lk supplies k = 8t + 2 lk (+1) to
-// steps 2t (2t+1) -- so every lane fetches its A and B operands for two steps with ONE 16-byte load:
-// 6 loads per 16 MFMAs instead of 2 loads per MFMA.
-template <int FAM, int MODE>
-__global__ __launch_bounds__(256) void proj_kernel(ProjArgs p) {
-  extern __shared__ double lds[];            // COLSUM: 4 x S column accumulators
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+typedef double pv2d __attribute__((ext_vector_type(2)));
+
+// NumPy's arg-max order on correlations: NaN (0/0 of a zero vector) beats every number, the first one wins;
+// otherwise larger value, then lower row (sparsevi.py:55 `corrs.argmax()`).
+__device__ __forceinline__ bool corr_better(double a, long long ia, double b, long long ib) {
+  const bool an = a != a, bn = b != b;
+  if (an || bn) return an && (!bn || ia < ib);
+  return a > b || (a == b && ia < ib);
+}
+
+// 16-byte piece {X[k], X[k+1]} of a row.  Branch-free: the address is clamped into the row here and the value is
+// masked (zero beyond D and for invalid rows) only when it is parked in LDS a stage later, so the six loads of a
+// stage are issued back to back with no consumer in between (with the mask next to the load, or with branches, the
+// compiler waited for each load before issuing the next one).  k is even.  ALIGNED (16-byte aligned rows, even
+// leading dimension >= D): the piece at the last even k < D may read element D of an odd-D row -- inside the row's
+// padding.
+template <bool ALIGNED>
+__device__ __forceinline__ pv2d load_piece(const double* __restrict__ row, int k, int D) {
+  pv2d v;
+  if (ALIGNED) {
+    v = *(const pv2d*)(row + min(k, (D - 1) & ~1));
+  } else {
+    v.x = row[min(k, D - 1)];
+    v.y = row[min(k + 1, D - 1)];
+  }
+  return v;
+}
+__device__ __forceinline__ pv2d mask_piece(pv2d v, bool valid, int k, int D) {
+  v.x = (valid && k < D) ? v.x : 0.0;
+  v.y = (valid && k + 1 < D) ? v.y : 0.0;
+  return v;
+}
+
+template <int FAM, int MODE, bool ALIGNED>
+__global__ __launch_bounds__(256, 2) void proj_kernel(ProjArgs p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char pj_lds[];   // staging (2 stages) | COLSUM: 4 x S column sums
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int li = lane & 15, lk = lane >> 4;
   const int S = p.S, D = p.D;
-  const int ngroup_c = (S + 63) / 64;
-  double* colacc = lds + (size_t)wave * S;
+  const int ngc = (S + PJ_COLS - 1) / PJ_COLS;
+  const int nst = (D + PJ_KC - 1) / PJ_KC;
+  const int64_t nblk = (p.N + PJ_ROWS - 1) / PJ_ROWS;
+  double* colacc = (double*)(pj_lds + PJ_STAGING_BYTES) + (size_t)wave * S;
   if (MODE == PMODE_COLSUM) {
     for (int c = lane; c < S; c += 64) colacc[c] = 0.0;
   }
   double bestv = -INFINITY;
-  int64_t besti = 0x7fffffffffffffffLL;
+  long long besti = 0x7fffffffffffffffLL;
   const double clin = (FAM == FAM_LINREG) ? -0.5 * log(2.0 * 3.14159265358979323846 * p.param) : 0.0;
-  const int64_t nblk_r = (p.N + 31) / 32;
-  for (int64_t br = (int64_t)blockIdx.x * 4 + wave; br < nblk_r; br += (int64_t)gridDim.x * 4) {
-    const int64_t r0 = br * 32;
-    const double* zrow[2];
-    bool avalid[2];
-#pragma unroll
-    for (int tr = 0; tr < 2; ++tr) {
-      const int64_t arow = r0 + 16 * tr + li;
-      avalid[tr] = arow < p.N;
-      zrow[tr] = p.Z + (avalid[tr] ? arow : 0) * p.ldz;
+
+  // global -> LDS assignment of this thread: piece q of rows (tid >> 3) + 32 j
+  const int q = tid & 7, grow = tid >> 3;
+  const unsigned st_off = (unsigned)((q >> 2) * PJ_BLK + (q & 3) * PJ_LK_STRIDE + (grow & 15) * 16);
+  const unsigned rd_off = (unsigned)(lk * PJ_LK_STRIDE + li * 16);
+
+  int64_t br = blockIdx.x;
+  if (br >= nblk) {
+    if (MODE == PMODE_COLSUM) {
+      __syncthreads();
+      double* outp = p.colpart + (size_t)blockIdx.x * S;
+      for (int c = tid; c < S; c += blockDim.x) outp[c] = 0.0;
     }
-    // responses / per-row constants of the 8 rows this lane's accumulator registers belong to
-    double yv[2][4], c0[2][4];
+    if (MODE == PMODE_SELECT && tid == 0) { p.best_val[blockIdx.x] = -INFINITY; p.best_idx[blockIdx.x] = besti; }
+    return;
+  }
+  int cg = 0, s = 0;
+  pv2d zreg[4], treg[2];
+  auto fetch = [&](int64_t fbr, int fcg, int fs) {
+    const int k = fs * PJ_KC + 2 * q;
 #pragma unroll
-    for (int tr = 0; tr < 2; ++tr)
+    for (int j = 0; j < 4; ++j) {
+      const int64_t row = fbr * PJ_ROWS + grow + 32 * j;
+      zreg[j] = load_piece<ALIGNED>(p.Z + (row < p.N ? row : p.N - 1) * p.ldz, k, D);
+    }
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int64_t row = r0 + 16 * tr + lk + 4 * r;
-        const double y = (p.ycol >= 0 && row < p.N) ? p.Z[row * p.ldz + p.ycol] : 0.0;
-        yv[tr][r] = y;
-        c0[tr][r] = (FAM == FAM_POISSON) ? lgamma(y + 1.0) : clin;
-      }
-    double rs[2][4] = {}, rq[2][4] = {}, rd[2][4] = {};
-    for (int cg = 0; cg < ngroup_c; ++cg) {
-      const double* trow[4];
-      bool bvalid[4];
+    for (int j = 0; j < 2; ++j) {
+      const int col = fcg * PJ_COLS + grow + 32 * j;
+      treg[j] = load_piece<ALIGNED>(p.theta + (size_t)(col < S ? col : S - 1) * p.ldt, k, D);
+    }
+  };
+  auto park = [&](int par, int64_t fbr, int fcg, int fs) {      // (same coordinates as the fetch it completes)
+    unsigned char* base = pj_lds + par * PJ_STAGE_BYTES;
+    const int k = fs * PJ_KC + 2 * q;
 #pragma unroll
-      for (int tc = 0; tc < 4; ++tc) {
-        const int bcol = cg * 64 + 16 * tc + li;
-        bvalid[tc] = bcol < S;
-        trow[tc] = p.theta + (size_t)(bvalid[tc] ? bcol : 0) * p.ldt;
-      }
-      pv4d acc[2][4];
+    for (int j = 0; j < 4; ++j)      // rows grow + 32 j: 16-row tile (grow >> 4) + 2 j
+      *(pv2d*)(base + ((grow >> 4) + 2 * j) * (PJ_KC / 8) * PJ_BLK + st_off) =
+          mask_piece(zreg[j], fbr * PJ_ROWS + grow + 32 * j < p.N, k, D);
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+      *(pv2d*)(base + (PJ_ZBLKS + ((grow >> 4) + 2 * j) * (PJ_KC / 8)) * PJ_BLK + st_off) =
+          mask_piece(treg[j], fcg * PJ_COLS + grow + 32 * j < S, k, D);
+  };
+
+  fetch(br, 0, 0);
+  park(0, br, 0, 0);
+  __syncthreads();
+  int par = 0;
+  // Orientation of the wave's 32 rows x 64 columns on the MFMA tiles.  WRITE: A = Z, B = Theta -- a lane holds 8 rows
+  // x 4 columns, the 16 lanes of a DPP row hold 16 consecutive columns of one data row (128-byte stores).
+  // COLSUM / SELECT: A = Theta, B = Z (the transposed product) -- a lane holds only 2 data rows (li, li + 16) x 16
+  // columns, so the per-row state of the epilogue (response, shift, three moments) is 2 values per lane instead
+  // of 8: what makes the kernel fit 256 registers at two waves per SIMD.
+  constexpr bool TRP = MODE != PMODE_WRITE;
+  pv4d acc[2][4];                    // [row tile][column tile]
+  double yv[TRP ? 2 : 8], cp[TRP ? 2 : 8];
+  double piv[2], rs[TRP ? 2 : 8], rq[2], rd[2];
+  while (true) {
+    // coordinates of the stage after this one
+    int ns = s + 1, ncg = cg;
+    int64_t nbr = br;
+    if (ns == nst) { ns = 0; if (++ncg == ngc) { ncg = 0; nbr += gridDim.x; } }
+    const bool more = nbr < nblk;
+    const bool last = s == nst - 1;
+    // the next stage's loads fly while this stage's MFMAs run; across a tile boundary they are issued after the
+    // epilogue instead (keeps the 12 prefetch registers out of the epilogue's live set)
+    if (more && !last) fetch(nbr, ncg, ns);
+    if (s == 0) {
 #pragma unroll
       for (int tr = 0; tr < 2; ++tr)
 #pragma unroll
         for (int tc = 0; tc < 4; ++tc) acc[tr][tc] = (pv4d){0.0, 0.0, 0.0, 0.0};
-      for (int k0 = 0; k0 < D; k0 += 8) {
-        const int k = k0 + 2 * lk;
-        pd2 av[2], bv[4];
-        if (k + 1 < D) {
+    }
+    {
+      const unsigned char* base = pj_lds + par * PJ_STAGE_BYTES + rd_off;
 #pragma unroll
-          for (int tr = 0; tr < 2; ++tr) av[tr] = *(const pd2*)(zrow[tr] + k);
+      for (int u = 0; u < PJ_KC / 8; ++u) {
+        pv2d zv[2], tv[4];
 #pragma unroll
-          for (int tc = 0; tc < 4; ++tc) bv[tc] = *(const pd2*)(trow[tc] + k);
-        } else {
+        for (int tr = 0; tr < 2; ++tr) zv[tr] = *(const pv2d*)(base + ((2 * wave + tr) * (PJ_KC / 8) + u) * PJ_BLK);
 #pragma unroll
-          for (int tr = 0; tr < 2; ++tr) { av[tr].x = k < D ? zrow[tr][k] : 0.0; av[tr].y = 0.0; }
-#pragma unroll
-          for (int tc = 0; tc < 4; ++tc) { bv[tc].x = k < D ? trow[tc][k] : 0.0; bv[tc].y = 0.0; }
-        }
-#pragma unroll
-        for (int tr = 0; tr < 2; ++tr) if (!avalid[tr]) { av[tr].x = 0.0; av[tr].y = 0.0; }
-#pragma unroll
-        for (int tc = 0; tc < 4; ++tc) if (!bvalid[tc]) { bv[tc].x = 0.0; bv[tc].y = 0.0; }
+        for (int tc = 0; tc < 4; ++tc) tv[tc] = *(const pv2d*)(base + (PJ_ZBLKS + tc * (PJ_KC / 8) + u) * PJ_BLK);
 #pragma unroll
         for (int tr = 0; tr < 2; ++tr)
 #pragma unroll
           for (int tc = 0; tc < 4; ++tc) {
-            acc[tr][tc] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[tr].x, bv[tc].x, acc[tr][tc], 0, 0, 0);
-            acc[tr][tc] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[tr].y, bv[tc].y, acc[tr][tc], 0, 0, 0);
-          }
-      }
-      // f64 C/D layout: col = lane & 15, row = (lane >> 4) + 4 * reg
-#pragma unroll
-      for (int tc = 0; tc < 4; ++tc) {
-        const int col = cg * 64 + 16 * tc + li;
-        const bool cvalid = col < S;
-        const double rsd = (MODE == PMODE_SELECT && cvalid) ? p.resid[col] : 0.0;
-        double csum = 0.0;
-#pragma unroll
-        for (int tr = 0; tr < 2; ++tr)
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const int64_t row = r0 + 16 * tr + lk + 4 * r;
-            const bool ok = cvalid && row < p.N;
-            const double ll = ok ? loglik<FAM>(acc[tr][tc][r], yv[tr][r], p.param, c0[tr][r]) : 0.0;
-            if (MODE == PMODE_WRITE) {
-              if (ok) p.out[row * p.ldo + col] = ll;
-              rs[tr][r] += ll;
-            } else if (MODE == PMODE_COLSUM) {
-              csum += ll;
+            if (TRP) {
+              acc[tr][tc] = __builtin_amdgcn_mfma_f64_16x16x4f64(tv[tc].x, zv[tr].x, acc[tr][tc], 0, 0, 0);
+              acc[tr][tc] = __builtin_amdgcn_mfma_f64_16x16x4f64(tv[tc].y, zv[tr].y, acc[tr][tc], 0, 0, 0);
             } else {
-              rs[tr][r] += ll; rq[tr][r] += ll * ll; rd[tr][r] += ll * rsd;
+              acc[tr][tc] = __builtin_amdgcn_mfma_f64_16x16x4f64(zv[tr].x, tv[tc].x, acc[tr][tc], 0, 0, 0);
+              acc[tr][tc] = __builtin_amdgcn_mfma_f64_16x16x4f64(zv[tr].y, tv[tc].y, acc[tr][tc], 0, 0, 0);
             }
           }
-        if (MODE == PMODE_COLSUM) {
-          // add the 4 lane groups that hold the same column (xor 16, xor 32)
-          csum += bcx_xor16_f64(csum);
-          csum += bcx_xor32_f64(csum);
-          if (lk == 0 && cvalid) colacc[col] += csum;
+      }
+    }
+    if (last) {
+      // ---- epilogue of tile (br, cg).  f64 C/D layout: D[i = (lane >> 4) + 4 * reg][j = lane & 15] ---------------
+      const int64_t r0 = br * PJ_ROWS + 32 * wave;
+      if (!TRP) {
+        // i = data row (lk + 4 reg), j = column (li)
+        if (cg == 0) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            const int64_t row = r0 + 16 * (e >> 2) + lk + 4 * (e & 3);
+            const double y = (p.ycol >= 0 && row < p.N) ? p.Z[row * p.ldz + p.ycol] : 0.0;
+            yv[e] = y;
+            cp[e] = (FAM == FAM_POISSON) ? lgamma(y + 1.0) : clin;
+            rs[e] = 0.0;
+            if (FAM == FAM_POISSON) __builtin_amdgcn_sched_barrier(0);   // one lgamma at a time
+          }
+        }
+#pragma unroll
+        for (int tc = 0; tc < 4; ++tc) {
+          const int col = cg * PJ_COLS + 16 * tc + li;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            const int64_t row = r0 + 16 * (e >> 2) + lk + 4 * (e & 3);
+            const bool ok = col < S && row < p.N;
+            const double ll = ok ? loglik<FAM>(acc[e >> 2][tc][e & 3], yv[e], p.param, cp[e]) : 0.0;
+            if (ok) p.out[row * p.ldo + col] = ll;
+            rs[e] += ll;
+          }
+        }
+        if (cg == ngc - 1) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            const double t = row16_sum(rs[e]);
+            const int64_t row = r0 + 16 * (e >> 2) + lk + 4 * (e & 3);
+            if (li == 0 && row < p.N) p.rowsum[row] = t;
+          }
+        }
+      } else {
+        // i = column (lk + 4 reg within column tile tc), j = data row (li within row tile tr)
+        if (cg == 0) {
+#pragma unroll
+          for (int tr = 0; tr < 2; ++tr) {
+            const int64_t row = r0 + 16 * tr + li;
+            const double y = (p.ycol >= 0 && row < p.N) ? p.Z[row * p.ldz + p.ycol] : 0.0;
+            yv[tr] = y;
+            cp[tr] = (FAM == FAM_POISSON) ? lgamma(y + 1.0) : clin;
+            rs[tr] = 0.0; rq[tr] = 0.0; rd[tr] = 0.0;
+            // per-row shift: the row's value in column 0 (lane group lk == 0, register 0 of column tile 0), handed to
+            // the four lanes that share the row.  Sums, squares and dot products are accumulated on (ll - shift): the
+            // one-pass moments then cancel on the scale of the row's SPREAD, not of |ll| (rows with |mean| >> spread:
+            // a concentrated posterior, saturated logistic rows) -- the accuracy of the reference's centre-then-norm
+            // order (sparsevi.py:49-51) without a second pass.
+            const double l0 = loglik<FAM>(acc[tr][0][0], yv[tr], p.param, cp[tr]);
+            piv[tr] = __shfl(l0, li, BCX_WAVE);
+          }
+        }
+#pragma unroll
+        for (int tc = 0; tc < 4; ++tc) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int col = cg * PJ_COLS + 16 * tc + lk + 4 * r;
+            const bool cvalid = col < S;
+            const double rsd = (MODE == PMODE_SELECT && cvalid) ? p.resid[col] : 0.0;
+            double csum = 0.0;
+#pragma unroll
+            for (int tr = 0; tr < 2; ++tr) {
+              const bool ok = cvalid && r0 + 16 * tr + li < p.N;
+              const double v = ok ? loglik<FAM>(acc[tr][tc][r], yv[tr], p.param, cp[tr]) - piv[tr] : 0.0;
+              if (MODE == PMODE_COLSUM) csum += v;
+              else { rs[tr] += v; rq[tr] += v * v; rd[tr] += v * rsd; }
+            }
+            if (MODE == PMODE_COLSUM) {
+              csum = row16_sum(csum);                      // the 16 lanes (data rows) that hold this column
+              if (li == 0 && cvalid) colacc[col] += csum;
+            }
+          }
+        }
+        if (MODE == PMODE_SELECT && cg == ngc - 1) {
+#pragma unroll
+          for (int tr = 0; tr < 2; ++tr) {
+            // the four lane groups hold disjoint columns of the same row
+            double s1 = rs[tr], s2 = rq[tr], sd = rd[tr];
+            s1 += bcx_xor16_f64(s1); s1 += bcx_xor32_f64(s1);
+            s2 += bcx_xor16_f64(s2); s2 += bcx_xor32_f64(s2);
+            sd += bcx_xor16_f64(sd); sd += bcx_xor32_f64(sd);
+            const long long row = r0 + 16 * tr + li;
+            const double mean = s1 / (double)S;                         // mean of (ll - shift)
+            const double dot = sd - mean * p.resid_sum;                 // (ll - mean ll) . resid
+            const double nrm2 = s2 - (double)S * mean * mean;           // ||ll - mean ll||^2
+            // a row that is constant over the samples has shifted values 0 exactly: 0/0 = NaN as in NumPy
+            const double corr = nrm2 > 0.0 ? dot / sqrt(nrm2) / (double)S : __builtin_nan("");
+            if (row < p.N && corr_better(corr, row, bestv, besti)) { bestv = corr; besti = row; }
+          }
         }
       }
     }
-    if (MODE == PMODE_WRITE) {
-#pragma unroll
-      for (int tr = 0; tr < 2; ++tr)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const double t = row16_sum(rs[tr][r]);
-          const int64_t row = r0 + 16 * tr + lk + 4 * r;
-          if (li == 0 && row < p.N) p.rowsum[row] = t;
-        }
-    }
-    if (MODE == PMODE_SELECT) {
-#pragma unroll
-      for (int tr = 0; tr < 2; ++tr)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const double s1 = row16_sum(rs[tr][r]), s2 = row16_sum(rq[tr][r]), sd = row16_sum(rd[tr][r]);
-          const int64_t row = r0 + 16 * tr + lk + 4 * r;
-          const double mean = s1 / (double)S;
-          const double dot = sd - mean * p.resid_sum;                  // (ll - mean) . resid
-          const double nrm2 = s2 - (double)S * mean * mean;            // ||ll - mean||^2
-          const double corr = dot / sqrt(nrm2) / (double)S;            // sparsevi.py:51
-          if (row < p.N && (corr > bestv || (corr == bestv && row < besti))) { bestv = corr; besti = row; }
-        }
-    }
+    if (!more) break;
+    if (last) fetch(nbr, ncg, ns);
+    park(par ^ 1, nbr, ncg, ns);
+    __syncthreads();
+    par ^= 1;
+    s = ns; cg = ncg; br = nbr;
   }
   if (MODE == PMODE_COLSUM) {
     __syncthreads();
     double* outp = p.colpart + (size_t)blockIdx.x * S;
-    for (int c = threadIdx.x; c < S; c += blockDim.x)
-      outp[c] = ((lds[c] + lds[(size_t)S + c]) + lds[2 * (size_t)S + c]) + lds[3 * (size_t)S + c];
+    const double* ca = (const double*)(pj_lds + PJ_STAGING_BYTES);
+    for (int c = tid; c < S; c += blockDim.x)
+      outp[c] = ((ca[c] + ca[(size_t)S + c]) + ca[2 * (size_t)S + c]) + ca[3 * (size_t)S + c];
   }
   if (MODE == PMODE_SELECT) {
-    // arg-max over the workgroup: (value desc, row asc)
+    // arg-max over the workgroup
     __shared__ double sv[4];
     __shared__ long long si[4];
     for (int off = 32; off >= 1; off >>= 1) {
       const double ov = __shfl_xor(bestv, off, BCX_WAVE);
-      const long long oi = __shfl_xor((long long)besti, off, BCX_WAVE);
-      if (ov > bestv || (ov == bestv && oi < besti)) { bestv = ov; besti = oi; }
+      const long long oi = __shfl_xor(besti, off, BCX_WAVE);
+      if (corr_better(ov, oi, bestv, besti)) { bestv = ov; besti = oi; }
     }
     if (lane == 0) { sv[wave] = bestv; si[wave] = besti; }
     __syncthreads();
-    if (threadIdx.x == 0) {
+    if (tid == 0) {
       for (int w = 1; w < 4; ++w)
-        if (sv[w] > bestv || (sv[w] == bestv && si[w] < besti)) { bestv = sv[w]; besti = si[w]; }
+        if (corr_better(sv[w], si[w], bestv, besti)) { bestv = sv[w]; besti = si[w]; }
       p.best_val[blockIdx.x] = bestv;
       p.best_idx[blockIdx.x] = besti;
     }
@@ -271,12 +404,12 @@ __global__ __launch_bounds__(256) void select_final_kernel(const double* bv, con
   __shared__ long long si[256];
   double v = -INFINITY; long long i = 0x7fffffffffffffffLL;
   for (int b = threadIdx.x; b < nparts; b += blockDim.x)
-    if (bv[b] > v || (bv[b] == v && bi[b] < i)) { v = bv[b]; i = bi[b]; }
+    if (corr_better(bv[b], bi[b], v, i)) { v = bv[b]; i = bi[b]; }
   sv[threadIdx.x] = v; si[threadIdx.x] = i;
   __syncthreads();
   if (threadIdx.x == 0) {
     for (int t = 1; t < 256; ++t)
-      if (sv[t] > v || (sv[t] == v && si[t] < i)) { v = sv[t]; i = si[t]; }
+      if (corr_better(sv[t], si[t], v, i)) { v = sv[t]; i = si[t]; }
     *out_val = v; *out_idx = i;
   }
 }
@@ -294,28 +427,43 @@ extern "C" const char* bcx_project_last_error(void) { return g_proj_err.c_str();
     }                                                                             \
   } while (0)
 
+// Persistent launch: as many workgroups as are resident at once (2 per CU: 54 KiB of staging LDS each), every one
+// striding over the 128-row blocks -- with more workgroups than that the last wave of blocks leaves most CUs idle.
 static int proj_grid(int64_t N) {
-  int64_t tiles = (N + 31) / 32;
-  int64_t wg = (tiles + 3) / 4;
-  if (wg > 2048) wg = 2048;
-  if (wg < 1) wg = 1;
-  return (int)wg;
+  static int resident = 0;
+  if (!resident) {
+    int dev = 0, cus = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
+      cus = 256;
+    resident = std::min(2 * cus, 2048);
+  }
+  const int64_t blocks = (N + PJ_ROWS - 1) / PJ_ROWS;
+  return (int)std::max<int64_t>(1, std::min<int64_t>(blocks, resident));
 }
 
-template <int MODE> static int launch_family(int family, dim3 grid, size_t shmem, hipStream_t st, const ProjArgs& p) {
-  if (shmem > 48 * 1024) {
-    PROJ_HIP(hipFuncSetAttribute((const void*)proj_kernel<FAM_LOGISTIC, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
-    PROJ_HIP(hipFuncSetAttribute((const void*)proj_kernel<FAM_POISSON, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
-    PROJ_HIP(hipFuncSetAttribute((const void*)proj_kernel<FAM_LINREG, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
-  }
-  switch (family) {
-    case FAM_LOGISTIC: hipLaunchKernelGGL((proj_kernel<FAM_LOGISTIC, MODE>), grid, dim3(256), shmem, st, p); break;
-    case FAM_POISSON: hipLaunchKernelGGL((proj_kernel<FAM_POISSON, MODE>), grid, dim3(256), shmem, st, p); break;
-    case FAM_LINREG: hipLaunchKernelGGL((proj_kernel<FAM_LINREG, MODE>), grid, dim3(256), shmem, st, p); break;
-    default: g_proj_err = "unknown likelihood family"; return BCX_ERR_ARG;
+template <int FAM, int MODE> static int launch_one(bool aligned, dim3 grid, size_t shmem, hipStream_t st, const ProjArgs& p) {
+  if (aligned) {
+    PROJ_HIP(hipFuncSetAttribute((const void*)proj_kernel<FAM, MODE, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
+    hipLaunchKernelGGL((proj_kernel<FAM, MODE, true>), grid, dim3(256), shmem, st, p);
+  } else {
+    PROJ_HIP(hipFuncSetAttribute((const void*)proj_kernel<FAM, MODE, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
+    hipLaunchKernelGGL((proj_kernel<FAM, MODE, false>), grid, dim3(256), shmem, st, p);
   }
   PROJ_HIP(hipGetLastError());
   return BCX_OK;
+}
+
+template <int MODE> static int launch_family(int family, dim3 grid, size_t extra_lds, hipStream_t st, const ProjArgs& p) {
+  const size_t shmem = PJ_STAGING_BYTES + extra_lds;
+  if (shmem > 160 * 1024) { g_proj_err = "bcx_project: S too large for the column-sum accumulators (S <= 3328)"; return BCX_ERR_ARG; }
+  // 16-byte loads need 16-byte aligned rows: even leading dimensions and aligned bases (else 8-byte loads)
+  const bool aligned = ((uintptr_t)p.Z % 16 == 0) && ((uintptr_t)p.theta % 16 == 0) && p.ldz % 2 == 0 && p.ldt % 2 == 0;
+  switch (family) {
+    case FAM_LOGISTIC: return launch_one<FAM_LOGISTIC, MODE>(aligned, grid, shmem, st, p);
+    case FAM_POISSON: return launch_one<FAM_POISSON, MODE>(aligned, grid, shmem, st, p);
+    case FAM_LINREG: return launch_one<FAM_LINREG, MODE>(aligned, grid, shmem, st, p);
+    default: g_proj_err = "unknown likelihood family"; return BCX_ERR_ARG;
+  }
 }
 
 static int fill(ProjArgs& p, int family, const void* Z, int64_t N, int64_t ldz, int D, int ycol, const void* theta,

@@ -64,12 +64,13 @@ class SnnlsOracle:
     N x d C-contiguous array to get the reference's memory layout.
     """
 
-    def __init__(self, A, b, alg="giga", tol=1e-12, mode="faithful"):
+    def __init__(self, A, b, alg="giga", tol=1e-12, mode="faithful", check_error_monotone=True):
         if alg not in ALGS:
             raise ValueError("alg must be one of %s" % (ALGS,))
         if mode not in ("faithful", "onepass"):
             raise ValueError("mode must be faithful|onepass")
         self.alg, self.mode, self.tol = alg, mode, tol
+        self.check_error_monotone = check_error_monotone    # snnls.py:9,16
         self.A, self.b = A, b
         self.N = A.shape[1]
         self.w = np.zeros(self.N)
@@ -197,7 +198,7 @@ class SnnlsOracle:
         retried = False
         for _ in range(itrs):
             f = -1
-            checked = self.size() > 0                        # snnls.py:44
+            checked = self.check_error_monotone and self.size() > 0   # snnls.py:44-45
             if checked:
                 prev_err = self.error()                      # snnls.py:46-47
                 prev_w, prev_xw = self.w.copy(), self._xw.copy()

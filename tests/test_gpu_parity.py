@@ -504,3 +504,67 @@ def test_repeated_runs_are_bit_identical(bc, alg, N, d, itrs, reps):
         h2 = hashlib.md5(s.weights().tobytes() + np.float64(s.error()).tobytes()).hexdigest()
         seen.add((h1, h2, bool(s.reached_numeric_limit)))
     assert len(seen) == 1, "%d distinct outcomes in %d identical runs" % (len(seen), reps)
+
+
+# ---- check_error_monotone = False on the device state machine (reference fixture F10, tests/golden/make_golden_host.py) ----
+@pytest.fixture(scope="module")
+def host_golden():
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    return np.load(os.path.join(root, "tests", "golden", "host_golden.npz"))
+
+
+@pytest.mark.parametrize("how", ("ctor", "attribute"))
+def test_F10_giga_without_monotone_check(bc, host_golden, normal_inputs, how):
+    """snnls.py:45,56-62 switched off: same 429 selections and the same latch as the reference run with
+    ``solver.check_error_monotone = False``."""
+    X = normal_inputs(1, 10000, 100, "F2_input_sha256")
+    if how == "ctor":
+        s = bc.snnls.GIGA(X.T, X.sum(axis=0), check_error_monotone=False)
+    else:
+        s = bc.snnls.GIGA(X.T, X.sum(axis=0))
+        s.check_error_monotone = False
+    assert s.check_error_monotone is False
+    s.build(int(host_golden["F10_giga_itrs"]))
+    sel, err, status = s.last_trace
+    assert np.array_equal(sel[sel >= 0], host_golden["F10_giga_sel"])
+    assert not (status == 3).any()                                   # no monotone failures can be reported
+    assert s.reached_numeric_limit == bool(host_golden["F10_giga_limit"]) and s.size() == int(host_golden["F10_giga_size"])
+    np.testing.assert_allclose(s.error(), float(host_golden["F10_giga_final_err"]), rtol=1e-3)
+
+
+def test_F10_fw_without_monotone_check(bc, host_golden, normal_inputs):
+    X = normal_inputs(1, 10000, 100, "F2_input_sha256")
+    s = bc.snnls.FrankWolfe(X.T, X.sum(axis=0), check_error_monotone=False)
+    s.build(int(host_golden["F10_fw_itrs"]))
+    sel, err, status = s.last_trace
+    n_ok = int((status == 0).sum())
+    assert np.array_equal(sel[sel >= 0][:400], host_golden["F10_fw_sel"][:400])
+    assert not (status == 3).any() and s.reached_numeric_limit == bool(host_golden["F10_fw_limit"])
+    np.testing.assert_allclose(err[status == 0][:400], host_golden["F10_fw_err"][:400], rtol=1e-4)
+    assert n_ok >= 400
+
+
+def test_monotone_flag_changes_the_state_machine(bc):
+    """A case where the two settings differ on the device as they do in the oracle: rows of rank 3 make Frank-Wolfe
+    reach its floor within a few steps; with the check every further step that raises the error is reverted and the
+    second such failure latches, without it steps keep being accepted."""
+    from oracle.snnls_oracle import SnnlsOracle
+    rs = np.random.RandomState(8)
+    X = rs.randn(600, 3).dot(rs.randn(3, 24))
+    out = {}
+    for flag in (True, False):
+        o = SnnlsOracle(X.T, X.sum(axis=0), alg="fw", mode="onepass", check_error_monotone=flag)
+        o.build(80)
+        s = bc.snnls.FrankWolfe(X.T, X.sum(axis=0), check_error_monotone=flag, dtype="float64")
+        s.build(80)
+        sel, err, status = s.last_trace
+        ost = np.array([t[2] for t in o.trace])
+        n = min(len(ost), len(status))
+        # identical control flow for as long as the error is far above rounding noise
+        scale = np.sqrt((X.sum(axis=0) ** 2).sum())
+        far = np.array([t[1] for t in o.trace])[:n] > 1e-9 * scale
+        k = int(np.argmin(far)) if not far.all() else n
+        assert k >= 3 and np.array_equal(status[:k], ost[:k]) and np.array_equal(sel[:k], np.array([t[0] for t in o.trace])[:k])
+        out[flag] = (status, s.reached_numeric_limit)
+    assert not (out[False][0] == 3).any()
