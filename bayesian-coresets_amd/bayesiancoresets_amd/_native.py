@@ -25,7 +25,7 @@ SYMBOLS = (
     "bcx_stats", "bcx_profile_scan", "bcx_profile_read", "bcx_version",
     "bcx_project_write", "bcx_project_colsum", "bcx_project_select", "bcx_project_last_error",
     "bcx_build_enqueue_exact", "bcx_exchange_export", "bcx_exchange_attach", "bcx_exchange_probe", "bcx_exchange_disable", "bcx_exchange_set_timeout",
-    "bcx_set_check_monotone",
+    "bcx_set_check_monotone", "bcx_project_profile", "bcx_project_profile_read",
 )
 
 
@@ -99,6 +99,8 @@ def load():
     sigs["bcx_project_write"] = proj_common + [vp, i64, vp]
     sigs["bcx_project_colsum"] = proj_common + [vp, vp]
     sigs["bcx_project_select"] = proj_common + [vp, dbl, vp, vp]
+    sigs["bcx_project_profile"] = [i32]
+    sigs["bcx_project_profile_read"] = [P(dbl), P(i64), P(dbl)]
     lib.bcx_project_last_error.restype = ctypes.c_char_p
     lib.bcx_project_last_error.argtypes = []
     for name, args in sigs.items():

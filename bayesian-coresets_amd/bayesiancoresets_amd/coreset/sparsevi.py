@@ -142,16 +142,21 @@ class SparseVICoreset(Coreset):
                 self.idcs = np.append(self.idcs, f).astype(np.int64)
                 self.pts = np.vstack((self.pts, self._fetch_row(f)[None, :]))
 
+    @staticmethod
+    def _host_row(row):
+        return row.detach().cpu().numpy() if hasattr(row, "detach") else np.asarray(row)
+
     def _fetch_row(self, f):
-        """data[f] for a global row index; in sharded mode the owning rank supplies it."""
+        """data[f] for a global row index (``data`` may be an ndarray or a device tensor); in sharded mode the
+        owning rank supplies it."""
         if not self._sharded:
-            return np.asarray(self.data[f])
+            return self._host_row(self.data[f])
         import torch
         import torch.distributed as dist
         lo = self.row_offset
         buf = torch.zeros(self.data.shape[1], dtype=torch.float64, device=self.ll_projector.device)
         if lo <= f < lo + self.data.shape[0]:
-            buf.copy_(torch.from_numpy(np.ascontiguousarray(self.data[f - lo], dtype=np.float64)))
+            buf.copy_(torch.as_tensor(np.ascontiguousarray(self._host_row(self.data[f - lo]), dtype=np.float64)))
         dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group)
         return buf.cpu().numpy()
 

@@ -90,6 +90,20 @@ class DeviceProjector(Projector):
         if rc != 0:
             raise self._nat.EngineError(rc, self._lib.bcx_project_last_error().decode())
 
+    # -- measurement: hipEvents around the projection kernel alone (csrc/proj.hip, bcx_project_profile) ------
+    def profile(self, on):
+        self._check(self._lib.bcx_project_profile(int(bool(on))))
+
+    def profile_read(self):
+        """(kernel milliseconds, launches, GEMM flops 2 N D S) since profile(True)."""
+        import ctypes
+        ms, n, fl = ctypes.c_double(), ctypes.c_int64(), ctypes.c_double()
+        self._check(self._lib.bcx_project_profile_read(ctypes.byref(ms), ctypes.byref(n), ctypes.byref(fl)))
+        return ms.value, n.value, fl.value
+
+    def _launch(self, fn, args, Z):
+        self._check(fn(*args))
+
     def _dev(self, pts):
         """Device copy of a host array.  The copy of the LAST large array is kept and reused only when the very same
         ndarray object comes back (SparseVI projects ``self.data`` 1 + opt_itrs times per step) -- the projector
@@ -155,7 +169,7 @@ class DeviceProjector(Projector):
         out = torch.empty((N, S), dtype=torch.float64, device=self.device)
         rowsum = torch.empty(max(N, 1), dtype=torch.float64, device=self.device)
         if N:
-            self._check(self._lib.bcx_project_write(*self._common(Z), out.data_ptr(), S, rowsum.data_ptr()))
+            self._launch(self._lib.bcx_project_write, self._common(Z) + [out.data_ptr(), S, rowsum.data_ptr()], Z)
         return out
 
     # -- fused consumers (SparseVI) -------------------------------------------------
@@ -172,7 +186,7 @@ class DeviceProjector(Projector):
         S = self.theta.shape[0]
         col = torch.empty(S, dtype=torch.float64, device=self.device)
         if Z.shape[0]:
-            self._check(self._lib.bcx_project_colsum(*self._common(Z), col.data_ptr(), self._workspace(S).data_ptr()))
+            self._launch(self._lib.bcx_project_colsum, self._common(Z) + [col.data_ptr(), self._workspace(S).data_ptr()], Z)
         else:
             col.zero_()
         if self._world > 1:
@@ -192,8 +206,8 @@ class DeviceProjector(Projector):
         r = torch.from_numpy(np.ascontiguousarray(resid, dtype=np.float64)).to(self.device)
         res = torch.empty(2, dtype=torch.float64, device=self.device)
         if Z.shape[0]:
-            self._check(self._lib.bcx_project_select(*self._common(Z), r.data_ptr(), float(np.sum(resid)), res.data_ptr(),
-                                                     self._workspace(S).data_ptr()))
+            self._launch(self._lib.bcx_project_select, self._common(Z) + [r.data_ptr(), float(np.sum(resid)), res.data_ptr(),
+                                                                  self._workspace(S).data_ptr()], Z)
             h = res.cpu()
             best, row = float(h[0]), int(h[1:2].view(torch.int64)[0])
             row = int(row_ids[row]) if row_ids is not None else row + self.row_offset

@@ -74,6 +74,10 @@ class ShardedSolver(object):
         self.last_trace = None
         self._flat_gather = True
         self.exchange = "collective"
+        # how the exchange mode was decided (reported by bench.py as config.exchange_probe)
+        self.probe_info = {"attempted": False, "result": None, "reason": "single shard" if self.world == 1 else
+                           ("BCX_EXCHANGE=%s" % os.environ.get("BCX_EXCHANGE") if os.environ.get("BCX_EXCHANGE", "mailbox") != "mailbox"
+                            else "engine has no peer mailbox")}
         if self.world > 1 and hasattr(self.engine, "exchange_export") \
                 and os.environ.get("BCX_EXCHANGE", "mailbox") == "mailbox":
             self._setup_mailbox()
@@ -90,6 +94,7 @@ class ShardedSolver(object):
         import logging
         import socket
         handle, why = None, ""
+        self.probe_info = {"attempted": True, "result": None, "reason": ""}
         try:
             handle = self.engine.exchange_export()
         except nat.EngineError as e:
@@ -110,10 +115,13 @@ class ShardedSolver(object):
                 res = -2
             ok = res == 1
             why = why or "probe result %d" % res
+            self.probe_info["result"] = int(res)
             if self._agree(ok):
                 self.exchange = "mailbox"
+                self.probe_info["reason"] = "probe exchange delivered every shard's record intact"
                 return
         self.engine.exchange_disable()
+        self.probe_info["reason"] = why or "a peer failed"
         if self.rank == 0:
             logging.getLogger().warning("sharded build: peer mailbox unavailable (%s); using the all-gather exchange",
                                         why or "a peer failed")

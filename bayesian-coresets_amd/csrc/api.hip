@@ -552,16 +552,15 @@ extern "C" int bcx_build_poll(bcx_solver* s, int64_t* n_done, int32_t* need_exac
   if (need_exact) *need_exact = (h.halt == HALT_NEED_EXACT);
   if (limit) *limit = h.limit;
   if (s->profile) {
-    // launches issued after the state machine stopped (end of call, latch) return at once: keep only
-    // launches that did the scan (within 4x of the slowest one of this batch)
-    std::vector<float> ms(s->prof_used, 0.f);
-    float mx = 0.f;
+    // launches issued after the state machine stopped (end of call, latch) return at once: keep only launches that
+    // did the scan -- one that "read" the shard faster than 1.5x the HBM peak cannot have (a whole batch may consist
+    // of such launches, e.g. everything enqueued after a latch, so the test is absolute, not relative to the batch)
+    const double min_ms = (double)s->cfg.n_local * s->cfg.d * s->elem / 12.0e9;
     for (size_t i = 0; i < s->prof_used; ++i) {
-      if (hipEventElapsedTime(&ms[i], s->prof_events[i].first, s->prof_events[i].second) != hipSuccess) ms[i] = 0.f;
-      mx = std::max(mx, ms[i]);
+      float ms = 0.f;
+      if (hipEventElapsedTime(&ms, s->prof_events[i].first, s->prof_events[i].second) != hipSuccess) continue;
+      if ((double)ms >= min_ms) { s->prof_ms += ms; s->prof_launches++; }
     }
-    for (size_t i = 0; i < s->prof_used; ++i)
-      if (ms[i] > 0.25f * mx) { s->prof_ms += ms[i]; s->prof_launches++; }
     s->prof_used = 0;
   }
   return BCX_OK;

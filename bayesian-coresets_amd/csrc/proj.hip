@@ -13,6 +13,8 @@
 // Arithmetic is fp64 throughout (the selection compares correlations to ~1e-7).
 #include <algorithm>
 #include <string>
+#include <utility>
+#include <vector>
 #include "bcx_internal.h"
 #include "dev_util.h"
 
@@ -441,7 +443,29 @@ static int proj_grid(int64_t N) {
   return (int)std::max<int64_t>(1, std::min<int64_t>(blocks, resident));
 }
 
+// ---- measurement: hipEvents around the projection kernel alone, on the stream it runs on (bcx_project_profile) ----
+namespace {
+struct ProjProfile {
+  bool on = false;
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> ev;
+  size_t used = 0;
+  double ms = 0.0, flops = 0.0;
+  int64_t launches = 0;
+};
+thread_local ProjProfile g_prof;
+}  // namespace
+
 template <int FAM, int MODE> static int launch_one(bool aligned, dim3 grid, size_t shmem, hipStream_t st, const ProjArgs& p) {
+  const bool timed = g_prof.on;
+  if (timed) {
+    if (g_prof.used == g_prof.ev.size()) {
+      hipEvent_t a, b;
+      PROJ_HIP(hipEventCreate(&a));
+      PROJ_HIP(hipEventCreate(&b));
+      g_prof.ev.emplace_back(a, b);
+    }
+    PROJ_HIP(hipEventRecord(g_prof.ev[g_prof.used].first, st));
+  }
   if (aligned) {
     PROJ_HIP(hipFuncSetAttribute((const void*)proj_kernel<FAM, MODE, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
     hipLaunchKernelGGL((proj_kernel<FAM, MODE, true>), grid, dim3(256), shmem, st, p);
@@ -450,6 +474,34 @@ template <int FAM, int MODE> static int launch_one(bool aligned, dim3 grid, size
     hipLaunchKernelGGL((proj_kernel<FAM, MODE, false>), grid, dim3(256), shmem, st, p);
   }
   PROJ_HIP(hipGetLastError());
+  if (timed) {
+    PROJ_HIP(hipEventRecord(g_prof.ev[g_prof.used].second, st));
+    g_prof.used++;
+    g_prof.flops += 2.0 * (double)p.N * p.D * p.S;
+  }
+  return BCX_OK;
+}
+
+// on != 0: start timing every projection-kernel launch of this host thread; on == 0: stop.
+extern "C" int bcx_project_profile(int32_t on) {
+  g_prof.on = on != 0;
+  if (on) { g_prof.used = 0; g_prof.ms = 0.0; g_prof.flops = 0.0; g_prof.launches = 0; }
+  return BCX_OK;
+}
+// Totals since bcx_project_profile(1): kernel milliseconds (synchronises on the recorded events), launches and the
+// algorithmic flops 2 N D S of those launches.
+extern "C" int bcx_project_profile_read(double* ms_total, int64_t* launches, double* flops) {
+  for (size_t i = 0; i < g_prof.used; ++i) {
+    float ms = 0.f;
+    PROJ_HIP(hipEventSynchronize(g_prof.ev[i].second));
+    PROJ_HIP(hipEventElapsedTime(&ms, g_prof.ev[i].first, g_prof.ev[i].second));
+    g_prof.ms += ms;
+    g_prof.launches++;
+  }
+  g_prof.used = 0;
+  if (ms_total) *ms_total = g_prof.ms;
+  if (launches) *launches = g_prof.launches;
+  if (flops) *flops = g_prof.flops;
   return BCX_OK;
 }
 

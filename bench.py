@@ -1,14 +1,22 @@
 #!/usr/bin/env python3
-"""Headline benchmark: greedy coreset iterations/sec on synthetic N x d vectors.
+"""Headline benchmark: greedy coreset iterations/sec on the workloads BASELINE.json names.
 
-    python bench.py [--gpus N --steps K --warmup W] [--alg fw|giga|omp] [--rows N] [--dim d]
+    python bench.py [--gpus N --steps K --warmup W] [--config c4|c2|c3|c5] [--alg fw|giga|omp --rows N --dim d]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-A "step" is one greedy iteration: one pass of the hot path (correlation scan over all N rows +
-arg-max + reweight) -- BASELINE.json metric "greedy coreset iterations/sec (N=10M, d=512)".
-Default workload = BASELINE.json configs[3] shape: N = 10,000,000 rows, d = 512, Frank-Wolfe,
-row-sharded over --gpus ranks (total N fixed => "scaling": "strong").  Inputs are generated on
-the device (seeded per 8192-row block, so the matrix is the same for every shard count) and are
+A "step" is one greedy iteration: one pass of the hot path over the resident rows.
+
+  c4 (default)  BASELINE.json configs[3] and the metric's own config: synthetic randn N = 10,000,000, d = 512,
+                Frank-Wolfe, row-sharded over --gpus ranks (total N fixed => "scaling": "strong").
+  c2            configs[1]: synthetic randn N = 1,000,000, d = 256, GIGA.
+  c3            configs[2]: Laplace-projected logistic-regression vectors (examples/simple_lr pipeline: data, Laplace fit
+                at the MAP, S = 512 posterior samples, log-likelihood projection ON THE DEVICE), N = 1,000,000, OMP.
+  c5            configs[4]: SparseVICoreset on the RBF-basis linear regression (D = 301 = 6 scales x 50 bases + 1,
+                S = 256, opt_itrs = 100), N = 5,000,000 rows sharded over --gpus ranks; a step is one greedy SparseVI
+                step = 1 + opt_itrs full-data projections; the dominant kernel is the fp64-MFMA projection.
+  --alg/--rows/--dim without --config: ad-hoc synthetic randn workload (sweeps, tests).
+
+Inputs are generated on the device (seeded per 8192-row block, so the matrix is the same for every shard count) and are
 resident in HBM before the timed region.  Rank 0 prints ONE JSON line.
 """
 import argparse
@@ -25,31 +33,58 @@ os.environ["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(ROOT, "bayesian-coresets_amd"))
+sys.path.insert(0, os.path.join(ROOT, "bayesian-coresets_amd", "examples", "common"))
 sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
-GEN_BLOCK = 8192        # rows per seeded generation block (multiple of the 1024-row engine chunk)
+HBM_PEAK_GBS = 8000.0     # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
+F64_MFMA_PEAK_TF = 78.6   # MI355X fp64 matrix peak
+GEN_BLOCK = 8192          # rows per seeded generation block (multiple of the 1024-row engine chunk)
 
-
-PROFILE_EVERY = 8   # hipEvent pairs around every 8th scan launch of the timed region (a pair costs 7-12 us of stream time)
+CONFIGS = {
+    "c2": dict(kind="synthetic", alg="giga", rows=1_000_000, dim=256, what="BASELINE.json configs[1]"),
+    "c3": dict(kind="logistic", alg="omp", rows=1_000_000, dim=512, what="BASELINE.json configs[2]"),
+    "c4": dict(kind="synthetic", alg="fw", rows=10_000_000, dim=512, what="BASELINE.json configs[3] (the metric's config)"),
+    "c5": dict(kind="sparsevi", alg=None, rows=5_000_000, dim=256, what="BASELINE.json configs[4]"),
+}
 
 
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=300)
-    ap.add_argument("--warmup", type=int, default=30)
-    ap.add_argument("--alg", default="fw", choices=["fw", "giga", "omp"])
-    ap.add_argument("--rows", type=int, default=10_000_000)
-    ap.add_argument("--dim", type=int, default=512)
+    ap.add_argument("--steps", type=int, default=None)
+    ap.add_argument("--warmup", type=int, default=None)
+    ap.add_argument("--config", default=None, choices=sorted(CONFIGS))
+    ap.add_argument("--alg", default=None, choices=["fw", "giga", "omp"])
+    ap.add_argument("--rows", type=int, default=None)
+    ap.add_argument("--dim", type=int, default=None, help="row length d of the vectors (c3 / c5: the number of samples S)")
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--dtype", default="float32", choices=["float32", "float64", "float16"],
                     help="storage of the normalised rows (state and re-score are always fp64)")
     ap.add_argument("--no-exact-rows", action="store_true", help="do not keep the raw fp64 rows resident")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-exact-mode", action="store_true", help="skip the fp64-stored-rows figure of the c4 line")
     ap.add_argument("--cpu-rows", type=int, default=200_000, help="rows of the CPU-baseline sample")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
-    return ap.parse_args()
+    ap.add_argument("--opt-itrs", type=int, default=100, help="c5: ADAM steps per greedy step (sparsevi.py:7)")
+    ap.add_argument("--features", type=int, default=10, help="c3: regression features D (simple_lr/main.py:24)")
+    a = ap.parse_args()
+    explicit = a.config is not None
+    if a.config is None:
+        a.config = "c4"
+    c = dict(CONFIGS[a.config])
+    adhoc = not explicit and (a.alg or a.rows or a.dim)
+    a.kind = c["kind"]
+    a.alg = a.alg or c["alg"]
+    a.rows = a.rows or c["rows"]
+    a.dim = a.dim or c["dim"]
+    a.what = "ad-hoc synthetic workload" if adhoc else c["what"]
+    # (c3: OMP on these vectors reaches its numeric floor after ~100 points -- the log-likelihood functions of a
+    # 10-parameter model span a space of low numerical rank -- and latches near iteration 160: stay below that)
+    if a.steps is None:
+        a.steps = {"sparsevi": 3, "logistic": 100}.get(a.kind, 300)
+    if a.warmup is None:
+        a.warmup = {"sparsevi": 1, "logistic": 20}.get(a.kind, 30)
+    return a
 
 
 def gen_block(torch, seed, block_id, rows, d, device):
@@ -58,23 +93,20 @@ def gen_block(torch, seed, block_id, rows, d, device):
     return torch.randn(rows, d, device=device, dtype=torch.float64, generator=g)
 
 
-def cpu_baseline(args, alg, torch):
-    """The oracle's faithful mode (reference op sequence: 5 passes of OpenBLAS dgemv/dgemm per
-    iteration, fp64) timed on this box's host cores on a bounded sample of the same workload."""
-    from oracle.snnls_oracle import SnnlsOracle
+def host_threads():
     try:
         from threadpoolctl import threadpool_info
-        threads = max([p.get("num_threads", 1) for p in threadpool_info()] or [1])
+        return max([p.get("num_threads", 1) for p in threadpool_info()] or [1])
     except Exception:
-        threads = os.cpu_count() or 1
-    n_s = min(args.cpu_rows, args.rows)
-    n_s = (n_s // GEN_BLOCK) * GEN_BLOCK or n_s
-    parts = []
-    for blk in range((n_s + GEN_BLOCK - 1) // GEN_BLOCK):
-        m = min(GEN_BLOCK, n_s - blk * GEN_BLOCK)
-        parts.append(gen_block(torch, args.seed, blk, m, args.dim, "cuda").cpu().numpy())
-    X = np.concatenate(parts, axis=0)
-    o = SnnlsOracle(X.T, X.sum(axis=0), alg=alg, mode="faithful")
+        return os.cpu_count() or 1
+
+
+def cpu_baseline_snnls(args, X, what):
+    """The oracle's faithful mode (reference op sequence: 5 passes of OpenBLAS dgemv/dgemm per iteration, fp64) timed on
+    this box's host cores on a bounded sample X (n_s x d) of the same workload, scaled linearly in N."""
+    from oracle.snnls_oracle import SnnlsOracle
+    n_s = X.shape[0]
+    o = SnnlsOracle(X.T, X.sum(axis=0), alg=args.alg, mode="faithful")
     o.build(3)  # warm-up
     done, t0 = 0, time.perf_counter()
     while True:
@@ -86,13 +118,351 @@ def cpu_baseline(args, alg, torch):
     its_sample = done / el
     scale = n_s / float(args.rows)   # cost per iteration is linear in N
     return {
-        "value": its_sample * scale,
-        "unit": "iterations/s",
-        "cores": int(threads),
-        "kind": "port",
-        "sample": "oracle faithful mode (NumPy/OpenBLAS fp64, reference op sequence), %s, first %d of %d rows, "
-                  "d=%d, %d iterations in %.1f s = %.2f it/s on the sample, scaled linearly in N (x%.4f)"
-                  % (alg, n_s, args.rows, args.dim, done, el, its_sample, scale),
+        "value": its_sample * scale, "unit": "iterations/s", "cores": int(host_threads()), "kind": "port",
+        "sample": "oracle faithful mode (NumPy/OpenBLAS fp64, reference op sequence), %s, %s, first %d of %d rows, d=%d, "
+                  "%d iterations in %.1f s = %.2f it/s on the sample, scaled linearly in N (x%.4f)"
+                  % (args.alg, what, n_s, args.rows, X.shape[1], done, el, its_sample, scale),
+    }
+
+
+# =====================================================================================================================
+# greedy sparse-NNLS workloads (c2, c3, c4, ad hoc): step = one greedy iteration of HilbertCoreset's solver
+# =====================================================================================================================
+def load_synthetic(args, torch, solver):
+    lo, hi = solver.row_begin, solver.row_end
+    SUPER = 32 * GEN_BLOCK   # rows handed to the engine per ingest call (1 GiB of fp64 at d=512)
+    buf = torch.empty(SUPER, args.dim, dtype=torch.float64, device="cuda")
+    r = lo
+    while r < hi:
+        s0 = (r // GEN_BLOCK) * GEN_BLOCK                 # first generation block touching row r
+        s1 = min(((hi + GEN_BLOCK - 1) // GEN_BLOCK) * GEN_BLOCK, s0 + SUPER,
+                 ((args.rows + GEN_BLOCK - 1) // GEN_BLOCK) * GEN_BLOCK)
+        for b0 in range(s0, s1, GEN_BLOCK):
+            m = min(GEN_BLOCK, args.rows - b0)
+            g = torch.Generator(device="cuda")
+            g.manual_seed(args.seed * 1_000_003 + b0 // GEN_BLOCK)
+            torch.randn(m, args.dim, dtype=torch.float64, device="cuda", generator=g, out=buf[b0 - s0:b0 - s0 + m])
+        a, b = max(lo, s0), min(hi, s1, args.rows)
+        solver.load_local(buf[a - s0:b - s0], a - lo)
+        torch.cuda.synchronize()
+        r = b
+    del buf
+
+
+def logistic_rows(args, torch, lo, hi):
+    """Rows [lo, hi) of the simple_lr data set (examples/simple_lr/main.py:22-35: x ~ N(0, I_D), theta = 3 * 1,
+    y ~ Bernoulli(sigmoid(x.theta)), z = y x), generated on the device per seeded 8192-row block."""
+    D = args.features
+    out = torch.empty(hi - lo, D, dtype=torch.float64, device="cuda")
+    for b0 in range((lo // GEN_BLOCK) * GEN_BLOCK, hi, GEN_BLOCK):
+        m = min(GEN_BLOCK, args.rows - b0)
+        g = torch.Generator(device="cuda")
+        g.manual_seed(args.seed * 1_000_003 + b0 // GEN_BLOCK)
+        X = torch.randn(m, D, dtype=torch.float64, device="cuda", generator=g)
+        u = torch.rand(m, dtype=torch.float64, device="cuda", generator=g)
+        y = (u <= torch.sigmoid(3.0 * X.sum(dim=1))).double() * 2.0 - 1.0
+        Zb = X * y[:, None]
+        a, b = max(lo, b0), min(hi, b0 + m)
+        out[a - lo:b - lo] = Zb[a - b0:b - b0]
+    return out
+
+
+def load_logistic(args, torch, dist, world, solver, info):
+    """config 3: Laplace fit at the MAP over ALL rows (simple_lr/main.py:57-63; data sums all-reduced when sharded),
+    S posterior samples, projection of the local rows on the device, ingest."""
+    import model_lr
+    import bayesiancoresets_amd as bc
+    lo, hi = solver.row_begin, solver.row_end
+    Z = logistic_rows(args, torch, lo, hi)
+
+    def allreduce(t):
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        return t
+    t0 = time.perf_counter()
+    mu, cov = model_lr.laplace_fit(Z, allreduce=allreduce if world > 1 else None)
+    samples = np.random.RandomState(args.seed + 1).multivariate_normal(mu, cov, args.dim)   # simple_lr/main.py:74
+    t1 = time.perf_counter()
+    prj = bc.DeviceProjector("logistic", lambda n, w, p: samples[:n], args.dim, device=torch.cuda.current_device())
+    prj.profile(True)
+    vecs = prj.project(Z)
+    torch.cuda.synchronize()
+    t2 = time.perf_counter()
+    pms, pl, pfl = prj.profile_read()
+    prj.profile(False)
+    solver.load_local(vecs)
+    torch.cuda.synchronize()
+    t3 = time.perf_counter()
+    nrm = torch.linalg.vector_norm(vecs, dim=1)
+    info.update({"laplace_fit_s": t1 - t0, "projection_s": t2 - t1, "ingest_s": t3 - t2, "features": args.features,
+                 "projection_kernel_ms": pms, "projection_kernel_gelem_per_s": (hi - lo) * args.dim / max(pms, 1e-9) / 1e6,
+                 "row_norm_min": float(nrm.min()), "row_norm_max": float(nrm.max())})
+    sample = vecs[:min(args.cpu_rows, hi - lo)].cpu().numpy() if lo == 0 else None
+    del vecs, Z
+    return sample
+
+
+def run_snnls(args, torch, dist, nat, world, rank, local_rank):
+    from bayesiancoresets_amd.sharded import ShardedSolver
+    alg = {"giga": nat.ALG_GIGA, "fw": nat.ALG_FW, "omp": nat.ALG_OMP}[args.alg]
+    store = {"float64": nat.F64, "float16": nat.F16}.get(args.dtype, nat.F32)
+    elem = {nat.F64: 8, nat.F16: 2}.get(store, 4)
+    info = {}
+    solver = ShardedSolver(alg, args.rows, args.dim, device=local_rank, store_dtype=store,
+                           keep_exact_rows=not args.no_exact_rows)
+    cpu_sample = None
+    if args.kind == "logistic":
+        cpu_sample = load_logistic(args, torch, dist, world, solver, info)
+    else:
+        load_synthetic(args, torch, solver)
+    rc = solver.finalize(None)
+    if rc != nat.OK:
+        raise SystemExit("finalize failed: %d" % rc)
+
+    def sync():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    def build(s, n):
+        """solver.build with the safety net of the sharded path: if the device-side record exchange fails
+        (it raises on every rank: timeout or trace mismatch), redo the work over the RCCL all-gather."""
+        try:
+            return s.build(n)
+        except Exception as e:   # (EngineError in practice; anything else is treated the same way)
+            if s.exchange != "mailbox":
+                raise
+            if rank == 0:
+                print("bench: peer mailbox exchange failed (%s); falling back to the all-gather" % e, file=sys.stderr)
+            s.fallback_to_collective()
+            s.probe_info["reason"] = "mailbox failed mid-run (%s); fell back to the all-gather" % e
+            s.engine.reset()
+            return s.build(n)
+
+    def timed(s, warmup, steps):
+        """(elapsed seconds over ranks, trace, scan ms total, scan launches, events-every) for exactly `steps` iterations"""
+        if warmup > 0:
+            build(s, warmup)
+        if os.environ.get("BENCH_TEST_EXPIRE_MAILBOX") and s.exchange == "mailbox":
+            s.engine.exchange_set_timeout(1e-7)      # tests: every later wait expires -> the fall-back above runs
+        # an event pair costs 7-12 us of stream time: sample every 8th scan launch on long runs, time EVERY launch when
+        # the timed region is short (< 64 steps: too few samples otherwise)
+        every = 1 if steps < 64 else 8
+        if not os.environ.get("BENCH_NO_EVENTS"):
+            s.engine.profile(every)
+        sync()
+        t0 = time.perf_counter()
+        tr = build(s, steps)
+        sync()
+        el = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([el], dtype=torch.float64, device="cuda")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            el = float(t.item())
+        ms, launches = s.engine.profile_read()
+        s.engine.profile(False)
+        return el, tr, ms, launches, every
+
+    elapsed, tr, scan_ms, scan_launches, every = timed(solver, args.warmup, args.steps)
+    sel, err, status = tr
+    steps_done = len(sel)
+    out = None
+    if rank == 0:
+        bytes_per_launch = float(solver.n_local) * args.dim * elem
+        avg_ms = scan_ms / max(scan_launches, 1)
+        achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+        names = {"fw": "Frank-Wolfe", "giga": "GIGA", "omp": "OMP"}
+        if args.kind == "logistic":
+            workload = ("Laplace-projected logistic-regression vectors (simple_lr pipeline, projection on the device) N=%d "
+                        "features=%d S=d=%d, %s, %d row shard(s), M=%d greedy iterations"
+                        % (args.rows, args.features, args.dim, names[args.alg], world, args.steps))
+        else:
+            workload = ("synthetic randn N=%d d=%d, %s, %d row shard(s), M=%d greedy iterations"
+                        % (args.rows, args.dim, names[args.alg], world, args.steps))
+        out = {
+            "metric": "greedy coreset iterations/sec (N=%d, d=%d)" % (args.rows, args.dim),
+            "value": steps_done / elapsed, "unit": "iterations/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / max(steps_done, 1) * 1e3, "higher_is_better": True, "scaling": "strong",
+            "vs_baseline": None,
+            "dtype": {nat.F32: "f32 scan + f64 state", nat.F16: "f16 rows, f32 scan + f64 state"}.get(store, "f64"),
+            "data": "synthetic",
+            "config": dict({
+                "workload": workload, "name": args.config, "baseline_config": args.what,
+                "alg": args.alg, "rows": args.rows, "dim": args.dim, "rows_per_gpu": solver.n_local,
+                "exchange": solver.exchange if world > 1 else None,   # mailbox = device-side P2P stores; collective = all-gather
+                "exchange_probe": solver.probe_info,
+                "exact_rows_resident": not args.no_exact_rows,
+                "iterations_run": int(steps_done), "reached_numeric_limit": bool(solver.reached_numeric_limit),
+                "steps_accepted": int((status == 0).sum()), "final_error": float(err[-1]) if len(err) else None,
+                "rescue": solver.engine.stats(),   # fp64 re-scored candidates / exact-scan fallbacks since construction
+            }, **info),
+            "roofline": {
+                "bound": "hbm", "kernel": "scan_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS, "traffic": measured_traffic(args, solver.n_local),
+                "avg_launch_ms": avg_ms, "launches": int(scan_launches), "timed_every": every,
+                "algorithmic_bytes_per_launch": bytes_per_launch,
+            },
+        }
+    # ---- the same workload with fp64-stored rows (the reference's own arithmetic end to end), c4 line only ----------
+    if args.config == "c4" and args.kind == "synthetic" and store == nat.F32 and not args.no_exact_mode and world == 1:
+        del solver
+        torch.cuda.empty_cache()
+        ex = ShardedSolver(alg, args.rows, args.dim, device=local_rank, store_dtype=nat.F64, keep_exact_rows=False)
+        load_synthetic(args, torch, ex)
+        if ex.finalize(None) != nat.OK:
+            raise SystemExit("finalize (exact mode) failed")
+        n_ex = min(args.steps, 60)
+        el, tr2, ms2, l2, ev2 = timed(ex, min(args.warmup, 5), n_ex)
+        if rank == 0:
+            b64 = float(ex.n_local) * args.dim * 8
+            a2 = b64 / (ms2 / max(l2, 1) * 1e-3) / 1e9 if ms2 > 0 else 0.0
+            out["config"]["exact_mode"] = {
+                "what": "rows stored in fp64 (dtype='float64'): every score is the reference's fp64 dot product, no candidate window",
+                "iterations_per_s": len(tr2[0]) / el, "ms_per_step": el / max(len(tr2[0]), 1) * 1e3, "steps": n_ex,
+                "scan_GBps": a2, "scan_frac_of_hbm_peak": a2 / HBM_PEAK_GBS, "algorithmic_bytes_per_launch": b64,
+            }
+        del ex
+    if rank == 0 and not args.no_cpu_baseline and world == 1:
+        if args.kind == "logistic":
+            X = cpu_sample
+            what = "Laplace-projected logistic vectors"
+        else:
+            n_s = min(args.cpu_rows, args.rows)
+            n_s = (n_s // GEN_BLOCK) * GEN_BLOCK or n_s
+            parts = [gen_block(torch, args.seed, blk, min(GEN_BLOCK, n_s - blk * GEN_BLOCK), args.dim, "cuda").cpu().numpy()
+                     for blk in range((n_s + GEN_BLOCK - 1) // GEN_BLOCK)]
+            X = np.concatenate(parts, axis=0)
+            what = "synthetic randn"
+        out["cpu_baseline"] = cpu_baseline_snnls(args, X, what)
+    return out
+
+
+def measured_traffic(args, n_local):
+    """HBM bytes per scan launch from the committed PMC pass (profiles/scan_traffic.json) -- only if that pass was taken
+    with THIS tree's kernel sources (stamp = tools/stamp.py); otherwise null rather than a stale constant."""
+    tpath = os.path.join(ROOT, "profiles", "scan_traffic.json")
+    try:
+        from tools.stamp import source_digest
+        tj = json.load(open(tpath))
+        if tj.get("_stamp") != source_digest():
+            return None
+        return tj.get("%s_n%d_d%d_%s" % (args.alg, n_local, args.dim, args.dtype))
+    except Exception:
+        return None
+
+
+# =====================================================================================================================
+# config 5: SparseVI on the RBF-basis regression; step = one greedy step = (1 + opt_itrs) full-data projections
+# =====================================================================================================================
+def run_sparsevi(args, torch, dist, nat, world, rank, local_rank):
+    import bayesiancoresets_amd as bc
+    import rbf_workload
+    import model_linreg
+    from bayesiancoresets_amd.sharded import shard_bounds
+    N, S, nb = args.rows, args.dim, 50
+    D = 6 * nb + 1
+    lo, hi = shard_bounds(N, world)[0][rank]
+    # observations: every rank draws the same small pilot (basis centres, prior statistics) and its own rows
+    rs = np.random.RandomState(args.seed)
+    pilot = rbf_workload.synthetic_observations(200_000, rs)
+    scales, centres = rbf_workload.basis_layout(pilot, nb, rs)
+    std, mean = pilot[:, 2].std(), pilot[:, 2].mean()
+    mu0, Sig0, sigsq = mean * np.ones(D), (std ** 2 + mean ** 2) * np.eye(D), float(std ** 2)
+    obs = torch.empty(hi - lo, 3, dtype=torch.float64, device="cuda")
+    for b0 in range((lo // GEN_BLOCK) * GEN_BLOCK, hi, GEN_BLOCK):
+        m = min(GEN_BLOCK, N - b0)
+        g = torch.Generator(device="cuda")
+        g.manual_seed(args.seed * 1_000_003 + b0 // GEN_BLOCK)
+        loc = torch.rand(m, 2, dtype=torch.float64, device="cuda", generator=g)
+        eps = torch.randn(m, dtype=torch.float64, device="cuda", generator=g)
+        price = 5.3 + 0.35 * torch.sin(3.0 * loc[:, 0]) * torch.cos(2.0 * loc[:, 1]) + 0.25 * loc[:, 0] * loc[:, 1] + 0.15 * eps
+        a, b = max(lo, b0), min(hi, b0 + m)
+        obs[a - lo:b - lo, :2] = loc[a - b0:b - b0]
+        obs[a - lo:b - lo, 2] = price[a - b0:b - b0]
+    Z = rbf_workload.design_rows_device(torch, obs, scales, centres)       # (hi - lo) x 302, resident
+    del obs
+    group = dist.group.WORLD if world > 1 else None
+    sampler = model_linreg.posterior_sampler(mu0, Sig0, sigsq, device="cuda", seed=args.seed + 7)
+    np.random.seed(args.seed)
+    prj = bc.DeviceProjector("linreg", sampler, S, sigsq=sigsq, device=local_rank, group=group, row_offset=lo)
+    alg = bc.SparseVICoreset(Z, prj, opt_itrs=args.opt_itrs, row_offset=lo, group=group) if world > 1 else \
+        bc.SparseVICoreset(Z, prj, opt_itrs=args.opt_itrs)
+
+    def sync():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+    if args.warmup > 0:
+        alg.build(args.warmup)
+    prj.profile(True)
+    sync()
+    t0 = time.perf_counter()
+    alg.build(args.steps)
+    sync()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    kms, launches, flops = prj.profile_read()
+    prj.profile(False)
+    if rank != 0:
+        return None
+    # (the k-point core projections are launches too: their flops and time are in the totals, weight ~1e-5)
+    per_launch_flops = 2.0 * (hi - lo) * D * S
+    achieved = flops / (kms * 1e-3) / 1e12 if kms > 0 else 0.0
+    out = {
+        "metric": "SparseVI greedy steps/sec (N=%d, D=%d, S=%d, opt_itrs=%d)" % (N, D, S, args.opt_itrs),
+        "value": args.steps / elapsed, "unit": "greedy steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+        "dtype": "f64", "data": "synthetic",
+        "config": {
+            "workload": "SparseVICoreset on the synthetic RBF-basis linear regression (6 scales x 50 bases + 1 = %d columns), "
+                        "N=%d, S=%d Monte-Carlo samples, opt_itrs=%d, %d row shard(s), %d greedy steps"
+                        % (D, N, S, args.opt_itrs, world, args.steps),
+            "name": "c5", "baseline_config": args.what, "rows": N, "features": D, "dim": S, "rows_per_gpu": hi - lo,
+            "opt_itrs": args.opt_itrs, "projections_per_step": 1 + args.opt_itrs,
+            "sampler": "weighted conjugate posterior on the device (examples/common/model_linreg.py; torch.linalg Cholesky of a "
+                       "%d x %d matrix per ADAM step: the user-callback side of the Projector interface)" % (D, D),
+            "coreset_size": int(alg.size()), "coreset_idcs": [int(i) for i in alg.idcs],
+            "projection_ms_per_step_kernels": kms / args.steps,
+        },
+        "roofline": {
+            "bound": "mfma", "kernel": "proj_kernel", "achieved": achieved, "peak": F64_MFMA_PEAK_TF, "unit": "TFLOP/s",
+            "frac": achieved / F64_MFMA_PEAK_TF, "traffic": None,
+            "avg_launch_ms": kms / max(launches, 1), "launches": int(launches),
+            "algorithmic_flops_per_full_launch": per_launch_flops,
+            "attainable_note": "v_mfma_f64_16x16x4_f64 sustains 47.6 TFLOP/s in a register-only loop on this chip "
+                               "(tools/probe/mfma_f64_peak.hip, profiles/r02_mfma_f64_probe.txt)",
+        },
+    }
+    if not args.no_cpu_baseline and world == 1:
+        out["cpu_baseline"] = cpu_baseline_sparsevi(args, Z, mu0, Sig0, sigsq, S)
+    return out
+
+
+def cpu_baseline_sparsevi(args, Z, mu0, Sig0, sigsq, S):
+    """oracle/sparsevi_oracle.py (NumPy restatement of sparsevi.py + projector.py + model_linreg.py, host sampler of
+    linear_regression/main.py:141-147) timed on a bounded sample of rows: one greedy step after one warm-up step."""
+    from oracle.sparsevi_oracle import SparseVIOracle, linreg_loglik
+    import model_linreg
+    n_s = min(20_000, Z.shape[0])
+    Zs = Z[:n_s].cpu().numpy()
+    np.random.seed(args.seed)
+    itrs = min(args.opt_itrs, 25)      # keep the sample to tens of seconds; cost is linear in 1 + opt_itrs
+    o = SparseVIOracle(Zs, model_linreg.posterior_sampler(mu0, Sig0, sigsq), lambda z, th: linreg_loglik(z, th, sigsq), S,
+                       opt_itrs=itrs)
+    o.step()
+    t0 = time.perf_counter()
+    o.step()
+    el = time.perf_counter() - t0
+    scale = (n_s / float(args.rows)) * ((1.0 + itrs) / (1.0 + args.opt_itrs))
+    return {
+        "value": scale / el, "unit": "greedy steps/s", "cores": int(host_threads()), "kind": "port",
+        "sample": "oracle/sparsevi_oracle.py (NumPy/OpenBLAS fp64: sparsevi.py select + ADAM optimise, host sampler), first %d of "
+                  "%d rows, opt_itrs=%d of %d: one greedy step in %.2f s, scaled linearly in N and in (1 + opt_itrs) (x%.6f)"
+                  % (n_s, args.rows, itrs, args.opt_itrs, el, scale),
     }
 
 
@@ -101,7 +471,6 @@ def main():
     import torch
     import torch.distributed as dist
     from bayesiancoresets_amd import _native as nat
-    from bayesiancoresets_amd.sharded import ShardedSolver
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -121,121 +490,9 @@ def main():
             dist.init_process_group("gloo")
         else:
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-    alg = {"giga": nat.ALG_GIGA, "fw": nat.ALG_FW, "omp": nat.ALG_OMP}[args.alg]
-    store = {"float64": nat.F64, "float16": nat.F16}.get(args.dtype, nat.F32)
-
-    solver = ShardedSolver(alg, args.rows, args.dim, device=local_rank, store_dtype=store,
-                           keep_exact_rows=not args.no_exact_rows)
-    # ---- synthetic data, generated shard-locally, resident before timing ------------------
-    lo, hi = solver.row_begin, solver.row_end
-    SUPER = 32 * GEN_BLOCK   # rows handed to the engine per ingest call (1 GiB of fp64 at d=512)
-    buf = torch.empty(SUPER, args.dim, dtype=torch.float64, device="cuda")
-    r = lo
-    while r < hi:
-        s0 = (r // GEN_BLOCK) * GEN_BLOCK                 # first generation block touching row r
-        s1 = min(((hi + GEN_BLOCK - 1) // GEN_BLOCK) * GEN_BLOCK, s0 + SUPER, 
-                 ((args.rows + GEN_BLOCK - 1) // GEN_BLOCK) * GEN_BLOCK)
-        for b0 in range(s0, s1, GEN_BLOCK):
-            m = min(GEN_BLOCK, args.rows - b0)
-            g = torch.Generator(device="cuda")
-            g.manual_seed(args.seed * 1_000_003 + b0 // GEN_BLOCK)
-            torch.randn(m, args.dim, dtype=torch.float64, device="cuda", generator=g, out=buf[b0 - s0:b0 - s0 + m])
-        a, b = max(lo, s0), min(hi, s1, args.rows)
-        solver.load_local(buf[a - s0:b - s0], a - lo)
-        torch.cuda.synchronize()
-        r = b
-    del buf
-    rc = solver.finalize(None)
-    if rc != nat.OK:
-        raise SystemExit("finalize failed: %d" % rc)
-
-    def sync():
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-            torch.cuda.synchronize()
-
-    def build(n):
-        """solver.build with the safety net of the sharded path: if the device-side record exchange fails
-        (it raises on every rank: timeout or trace mismatch), redo the work over the RCCL all-gather."""
-        try:
-            return solver.build(n)
-        except Exception as e:   # (EngineError in practice; anything else is treated the same way)
-            if solver.exchange != "mailbox":
-                raise
-            if rank == 0:
-                print("bench: peer mailbox exchange failed (%s); falling back to the all-gather" % e, file=sys.stderr)
-            solver.fallback_to_collective()
-            solver.engine.reset()
-            return solver.build(n)
-
-    # ---- warm-up, then time exactly K greedy iterations --------------------------------------
-    if args.warmup > 0:
-        build(args.warmup)
-    if os.environ.get("BENCH_TEST_EXPIRE_MAILBOX") and solver.exchange == "mailbox":
-        solver.engine.exchange_set_timeout(1e-7)      # tests: every later wait expires -> the fall-back below runs
-    if not os.environ.get("BENCH_NO_EVENTS"):      # dev: what do the per-launch hipEvents cost?
-        solver.engine.profile(PROFILE_EVERY)
-    sync()
-    t0 = time.perf_counter()
-    tr = build(args.steps)
-    sync()
-    t1 = time.perf_counter()
-    elapsed = t1 - t0
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-    scan_ms, scan_launches = solver.engine.profile_read()
-    solver.engine.profile(False)
-    sel, err, status = tr
-    steps_done = len(sel)
-
+    run = run_sparsevi if args.kind == "sparsevi" else run_snnls
+    out = run(args, torch, dist, nat, world, rank, local_rank)
     if rank == 0:
-        bytes_per_launch = float(solver.n_local) * args.dim * {nat.F64: 8, nat.F16: 2}.get(store, 4)
-        avg_ms = scan_ms / max(scan_launches, 1)
-        achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "scan_traffic.json")
-        if os.path.exists(tpath):
-            try:
-                tj = json.load(open(tpath))
-                key = "%s_n%d_d%d_%s" % (args.alg, solver.n_local, args.dim, args.dtype)
-                traffic = tj.get(key)
-            except Exception:
-                traffic = None
-        out = {
-            "metric": "greedy coreset iterations/sec (N=%d, d=%d)" % (args.rows, args.dim),
-            "value": steps_done / elapsed,
-            "unit": "iterations/s",
-            "n_gpus": world,
-            "steps": args.steps,
-            "warmup": args.warmup,
-            "ms_per_step": elapsed / max(steps_done, 1) * 1e3,
-            "higher_is_better": True,
-            "scaling": "strong",
-            "vs_baseline": None,
-            "dtype": {nat.F32: "f32 scan + f64 state", nat.F16: "f16 rows, f32 scan + f64 state"}.get(store, "f64"),
-            "data": "synthetic",
-            "config": {
-                "workload": "synthetic randn N=%d d=%d, %s, %d row shard(s), M=%d greedy iterations"
-                            % (args.rows, args.dim, {"fw": "Frank-Wolfe", "giga": "GIGA", "omp": "OMP"}[args.alg],
-                               world, args.steps),
-                "alg": args.alg, "rows": args.rows, "dim": args.dim, "rows_per_gpu": solver.n_local,
-                "exchange": solver.exchange if world > 1 else None,   # mailbox = device-side P2P stores; collective = all-gather
-                "exact_rows_resident": not args.no_exact_rows,
-                "steps_accepted": int((status == 0).sum()), "final_error": float(err[-1]) if len(err) else None,
-                "rescue": solver.engine.stats(),   # fp64 re-scored candidates / exact-scan fallbacks since construction
-            },
-            "roofline": {
-                "bound": "hbm", "kernel": "scan_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                "avg_launch_ms": avg_ms, "launches": int(scan_launches), "timed_every": PROFILE_EVERY,
-                "algorithmic_bytes_per_launch": bytes_per_launch,
-            },
-        }
-        if not args.no_cpu_baseline and world == 1:   # reported once, on the single-GPU run
-            out["cpu_baseline"] = cpu_baseline(args, args.alg, torch)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

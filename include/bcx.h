@@ -195,6 +195,12 @@ int bcx_project_select(void* stream, int32_t family, const void* Z_dev, int64_t 
                        int32_t ycol, const void* theta_dev, int32_t S, int32_t ldt, double param,
                        const void* resid_dev, double resid_sum, void* result_dev, void* work_dev);
 const char* bcx_project_last_error(void);
+/* Measurement: hipEvents around the projection kernel alone, recorded on the stream the kernel is launched on.
+ * bcx_project_profile(1) starts timing every later projection launch of the calling host thread, (0) stops;
+ * bcx_project_profile_read returns the totals since the start: kernel milliseconds, launches, and the algorithmic
+ * flops 2 N D S of those launches (the roofline figure of bench.py --config c5 / c3). */
+int bcx_project_profile(int32_t on);
+int bcx_project_profile_read(double* ms_total, int64_t* launches, double* flops);
 /* Library/arch identification, e.g. "bcx 0.1 gfx950". */
 const char* bcx_version(void);
 

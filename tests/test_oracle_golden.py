@@ -111,3 +111,44 @@ def test_F8_error_paths():
     Y = np.random.RandomState(0).randn(50, 8)
     with pytest.raises(ArithmeticError):
         SnnlsOracle(Y.T, np.zeros(8), alg="giga")
+
+
+# ---- SparseVI oracle (oracle/sparsevi_oracle.py) against the reference's runs F6 / F6b ---------------------------------
+def _svi_oracle_run(data, mu0, Sig0, sigsq, S, opt_itrs, steps):
+    from oracle.sparsevi_oracle import SparseVIOracle, linreg_loglik
+    from models import linreg_sampler
+    np.random.seed(2)
+    o = SparseVIOracle(data, linreg_sampler(mu0, Sig0, sigsq), lambda z, th: linreg_loglik(z, th, sigsq), S, opt_itrs=opt_itrs)
+    hist = []
+    for _ in range(steps):
+        o.step()
+        hist.append((o.idcs.copy(), o.wts.copy()))
+    return hist
+
+
+def test_F6_sparsevi_oracle_matches_reference():
+    import os
+    from models import make_linreg_data
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    g = np.load(os.path.join(root, "tests", "golden", "svi_golden.npz"))
+    N, D, S, sigsq = int(g["N"]), int(g["D"]), int(g["S"]), float(g["sigsq"])
+    hist = _svi_oracle_run(make_linreg_data(1, N, D), np.zeros(D), np.eye(D), sigsq, S, int(g["opt_itrs"]), 3)
+    for i, (idcs, wts) in enumerate(hist):
+        assert np.array_equal(idcs, g["step%d_idcs" % i])
+        np.testing.assert_allclose(wts, g["step%d_wts" % i], rtol=1e-9, atol=1e-12)
+
+
+@pytest.mark.slow
+def test_F6b_sparsevi_oracle_matches_reference_on_rbf_design():
+    import importlib.util
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("rbf_workload", os.path.join(root, "bayesian-coresets_amd", "examples", "common", "rbf_workload.py"))
+    rbf = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(rbf)
+    g = np.load(os.path.join(root, "tests", "golden", "rbf_golden.npz"))
+    wl = rbf.make_rbf_regression(int(g["N"]), int(g["nb"]), seed=1)
+    hist = _svi_oracle_run(wl["Z"], wl["mu0"], wl["Sig0"], wl["sigsq"], int(g["S"]), int(g["opt_itrs"]), 2)
+    for i, (idcs, wts) in enumerate(hist):
+        assert np.array_equal(idcs, g["step%d_idcs" % i])
+        np.testing.assert_allclose(wts, g["step%d_wts" % i], rtol=1e-7, atol=1e-10)
