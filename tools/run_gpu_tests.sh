@@ -7,7 +7,7 @@ TAG=${1:-run}; shift
 OUT=gpurun_out/gputests_$TAG
 mkdir -p "$OUT"
 : > "$OUT/summary.txt"
-echo "head $(git rev-parse --short HEAD 2>/dev/null || echo n/a) libbcx $(sha256sum bayesian-coresets_amd/lib/libbcx.so | cut -c1-16)" >> "$OUT/summary.txt"
+echo "head $(cat bayesian-coresets_amd/lib/HEAD.txt 2>/dev/null || echo n/a) libbcx $(sha256sum bayesian-coresets_amd/lib/libbcx.so | cut -c1-16)" >> "$OUT/summary.txt"
 rc_all=0
 for f in tests/test_gpu_*.py tests/test_*.py; do
   case " $seen " in *" $f "*) continue;; esac
