@@ -21,15 +21,26 @@ def log_likelihood(z, th):
     return out
 
 
+def _matvec(xp, Z, th):
+    # row-wise dot products as an elementwise product + sum: D is ~10, and this keeps the device path free of any
+    # BLAS call (a 1M x 10 GEMV / GEMM through a vendor library costs more in set-up than the arithmetic is worth)
+    return (Z * th).sum(1)
+
+
 def _sums(xp, Z, th, wts):
     """sum_n w_n s_n z_n and sum_n w_n s_n (1 - s_n) z_n z_n^T with s = sigmoid(-z.theta) (0 curvature on the linear tail)."""
-    arg = -(Z @ th)
+    arg = -_matvec(xp, Z, th)
     e = xp.exp(xp.clip(arg, None, 100.0)) if xp is np else xp.exp(xp.clamp(arg, max=100.0))
     s = xp.where(arg < 100, e / (1.0 + e), xp.ones_like(arg))
     c = xp.where(arg < 100, e / (1.0 + e) ** 2, xp.zeros_like(arg))
     if wts is not None:
         s, c = s * wts, c * wts
-    return (s[:, None] * Z).sum(0), (Z * c[:, None]).T @ Z
+    D = Z.shape[1]
+    H = xp.zeros((D, D), dtype=Z.dtype) if xp is np else xp.zeros((D, D), dtype=Z.dtype, device=Z.device)
+    cz = Z * c[:, None]
+    for j in range(D):                                          # D column sums of N-vectors
+        H[j] = (cz * Z[:, j:j + 1]).sum(0)
+    return (s[:, None] * Z).sum(0), H
 
 
 def laplace_fit(Z, wts=None, device=None, tol=1e-10, max_iter=100, allreduce=None):
@@ -52,10 +63,13 @@ def laplace_fit(Z, wts=None, device=None, tol=1e-10, max_iter=100, allreduce=Non
         Z = np.asarray(Z, dtype=np.float64)
         eye = np.eye(Z.shape[1])
         th = Z.mean(axis=0)                                     # simple_lr/main.py:59 starts there too
-    solve = (lambda A, b: np.linalg.solve(A, b)) if xp is np else (lambda A, b: xp.linalg.solve(A, b))
+    if xp is np:
+        solve = np.linalg.solve
+    else:   # the D x D Newton system is solved on the host (D ~ 10): only the N-sized sums run on the device
+        solve = lambda A, b: xp.as_tensor(np.linalg.solve(A.cpu().numpy(), b.cpu().numpy()), device=Z.device)
 
     def objective(t):
-        arg = -(Z @ t)
+        arg = -_matvec(xp, Z, t)
         ll = xp.where(arg < 100, -xp.log1p(xp.exp(xp.clip(arg, None, 100.0) if xp is np else xp.clamp(arg, max=100.0))), -arg)
         if wts is not None:
             ll = ll * wts
@@ -82,10 +96,9 @@ def laplace_fit(Z, wts=None, device=None, tol=1e-10, max_iter=100, allreduce=Non
             break
     _, H1 = _sums(xp, Z, th, wts)
     H1 = ar(H1)
-    cov = (np.linalg.inv(H1 + eye) if xp is np else xp.linalg.inv(H1 + eye))
     if xp is not np:
-        return th.cpu().numpy(), cov.cpu().numpy()
-    return th, cov
+        return th.cpu().numpy(), np.linalg.inv((H1 + eye).cpu().numpy())
+    return th, np.linalg.inv(H1 + eye)
 
 
 def synthetic_rows(n, d, rs):

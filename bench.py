@@ -78,6 +78,7 @@ def parse():
     a.rows = a.rows or c["rows"]
     a.dim = a.dim or c["dim"]
     a.what = "ad-hoc synthetic workload" if adhoc else c["what"]
+    a.adhoc = bool(adhoc)
     # (c3: OMP on these vectors reaches its numeric floor after ~100 points -- the log-likelihood functions of a
     # 10-parameter model span a space of low numerical rank -- and latches near iteration 160: stay below that)
     if a.steps is None:
@@ -287,7 +288,7 @@ def run_snnls(args, torch, dist, nat, world, rank, local_rank):
             "dtype": {nat.F32: "f32 scan + f64 state", nat.F16: "f16 rows, f32 scan + f64 state"}.get(store, "f64"),
             "data": "synthetic",
             "config": dict({
-                "workload": workload, "name": args.config, "baseline_config": args.what,
+                "workload": workload, "name": "adhoc" if args.adhoc else args.config, "baseline_config": args.what,
                 "alg": args.alg, "rows": args.rows, "dim": args.dim, "rows_per_gpu": solver.n_local,
                 "exchange": solver.exchange if world > 1 else None,   # mailbox = device-side P2P stores; collective = all-gather
                 "exchange_probe": solver.probe_info,
@@ -304,7 +305,7 @@ def run_snnls(args, torch, dist, nat, world, rank, local_rank):
             },
         }
     # ---- the same workload with fp64-stored rows (the reference's own arithmetic end to end), c4 line only ----------
-    if args.config == "c4" and args.kind == "synthetic" and store == nat.F32 and not args.no_exact_mode and world == 1:
+    if args.config == "c4" and not args.adhoc and store == nat.F32 and not args.no_exact_mode and world == 1:
         del solver
         torch.cuda.empty_cache()
         ex = ShardedSolver(alg, args.rows, args.dim, device=local_rank, store_dtype=nat.F64, keep_exact_rows=False)

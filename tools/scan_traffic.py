@@ -12,16 +12,17 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from tools.stamp import source_digest
 
 
-def fetch_bytes(db):
+def fetch_bytes(db, key):
+    # the key ends in the storage type: only that instantiation of the scan kernel counts (a bench run may also hold
+    # the fp64-rows scan of its exact-mode leg)
+    inst = {"float32": "scan_kernel<float", "float64": "scan_kernel<double", "float16": "scan_kernel<half_t"}[key.rsplit("_", 1)[1]]
     c = sqlite3.connect(db)
-    rows = c.execute("select avg(counter_value), count(*) from pmc_events where name like '%scan_kernel%' and counter_name = 'FETCH_SIZE' "
-                     "and counter_value > 0").fetchall()
-    # rocpd stores one row per (dispatch, counter instance); sum the instances of a dispatch first when there are several
-    per = c.execute("select dispatch_id, sum(counter_value) from pmc_events where name like '%scan_kernel%' and counter_name = 'FETCH_SIZE' "
-                    "group by dispatch_id").fetchall()
+    # rocpd stores one row per (dispatch, counter instance): sum the instances of a dispatch first
+    per = c.execute("select dispatch_id, sum(counter_value) from pmc_events where name like ? and counter_name = 'FETCH_SIZE' "
+                    "group by dispatch_id", ("%" + inst + "%",)).fetchall()
     vals = sorted(v for _, v in per if v and v > 0)
     if not vals:
-        raise SystemExit("no scan_kernel FETCH_SIZE rows in " + db)
+        raise SystemExit("no %s FETCH_SIZE rows in %s" % (inst, db))
     # launches issued after the state machine stopped read nothing: keep the ones within 2x of the median
     med = vals[len(vals) // 2]
     keep = [v for v in vals if v > 0.5 * med]
@@ -38,7 +39,7 @@ def main():
             data = old
     for item in sys.argv[2:]:
         key, db = item.split("=", 1)
-        b, n = fetch_bytes(db)
+        b, n = fetch_bytes(db, key)
         data[key] = b
         data["_sources"][key] = "%s: %d dispatches" % (os.path.basename(os.path.dirname(db)), n)
         print(key, b, n)
