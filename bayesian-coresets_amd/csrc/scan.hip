@@ -543,10 +543,24 @@ int bcx_launch_scan(bcx_solver* s, int exact) {
   int ur = (CH >= BCX_LOADS_IN_FLIGHT) ? 1 : (BCX_LOADS_IN_FLIGHT / CH > BCX_UR_MAX ? BCX_UR_MAX : BCX_LOADS_IN_FLIGHT / CH);
   const double util = (double)nvec / ((double)G * CH);
   static const int deep_env = getenv("BCX_SCAN_DEEP") ? atoi(getenv("BCX_SCAN_DEEP")) : -1;   // dev: force 0 / 1
-  const bool deep = CH < 16 && (deep_env >= 0 ? deep_env == 1 : (G == 64 && CH >= 2 && util < 0.80));
+  // Row lengths that leave lanes of the group idle (util < 0.85; d = 100: 25 of 32 lanes, d = 300: 75 of 128 slots) run
+  // best with TWO workgroups per CU and 4.5 - 6 USEFUL loads in flight per lane: the row steps are doubled only when
+  // the base depth carries fewer than 4.5 (interleaved A/B on one box, tools/scan_knobs.sh, % of 8 TB/s, FW / GIGA:
+  // d = 100 81/80 -> 84/82, d = 200 81/81 -> 84/81, d = 300 82/76 -> 86/83).  Full groups keep one workgroup per CU.
+  // Shorter groups (G <= 16) and longer rows (CH >= 4) keep the earlier rule (row steps doubled for G = 64, CH >= 2 below
+  // 80 % lane use, launch width from the useful loads per lane): the two-workgroup form measured slower there.
+  const bool ragged = util < 0.85 && G >= 32 && CH <= 2;
+  bool deep;
+  if (deep_env >= 0) deep = CH < 16 && deep_env == 1;
+  else if (ragged) deep = (double)CH * ur * util < 4.5;
+  else deep = CH < 16 && G == 64 && CH >= 2 && util < 0.80;
   if (deep) ur *= 2;
   const int rpb = (BCX_SCAN_THREADS / 64) * (64 / G) * ur;
-  const int grid = scan_grid_for(a.n, rpb, CH * ur * util, f64 && dual);   // idle lanes do not count as loads in flight
+  int grid = scan_grid_for(a.n, rpb, CH * ur * util, f64 && dual);   // idle lanes do not count as loads in flight
+  if (ragged && !(f64 && dual) && !getenv("BCX_SCAN_GRID")) {
+    const int64_t want = (a.n + rpb - 1) / rpb;
+    grid = (int)(want < 512 ? (want < 1 ? 1 : want) : 512);
+  }
   s->n_partials = grid;                     // resolve reads exactly this launch's partials
   a.out = partial_view(s->partials, grid);
   int rc;
