@@ -167,3 +167,81 @@ def test_config4_fw_10m_x_512(bc):
     assert s.size() >= 390
     st = s._eng.stats()
     assert st["exact_fallbacks"] == 0
+
+
+def test_config5_sparsevi_5m_rbf(bc):
+    """BASELINE.json configs[4] at full size on one GPU (the sharded run reproduces it: tests/test_gpu_sharded.py): SparseVI
+    on the RBF-basis regression, N = 5M, D = 301, S = 256.  Two greedy steps (5 ADAM steps each); for every select the
+    reference's arithmetic (sparsevi.py:44-56: full projection, centre, residual, correlations, first arg-max) restated
+    in torch fp64 over ALL rows with the very samples the projector drew must name the point that was added, and the
+    fused column sums must equal the restated ones."""
+    import importlib.util
+    import os
+    import torch
+    from models import linreg_sampler
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("rbf_workload", os.path.join(root, "bayesian-coresets_amd", "examples", "common", "rbf_workload.py"))
+    rbf = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(rbf)
+    N, nb, S, D = 5_000_000, 50, 256, 301
+    rs = np.random.RandomState(1)
+    pilot = rbf.synthetic_observations(100_000, rs)
+    scales, centres = rbf.basis_layout(pilot, nb, rs)
+    std, mean = pilot[:, 2].std(), pilot[:, 2].mean()
+    sigsq = float(std ** 2)
+    g = torch.Generator(device="cuda"); g.manual_seed(11)
+    loc = torch.rand(N, 2, dtype=torch.float64, device="cuda", generator=g)
+    price = 5.3 + 0.35 * torch.sin(3.0 * loc[:, 0]) * torch.cos(2.0 * loc[:, 1]) + 0.25 * loc[:, 0] * loc[:, 1] \
+        + 0.15 * torch.randn(N, dtype=torch.float64, device="cuda", generator=g)
+    Z = rbf.design_rows_device(torch, torch.cat((loc, price[:, None]), dim=1), scales, centres)
+    del loc, price
+    assert Z.shape == (N, D + 1)
+    drawn = []
+    base = linreg_sampler(mean * np.ones(D), (std ** 2 + mean ** 2) * np.eye(D), sigsq)
+
+    def sampler(n, wts, pts):
+        th = base(n, wts, pts)
+        drawn.append(th)
+        return th
+    np.random.seed(5)
+    prj = bc.DeviceProjector("linreg", sampler, S, sigsq=sigsq)
+    alg = bc.SparseVICoreset(Z, prj, opt_itrs=5)
+    clin = -0.5 * np.log(2.0 * np.pi * sigsq)
+
+    def restated(theta, wts, pts):
+        th = torch.from_numpy(theta).cuda()
+
+        def vecs_of(z):
+            m = z[:, :D] @ th.T
+            y = z[:, D:D + 1]
+            ll = clin - (y * y - 2.0 * m * y + m * m) / (2.0 * sigsq)
+            return ll - ll.mean(dim=1, keepdim=True)
+        colsum = torch.zeros(S, dtype=torch.float64, device="cuda")
+        for r in range(0, N, 1 << 17):
+            colsum += vecs_of(Z[r:r + (1 << 17)]).sum(dim=0)
+        resid = colsum.clone()
+        if len(wts):
+            resid -= torch.from_numpy(wts).cuda() @ vecs_of(torch.from_numpy(pts).cuda())
+        best, arg, second = -np.inf, -1, -np.inf
+        for r in range(0, N, 1 << 17):
+            v = vecs_of(Z[r:r + (1 << 17)])
+            corr = (v @ resid) / torch.sqrt((v * v).sum(dim=1)) / S
+            top = torch.topk(corr, 2)
+            for val, idx in zip(top.values.tolist(), top.indices.tolist()):
+                if val > best:
+                    second, best, arg = best, val, r + idx
+                elif val > second:
+                    second = val
+        return colsum.cpu().numpy(), arg, best, second
+
+    for step in range(2):
+        wts0, pts0, n0 = alg.wts.copy(), alg.pts.copy(), len(alg.idcs)
+        alg._select()
+        theta = drawn[-1]                                    # the samples this select projected with
+        colsum, arg, best, second = restated(theta, wts0, pts0)
+        assert best - second > 1e-9 * abs(best), "near-tie in the test input"
+        np.testing.assert_allclose(prj.project_colsum(Z), colsum, rtol=1e-7, atol=1e-9 * np.abs(colsum).max())
+        assert len(alg.idcs) == n0 + 1 and int(alg.idcs[-1]) == arg, "step %d: engine added %s, restated reference %d" % (step, alg.idcs, arg)
+        np.testing.assert_array_equal(alg.pts[-1], Z[arg].cpu().numpy())
+        alg._optimize()
+        assert (alg.wts >= 0).all() and alg.wts[-1] > 0
