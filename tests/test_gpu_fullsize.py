@@ -83,14 +83,14 @@ def _state(torch, s):
     return (torch.as_tensor(idx[keep], device="cuda"), torch.as_tensor(w[keep], device="cuda"), idx, w)
 
 
-def _drive(bc, torch, alg, X, total, omp_kkt=False):
+def _drive(bc, torch, alg, X, total, omp_kkt=False, check_at=CHECK_AT, kkt_tol=1e-9):
     cls = {"giga": bc.snnls.GIGA, "fw": bc.snnls.FrankWolfe, "omp": bc.snnls.OrthoPursuit}[alg]
     s = cls(X.t(), None)
     b = torch.as_tensor(s.b, device="cuda")
     np.testing.assert_allclose(s.b, X.sum(dim=0).cpu().numpy(), rtol=1e-11, atol=1e-9)   # chunked fp64 column sums
     norms = _norms(torch, X)
     done, all_err, all_status = 0, [], []
-    for k in CHECK_AT + (total,):
+    for k in tuple(check_at) + (total,):
         if k > total:
             continue
         if k > done:
@@ -123,7 +123,7 @@ def _drive(bc, torch, alg, X, total, omp_kkt=False):
         # left the problem, orthopursuit.py:39 `active = w > 0`, so nothing is required of them.)
         g = X[ti] @ resid
         scale = float((X[ti].norm(dim=1) * b.norm()).max())
-        assert float(g.abs().max()) <= 1e-9 * scale
+        assert float(g.abs().max()) <= kkt_tol * scale
     return s, acc
 
 
@@ -138,23 +138,36 @@ def test_config2_giga_1m_x_256(bc):
 
 
 def test_config3_omp_1m_x_512_logistic_projection(bc):
-    """BASELINE.json configs[2]: Laplace-projected logistic-regression vectors, N=1M, S=512, OMP, M=512
-    (projection on the device: projector.py:19-21 with model_lr.py:25-32)."""
+    """BASELINE.json configs[2]: Laplace-projected logistic-regression vectors, N=1M, S=512, OMP -- the pipeline of
+    examples/simple_lr/main.py:22-74 as bench.py --config c3 runs it: Laplace fit at the MAP over all rows, S samples of
+    N(mu, cov), projection on the device (projector.py:19-21 with model_lr.py:25-32).  The projected vectors' norms
+    span ~20 decades (saturated rows), and their numerical rank is ~100 (log-likelihood functions of a 10-parameter
+    model), so OMP reaches its floor after ~100 points: 150 iterations, selections verified up to 100 points."""
+    import importlib.util
+    import os
     import torch
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("model_lr", os.path.join(root, "bayesian-coresets_amd", "examples", "common", "model_lr.py"))
+    model_lr = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(model_lr)
     N, D, S = 1_000_000, 10, 512
     g = torch.Generator(device="cuda"); g.manual_seed(3)
     Xf = torch.randn(N, D, dtype=torch.float64, device="cuda", generator=g)
-    theta0 = torch.full((D,), 3.0 / np.sqrt(D), dtype=torch.float64, device="cuda")
-    y = (torch.rand(N, dtype=torch.float64, device="cuda", generator=g) < torch.sigmoid(Xf @ theta0)).double() * 2 - 1
+    y = (torch.rand(N, dtype=torch.float64, device="cuda", generator=g) <= torch.sigmoid(3.0 * Xf.sum(dim=1))).double() * 2 - 1
     Z = Xf * y[:, None]
-    rs = np.random.RandomState(4)
-    samples = theta0.cpu().numpy() + 0.05 * rs.randn(S, D)   # stand-in for the Laplace posterior samples
+    mu, cov = model_lr.laplace_fit(Z)                                        # simple_lr/main.py:57-63
+    assert np.all(np.abs(mu - 3.0) < 0.2)                                    # the MAP sits near the generating parameter
+    samples = np.random.RandomState(4).multivariate_normal(mu, cov, S)       # simple_lr/main.py:74
     proj = bc.DeviceProjector("logistic", lambda S_, wts, pts: samples[:S_], S)
     vecs = proj.project(Z)
     assert vecs.shape == (N, S) and vecs.is_cuda
-    np.testing.assert_allclose(vecs.sum(dim=1).abs().max().item(), 0.0, atol=1e-9)     # rows are centred (projector.py:21)
-    s, acc = _drive(bc, torch, "omp", vecs, 512, omp_kkt=True)
-    assert acc[-1] < 1e-2 * acc[0]
+    nrm = torch.linalg.vector_norm(vecs, dim=1)
+    assert float(nrm.min()) < 1e-15 and float(nrm.max()) > 1e-2 and float(nrm.min()) > 0     # >= 13 decades of row norm
+    assert float(vecs.sum(dim=1).abs().max()) <= 1e-12 * float(nrm.max()) * S   # rows are centred (projector.py:21)
+    # (stationarity to 1e-7: the ~100 active columns are nearly dependent -- the Gram system's conditioning, not the
+    #  solver, sets the attainable gradient; selections and control flow equal the CPU oracle's at N = 200k, tools/c3_check.py)
+    s, acc = _drive(bc, torch, "omp", vecs, 150, omp_kkt=True, check_at=(0, 1, 7, 30, 60, 100), kkt_tol=1e-7)
+    assert acc[-1] < 0.2 * acc[0] and 60 <= s.size() <= 150
 
 
 def test_config4_fw_10m_x_512(bc):
