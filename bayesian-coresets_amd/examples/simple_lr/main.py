@@ -11,19 +11,11 @@ import sys
 import time
 
 import numpy as np
-from scipy.optimize import minimize
 
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."))
+sys.path.insert(1, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "common"))
 import bayesiancoresets_amd as bc  # noqa: E402
-
-
-def log_joint_and_grad(Z, th, w):
-    m = -Z.dot(th)
-    ll = np.where(m < 100, -np.log1p(np.exp(np.minimum(m, 100))), -m)
-    sig = np.where(m < 100, np.exp(np.minimum(m, 100)) / (1.0 + np.exp(np.minimum(m, 100))), 1.0)
-    val = (w * ll).sum() - 0.5 * th.shape[0] * np.log(2 * np.pi) - 0.5 * (th ** 2).sum()
-    grad = ((w * sig)[:, None] * Z).sum(axis=0) - th
-    return val, grad, sig
+import model_lr  # noqa: E402
 
 
 def main():
@@ -36,18 +28,8 @@ def main():
     a = ap.parse_args()
     np.random.seed(1)
     N, D = a.rows, a.dim
-    X = np.random.randn(N, D)
-    th_true = 3.0 * np.ones(D)
-    y = (np.random.rand(N) <= 1.0 / (1.0 + np.exp(-X.dot(th_true)))).astype(int)
-    y[y == 0] = -1
-    Z = y[:, None] * X
-    ones = np.ones(N)
-    res = minimize(lambda t: -log_joint_and_grad(Z, t, ones)[0], Z.mean(axis=0),
-                   jac=lambda t: -log_joint_and_grad(Z, t, ones)[1])
-    mu = res.x
-    sig = log_joint_and_grad(Z, mu, ones)[2]
-    H = (Z * (sig * (1 - sig))[:, None]).T.dot(Z) + np.eye(D)        # negative Hessian of the log joint
-    cov = np.linalg.inv(H)
+    Z = model_lr.synthetic_rows(N, D, np.random)                 # simple_lr/main.py:22-35
+    mu, cov = model_lr.laplace_fit(Z, device="cuda")             # MAP + inverse negative Hessian (main.py:57-63)
     sampler = lambda n, w, p: np.atleast_2d(np.random.multivariate_normal(mu, cov, n))
     algs = {"FW": bc.snnls.FrankWolfe, "GIGA": bc.snnls.GIGA, "OMP": bc.snnls.OrthoPursuit}
     t0 = time.perf_counter()
