@@ -386,3 +386,95 @@ def test_one_rank_per_device_matches_one_shard(tmp_path, alg, exchange):
             assert str(r["exchange"]) == "collective"
         else:   # the probe decides; either outcome must give the same bits, and it must say why
             assert str(r["exchange"]) in ("mailbox", "collective") and "reason" in str(r["probe"])
+
+
+# ---- subsampling on row shards (hilbert.py:13-22, sparsevi.py:32-35) with the real engine, ranks sharing cuda:0 ----------
+def _subsample_worker(rank, world, port, out_dir):
+    for p in (ROOT, os.path.join(ROOT, "bayesian-coresets_amd"), os.path.join(ROOT, "tests")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    import torch
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import bayesiancoresets_amd as bc
+
+    class Cubed(bc.Projector):                      # any row-wise map; zero rows stay zero
+        def update(self, wts, pts):
+            pass
+
+        def project(self, pts, grad=False):
+            return pts ** 3
+
+    N, d, n_sub = 9000, 24, 5000
+    data = _data(N, d)
+    data[3::11] = 0.0
+    np.random.seed(77)                              # the same draw on every rank and in the single-process run
+    if world == 1:
+        cs = bc.HilbertCoreset(data, Cubed(), n_subsample=n_sub, snnls=bc.snnls.FrankWolfe)
+    else:
+        lo, hi = bc.ShardedHilbertCoreset.local_rows(N)
+        cs = bc.ShardedHilbertCoreset(data[lo:hi], Cubed(), N, n_subsample=n_sub, snnls=bc.snnls.FrankWolfe)
+    cs.build(25)
+    wts, pts, idcs = cs.get()
+    np.savez(os.path.join(out_dir, "sub_w%d_r%d.npz" % (world, rank)), wts=wts, pts=pts, idcs=idcs, err=cs.error(), sub=cs.sub_idcs)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_sharded_hilbert_subsample_equals_hilbert_subsample(tmp_path):
+    import torch.multiprocessing as mp
+    for world in (1, 2):
+        mp.spawn(_subsample_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    ref = np.load(tmp_path / "sub_w1_r0.npz")
+    assert len(ref["sub"]) > 2048 and len(ref["idcs"]) >= 20
+    for rank in range(2):
+        r = np.load(tmp_path / ("sub_w2_r%d.npz" % rank))
+        for k in ("sub", "idcs", "wts", "pts", "err"):
+            assert np.array_equal(ref[k], r[k]), (rank, k)
+
+
+def _svi_subsample_worker(rank, world, port, out_dir):
+    for p in (ROOT, os.path.join(ROOT, "bayesian-coresets_amd"), os.path.join(ROOT, "tests")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    import torch
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import bayesiancoresets_amd as bc
+    from models import make_linreg_data, linreg_sampler
+    N, D, S, sigsq = 30000, 12, 48, 1.0
+    Z = make_linreg_data(3, N, D)
+    per = (N + world - 1) // world
+    lo, hi = rank * per, min(N, (rank + 1) * per)
+    np.random.seed(9)
+    grp = dist.group.WORLD if world > 1 else None
+    prj = bc.DeviceProjector("linreg", linreg_sampler(np.zeros(D), np.eye(D), sigsq), S, sigsq=sigsq, group=grp, row_offset=lo)
+    if world > 1:
+        alg = bc.SparseVICoreset(Z[lo:hi], prj, n_subsample_select=8000, n_subsample_opt=5000, opt_itrs=8, row_offset=lo, group=grp)
+    else:
+        alg = bc.SparseVICoreset(Z, prj, n_subsample_select=8000, n_subsample_opt=5000, opt_itrs=8)
+    alg.build(3)
+    np.savez(os.path.join(out_dir, "svis_w%d_r%d.npz" % (world, rank)), idcs=alg.idcs, wts=alg.wts, pts=alg.pts)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_sparsevi_subsampling_on_row_shards(tmp_path):
+    """n_subsample_select / n_subsample_opt (sparsevi.py:32-35) with rows sharded over two ranks: the replicated draw
+    picks the same points as the single-process run; weights agree to the rounding of the all-reduced column sums."""
+    import torch.multiprocessing as mp
+    for world in (1, 2):
+        mp.spawn(_svi_subsample_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    ref = np.load(tmp_path / "svis_w1_r0.npz")
+    assert len(ref["idcs"]) >= 2
+    r0, r1 = np.load(tmp_path / "svis_w2_r0.npz"), np.load(tmp_path / "svis_w2_r1.npz")
+    for k in ("idcs", "wts", "pts"):
+        assert np.array_equal(r0[k], r1[k]), k
+    assert np.array_equal(ref["idcs"], r0["idcs"]) and np.array_equal(ref["pts"], r0["pts"])
+    np.testing.assert_allclose(r0["wts"], ref["wts"], rtol=1e-6, atol=1e-10)
