@@ -150,7 +150,14 @@ static int upload_host_rows(bcx_solver* s, void* dst_dev, size_t dpitch, const v
   if (width > kBounceBytes) { s->err = "bcx_load_rows: a row exceeds the upload buffer"; return BCX_ERR_ARG; }
   hipEvent_t done[2] = {nullptr, nullptr};     // (per call: events belong to the device that is current now)
   bool busy[2] = {false, false};
-  for (int i = 0; i < 2; ++i) BCX_HIP(hipEventCreateWithFlags(&done[i], hipEventDisableTiming));
+  for (int i = 0; i < 2; ++i) {
+    const hipError_t ee = hipEventCreateWithFlags(&done[i], hipEventDisableTiming);
+    if (ee != hipSuccess) {
+      if (i == 1) (void)hipEventDestroy(done[0]);
+      s->err = std::string("upload: ") + hipGetErrorString(ee);
+      return BCX_ERR_HIP;
+    }
+  }
   const int64_t rows_per = std::max<int64_t>(1, (int64_t)(kBounceBytes / width));
   int which = 0;
   int rc = BCX_OK;
