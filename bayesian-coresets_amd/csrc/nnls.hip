@@ -1021,30 +1021,72 @@ int bcx_launch_apply_omp(bcx_solver* s, const double* recv_dev) {
 // ---- optimize(): Gram matrix on the fp64 matrix cores + cold-start NNLS ---------------------------
 typedef double v4d __attribute__((ext_vector_type(4)));
 
-// G[i][j] = row_i . row_j for i, j < k.  One wave per 16 x 16 tile, K-loop in steps of 4 with
-// v_mfma_f64_16x16x4_f64: A[i][kk] = rows[I*16+i][k0+kk], B[kk][j] = rows[J*16+j][k0+kk].
+// G[i][j] = row_i . row_j for i, j < k on v_mfma_f64_16x16x4_f64.  A wave owns a 32 x 32 block of G (2 x 2 MFMA tiles)
+// and only blocks on or above the diagonal are computed, the mirror image is stored with them.  The four k-slots of an
+// MFMA step are fed in a permuted k order -- lane group lk supplies k = 8t + 2 lk (+1) to steps 2t (2t+1) -- so one
+// 16-byte load per operand tile feeds two steps: 4 loads per 8 MFMAs (round 1: one wave per 16 x 16 tile, 2 scalar
+// loads per MFMA, 7.8 TFLOP/s).  Rows are d doubles apart; 8-byte loads when d is odd.
+struct __attribute__((aligned(8))) gpd2 { double x, y; };
 __global__ __launch_bounds__(256) void gram_mfma_kernel(const double* __restrict__ rows, int k, int d,
-                                                        double* __restrict__ G, int64_t ldg) {
+                                                        double* __restrict__ G, int64_t ldg, int nblk) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int I = blockIdx.x, J = blockIdx.y * 4 + wave;
-  if (J * 16 >= k) return;
-  const int ri = I * 16 + (lane & 15), rj = J * 16 + (lane & 15), kk = lane >> 4;
-  const bool vi = ri < k, vj = rj < k;
-  const double* pa = rows + (size_t)(vi ? ri : 0) * d;
-  const double* pb = rows + (size_t)(vj ? rj : 0) * d;
-  v4d acc = {0.0, 0.0, 0.0, 0.0};
-  for (int k0 = 0; k0 < d; k0 += 4) {
-    const int c = k0 + kk;
-    const double av = (vi && c < d) ? pa[c] : 0.0;
-    const double bv = (vj && c < d) ? pb[c] : 0.0;
-    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc, 0, 0, 0);
+  const int li = lane & 15, lk = lane >> 4;
+  // upper-triangular block index -> (I, J), I <= J < nblk
+  int t = blockIdx.x * 4 + wave;
+  if (t >= nblk * (nblk + 1) / 2) return;
+  int I = 0;
+  while (t >= nblk - I) { t -= nblk - I; ++I; }
+  const int J = I + t;
+  const double* pa[2];
+  const double* pb[2];
+  bool va[2], vb[2];
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+    const int ri = I * 32 + 16 * u + li, rj = J * 32 + 16 * u + li;
+    va[u] = ri < k; vb[u] = rj < k;
+    pa[u] = rows + (size_t)(va[u] ? ri : 0) * d;
+    pb[u] = rows + (size_t)(vb[u] ? rj : 0) * d;
+  }
+  v4d acc[2][2];
+#pragma unroll
+  for (int u = 0; u < 2; ++u)
+#pragma unroll
+    for (int v = 0; v < 2; ++v) acc[u][v] = (v4d){0.0, 0.0, 0.0, 0.0};
+  const bool even = (d & 1) == 0;
+  for (int k0 = 0; k0 < d; k0 += 8) {
+    const int c = k0 + 2 * lk;
+    gpd2 av[2], bv[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      if (even && c + 1 < d) { av[u] = *(const gpd2*)(pa[u] + c); bv[u] = *(const gpd2*)(pb[u] + c); }
+      else {
+        av[u].x = c < d ? pa[u][c] : 0.0; av[u].y = c + 1 < d ? pa[u][c + 1] : 0.0;
+        bv[u].x = c < d ? pb[u][c] : 0.0; bv[u].y = c + 1 < d ? pb[u][c + 1] : 0.0;
+      }
+      if (!va[u]) { av[u].x = 0.0; av[u].y = 0.0; }
+      if (!vb[u]) { bv[u].x = 0.0; bv[u].y = 0.0; }
+    }
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+      for (int v = 0; v < 2; ++v) {
+        acc[u][v] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[u].x, bv[v].x, acc[u][v], 0, 0, 0);
+        acc[u][v] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[u].y, bv[v].y, acc[u][v], 0, 0, 0);
+      }
   }
   // f64 C/D layout: col = lane & 15, row = (lane >> 4) + 4 * reg
 #pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    const int row = I * 16 + (lane >> 4) + 4 * r, col = J * 16 + (lane & 15);
-    if (row < k && col < k) G[(size_t)row * ldg + col] = acc[r];
-  }
+  for (int u = 0; u < 2; ++u)
+#pragma unroll
+    for (int v = 0; v < 2; ++v)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = I * 32 + 16 * u + lk + 4 * r, col = J * 32 + 16 * v + li;
+        if (row < k && col < k) {
+          G[(size_t)row * ldg + col] = acc[u][v][r];
+          if (I != J) G[(size_t)col * ldg + row] = acc[u][v][r];
+        }
+      }
 }
 
 __global__ __launch_bounds__(NN_THREADS) void optimize_kernel(NnlsArgs n, double tol) {
@@ -1096,9 +1138,10 @@ int bcx_launch_optimize(bcx_solver* s, double tol) {
   BCX_HIP(hipMemcpy(&h, s->st, sizeof h, hipMemcpyDeviceToHost));
   const int k = h.k;
   if (k > 0) {
-    const int tiles = (k + 15) / 16;
-    hipLaunchKernelGGL(gram_mfma_kernel, dim3(tiles, (tiles + 3) / 4), dim3(256), 0, s->stream, s->act_rows, k,
-                       s->cfg.d, s->gram, (int64_t)s->gram_cap);
+    const int nblk = (k + 31) / 32;
+    const int nwave = nblk * (nblk + 1) / 2;
+    hipLaunchKernelGGL(gram_mfma_kernel, dim3((nwave + 3) / 4), dim3(256), 0, s->stream, s->act_rows, k,
+                       s->cfg.d, s->gram, (int64_t)s->gram_cap, nblk);
     BCX_HIP(hipGetLastError());
   }
   if (k > 0) {
