@@ -112,12 +112,22 @@ class DeviceProjector(Projector):
         torch = self._torch
         if isinstance(pts, torch.Tensor):
             t = pts.to(self.device, dtype=torch.float64)
-            return t if t.is_contiguous() else t.contiguous()
+            if t.dim() == 1:
+                t = t[None, :]
+            return t if t.stride(1) == 1 else t.contiguous()       # any row stride is fine, columns must be adjacent
         arr = np.atleast_2d(np.asarray(pts, dtype=np.float64))
         big = arr.shape[0] >= 4096
         if big and self._cache_ref is pts and self._cache_val.shape == arr.shape:
             return self._cache_val
-        t = torch.from_numpy(np.ascontiguousarray(arr)).to(self.device)
+        if arr.shape[1] % 2:
+            # odd row length: pad the device copy's leading dimension to even so rows stay 16-byte aligned (the kernel then
+            # reads operands with 16-byte loads instead of 8-byte ones); the view has the caller's shape
+            buf = torch.empty((arr.shape[0], arr.shape[1] + 1), dtype=torch.float64, device=self.device)
+            buf[:, :arr.shape[1]] = torch.from_numpy(np.ascontiguousarray(arr)).to(self.device)
+            buf[:, arr.shape[1]] = 0.0
+            t = buf[:, :arr.shape[1]]
+        else:
+            t = torch.from_numpy(np.ascontiguousarray(arr)).to(self.device)
         if big:
             self._cache_val, self._cache_ref = t, pts
         return t
