@@ -568,3 +568,17 @@ def test_monotone_flag_changes_the_state_machine(bc):
         assert k >= 3 and np.array_equal(status[:k], ost[:k]) and np.array_equal(sel[:k], np.array([t[0] for t in o.trace])[:k])
         out[flag] = (status, s.reached_numeric_limit)
     assert not (out[False][0] == 3).any()
+
+
+def test_torch_inputs_of_other_dtypes_are_converted(bc):
+    """Round-1 ADVICE: a half-precision or integer tensor must not be reinterpreted as fp32 / fp64 bytes."""
+    import torch
+    rs = np.random.RandomState(2)
+    Xi = rs.randint(-5, 6, size=(3000, 24))
+    Xi[np.abs(Xi).sum(axis=1) == 0, 0] = 1
+    want = _run(bc, Xi.astype(np.float64), "fw", 15)
+    for t in (torch.from_numpy(Xi), torch.from_numpy(Xi).cuda(), torch.from_numpy(Xi.astype(np.float16)).cuda()):
+        s = bc.snnls.FrankWolfe(t.t(), None)
+        s.build(15)
+        assert np.array_equal(s.last_trace[0], want.last_trace[0])
+        np.testing.assert_allclose(s.weights(), want.weights(), rtol=1e-9)

@@ -404,3 +404,50 @@ def test_simple_lr_example_cli():
                          capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-3000:]
     assert "coreset size" in out.stdout and "error" in out.stdout
+
+
+def test_blackbox_sparsevi_survives_a_zero_projected_vector(bc):
+    """Round-1 ADVICE: SparseVI with a user-callback projector reuses one engine across steps; a zero projected vector
+    (here: a data row with x = 0, whose likelihood does not depend on theta) must only affect the arithmetic the way it
+    does in the reference -- corrs is NaN there, `corrs.argmax()` picks it, and it enters an EMPTY coreset only
+    (sparsevi.py:49-60) -- and must not leave the engine unusable for the next step."""
+    from oracle.sparsevi_oracle import SparseVIOracle, linreg_loglik
+    N, D, S, sigsq = 6000, 8, 32, 1.0
+    Z = make_linreg_data(7, N, D)
+    Z[4321, :D] = 0.0
+    sampler = linreg_sampler(np.zeros(D), np.eye(D), sigsq)
+    np.random.seed(3)
+    prj = bc.BlackBoxProjector(sampler, S, lambda z, th: linreg_log_likelihood(z, th, sigsq))
+    alg = bc.SparseVICoreset(Z, prj, opt_itrs=4)
+    np.random.seed(3)
+    o = SparseVIOracle(Z, sampler, lambda z, th: linreg_loglik(z, th, sigsq), S, opt_itrs=4)
+    import warnings
+    for step in range(4):
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")              # the oracle divides 0 by 0 on purpose (as the reference does)
+            with np.errstate(all="ignore"):
+                o.step()
+        alg.build(1)
+        assert np.array_equal(alg.idcs, o.idcs), (step, alg.idcs, o.idcs)
+        np.testing.assert_allclose(alg.wts, o.wts, rtol=1e-6, atol=1e-9)
+    assert alg.idcs[0] == 4321 and len(alg.idcs) == 1      # the NaN pick entered the empty coreset; later NaN > x is False
+
+
+def test_host_solver_behind_device_projector(bc):
+    """hilbert.py:24-25 with a host-side solver class (sampling baseline) and a projector that returns a GPU tensor: the
+    vectors are brought to the host for that solver (round-1 ADVICE: np.sqrt / A.dot on a CUDA tensor used to crash)."""
+    g = np.load(os.path.join(ROOT, "tests", "golden", "lr_golden.npz"))
+    Z = make_lr_data(1, 2000, int(g["D"]))
+    samples = g["samples"][:16]
+    dev = bc.DeviceProjector("logistic", lambda n, w, p: samples, 16)
+    np.random.seed(5)
+    c = bc.HilbertCoreset(Z, dev, snnls=bc.snnls.UniformSampling)
+    c.build(30)
+    wts, pts, idcs = c.get()
+    assert isinstance(c.snnls, bc.snnls.SparseNNLS) and len(wts) > 0 and np.array_equal(pts, Z[idcs])
+    host = bc.BlackBoxProjector(lambda n, w, p: samples, 16, logistic_log_likelihood)
+    np.random.seed(5)
+    c2 = bc.HilbertCoreset(Z, host, snnls=bc.snnls.UniformSampling)
+    c2.build(30)
+    assert np.array_equal(c2.get()[2], idcs)
+    np.testing.assert_allclose(c2.error(), c.error(), rtol=1e-9)
