@@ -53,6 +53,13 @@ def load():
     # the HSA runtime reads this when the first HIP call initialises it; default to the dmabuf IPC mode the peer
     # mailbox (hipIpcGetMemHandle) and RCCL need unless the user chose otherwise
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    # PyTorch-ROCm bundles its own HIP / HSA runtime; libbcx.so must bind to THAT copy (same SONAME, already loaded),
+    # not pull the system one in next to it -- two HIP runtimes in one process fight over the device ("No HIP GPUs are
+    # available" in whichever initialises second).  So torch is imported before the library is opened.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     lib = ctypes.CDLL(LIB_PATH)
     vp, i32, i64, dbl = ctypes.c_void_p, ctypes.c_int32, ctypes.c_int64, ctypes.c_double
     P = ctypes.POINTER
