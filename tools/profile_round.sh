@@ -50,7 +50,8 @@ c5pmc) pmc proj_c5shard_mfma "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_A
        kt proj_c5shard_write python $R/tools/proj_shape.py --mode write --reps 30 ;;
 opt) kt optimize python $R/tools/optimize_bench.py
      pmc optimize_mfma "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE" python $R/tools/optimize_bench.py ;;
-probe) $R/tools/probe/mfma_f64_peak > $O/mfma_f64_probe.txt 2>&1
+probe) [ -x $R/tools/probe/mfma_f64_peak ] || /opt/rocm/bin/hipcc -O3 --offload-arch=gfx950 -o $R/tools/probe/mfma_f64_peak $R/tools/probe/mfma_f64_peak.hip
+       $R/tools/probe/mfma_f64_peak > $O/mfma_f64_probe.txt 2>&1
        pmc mfma_f64_probe_pmc "GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES" $R/tools/probe/mfma_f64_peak ;;
 esac
 done
