@@ -72,19 +72,30 @@ __device__ __forceinline__ double row16_sum(double v) {
 // operand registers, with the load latency exposed to the matrix pipe) and one barrier separates two stages.
 // The stage sequence runs across tile boundaries (next column group / next row block), so the first loads of a new
 // tile are in flight during the epilogue of the previous one.
-// LDS layout: one block per (16-row operand tile, 8-k step), holding the 64 lanes' 16-byte operand pieces
-// {X[row li][k0 + 2 lk], X[row li][k0 + 2 lk + 1]} in lane order -- lane (li, lk) feeds k-slot lk of two
-// consecutive MFMA steps from one ds_read_b128 -- with the four lk groups 288 bytes apart instead of 256, which
-// makes both the stores (lanes vary k fastest) and the reads (lanes vary li fastest) bank-conflict free.
+// LDS layout: one block per (16-row operand tile, 8-k step u), holding the 16-byte operand pieces
+// {X[row li][k0 + 2 lk], X[row li][k0 + 2 lk + 1]} at byte lk * 256 + shift(lk) * 16 + li * 16 -- one ds_read_b128 feeds
+// k-slot lk of two consecutive MFMA steps, every read of the compute loop is one per-lane base register plus an
+// immediate offset.  ds_read_b128 is serviced in four fixed 16-lane groups that mix two lk values -- {0-3, 12-15 of lk 0
+// with 4-11 of lk 1}, ... (MI355X_MICROARCH.md, LDS) -- so the shift is chosen per operand kind to keep every group on 16
+// distinct 16-byte slots of the 256-byte bank row:
+//   natural operand (lane (li, lk) reads piece [lk][li])                      shift = (0, 0, 2, 2), block 1088 B
+//   replicated operand (lane reads piece [lk][4 r + (lane & 3)], 4 rows x 4)   shift = (0, 4, 4, 8), block 1184 B
+// The block sizes are picked so that the eight lanes of a ds_write_b128 group (the eight (u, lk) pieces of one row: they
+// loaded one 128-byte line of it) land on four different 16-byte slots of the 128-byte store row: 2-way, which a
+// 13-cycle store absorbs.  (With one 288-byte stride for everything, as in the first LDS version, half of the LDS
+// cycles were read conflicts: SQ_LDS_BANK_CONFLICT.)  Which matrix is natural and which replicated depends on the
+// orientation (TRP): Z natural / Theta replicated for COLSUM and SELECT, the other way round for WRITE.
 #define PJ_KC 16
 #define PJ_ROWS 128
 #define PJ_COLS 64
-#define PJ_LK_STRIDE 288
-#define PJ_BLK (4 * PJ_LK_STRIDE)
+#define PJ_NAT_BLK 1088
+#define PJ_REP_BLK 1184
 #define PJ_ZBLKS (PJ_ROWS / 16 * (PJ_KC / 8))
 #define PJ_TBLKS (PJ_COLS / 16 * (PJ_KC / 8))
-#define PJ_STAGE_BYTES ((PJ_ZBLKS + PJ_TBLKS) * PJ_BLK)
+#define PJ_STAGE_BYTES (PJ_ZBLKS * PJ_REP_BLK + PJ_TBLKS * PJ_NAT_BLK)   /* the larger of the two orientations */
 #define PJ_STAGING_BYTES (2 * PJ_STAGE_BYTES)
+__device__ __forceinline__ unsigned pj_nat_row(int lk) { return (unsigned)(lk * 256 + 32 * (lk >> 1)); }
+__device__ __forceinline__ unsigned pj_rep_row(int lk) { return (unsigned)(lk * 256 + 64 * ((lk + 1) >> 1)); }
 
 typedef double pv2d __attribute__((ext_vector_type(2)));
 
@@ -96,23 +107,12 @@ __device__ __forceinline__ bool corr_better(double a, long long ia, double b, lo
   return a > b || (a == b && ia < ib);
 }
 
-// 16-byte piece {X[k], X[k+1]} of a row.  Branch-free: the address is clamped into the row here and the value is
-// masked (zero beyond D and for invalid rows) only when it is parked in LDS a stage later, so the six loads of a
-// stage are issued back to back with no consumer in between (with the mask next to the load, or with branches, the
-// compiler waited for each load before issuing the next one).  k is even.  ALIGNED (16-byte aligned rows, even
-// leading dimension >= D): the piece at the last even k < D may read element D of an odd-D row -- inside the row's
-// padding.
-template <bool ALIGNED>
-__device__ __forceinline__ pv2d load_piece(const double* __restrict__ row, int k, int D) {
-  pv2d v;
-  if (ALIGNED) {
-    v = *(const pv2d*)(row + min(k, (D - 1) & ~1));
-  } else {
-    v.x = row[min(k, D - 1)];
-    v.y = row[min(k + 1, D - 1)];
-  }
-  return v;
-}
+// Zero-fill of a 16-byte piece {X[k], X[k+1]} beyond D and for rows that do not exist.  The loads themselves are
+// branch-free (address clamped into the row) and the mask is applied only when the piece is parked in LDS a stage
+// later, so the six loads of a stage are issued back to back with no consumer in between (with the mask next to the
+// load, or with branches, the compiler waited for each load before issuing the next one).  k is even.  ALIGNED (16-byte
+// aligned rows, even leading dimension >= D): the piece at the last even k < D may read element D of an odd-D row --
+// inside the row's padding.
 __device__ __forceinline__ pv2d mask_piece(pv2d v, bool valid, int k, int D) {
   v.x = (valid && k < D) ? v.x : 0.0;
   v.y = (valid && k + 1 < D) ? v.y : 0.0;
@@ -136,10 +136,13 @@ __global__ __launch_bounds__(256, 2) void proj_kernel(ProjArgs p) {
   long long besti = 0x7fffffffffffffffLL;
   const double clin = (FAM == FAM_LINREG) ? -0.5 * log(2.0 * 3.14159265358979323846 * p.param) : 0.0;
 
-  // global -> LDS assignment of this thread: piece q of rows (tid >> 3) + 32 j
+  // Orientation of the wave's 32 rows x 64 columns (see the compute loop): COLSUM / SELECT compute the transposed product.
+  constexpr bool TRP = MODE != PMODE_WRITE;
+  // global -> LDS assignment of this thread: piece q = tid & 7 (u = q >> 2, lk = q & 3) of rows (tid >> 3) + 32 j
+  constexpr int ZBLK = TRP ? PJ_NAT_BLK : PJ_REP_BLK, TBLK = TRP ? PJ_REP_BLK : PJ_NAT_BLK, ZBYTES = PJ_ZBLKS * ZBLK;
   const int q = tid & 7, grow = tid >> 3;
-  const unsigned st_off = (unsigned)((q >> 2) * PJ_BLK + (q & 3) * PJ_LK_STRIDE + (grow & 15) * 16);
-  const unsigned rd_off = (unsigned)(lk * PJ_LK_STRIDE + li * 16);
+  const unsigned zst_off = (unsigned)((q >> 2) * ZBLK + (TRP ? pj_nat_row(q & 3) : pj_rep_row(q & 3)) + (grow & 15) * 16);
+  const unsigned tst_off = (unsigned)((q >> 2) * TBLK + (TRP ? pj_rep_row(q & 3) : pj_nat_row(q & 3)) + (grow & 15) * 16);
 
   int64_t br = blockIdx.x;
   if (br >= nblk) {
@@ -153,34 +156,66 @@ __global__ __launch_bounds__(256, 2) void proj_kernel(ProjArgs p) {
   }
   int cg = 0, s = 0;
   pv2d zreg[4], treg[2];
-  auto fetch = [&](int64_t fbr, int fcg, int fs) {
-    const int k = fs * PJ_KC + 2 * q;
+  // The prefetch stream keeps, per thread, the row pointers of the tile it is loading (they change once per tile = every
+  // nst stages) and one bit per row / column saying whether it exists; a stage then costs one index clamp and six
+  // pointer adds, and parking is six plain stores unless the stage is the last of the k range or the tile hangs over
+  // the edge of the matrix (only then pieces need zero-filling).  The first version recomputed 64-bit row addresses and
+  // four selects per piece every stage: fetch + park took a quarter of the kernel's time.
+  const double* zp[4];
+  const double* tp[2];
+  unsigned fvalid = 0;                       // bits 0-3: Z rows, bits 4-5: Theta columns of the tile being fetched
+  const int kmax = ALIGNED ? ((D - 1) & ~1) : (D - 1);
+  auto set_tile = [&](int64_t fbr, int fcg) {
+    fvalid = 0;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const int64_t row = fbr * PJ_ROWS + grow + 32 * j;
-      zreg[j] = load_piece<ALIGNED>(p.Z + (row < p.N ? row : p.N - 1) * p.ldz, k, D);
+      zp[j] = p.Z + (row < p.N ? row : p.N - 1) * p.ldz;
+      fvalid |= (row < p.N ? 1u : 0u) << j;
     }
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
       const int col = fcg * PJ_COLS + grow + 32 * j;
-      treg[j] = load_piece<ALIGNED>(p.theta + (size_t)(col < S ? col : S - 1) * p.ldt, k, D);
+      tp[j] = p.theta + (size_t)(col < S ? col : S - 1) * p.ldt;
+      fvalid |= (col < S ? 1u : 0u) << (4 + j);
     }
   };
-  auto park = [&](int par, int64_t fbr, int fcg, int fs) {      // (same coordinates as the fetch it completes)
-    unsigned char* base = pj_lds + par * PJ_STAGE_BYTES;
+  auto fetch = [&](int fs) {
     const int k = fs * PJ_KC + 2 * q;
+    const int kc = min(k, kmax);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      if (ALIGNED) zreg[j] = *(const pv2d*)(zp[j] + kc);
+      else { zreg[j].x = zp[j][kc]; zreg[j].y = zp[j][min(k + 1, D - 1)]; }
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      if (ALIGNED) treg[j] = *(const pv2d*)(tp[j] + kc);
+      else { treg[j].x = tp[j][kc]; treg[j].y = tp[j][min(k + 1, D - 1)]; }
+    }
+  };
+  auto park = [&](int par, int fs) {      // (fs: the stage of the fetch it completes)
+    unsigned char* base = pj_lds + par * PJ_STAGE_BYTES;
+    // wave-uniform: every row / column of the tile exists and the stage lies inside the k range for all eight pieces
+    const bool plain = fs < nst - 1 && __all(fvalid == 0x3fu);
+    if (!plain) {
+      const int k = fs * PJ_KC + 2 * q;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) zreg[j] = mask_piece(zreg[j], (fvalid >> j) & 1u, k, D);
+#pragma unroll
+      for (int j = 0; j < 2; ++j) treg[j] = mask_piece(treg[j], (fvalid >> (4 + j)) & 1u, k, D);
+    }
 #pragma unroll
     for (int j = 0; j < 4; ++j)      // rows grow + 32 j: 16-row tile (grow >> 4) + 2 j
-      *(pv2d*)(base + ((grow >> 4) + 2 * j) * (PJ_KC / 8) * PJ_BLK + st_off) =
-          mask_piece(zreg[j], fbr * PJ_ROWS + grow + 32 * j < p.N, k, D);
+      *(pv2d*)(base + ((grow >> 4) + 2 * j) * (PJ_KC / 8) * ZBLK + zst_off) = zreg[j];
 #pragma unroll
     for (int j = 0; j < 2; ++j)
-      *(pv2d*)(base + (PJ_ZBLKS + ((grow >> 4) + 2 * j) * (PJ_KC / 8)) * PJ_BLK + st_off) =
-          mask_piece(treg[j], fcg * PJ_COLS + grow + 32 * j < S, k, D);
+      *(pv2d*)(base + ZBYTES + ((grow >> 4) + 2 * j) * (PJ_KC / 8) * TBLK + tst_off) = treg[j];
   };
 
-  fetch(br, 0, 0);
-  park(0, br, 0, 0);
+  set_tile(br, 0);
+  fetch(0);
+  park(0, 0);
   __syncthreads();
   int par = 0;
   // Orientation of the wave's 32 rows x 64 columns on the MFMA tiles.  WRITE: A = Z, B = Theta -- a lane holds 8 rows
@@ -188,7 +223,6 @@ __global__ __launch_bounds__(256, 2) void proj_kernel(ProjArgs p) {
   // COLSUM / SELECT: A = Theta, B = Z (the transposed product) -- a lane holds only 2 data rows (li, li + 16) x 16
   // columns, so the per-row state of the epilogue (response, shift, three moments) is 2 values per lane instead
   // of 8: what makes the kernel fit 256 registers at two waves per SIMD.
-  constexpr bool TRP = MODE != PMODE_WRITE;
   pv4d acc[2][4];                    // [row tile][column tile]
   double yv[TRP ? 2 : 8], cp[TRP ? 2 : 8];
   double piv[2], rs[TRP ? 2 : 8], rq[2], rd[2];
@@ -201,7 +235,7 @@ __global__ __launch_bounds__(256, 2) void proj_kernel(ProjArgs p) {
     const bool last = s == nst - 1;
     // the next stage's loads fly while this stage's MFMAs run; across a tile boundary they are issued after the
     // epilogue instead (keeps the 12 prefetch registers out of the epilogue's live set)
-    if (more && !last) fetch(nbr, ncg, ns);
+    if (more && !last) fetch(ns);
     if (s == 0) {
 #pragma unroll
       for (int tr = 0; tr < 2; ++tr)
@@ -209,26 +243,61 @@ __global__ __launch_bounds__(256, 2) void proj_kernel(ProjArgs p) {
         for (int tc = 0; tc < 4; ++tc) acc[tr][tc] = (pv4d){0.0, 0.0, 0.0, 0.0};
     }
     {
-      const unsigned char* base = pj_lds + par * PJ_STAGE_BYTES + rd_off;
+      // v_mfma_f64_4x4x4_4b_f64: four independent 4x4x4 products per instruction (lanes 16k + 4b + i hold A_b[i][k],
+      // lanes 16k + 4b + j hold B_b[k][j], D_b[i][j] comes back in lane 16i + 4b + j).  It sustains 72 TFLOP/s on this
+      // chip where the 16x16x4 form tops out at 47.6 (tools/probe/mfma_f64_peak.hip), so the 16x16 tile is built from it:
+      // the "B" operand is a natural 16-wide tile (block b = its columns 4b .. 4b+3), the "A" operand four rows replicated
+      // into all four blocks -- D is then a 4 x 16 strip, and register r of the old 16x16 accumulator IS the strip of rows
+      // 4r .. 4r+3, so accumulator layout and epilogue are those of the 16x16x4 version.
+      const unsigned char* base = pj_lds + par * PJ_STAGE_BYTES;
+      const unsigned nat_off = pj_nat_row(lk) + li * 16;                 // piece [lk][li]
+      const unsigned rep_off = pj_rep_row(lk) + (lane & 3) * 16;         // piece [lk][4 r + (lane & 3)], + 64 r
+      // Operand registers are double-buffered by hand: the four replicated pieces of group g + 1 are requested before the
+      // 16 MFMAs of group g are issued (an LDS read takes ~130 cycles, four MFMAs 64), and within a group the .x MFMAs of
+      // all accumulators precede their dependent .y MFMAs.  A group = one column tile (TRP) / one row tile (WRITE) of one
+      // 8-k step; NG groups per stage.
+      constexpr int NU = PJ_KC / 8, NG = TRP ? 4 * NU : 2 * NU;
+      auto nat_ptr = [&](int u, int t) {      // natural operand tile t of 8-k step u
+        return TRP ? (const pv2d*)(base + ((2 * wave + t) * NU + u) * ZBLK + nat_off)
+                   : (const pv2d*)(base + ZBYTES + (t * NU + u) * TBLK + nat_off);
+      };
+      auto rep_ptr = [&](int g, int r) {      // replicated operand, group g = (u, tile), rows 4 r .. 4 r + 3
+        const int u = TRP ? g / 4 : g / 2, t = TRP ? g % 4 : g % 2;
+        return TRP ? (const pv2d*)(base + ZBYTES + (t * NU + u) * TBLK + rep_off + 64 * r)
+                   : (const pv2d*)(base + ((2 * wave + t) * NU + u) * ZBLK + rep_off + 64 * r);
+      };
+      pv2d rp[2][4];
 #pragma unroll
-      for (int u = 0; u < PJ_KC / 8; ++u) {
-        pv2d zv[2], tv[4];
+      for (int r = 0; r < 4; ++r) rp[0][r] = *rep_ptr(0, r);
+      pv2d nt[TRP ? 2 : 4];
 #pragma unroll
-        for (int tr = 0; tr < 2; ++tr) zv[tr] = *(const pv2d*)(base + ((2 * wave + tr) * (PJ_KC / 8) + u) * PJ_BLK);
+      for (int g = 0; g < NG; ++g) {
+        const int u = TRP ? g / 4 : g / 2, t = TRP ? g % 4 : g % 2;
+        if (t == 0) {
 #pragma unroll
-        for (int tc = 0; tc < 4; ++tc) tv[tc] = *(const pv2d*)(base + (PJ_ZBLKS + tc * (PJ_KC / 8) + u) * PJ_BLK);
+          for (int i = 0; i < (TRP ? 2 : 4); ++i) nt[i] = *nat_ptr(u, i);
+        }
+        if (g + 1 < NG) {
 #pragma unroll
-        for (int tr = 0; tr < 2; ++tr)
+          for (int r = 0; r < 4; ++r) rp[(g + 1) & 1][r] = *rep_ptr(g + 1, r);
+        }
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-          for (int tc = 0; tc < 4; ++tc) {
-            if (TRP) {
-              acc[tr][tc] = __builtin_amdgcn_mfma_f64_16x16x4f64(tv[tc].x, zv[tr].x, acc[tr][tc], 0, 0, 0);
-              acc[tr][tc] = __builtin_amdgcn_mfma_f64_16x16x4f64(tv[tc].y, zv[tr].y, acc[tr][tc], 0, 0, 0);
-            } else {
-              acc[tr][tc] = __builtin_amdgcn_mfma_f64_16x16x4f64(zv[tr].x, tv[tc].x, acc[tr][tc], 0, 0, 0);
-              acc[tr][tc] = __builtin_amdgcn_mfma_f64_16x16x4f64(zv[tr].y, tv[tc].y, acc[tr][tc], 0, 0, 0);
-            }
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+          for (int i = 0; i < (TRP ? 2 : 4); ++i) {
+            pv4d& a4 = TRP ? acc[i][t] : acc[t][i];
+            a4[r] = TRP ? __builtin_amdgcn_mfma_f64_4x4x4f64(rp[g & 1][r].x, nt[i].x, a4[r], 0, 0, 0)
+                        : __builtin_amdgcn_mfma_f64_4x4x4f64(rp[g & 1][r].x, nt[i].x, a4[r], 0, 0, 0);
           }
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+          for (int i = 0; i < (TRP ? 2 : 4); ++i) {
+            pv4d& a4 = TRP ? acc[i][t] : acc[t][i];
+            a4[r] = __builtin_amdgcn_mfma_f64_4x4x4f64(rp[g & 1][r].y, nt[i].y, a4[r], 0, 0, 0);
+          }
+        __builtin_amdgcn_sched_barrier(0);
       }
     }
     if (last) {
@@ -327,8 +396,8 @@ __global__ __launch_bounds__(256, 2) void proj_kernel(ProjArgs p) {
       }
     }
     if (!more) break;
-    if (last) fetch(nbr, ncg, ns);
-    park(par ^ 1, nbr, ncg, ns);
+    if (last) { set_tile(nbr, ncg); fetch(ns); }
+    park(par ^ 1, ns);
     __syncthreads();
     par ^= 1;
     s = ns; cg = ncg; br = nbr;
