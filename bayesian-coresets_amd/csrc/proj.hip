@@ -49,7 +49,10 @@ template <int FAM> __device__ __forceinline__ double loglik(double m, double y, 
     if (s > -100.0) s = log(fmax(s, 0.0) + log1p(exp(-fabs(s))));
     return y * s - c0 - exp(s);                            // model_poiss.py:38  (c0 = gammaln(y+1))
   } else {
-    return c0 - (y * y - 2.0 * m * y + m * m) / (2.0 * param);   // model_linreg.py:10 (c0 = -0.5 log(2 pi sigsq))
+    // model_linreg.py:10 (c0 = -0.5 log(2 pi sigsq)); param = 1 / (2 sigsq), formed once per kernel: the quotient by the
+    // common divisor as a product (<= 1 ulp from the division; an fp64 division is ~25 instructions on the unit the
+    // fp64 MFMAs run on, and the epilogue has 32 of them per lane and tile)
+    return c0 - (y * y - 2.0 * m * y + m * m) * param;
   }
 }
 
@@ -130,6 +133,15 @@ __device__ __forceinline__ pv2d mask_piece(pv2d v, bool valid, int k, int D) {
   return v;
 }
 
+// one level of the transposed butterfly: keep b (a) if this lane's bit is set (clear), add the partner's other half
+template <int CTRL> __device__ __forceinline__ double pj_fold(double a, double b, bool hi) {
+  const double keep = hi ? b : a, send = hi ? a : b;
+  const unsigned long long w = (unsigned long long)__double_as_longlong(send);
+  const unsigned lo = (unsigned)__builtin_amdgcn_mov_dpp((int)(unsigned)w, CTRL, 0xf, 0xf, true);
+  const unsigned hi32 = (unsigned)__builtin_amdgcn_mov_dpp((int)(unsigned)(w >> 32), CTRL, 0xf, 0xf, true);
+  return keep + __longlong_as_double((long long)(((unsigned long long)hi32 << 32) | lo));
+}
+
 struct PjPos {       // one stage of the workgroup's sequence: k stage s of column group cg of row block br
   int s, cg;
   int64_t br;
@@ -153,6 +165,7 @@ __global__ __launch_bounds__(256, 2) void proj_kernel(ProjArgs p) {
   double bestv = -INFINITY;
   long long besti = 0x7fffffffffffffffLL;
   const double clin = (FAM == FAM_LINREG) ? -0.5 * log(2.0 * 3.14159265358979323846 * p.param) : 0.0;
+  const double parg = (FAM == FAM_LINREG) ? 1.0 / (2.0 * p.param) : p.param;
 
   // Orientation of the wave's 32 rows x 64 columns (see the compute loop): COLSUM / SELECT compute the transposed product.
   constexpr bool TRP = MODE != PMODE_WRITE;
@@ -378,7 +391,7 @@ __global__ __launch_bounds__(256, 2) void proj_kernel(ProjArgs p) {
           for (int e = 0; e < 8; ++e) {
             const int64_t row = r0 + 16 * (e >> 2) + lk + 4 * (e & 3);
             const bool ok = col < S && row < p.N;
-            const double ll = ok ? loglik<FAM>(acc[e >> 2][tc][e & 3], yv[e], p.param, cp[e]) : 0.0;
+            const double ll = ok ? loglik<FAM>(acc[e >> 2][tc][e & 3], yv[e], parg, cp[e]) : 0.0;
             if (ok) p.out[row * p.ldo + col] = ll;
             rs[e] += ll;
           }
@@ -406,10 +419,11 @@ __global__ __launch_bounds__(256, 2) void proj_kernel(ProjArgs p) {
             // one-pass moments then cancel on the scale of the row's SPREAD, not of |ll| (rows with |mean| >> spread:
             // a concentrated posterior, saturated logistic rows) -- the accuracy of the reference's centre-then-norm
             // order (sparsevi.py:49-51) without a second pass.
-            const double l0 = loglik<FAM>(acc[tr][0][0], yv[tr], p.param, cp[tr]);
+            const double l0 = loglik<FAM>(acc[tr][0][0], yv[tr], parg, cp[tr]);
             piv[tr] = __shfl(l0, li, BCX_WAVE);
           }
         }
+        double cs[16];                 // COLSUM: this lane's two rows of column (tc, r), index 4 tc + r
 #pragma unroll
         for (int tc = 0; tc < 4; ++tc) {
 #pragma unroll
@@ -421,15 +435,29 @@ __global__ __launch_bounds__(256, 2) void proj_kernel(ProjArgs p) {
 #pragma unroll
             for (int tr = 0; tr < 2; ++tr) {
               const bool ok = cvalid && r0 + 16 * tr + li < p.N;
-              const double v = ok ? loglik<FAM>(acc[tr][tc][r], yv[tr], p.param, cp[tr]) - piv[tr] : 0.0;
+              const double v = ok ? loglik<FAM>(acc[tr][tc][r], yv[tr], parg, cp[tr]) - piv[tr] : 0.0;
               if (MODE == PMODE_COLSUM) csum += v;
               else { rs[tr] += v; rq[tr] += v * v; rd[tr] += v * rsd; }
             }
-            if (MODE == PMODE_COLSUM) {
-              csum = row16_sum(csum);                      // the 16 lanes (data rows) that hold this column
-              if (li == 0 && cvalid) colacc[col] += csum;
-            }
+            cs[4 * tc + r] = csum;
           }
+        }
+        if (MODE == PMODE_COLSUM) {
+          // Sum over the 16 lanes (data rows) of a DPP row, all 16 columns at once: a transposed butterfly -- at each
+          // level a lane keeps the half of its values whose index bit matches its lane bit and adds the partner's
+          // partial sums of that half (partners: mirror, half mirror, xor 2, xor 1 -- the lane bit flips each time), so
+          // lane li ends with the total of column index li: 15 exchanges instead of 64, then ONE LDS update per lane
+          // instead of 16 dependent read-add-write round trips.
+          double c8[8], c4[4], c2[2];
+#pragma unroll
+          for (int e = 0; e < 8; ++e) c8[e] = pj_fold<0x140>(cs[e], cs[e + 8], (li & 8) != 0);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) c4[e] = pj_fold<0x141>(c8[e], c8[e + 4], (li & 4) != 0);
+#pragma unroll
+          for (int e = 0; e < 2; ++e) c2[e] = pj_fold<0x4E>(c4[e], c4[e + 2], (li & 2) != 0);
+          const double tot = pj_fold<0xB1>(c2[0], c2[1], (li & 1) != 0);
+          const int col = cg * PJ_COLS + 16 * (li >> 2) + lk + 4 * (li & 3);
+          if (col < S) colacc[col] += tot;
         }
         if (MODE == PMODE_SELECT && cg == ngc - 1) {
 #pragma unroll
