@@ -299,9 +299,11 @@ __global__ __launch_bounds__(256, 2) void proj_kernel(ProjArgs p) {
     const bool last = s == nst - 1;
     const int zs1 = zs == 2 ? 0 : zs + 1, zs2 = zs1 == 2 ? 0 : zs1 + 1, ts1 = ts ^ 1;
     // requests for the stages ahead fly while this stage's MFMAs run
+    int kct = 0, kcz = 0;
     if (ALIGNED) {
-      if (more) issue_t(n1, ts1);
-      if (more2) issue_z(n2, zs2);
+      // (the six requests themselves are spread over the first groups of the compute loop)
+      if (more) { if (n1.cg != tp_cg) set_t(n1.cg); kct = min(n1.s * PJ_KC + 2 * fq, kmax); }
+      if (more2) { if (n2.br != zp_br) set_z(n2.br); kcz = min(n2.s * PJ_KC + 2 * fq, kmax); }
     } else if (more) {
       fetch_regs(n1);
     }
@@ -348,6 +350,15 @@ __global__ __launch_bounds__(256, 2) void proj_kernel(ProjArgs p) {
         if (g + 1 < NG) {
 #pragma unroll
           for (int r = 0; r < 4; ++r) rp[(g + 1) & 1][r] = *rep_ptr(g + 1, r);
+        }
+        if (ALIGNED) {
+          // this group's share of the six LDS-DMA requests (Theta first: the stage-end wait counts on the order)
+#pragma unroll
+          for (int q = 0; q < 6; ++q) {
+            if (q * NG / 8 != g) continue;
+            if (q < 2) { if (more) pj_glds16(tp[q] + kct, lds0 + (unsigned)(PJ_TBASE + ts1 * PJ_TBYTES + (2 * wave + q) * 1024)); }
+            else if (more2) pj_glds16(zp[q - 2] + kcz, lds0 + (unsigned)(zs2 * PJ_ZBYTES + (4 * wave + q - 2) * 1024));
+          }
         }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
