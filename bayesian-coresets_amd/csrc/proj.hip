@@ -12,6 +12,7 @@
 //   SELECT  : per row  corr_n = vecs[n].resid / ||vecs[n]|| / S  and its arg-max   (sparsevi.py:44-55)
 // Arithmetic is fp64 throughout (the selection compares correlations to ~1e-7).
 #include <algorithm>
+#include <cstdlib>
 #include <string>
 #include <utility>
 #include <vector>
@@ -97,13 +98,16 @@ __device__ __forceinline__ double row16_sum(double v) {
 // written to the same LDS image).
 #define PJ_KC 16
 #define PJ_ROWS 128
-#define PJ_COLS 64
 #define PJ_ZBYTES (PJ_ROWS * PJ_KC * 8)
-#define PJ_TBYTES (PJ_COLS * PJ_KC * 8)
-#define PJ_ZRING 3
+// NCT = 16-column tiles per wave: 4 (a 128 x 64 workgroup tile) or 8 (128 x 128: two thirds of the global -> LDS traffic
+// and half the barriers per flop, 64 more accumulator VGPRs; the Z ring is then two deep so that two workgroups and the
+// column-sum accumulators still fit the CU's 160 KiB)
+#define PJ_COLS(NCT) (16 * (NCT))
+#define PJ_TBYTES(NCT) (PJ_COLS(NCT) * PJ_KC * 8)
+#define PJ_ZRING(NCT) ((NCT) == 4 ? 3 : 2)
 #define PJ_TRING 2
-#define PJ_TBASE (PJ_ZRING * PJ_ZBYTES)
-#define PJ_STAGING_BYTES (PJ_TBASE + PJ_TRING * PJ_TBYTES)
+#define PJ_TBASE(NCT) (PJ_ZRING(NCT) * PJ_ZBYTES)
+#define PJ_STAGING_BYTES(NCT) (PJ_TBASE(NCT) + PJ_TRING * PJ_TBYTES(NCT))
 
 typedef double pv2d __attribute__((ext_vector_type(2)));
 
@@ -147,18 +151,20 @@ struct PjPos {       // one stage of the workgroup's sequence: k stage s of colu
   int64_t br;
 };
 
-template <int FAM, int MODE, bool ALIGNED>
+template <int FAM, int MODE, bool ALIGNED, int NCT>
 __global__ __launch_bounds__(256, 2) void proj_kernel(ProjArgs p) {
+  constexpr int COLS = PJ_COLS(NCT), TBYTES = PJ_TBYTES(NCT), TBASE = PJ_TBASE(NCT), ZRING = PJ_ZRING(NCT);
+  constexpr int TCH = NCT / 2;               // Theta chunks (8 columns each) per wave and stage
   // ONE LDS object: staging rings | COLSUM: 4 x S column sums | SELECT: the four waves' candidates (a second __shared__
   // array makes hipcc drain the DMA queue before every LDS read)
   extern __shared__ __attribute__((aligned(16))) unsigned char pj_lds[];
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int li = lane & 15, lk = lane >> 4;
   const int S = p.S, D = p.D;
-  const int ngc = (S + PJ_COLS - 1) / PJ_COLS;
+  const int ngc = (S + COLS - 1) / COLS;
   const int nst = (D + PJ_KC - 1) / PJ_KC;
   const int64_t nblk = (p.N + PJ_ROWS - 1) / PJ_ROWS;
-  double* colacc = (double*)(pj_lds + PJ_STAGING_BYTES) + (size_t)wave * S;
+  double* colacc = (double*)(pj_lds + PJ_STAGING_BYTES(NCT)) + (size_t)wave * S;
   if (MODE == PMODE_COLSUM) {
     for (int c = lane; c < S; c += 64) colacc[c] = 0.0;
   }
@@ -184,7 +190,7 @@ __global__ __launch_bounds__(256, 2) void proj_kernel(ProjArgs p) {
   // 2 wave + j (columns 16 wave + 8 j + fr), piece fq of the row's 128-byte line
   const int fr = lane >> 3, fq = ((lane & 7) - 2 * ((fr >> 1) & 3)) & 7;
   const double* zp[4];                       // row pointers of the Z tile being requested (they change once per row block)
-  const double* tp[2];                       // column pointers of the Theta tile being requested (once per column group)
+  const double* tp[TCH];                     // column pointers of the Theta tile being requested (once per column group)
   int64_t zp_br = -1;
   int tp_cg = -1;
   const int kmax = ALIGNED ? ((D - 1) & ~1) : (D - 1);
@@ -199,8 +205,8 @@ __global__ __launch_bounds__(256, 2) void proj_kernel(ProjArgs p) {
   auto set_t = [&](int fcg) {
     tp_cg = fcg;
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const int col = fcg * PJ_COLS + 16 * wave + 8 * j + fr;
+    for (int j = 0; j < TCH; ++j) {
+      const int col = fcg * COLS + 8 * (TCH * wave + j) + fr;
       tp[j] = p.theta + (size_t)(col < S ? col : S - 1) * p.ldt;
     }
   };
@@ -210,7 +216,7 @@ __global__ __launch_bounds__(256, 2) void proj_kernel(ProjArgs p) {
   };
   // every piece of the stage exists (no zero-fill needed): scalar
   auto plain = [&](const PjPos& a) {
-    return a.s < nst - 1 && (a.br + 1) * PJ_ROWS <= p.N && (a.cg + 1) * PJ_COLS <= S;
+    return a.s < nst - 1 && (a.br + 1) * PJ_ROWS <= p.N && (a.cg + 1) * COLS <= S;
   };
   const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)pj_lds;   // LDS byte address of the staging area
   // LDS-DMA requests (ALIGNED).  zslot / tslot: ring slot.  The clamped piece index keeps every address inside its row.
@@ -225,30 +231,30 @@ __global__ __launch_bounds__(256, 2) void proj_kernel(ProjArgs p) {
     if (a.cg != tp_cg) set_t(a.cg);
     const int kc = min(a.s * PJ_KC + 2 * fq, kmax);
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
-      pj_glds16(tp[j] + kc, lds0 + (unsigned)(PJ_TBASE + tslot * PJ_TBYTES + (2 * wave + j) * 1024));
+    for (int j = 0; j < TCH; ++j)
+      pj_glds16(tp[j] + kc, lds0 + (unsigned)(TBASE + tslot * TBYTES + (TCH * wave + j) * 1024));
   };
   // zero-fill of this lane's own slots of a stage that is not plain (after its DMA has landed)
   auto zero_fill = [&](const PjPos& a, int zslot, int tslot) {
     const int k = a.s * PJ_KC + 2 * fq;
 #pragma unroll
-    for (int j = 0; j < 6; ++j) {
-      const bool valid = j < 4 ? a.br * PJ_ROWS + 32 * wave + 8 * j + fr < p.N : a.cg * PJ_COLS + 16 * wave + 8 * (j - 4) + fr < S;
+    for (int j = 0; j < 4 + TCH; ++j) {
+      const bool valid = j < 4 ? a.br * PJ_ROWS + 32 * wave + 8 * j + fr < p.N : a.cg * COLS + 8 * (TCH * wave + j - 4) + fr < S;
       unsigned char* dst = j < 4 ? pj_lds + zslot * PJ_ZBYTES + (4 * wave + j) * 1024 + lane * 16
-                                 : pj_lds + PJ_TBASE + tslot * PJ_TBYTES + (2 * wave + j - 4) * 1024 + lane * 16;
+                                 : pj_lds + TBASE + tslot * TBYTES + (TCH * wave + j - 4) * 1024 + lane * 16;
       if (!valid || k >= D) *(pv2d*)dst = (pv2d){0.0, 0.0};
       else if (k + 1 >= D) *(double*)(dst + 8) = 0.0;
     }
   };
   // register staging (!ALIGNED): 8-byte loads of the next stage during this stage's MFMAs, masked and written before the barrier
-  pv2d sreg[ALIGNED ? 1 : 6];
+  pv2d sreg[ALIGNED ? 1 : 4 + TCH];
   auto fetch_regs = [&](const PjPos& a) {
     if (a.br != zp_br) set_z(a.br);
     if (a.cg != tp_cg) set_t(a.cg);
     const int k = a.s * PJ_KC + 2 * fq;
     const int k0 = min(k, D - 1), k1 = min(k + 1, D - 1);
 #pragma unroll
-    for (int j = 0; j < 6; ++j) {
+    for (int j = 0; j < 4 + TCH; ++j) {
       const double* src = j < 4 ? zp[j] : tp[j - 4];
       sreg[ALIGNED ? 0 : j].x = src[k0];
       sreg[ALIGNED ? 0 : j].y = src[k1];
@@ -257,21 +263,21 @@ __global__ __launch_bounds__(256, 2) void proj_kernel(ProjArgs p) {
   auto park_regs = [&](const PjPos& a, int zslot, int tslot) {
     const int k = a.s * PJ_KC + 2 * fq;
 #pragma unroll
-    for (int j = 0; j < 6; ++j) {
-      const bool valid = j < 4 ? a.br * PJ_ROWS + 32 * wave + 8 * j + fr < p.N : a.cg * PJ_COLS + 16 * wave + 8 * (j - 4) + fr < S;
+    for (int j = 0; j < 4 + TCH; ++j) {
+      const bool valid = j < 4 ? a.br * PJ_ROWS + 32 * wave + 8 * j + fr < p.N : a.cg * COLS + 8 * (TCH * wave + j - 4) + fr < S;
       unsigned char* dst = j < 4 ? pj_lds + zslot * PJ_ZBYTES + (4 * wave + j) * 1024 + lane * 16
-                                 : pj_lds + PJ_TBASE + tslot * PJ_TBYTES + (2 * wave + j - 4) * 1024 + lane * 16;
+                                 : pj_lds + TBASE + tslot * TBYTES + (TCH * wave + j - 4) * 1024 + lane * 16;
       *(pv2d*)dst = mask_piece(sreg[ALIGNED ? 0 : j], valid, k, D);
     }
   };
 
   PjPos cur = {0, 0, (int64_t)blockIdx.x};
   PjPos n1 = advance(cur), n2 = advance(n1);
-  int zs = 0, ts = 0;                        // ring slots of the current stage (Z: stage mod 3, Theta: stage mod 2)
+  int zs = 0, ts = 0;                        // ring slots of the current stage (Z: stage mod ZRING, Theta: stage mod 2)
   if (ALIGNED) {
     issue_z(cur, 0);
     issue_t(cur, 0);
-    if (n1.br < nblk) { issue_z(n1, 1); asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); }
+    if (ZRING == 3 && n1.br < nblk) { issue_z(n1, 1); asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); }
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if (!plain(cur)) zero_fill(cur, 0, 0);
   } else {
@@ -289,7 +295,7 @@ __global__ __launch_bounds__(256, 2) void proj_kernel(ProjArgs p) {
   // COLSUM / SELECT: A = Theta, B = Z (the transposed product) -- a lane holds only 2 data rows (li, li + 16) x 16
   // columns, so the per-row state of the epilogue (response, shift, three moments) is 2 values per lane instead
   // of 8: what makes the kernel fit 256 registers at two waves per SIMD.
-  pv4d acc[2][4];                    // [row tile][column tile]
+  pv4d acc[2][NCT];                  // [row tile][column tile]
   double yv[TRP ? 2 : 8], cp[TRP ? 2 : 8];
   double piv[2], rs[TRP ? 2 : 8], rq[2], rd[2];
   while (true) {
@@ -297,13 +303,17 @@ __global__ __launch_bounds__(256, 2) void proj_kernel(ProjArgs p) {
     const int64_t br = cur.br;
     const bool more = n1.br < nblk, more2 = n2.br < nblk;
     const bool last = s == nst - 1;
-    const int zs1 = zs == 2 ? 0 : zs + 1, zs2 = zs1 == 2 ? 0 : zs1 + 1, ts1 = ts ^ 1;
+    const int zs1 = zs == ZRING - 1 ? 0 : zs + 1, zs2 = zs1 == ZRING - 1 ? 0 : zs1 + 1, ts1 = ts ^ 1;
     // requests for the stages ahead fly while this stage's MFMAs run
     int kct = 0, kcz = 0;
     if (ALIGNED) {
-      // (the six requests themselves are spread over the first groups of the compute loop)
+      // (the requests themselves are spread over the first groups of the compute loop)
       if (more) { if (n1.cg != tp_cg) set_t(n1.cg); kct = min(n1.s * PJ_KC + 2 * fq, kmax); }
-      if (more2) { if (n2.br != zp_br) set_z(n2.br); kcz = min(n2.s * PJ_KC + 2 * fq, kmax); }
+      if (ZRING == 3 ? more2 : more) {
+        const PjPos& zn = ZRING == 3 ? n2 : n1;
+        if (zn.br != zp_br) set_z(zn.br);
+        kcz = min(zn.s * PJ_KC + 2 * fq, kmax);
+      }
     } else if (more) {
       fetch_regs(n1);
     }
@@ -311,7 +321,7 @@ __global__ __launch_bounds__(256, 2) void proj_kernel(ProjArgs p) {
 #pragma unroll
       for (int tr = 0; tr < 2; ++tr)
 #pragma unroll
-        for (int tc = 0; tc < 4; ++tc) acc[tr][tc] = (pv4d){0.0, 0.0, 0.0, 0.0};
+        for (int tc = 0; tc < NCT; ++tc) acc[tr][tc] = (pv4d){0.0, 0.0, 0.0, 0.0};
     }
     {
       // v_mfma_f64_4x4x4_4b_f64: four independent 4x4x4 products per instruction (lanes 16k + 4b + i hold A_b[i][k],
@@ -321,50 +331,51 @@ __global__ __launch_bounds__(256, 2) void proj_kernel(ProjArgs p) {
       // into all four blocks -- D is then a 4 x 16 strip, and register r of the old 16x16 accumulator IS the strip of rows
       // 4r .. 4r+3, so accumulator layout and epilogue are those of the 16x16x4 version.
       const unsigned char* zb = pj_lds + zs * PJ_ZBYTES + wave * 4096;       // this wave's two Z tiles
-      const unsigned char* tb = pj_lds + PJ_TBASE + ts * PJ_TBYTES;
+      const unsigned char* tb = pj_lds + TBASE + ts * TBYTES;
       const unsigned char* natb[2] = {(TRP ? zb : tb) + nat0, (TRP ? zb : tb) + (nat0 ^ 64u)};
       const unsigned char* repb[2] = {(TRP ? tb : zb) + rep0, (TRP ? tb : zb) + (rep0 ^ 64u)};
       // Operand registers are double-buffered by hand: the four replicated pieces of group g + 1 are requested before the
       // 16 MFMAs of group g are issued (an LDS read takes ~130 cycles, four MFMAs 64), and within a group the .x MFMAs of
       // all accumulators precede their dependent .y MFMAs.  A group = one column tile (TRP) / one row tile (WRITE) of one
       // 8-k step; NG groups per stage.
-      constexpr int NU = PJ_KC / 8, NG = TRP ? 4 * NU : 2 * NU;
+      constexpr int NU = PJ_KC / 8, NA = TRP ? NCT : 2, NB = TRP ? 2 : NCT, NG = NA * NU;
       auto nat_ptr = [&](int u, int t) {      // natural operand tile t of 8-k step u
         return (const pv2d*)(natb[u & 1] + t * 2048);
       };
       auto rep_ptr = [&](int g, int r) {      // replicated operand, group g = (u, tile), rows 4 r .. 4 r + 3
-        const int u = TRP ? g / 4 : g / 2, t = TRP ? g % 4 : g % 2;
+        const int u = g / NA, t = g % NA;
         return (const pv2d*)(repb[(u + r) & 1] + t * 2048 + (r >> 1) * 1024 + (r & 1) * 512);
       };
       pv2d rp[2][4];
 #pragma unroll
       for (int r = 0; r < 4; ++r) rp[0][r] = *rep_ptr(0, r);
-      pv2d nt[TRP ? 2 : 4];
+      pv2d nt[NB];
 #pragma unroll
       for (int g = 0; g < NG; ++g) {
-        const int u = TRP ? g / 4 : g / 2, t = TRP ? g % 4 : g % 2;
+        const int u = g / NA, t = g % NA;
         if (t == 0) {
 #pragma unroll
-          for (int i = 0; i < (TRP ? 2 : 4); ++i) nt[i] = *nat_ptr(u, i);
+          for (int i = 0; i < NB; ++i) nt[i] = *nat_ptr(u, i);
         }
         if (g + 1 < NG) {
 #pragma unroll
           for (int r = 0; r < 4; ++r) rp[(g + 1) & 1][r] = *rep_ptr(g + 1, r);
         }
         if (ALIGNED) {
-          // this group's share of the six LDS-DMA requests (Theta first: the stage-end wait counts on the order)
+          // this group's share of the LDS-DMA requests (Theta first: the stage-end wait counts on the order)
 #pragma unroll
-          for (int q = 0; q < 6; ++q) {
-            if (q * NG / 8 != g) continue;
-            if (q < 2) { if (more) pj_glds16(tp[q] + kct, lds0 + (unsigned)(PJ_TBASE + ts1 * PJ_TBYTES + (2 * wave + q) * 1024)); }
-            else if (more2) pj_glds16(zp[q - 2] + kcz, lds0 + (unsigned)(zs2 * PJ_ZBYTES + (4 * wave + q - 2) * 1024));
+          for (int q = 0; q < TCH + 4; ++q) {
+            if ((NG >= 8 ? q : q * NG / 8) != g) continue;
+            if (q < TCH) { if (more) pj_glds16(tp[q] + kct, lds0 + (unsigned)(TBASE + ts1 * TBYTES + (TCH * wave + q) * 1024)); }
+            else if (ZRING == 3 ? more2 : more)
+              pj_glds16(zp[q - TCH] + kcz, lds0 + (unsigned)((ZRING == 3 ? zs2 : zs1) * PJ_ZBYTES + (4 * wave + q - TCH) * 1024));
           }
         }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int r = 0; r < 4; ++r)
 #pragma unroll
-          for (int i = 0; i < (TRP ? 2 : 4); ++i) {
+          for (int i = 0; i < NB; ++i) {
             pv4d& a4 = TRP ? acc[i][t] : acc[t][i];
             a4[r] = TRP ? __builtin_amdgcn_mfma_f64_4x4x4f64(rp[g & 1][r].x, nt[i].x, a4[r], 0, 0, 0)
                         : __builtin_amdgcn_mfma_f64_4x4x4f64(rp[g & 1][r].x, nt[i].x, a4[r], 0, 0, 0);
@@ -372,7 +383,7 @@ __global__ __launch_bounds__(256, 2) void proj_kernel(ProjArgs p) {
 #pragma unroll
         for (int r = 0; r < 4; ++r)
 #pragma unroll
-          for (int i = 0; i < (TRP ? 2 : 4); ++i) {
+          for (int i = 0; i < NB; ++i) {
             pv4d& a4 = TRP ? acc[i][t] : acc[t][i];
             a4[r] = __builtin_amdgcn_mfma_f64_4x4x4f64(rp[g & 1][r].y, nt[i].y, a4[r], 0, 0, 0);
           }
@@ -396,8 +407,8 @@ __global__ __launch_bounds__(256, 2) void proj_kernel(ProjArgs p) {
           }
         }
 #pragma unroll
-        for (int tc = 0; tc < 4; ++tc) {
-          const int col = cg * PJ_COLS + 16 * tc + li;
+        for (int tc = 0; tc < NCT; ++tc) {
+          const int col = cg * COLS + 16 * tc + li;
 #pragma unroll
           for (int e = 0; e < 8; ++e) {
             const int64_t row = r0 + 16 * (e >> 2) + lk + 4 * (e & 3);
@@ -434,41 +445,48 @@ __global__ __launch_bounds__(256, 2) void proj_kernel(ProjArgs p) {
             piv[tr] = __shfl(l0, li, BCX_WAVE);
           }
         }
-        double cs[16];                 // COLSUM: this lane's two rows of column (tc, r), index 4 tc + r
+        // 64 columns at a time, fenced: with all NCT column tiles in one scheduling region the compiler keeps every
+        // likelihood value of the tile live at once (the 128 x 128 tile then spills)
 #pragma unroll
-        for (int tc = 0; tc < 4; ++tc) {
+        for (int h = 0; h < NCT / 4; ++h) {
+          double cs[16];               // COLSUM: this lane's two rows of column (tc, r) of the half, index 4 tc + r
 #pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const int col = cg * PJ_COLS + 16 * tc + lk + 4 * r;
-            const bool cvalid = col < S;
-            const double rsd = (MODE == PMODE_SELECT && cvalid) ? p.resid[col] : 0.0;
-            double csum = 0.0;
+          for (int t4 = 0; t4 < 4; ++t4) {
+            const int tc = 4 * h + t4;
 #pragma unroll
-            for (int tr = 0; tr < 2; ++tr) {
-              const bool ok = cvalid && r0 + 16 * tr + li < p.N;
-              const double v = ok ? loglik<FAM>(acc[tr][tc][r], yv[tr], parg, cp[tr]) - piv[tr] : 0.0;
-              if (MODE == PMODE_COLSUM) csum += v;
-              else { rs[tr] += v; rq[tr] += v * v; rd[tr] += v * rsd; }
+            for (int r = 0; r < 4; ++r) {
+              const int col = cg * COLS + 16 * tc + lk + 4 * r;
+              const bool cvalid = col < S;
+              const double rsd = (MODE == PMODE_SELECT && cvalid) ? p.resid[col] : 0.0;
+              double csum = 0.0;
+#pragma unroll
+              for (int tr = 0; tr < 2; ++tr) {
+                const bool ok = cvalid && r0 + 16 * tr + li < p.N;
+                const double v = ok ? loglik<FAM>(acc[tr][tc][r], yv[tr], parg, cp[tr]) - piv[tr] : 0.0;
+                if (MODE == PMODE_COLSUM) csum += v;
+                else { rs[tr] += v; rq[tr] += v * v; rd[tr] += v * rsd; }
+              }
+              cs[4 * t4 + r] = csum;
             }
-            cs[4 * tc + r] = csum;
           }
-        }
-        if (MODE == PMODE_COLSUM) {
-          // Sum over the 16 lanes (data rows) of a DPP row, all 16 columns at once: a transposed butterfly -- at each
-          // level a lane keeps the half of its values whose index bit matches its lane bit and adds the partner's
-          // partial sums of that half (partners: mirror, half mirror, xor 2, xor 1 -- the lane bit flips each time), so
-          // lane li ends with the total of column index li: 15 exchanges instead of 64, then ONE LDS update per lane
-          // instead of 16 dependent read-add-write round trips.
-          double c8[8], c4[4], c2[2];
+          if (MODE == PMODE_COLSUM) {
+            // Sum over the 16 lanes (data rows) of a DPP row, all 16 columns at once: a transposed butterfly -- at each
+            // level a lane keeps the half of its values whose index bit matches its lane bit and adds the partner's
+            // partial sums of that half (partners: mirror, half mirror, xor 2, xor 1 -- the lane bit flips each time),
+            // so lane li ends with the total of column index li: 15 exchanges instead of 64, then ONE LDS update per
+            // lane instead of 16 dependent read-add-write round trips.
+            double c8[8], c4[4], c2[2];
 #pragma unroll
-          for (int e = 0; e < 8; ++e) c8[e] = pj_fold<0x140>(cs[e], cs[e + 8], (li & 8) != 0);
+            for (int e = 0; e < 8; ++e) c8[e] = pj_fold<0x140>(cs[e], cs[e + 8], (li & 8) != 0);
 #pragma unroll
-          for (int e = 0; e < 4; ++e) c4[e] = pj_fold<0x141>(c8[e], c8[e + 4], (li & 4) != 0);
+            for (int e = 0; e < 4; ++e) c4[e] = pj_fold<0x141>(c8[e], c8[e + 4], (li & 4) != 0);
 #pragma unroll
-          for (int e = 0; e < 2; ++e) c2[e] = pj_fold<0x4E>(c4[e], c4[e + 2], (li & 2) != 0);
-          const double tot = pj_fold<0xB1>(c2[0], c2[1], (li & 1) != 0);
-          const int col = cg * PJ_COLS + 16 * (li >> 2) + lk + 4 * (li & 3);
-          if (col < S) colacc[col] += tot;
+            for (int e = 0; e < 2; ++e) c2[e] = pj_fold<0x4E>(c4[e], c4[e + 2], (li & 2) != 0);
+            const double tot = pj_fold<0xB1>(c2[0], c2[1], (li & 1) != 0);
+            const int col = cg * COLS + 64 * h + 16 * (li >> 2) + lk + 4 * (li & 3);
+            if (col < S) colacc[col] += tot;
+          }
+          if (NCT > 4) __builtin_amdgcn_sched_barrier(0);
         }
         if (MODE == PMODE_SELECT && cg == ngc - 1) {
 #pragma unroll
@@ -493,7 +511,7 @@ __global__ __launch_bounds__(256, 2) void proj_kernel(ProjArgs p) {
     if (ALIGNED) {
       // everything but the Z requests of the stage after next has to have landed (requests complete in issue order;
       // after WRITE's epilogue the queue also holds stores, which do not: drain it)
-      if (more2 && !(last && !TRP)) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+      if (ZRING == 3 && more2 && !(last && !TRP)) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
       else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       if (!plain(n1)) zero_fill(n1, zs1, ts1);
     } else {
@@ -508,7 +526,7 @@ __global__ __launch_bounds__(256, 2) void proj_kernel(ProjArgs p) {
   if (MODE == PMODE_COLSUM) {
     __syncthreads();
     double* outp = p.colpart + (size_t)blockIdx.x * S;
-    const double* ca = (const double*)(pj_lds + PJ_STAGING_BYTES);
+    const double* ca = (const double*)(pj_lds + PJ_STAGING_BYTES(NCT));
     for (int c = tid; c < S; c += blockDim.x)
       outp[c] = ((ca[c] + ca[(size_t)S + c]) + ca[2 * (size_t)S + c]) + ca[3 * (size_t)S + c];
   }
@@ -628,7 +646,7 @@ struct ProjProfile {
 thread_local ProjProfile g_prof;
 }  // namespace
 
-template <int FAM, int MODE> static int launch_one(bool aligned, dim3 grid, size_t shmem, hipStream_t st, const ProjArgs& p) {
+template <int FAM, int MODE, int NCT> static int launch_one(bool aligned, dim3 grid, size_t shmem, hipStream_t st, const ProjArgs& p) {
   const bool timed = g_prof.on;
   if (timed) {
     if (g_prof.used == g_prof.ev.size()) {
@@ -640,11 +658,11 @@ template <int FAM, int MODE> static int launch_one(bool aligned, dim3 grid, size
     PROJ_HIP(hipEventRecord(g_prof.ev[g_prof.used].first, st));
   }
   if (aligned) {
-    PROJ_HIP(hipFuncSetAttribute((const void*)proj_kernel<FAM, MODE, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
-    hipLaunchKernelGGL((proj_kernel<FAM, MODE, true>), grid, dim3(256), shmem, st, p);
+    PROJ_HIP(hipFuncSetAttribute((const void*)proj_kernel<FAM, MODE, true, NCT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
+    hipLaunchKernelGGL((proj_kernel<FAM, MODE, true, NCT>), grid, dim3(256), shmem, st, p);
   } else {
-    PROJ_HIP(hipFuncSetAttribute((const void*)proj_kernel<FAM, MODE, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
-    hipLaunchKernelGGL((proj_kernel<FAM, MODE, false>), grid, dim3(256), shmem, st, p);
+    PROJ_HIP(hipFuncSetAttribute((const void*)proj_kernel<FAM, MODE, false, NCT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
+    hipLaunchKernelGGL((proj_kernel<FAM, MODE, false, NCT>), grid, dim3(256), shmem, st, p);
   }
   PROJ_HIP(hipGetLastError());
   if (timed) {
@@ -678,15 +696,32 @@ extern "C" int bcx_project_profile_read(double* ms_total, int64_t* launches, dou
   return BCX_OK;
 }
 
+// Width of the workgroup tile: 128 columns (NCT = 8) for COLSUM of the linear-regression family when that does not add
+// padded columns over 64-wide groups (54 against 50 TFLOP/s at the configs[4] shard shape).  Everything else keeps 64:
+// SELECT's per-row moments and the transcendental epilogues (logistic, Poisson) spill with 128 accumulator VGPRs and
+// measured slower (logistic D=300: 29 against 35 TFLOP/s), WRITE holds eight rows per lane.
+static int proj_nct(int mode, int family, int S) {
+  if (mode != PMODE_COLSUM || family != FAM_LINREG) return 4;
+  static const int forced = [] { const char* e = getenv("BCX_PROJ_NCT"); return e ? atoi(e) : 0; }();   // dev knob
+  if (forced == 4 || forced == 8) return forced;
+  return (S + 127) / 128 * 128 == (S + 63) / 64 * 64 ? 8 : 4;
+}
+static bool proj_aligned(const ProjArgs& p) {
+  // 16-byte requests need 16-byte aligned rows: even leading dimensions and aligned bases (else 8-byte loads)
+  return ((uintptr_t)p.Z % 16 == 0) && ((uintptr_t)p.theta % 16 == 0) && p.ldz % 2 == 0 && p.ldt % 2 == 0;
+}
 template <int MODE> static int launch_family(int family, dim3 grid, size_t extra_lds, hipStream_t st, const ProjArgs& p) {
-  const size_t shmem = PJ_STAGING_BYTES + extra_lds;
-  if (shmem > 160 * 1024) { g_proj_err = "bcx_project: S too large for the column-sum accumulators (S <= 3328)"; return BCX_ERR_ARG; }
-  // 16-byte loads need 16-byte aligned rows: even leading dimensions and aligned bases (else 8-byte loads)
-  const bool aligned = ((uintptr_t)p.Z % 16 == 0) && ((uintptr_t)p.theta % 16 == 0) && p.ldz % 2 == 0 && p.ldt % 2 == 0;
+  const int nct = proj_nct(MODE, family, p.S);
+  const size_t shmem = (nct == 8 ? PJ_STAGING_BYTES(8) : PJ_STAGING_BYTES(4)) + extra_lds;
+  if (shmem > 160 * 1024) { g_proj_err = "bcx_project: S too large for the column-sum accumulators (S <= 3072)"; return BCX_ERR_ARG; }
+  const bool aligned = proj_aligned(p);
+  if constexpr (MODE == PMODE_COLSUM) {
+    if (nct == 8) return launch_one<FAM_LINREG, MODE, 8>(aligned, grid, shmem, st, p);
+  }
   switch (family) {
-    case FAM_LOGISTIC: return launch_one<FAM_LOGISTIC, MODE>(aligned, grid, shmem, st, p);
-    case FAM_POISSON: return launch_one<FAM_POISSON, MODE>(aligned, grid, shmem, st, p);
-    case FAM_LINREG: return launch_one<FAM_LINREG, MODE>(aligned, grid, shmem, st, p);
+    case FAM_LOGISTIC: return launch_one<FAM_LOGISTIC, MODE, 4>(aligned, grid, shmem, st, p);
+    case FAM_POISSON: return launch_one<FAM_POISSON, MODE, 4>(aligned, grid, shmem, st, p);
+    case FAM_LINREG: return launch_one<FAM_LINREG, MODE, 4>(aligned, grid, shmem, st, p);
     default: g_proj_err = "unknown likelihood family"; return BCX_ERR_ARG;
   }
 }
