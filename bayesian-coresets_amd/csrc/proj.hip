@@ -560,12 +560,24 @@ __global__ __launch_bounds__(256, 2) void proj_kernel(ProjArgs p) {
 }
 
 // out[n][s] -= rowsum[n] / S    (lls -= lls.mean(axis=1)[:, None], projector.py:21)
+// One wave per row at a time, 16-byte accesses when the rows allow them (the first form divided a flat 64-bit index by
+// S per element and ran at 4.6 TB/s of traffic; this one is a plain stream).
+template <bool VEC>
 __global__ __launch_bounds__(256) void center_kernel(double* out, int64_t ldo, const double* rowsum, int64_t N, int S) {
-  const int64_t total = N * (int64_t)S;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-    const int64_t n = i / S;
-    const int s = (int)(i - n * S);
-    out[n * ldo + s] -= rowsum[n] / (double)S;
+  const int lane = threadIdx.x & 63;
+  const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = (int64_t)gridDim.x * 4;
+  for (int64_t n = wave; n < N; n += nwaves) {
+    const double m = rowsum[n] / (double)S;
+    double* row = out + n * ldo;
+    if (VEC) {
+      for (int c = 2 * lane; c < S; c += 128) {
+        pv2d v = *(pv2d*)(row + c);
+        v.x -= m; v.y -= m;
+        *(pv2d*)(row + c) = v;
+      }
+    } else {
+      for (int c = lane; c < S; c += 64) row[c] -= m;
+    }
   }
 }
 
@@ -760,9 +772,11 @@ extern "C" int bcx_project_write(void* stream, int32_t family, const void* Z_dev
   p.out = (double*)out_dev; p.ldo = ldo; p.rowsum = (double*)rowsum_dev;
   hipStream_t st = (hipStream_t)stream;
   if ((rc = launch_family<PMODE_WRITE>(family, dim3(proj_grid(N)), 0, st, p))) return rc;
-  const int64_t total = N * (int64_t)S;
-  const int g = (int)std::min<int64_t>((total + 255) / 256, 4096);
-  hipLaunchKernelGGL(center_kernel, dim3(g), dim3(256), 0, st, p.out, ldo, p.rowsum, N, S);
+  const int g = (int)std::min<int64_t>((N + 3) / 4, 8192);
+  if (S % 2 == 0 && ldo % 2 == 0 && (uintptr_t)p.out % 16 == 0)
+    hipLaunchKernelGGL(center_kernel<true>, dim3(g), dim3(256), 0, st, p.out, ldo, p.rowsum, N, S);
+  else
+    hipLaunchKernelGGL(center_kernel<false>, dim3(g), dim3(256), 0, st, p.out, ldo, p.rowsum, N, S);
   PROJ_HIP(hipGetLastError());
   return BCX_OK;
 }
