@@ -352,6 +352,19 @@ def measured_traffic(args, n_local):
         return None
 
 
+def projection_traffic(n_local, D, S):
+    """HBM bytes per full-data projection launch (COLSUM, linear-regression family) from the committed FETCH_SIZE pass,
+    under the same stamp rule as the scan's."""
+    try:
+        from tools.stamp import source_digest
+        tj = json.load(open(os.path.join(ROOT, "profiles", "scan_traffic.json")))
+        if tj.get("_stamp") != source_digest():
+            return None
+        return tj.get("proj_colsum_linreg_n%d_d%d_s%d" % (n_local, D, S))
+    except Exception:
+        return None
+
+
 # =====================================================================================================================
 # config 5: SparseVI on the RBF-basis regression; step = one greedy step = (1 + opt_itrs) full-data projections
 # =====================================================================================================================
@@ -431,7 +444,7 @@ def run_sparsevi(args, torch, dist, nat, world, rank, local_rank):
         },
         "roofline": {
             "bound": "mfma", "kernel": "proj_kernel", "achieved": achieved, "peak": F64_MFMA_PEAK_TF, "unit": "TFLOP/s",
-            "frac": achieved / F64_MFMA_PEAK_TF, "traffic": None,
+            "frac": achieved / F64_MFMA_PEAK_TF, "traffic": projection_traffic(hi - lo, D, S),
             "avg_launch_ms": kms / max(launches, 1), "launches": int(launches),
             "algorithmic_flops_per_full_launch": per_launch_flops,
             "attainable_note": "register-only loops on this chip sustain 72.8 TFLOP/s with v_mfma_f64_4x4x4_4b_f64 (the form "
