@@ -4,8 +4,8 @@
 //   logistic regression   examples/common/model_lr.py:25-32
 //   Poisson (softplus)    examples/common/model_poiss.py:25-38
 //   Gaussian linear regr. examples/common/model_linreg.py:4-10
-// as one fused kernel: Z . Theta^T on the fp64 matrix cores (v_mfma_f64_16x16x4_f64, one wave per
-// 16-row tile, all S columns in 16-column tiles) with the likelihood as the epilogue, and three
+// as one fused kernel: Z . Theta^T on the fp64 matrix cores (v_mfma_f64_4x4x4_4b_f64; operands staged through LDS by
+// LDS-DMA, 128 x 64 or 128 x 128 workgroup tiles) with the likelihood as the epilogue, and three
 // consumers that never need the N x S matrix twice:
 //   WRITE   : store the uncentred values + per-row sums (a second elementwise pass subtracts the mean)
 //   COLSUM  : only the column sums  sum_n vecs[n][s]        (SparseVI gradient, sparsevi.py:70-74)
@@ -37,6 +37,7 @@ struct ProjArgs {
   double* colpart;      // COLSUM: gridDim.x x S partial column sums
   const double* resid;  // SELECT: S
   double resid_sum;     // SELECT: sum_s resid[s]
+  int team;             // COLSUM: column groups of a row block spread over `team` workgroups of one XCD (0: one workgroup)
   double* best_val;     // SELECT: gridDim.x
   int64_t* best_idx;    // SELECT: gridDim.x
 };
@@ -184,7 +185,22 @@ __global__ __launch_bounds__(256, 2) void proj_kernel(ProjArgs p) {
   // Orientation of the wave's 32 rows x 64 columns (see the compute loop): COLSUM / SELECT compute the transposed product.
   constexpr bool TRP = MODE != PMODE_WRITE;
 
-  if ((int64_t)blockIdx.x >= nblk) {
+  // Block -> tile sequence.  Default: workgroup b takes row blocks b, b + gridDim, ... and walks their column groups
+  // itself -- Z is then streamed from HBM once per column group (the 64 workgroups of an XCD push ~20 MB through its 4 MB
+  // L2 between two passes of one of them).  COLSUM's tiles are independent, so there (p.team = number of column groups)
+  // the column groups of a row block go to workgroups that sit on the SAME XCD and run in step: blocks b and b + 8 share
+  // an XCD (dispatch is round-robin over the 8 XCDs: a speed assumption, not a correctness one), team = (b / 8) / ngc,
+  // member = column group = (b / 8) % ngc; the second reader of a Z line finds it in L2.
+  const bool teamed = MODE == PMODE_COLSUM && p.team > 1;
+  int cg0 = 0;
+  int64_t br0 = blockIdx.x, brstep = gridDim.x;
+  if (teamed) {
+    const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3, per = (int)(gridDim.x >> 3) / ngc;
+    cg0 = j % ngc;
+    br0 = (int64_t)xcd * per + j / ngc;
+    brstep = gridDim.x / ngc;
+  }
+  if (br0 >= nblk) {
     if (MODE == PMODE_COLSUM) {
       __syncthreads();
       double* outp = p.colpart + (size_t)blockIdx.x * S;
@@ -219,7 +235,11 @@ __global__ __launch_bounds__(256, 2) void proj_kernel(ProjArgs p) {
     }
   };
   auto advance = [&](PjPos a) {
-    if (++a.s == nst) { a.s = 0; if (++a.cg == ngc) { a.cg = 0; a.br += gridDim.x; } }
+    if (++a.s == nst) {
+      a.s = 0;
+      if (teamed) a.br += brstep;
+      else if (++a.cg == ngc) { a.cg = 0; a.br += brstep; }
+    }
     return a;
   };
   // every piece of the stage exists (no zero-fill needed): scalar
@@ -279,7 +299,7 @@ __global__ __launch_bounds__(256, 2) void proj_kernel(ProjArgs p) {
     }
   };
 
-  PjPos cur = {0, 0, (int64_t)blockIdx.x};
+  PjPos cur = {0, cg0, br0};
   PjPos n1 = advance(cur), n2 = advance(n1);
   int zs = 0, ts = 0;                        // ring slots of the current stage (Z: stage mod ZRING, Theta: stage mod 2)
   if (ALIGNED) {
@@ -436,7 +456,7 @@ __global__ __launch_bounds__(256, 2) void proj_kernel(ProjArgs p) {
         }
       } else {
         // i = column (lk + 4 reg within column tile tc), j = data row (li within row tile tr)
-        if (cg == 0) {
+        if (cg == 0 || teamed) {
 #pragma unroll
           for (int tr = 0; tr < 2; ++tr) {
             const int64_t row = r0 + 16 * tr + li;
@@ -449,8 +469,11 @@ __global__ __launch_bounds__(256, 2) void proj_kernel(ProjArgs p) {
             // one-pass moments then cancel on the scale of the row's SPREAD, not of |ll| (rows with |mean| >> spread:
             // a concentrated posterior, saturated logistic rows) -- the accuracy of the reference's centre-then-norm
             // order (sparsevi.py:49-51) without a second pass.
-            const double l0 = loglik<FAM>(acc[tr][0][0], yv[tr], parg, cp[tr]);
-            piv[tr] = __shfl(l0, li, BCX_WAVE);
+            // COLSUM only needs SOME shift that is constant along the row (the centring correction removes it); its
+            // column groups may sit in different workgroups, so it takes one every workgroup can form from the row
+            // alone: the likelihood at a zero linear predictor.
+            const double l0 = loglik<FAM>(MODE == PMODE_COLSUM ? 0.0 : acc[tr][0][0], yv[tr], parg, cp[tr]);
+            piv[tr] = MODE == PMODE_COLSUM ? l0 : __shfl(l0, li, BCX_WAVE);
           }
         }
         // 64 columns at a time, fenced: with all NCT column tiles in one scheduling region the compiler keeps every
@@ -756,7 +779,7 @@ static int fill(ProjArgs& p, int family, const void* Z, int64_t N, int64_t ldz, 
   p.Z = (const double*)Z; p.theta = (const double*)theta; p.N = N; p.ldz = ldz; p.ldt = ldt; p.D = D; p.S = S;
   p.ycol = family == FAM_LOGISTIC ? -1 : ycol; p.param = param;
   p.out = nullptr; p.ldo = 0; p.rowsum = nullptr; p.colpart = nullptr; p.resid = nullptr; p.resid_sum = 0.0;
-  p.best_val = nullptr; p.best_idx = nullptr;
+  p.best_val = nullptr; p.best_idx = nullptr; p.team = 0;
   return BCX_OK;
 }
 
@@ -792,6 +815,11 @@ extern "C" int bcx_project_colsum(void* stream, int32_t family, const void* Z_de
   hipStream_t st = (hipStream_t)stream;
   const int grid = proj_grid(N);
   p.colpart = (double*)work_dev;
+  {  // teams need a full grid that splits evenly: 8 XCDs x (workgroups per XCD divisible by the number of column groups)
+    const int cols = 16 * proj_nct(PMODE_COLSUM, family, S), ngc = (S + cols - 1) / cols;
+    static const bool no_team = getenv("BCX_PROJ_NO_TEAM") != nullptr;   // dev knob
+    p.team = (!no_team && ngc > 1 && grid % 8 == 0 && (grid / 8) % ngc == 0) ? ngc : 0;
+  }
   if ((rc = launch_family<PMODE_COLSUM>(family, dim3(grid), 4 * (size_t)S * sizeof(double), st, p))) return rc;
   hipLaunchKernelGGL(colsum_reduce_kernel, dim3((S + 63) / 64), dim3(256), 0, st, p.colpart, grid, S, (double*)colsum_dev);
   hipLaunchKernelGGL(colsum_center_kernel, dim3(1), dim3(256), 0, st, S, (double*)colsum_dev);
