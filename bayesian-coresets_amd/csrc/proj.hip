@@ -195,10 +195,10 @@ __global__ __launch_bounds__(256, 2) void proj_kernel(ProjArgs p) {
   int cg0 = 0;
   int64_t br0 = blockIdx.x, brstep = gridDim.x;
   if (teamed) {
-    const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3, per = (int)(gridDim.x >> 3) / ngc;
+    const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3, per = (int)(gridDim.x >> 3) / ngc;   // teams per XCD
     cg0 = j % ngc;
-    br0 = (int64_t)xcd * per + j / ngc;
-    brstep = gridDim.x / ngc;
+    br0 = j < per * ngc ? (int64_t)xcd * per + j / ngc : nblk;      // the (gridDim / 8) % ngc left-over workgroups of an XCD idle
+    brstep = 8 * per;
   }
   if (br0 >= nblk) {
     if (MODE == PMODE_COLSUM) {
@@ -815,10 +815,10 @@ extern "C" int bcx_project_colsum(void* stream, int32_t family, const void* Z_de
   hipStream_t st = (hipStream_t)stream;
   const int grid = proj_grid(N);
   p.colpart = (double*)work_dev;
-  {  // teams need a full grid that splits evenly: 8 XCDs x (workgroups per XCD divisible by the number of column groups)
+  {  // teams need a grid that covers the 8 XCDs evenly; workgroups of an XCD that do not fill a team stay idle
     const int cols = 16 * proj_nct(PMODE_COLSUM, family, S), ngc = (S + cols - 1) / cols;
     static const bool no_team = getenv("BCX_PROJ_NO_TEAM") != nullptr;   // dev knob
-    p.team = (!no_team && ngc > 1 && grid % 8 == 0 && (grid / 8) % ngc == 0) ? ngc : 0;
+    p.team = (!no_team && ngc > 1 && grid % 8 == 0 && grid / 8 >= 4 * ngc) ? ngc : 0;   // (<= 1/5 of an XCD's workgroups idle)
   }
   if ((rc = launch_family<PMODE_COLSUM>(family, dim3(grid), 4 * (size_t)S * sizeof(double), st, p))) return rc;
   hipLaunchKernelGGL(colsum_reduce_kernel, dim3((S + 63) / 64), dim3(256), 0, st, p.colpart, grid, S, (double*)colsum_dev);
