@@ -66,6 +66,15 @@ template <int FAM> __device__ __forceinline__ double loglik(double m, double y, 
   }
 }
 
+// loglik - shift.  For the column sums of the linear-regression family the shift is the likelihood at a zero linear
+// predictor (see the epilogue), and the difference has a closed form without the cancellation:
+//   [c0 - (y^2 - 2 m y + m^2) / (2 sigsq)] - [c0 - y^2 / (2 sigsq)] = (2 y - m) m / (2 sigsq)
+// -- three operations instead of seven per element, and more accurate than forming both terms.
+template <int FAM, int MODE> __device__ __forceinline__ double loglik_shifted(double m, double y, double param, double c0, double shift) {
+  if (FAM == FAM_LINREG && MODE == PMODE_COLSUM) return (2.0 * y - m) * m * param;
+  return loglik<FAM>(m, y, param, c0) - shift;
+}
+
 // sum over the 16 lanes of a DPP row (lanes that share l >> 4)
 __device__ __forceinline__ double row16_sum(double v) {
   v += bcx_dpp_f64<0xB1>(v);
@@ -187,11 +196,11 @@ __global__ __launch_bounds__(256, 2) void proj_kernel(ProjArgs p) {
 
   // Block -> tile sequence.  Default: workgroup b takes row blocks b, b + gridDim, ... and walks their column groups
   // itself -- Z is then streamed from HBM once per column group (the 64 workgroups of an XCD push ~20 MB through its 4 MB
-  // L2 between two passes of one of them).  COLSUM's tiles are independent, so there (p.team = number of column groups)
+  // L2 between two passes of one of them).  COLSUM's and WRITE's tiles are independent, so there (p.team = number of column groups)
   // the column groups of a row block go to workgroups that sit on the SAME XCD and run in step: blocks b and b + 8 share
   // an XCD (dispatch is round-robin over the 8 XCDs: a speed assumption, not a correctness one), team = (b / 8) / ngc,
   // member = column group = (b / 8) % ngc; the second reader of a Z line finds it in L2.
-  const bool teamed = MODE == PMODE_COLSUM && p.team > 1;
+  const bool teamed = MODE != PMODE_SELECT && p.team > 1;
   int cg0 = 0;
   int64_t br0 = blockIdx.x, brstep = gridDim.x;
   if (teamed) {
@@ -325,7 +334,7 @@ __global__ __launch_bounds__(256, 2) void proj_kernel(ProjArgs p) {
   // of 8: what makes the kernel fit 256 registers at two waves per SIMD.
   pv4d acc[2][NCT];                  // [row tile][column tile]
   double yv[TRP ? 2 : 8], cp[TRP ? 2 : 8];
-  double piv[2], rs[TRP ? 2 : 8], rq[2], rd[2];
+  double piv[2], rs[2], rq[2], rd[2];
   while (true) {
     const int s = cur.s, cg = cur.cg;
     const int64_t br = cur.br;
@@ -423,35 +432,24 @@ __global__ __launch_bounds__(256, 2) void proj_kernel(ProjArgs p) {
       const int64_t r0 = br * PJ_ROWS + 32 * wave;
       if (!TRP) {
         // i = data row (lk + 4 reg), j = column (li)
-        if (cg == 0) {
+        if (cg == 0 || teamed) {
 #pragma unroll
           for (int e = 0; e < 8; ++e) {
             const int64_t row = r0 + 16 * (e >> 2) + lk + 4 * (e & 3);
             const double y = (p.ycol >= 0 && row < p.N) ? p.Z[row * p.ldz + p.ycol] : 0.0;
             yv[e] = y;
             cp[e] = (FAM == FAM_POISSON) ? pj_lgamma1p<MODE>(y) : clin;
-            rs[e] = 0.0;
             if (FAM == FAM_POISSON) __builtin_amdgcn_sched_barrier(0);   // one lgamma at a time
           }
         }
+        // (the row means are formed by the centring pass from the stored values: no state crosses the column groups)
 #pragma unroll
         for (int tc = 0; tc < NCT; ++tc) {
           const int col = cg * COLS + 16 * tc + li;
 #pragma unroll
           for (int e = 0; e < 8; ++e) {
             const int64_t row = r0 + 16 * (e >> 2) + lk + 4 * (e & 3);
-            const bool ok = col < S && row < p.N;
-            const double ll = ok ? loglik<FAM>(acc[e >> 2][tc][e & 3], yv[e], parg, cp[e]) : 0.0;
-            if (ok) p.out[row * p.ldo + col] = ll;
-            rs[e] += ll;
-          }
-        }
-        if (cg == ngc - 1) {
-#pragma unroll
-          for (int e = 0; e < 8; ++e) {
-            const double t = row16_sum(rs[e]);
-            const int64_t row = r0 + 16 * (e >> 2) + lk + 4 * (e & 3);
-            if (li == 0 && row < p.N) p.rowsum[row] = t;
+            if (col < S && row < p.N) p.out[row * p.ldo + col] = loglik<FAM>(acc[e >> 2][tc][e & 3], yv[e], parg, cp[e]);
           }
         }
       } else {
@@ -493,7 +491,7 @@ __global__ __launch_bounds__(256, 2) void proj_kernel(ProjArgs p) {
 #pragma unroll
               for (int tr = 0; tr < 2; ++tr) {
                 const bool ok = cvalid && r0 + 16 * tr + li < p.N;
-                const double v = ok ? loglik<FAM>(acc[tr][tc][r], yv[tr], parg, cp[tr]) - piv[tr] : 0.0;
+                const double v = ok ? loglik_shifted<FAM, MODE>(acc[tr][tc][r], yv[tr], parg, cp[tr], piv[tr]) : 0.0;
                 if (MODE == PMODE_COLSUM) csum += v;
                 else { rs[tr] += v; rq[tr] += v * v; rd[tr] += v * rsd; }
               }
@@ -582,23 +580,36 @@ __global__ __launch_bounds__(256, 2) void proj_kernel(ProjArgs p) {
   }
 }
 
-// out[n][s] -= rowsum[n] / S    (lls -= lls.mean(axis=1)[:, None], projector.py:21)
-// One wave per row at a time, 16-byte accesses when the rows allow them (the first form divided a flat 64-bit index by
-// S per element and ran at 4.6 TB/s of traffic; this one is a plain stream).
+// out[n][:] -= mean(out[n][:])    (lls -= lls.mean(axis=1)[:, None], projector.py:21)
+// One wave per row at a time: the row is read once (16-byte accesses when the rows allow them; up to 512 columns stay in
+// registers between the sum and the subtraction, longer rows are re-read from L2), summed in a fixed order (lane-strided
+// partial sums, then the wave butterfly) and written back.  (The projection kernel used to hand over row sums; forming
+// them here costs no traffic and leaves WRITE without state that crosses its column groups.)
 template <bool VEC>
-__global__ __launch_bounds__(256) void center_kernel(double* out, int64_t ldo, const double* rowsum, int64_t N, int S) {
+__global__ __launch_bounds__(256) void center_kernel(double* out, int64_t ldo, int64_t N, int S) {
   const int lane = threadIdx.x & 63;
   const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = (int64_t)gridDim.x * 4;
   for (int64_t n = wave; n < N; n += nwaves) {
-    const double m = rowsum[n] / (double)S;
     double* row = out + n * ldo;
-    if (VEC) {
-      for (int c = 2 * lane; c < S; c += 128) {
-        pv2d v = *(pv2d*)(row + c);
-        v.x -= m; v.y -= m;
-        *(pv2d*)(row + c) = v;
+    if (VEC && S <= 512) {
+      pv2d v[4];
+      double acc = 0.0;
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const int c = 2 * lane + 128 * t;
+        v[t] = c < S ? *(const pv2d*)(row + c) : (pv2d){0.0, 0.0};
+        acc += v[t].x + v[t].y;
+      }
+      const double m = wave_allsum(acc) / (double)S;
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const int c = 2 * lane + 128 * t;
+        if (c < S) { v[t].x -= m; v[t].y -= m; *(pv2d*)(row + c) = v[t]; }
       }
     } else {
+      double acc = 0.0;
+      for (int c = lane; c < S; c += 64) acc += row[c];
+      const double m = wave_allsum(acc) / (double)S;
       for (int c = lane; c < S; c += 64) row[c] -= m;
     }
   }
@@ -749,6 +760,13 @@ static int proj_nct(int mode, int family, int S) {
   if (forced == 4 || forced == 8) return forced;
   return (S + 127) / 128 * 128 == (S + 63) / 64 * 64 ? 8 : 4;
 }
+// XCD teams (COLSUM, WRITE) need a grid that covers the 8 XCDs evenly; workgroups of an XCD that do not fill a team stay
+// idle (at most a fifth of them).  Returns the team size = number of column groups, 0 for the one-workgroup walk.
+static int proj_team(int mode, int family, int S, int grid) {
+  static const bool no_team = getenv("BCX_PROJ_NO_TEAM") != nullptr;   // dev knob
+  const int cols = 16 * proj_nct(mode, family, S), ngc = (S + cols - 1) / cols;
+  return (!no_team && ngc > 1 && grid % 8 == 0 && grid / 8 >= 4 * ngc) ? ngc : 0;
+}
 static bool proj_aligned(const ProjArgs& p) {
   // 16-byte requests need 16-byte aligned rows: even leading dimensions and aligned bases (else 8-byte loads)
   return ((uintptr_t)p.Z % 16 == 0) && ((uintptr_t)p.theta % 16 == 0) && p.ldz % 2 == 0 && p.ldt % 2 == 0;
@@ -783,7 +801,7 @@ static int fill(ProjArgs& p, int family, const void* Z, int64_t N, int64_t ldz, 
   return BCX_OK;
 }
 
-// vecs (N x S, centred) into out_dev; rowsum_dev is N doubles of scratch.
+// vecs (N x S, centred) into out_dev; rowsum_dev (N doubles) is no longer used: the centring pass forms the means.
 extern "C" int bcx_project_write(void* stream, int32_t family, const void* Z_dev, int64_t N, int64_t ldz, int32_t D,
                                  int32_t ycol, const void* theta_dev, int32_t S, int32_t ldt, double param,
                                  void* out_dev, int64_t ldo, void* rowsum_dev) {
@@ -794,12 +812,14 @@ extern "C" int bcx_project_write(void* stream, int32_t family, const void* Z_dev
   if (N == 0) return BCX_OK;
   p.out = (double*)out_dev; p.ldo = ldo; p.rowsum = (double*)rowsum_dev;
   hipStream_t st = (hipStream_t)stream;
-  if ((rc = launch_family<PMODE_WRITE>(family, dim3(proj_grid(N)), 0, st, p))) return rc;
+  const int wgrid = proj_grid(N);
+  p.team = proj_team(PMODE_WRITE, family, S, wgrid);
+  if ((rc = launch_family<PMODE_WRITE>(family, dim3(wgrid), 0, st, p))) return rc;
   const int g = (int)std::min<int64_t>((N + 3) / 4, 8192);
   if (S % 2 == 0 && ldo % 2 == 0 && (uintptr_t)p.out % 16 == 0)
-    hipLaunchKernelGGL(center_kernel<true>, dim3(g), dim3(256), 0, st, p.out, ldo, p.rowsum, N, S);
+    hipLaunchKernelGGL(center_kernel<true>, dim3(g), dim3(256), 0, st, p.out, ldo, N, S);
   else
-    hipLaunchKernelGGL(center_kernel<false>, dim3(g), dim3(256), 0, st, p.out, ldo, p.rowsum, N, S);
+    hipLaunchKernelGGL(center_kernel<false>, dim3(g), dim3(256), 0, st, p.out, ldo, N, S);
   PROJ_HIP(hipGetLastError());
   return BCX_OK;
 }
@@ -815,11 +835,7 @@ extern "C" int bcx_project_colsum(void* stream, int32_t family, const void* Z_de
   hipStream_t st = (hipStream_t)stream;
   const int grid = proj_grid(N);
   p.colpart = (double*)work_dev;
-  {  // teams need a grid that covers the 8 XCDs evenly; workgroups of an XCD that do not fill a team stay idle
-    const int cols = 16 * proj_nct(PMODE_COLSUM, family, S), ngc = (S + cols - 1) / cols;
-    static const bool no_team = getenv("BCX_PROJ_NO_TEAM") != nullptr;   // dev knob
-    p.team = (!no_team && ngc > 1 && grid % 8 == 0 && grid / 8 >= 4 * ngc) ? ngc : 0;   // (<= 1/5 of an XCD's workgroups idle)
-  }
+  p.team = proj_team(PMODE_COLSUM, family, S, grid);
   if ((rc = launch_family<PMODE_COLSUM>(family, dim3(grid), 4 * (size_t)S * sizeof(double), st, p))) return rc;
   hipLaunchKernelGGL(colsum_reduce_kernel, dim3((S + 63) / 64), dim3(256), 0, st, p.colpart, grid, S, (double*)colsum_dev);
   hipLaunchKernelGGL(colsum_center_kernel, dim3(1), dim3(256), 0, st, S, (double*)colsum_dev);
