@@ -177,9 +177,8 @@ class DeviceProjector(Projector):
         Z = self._dev(pts)
         N, S = Z.shape[0], self.theta.shape[0]
         out = torch.empty((N, S), dtype=torch.float64, device=self.device)
-        rowsum = torch.empty(max(N, 1), dtype=torch.float64, device=self.device)
         if N:
-            self._launch(self._lib.bcx_project_write, self._common(Z) + [out.data_ptr(), S, rowsum.data_ptr()], Z)
+            self._launch(self._lib.bcx_project_write, self._common(Z) + [out.data_ptr(), S, None], Z)
         return out
 
     # -- fused consumers (SparseVI) -------------------------------------------------

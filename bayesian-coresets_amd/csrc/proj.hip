@@ -33,7 +33,7 @@ struct ProjArgs {
   double param;         // linreg: sigma^2
   double* out;          // WRITE: N x ldo
   int64_t ldo;
-  double* rowsum;       // WRITE: N
+  double* rowsum;       // (unused)
   double* colpart;      // COLSUM: gridDim.x x S partial column sums
   const double* resid;  // SELECT: S
   double resid_sum;     // SELECT: sum_s resid[s]
@@ -808,7 +808,7 @@ extern "C" int bcx_project_write(void* stream, int32_t family, const void* Z_dev
   ProjArgs p;
   int rc = fill(p, family, Z_dev, N, ldz, D, ycol, theta_dev, S, ldt, param);
   if (rc) return rc;
-  if (!out_dev || !rowsum_dev || ldo < S) { g_proj_err = "bcx_project_write: bad output"; return BCX_ERR_ARG; }
+  if (!out_dev || ldo < S) { g_proj_err = "bcx_project_write: bad output"; return BCX_ERR_ARG; }
   if (N == 0) return BCX_OK;
   p.out = (double*)out_dev; p.ldo = ldo; p.rowsum = (double*)rowsum_dev;
   hipStream_t st = (hipStream_t)stream;

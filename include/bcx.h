@@ -181,7 +181,7 @@ int bcx_profile_read(bcx_solver* s, double* scan_ms_total, int64_t* scan_launche
  * 1 = Poisson/softplus (model_poiss.py:25-38), 2 = Gaussian linear regression (model_linreg.py:4-10;
  * param = sigma^2).  Z_dev: N x ldz doubles (features in columns [0, D), response in column ycol for
  * families 1 and 2), theta_dev: S x ldt doubles.  Stateless; asynchronous on `stream`.
- *   write  : vecs (N x S) into out_dev; rowsum_dev = N doubles scratch
+ *   write  : vecs (N x S) into out_dev; rowsum_dev: unused (may be NULL; earlier builds wanted N doubles of scratch)
  *   colsum : sum_n vecs[n][s] without materialising vecs (sparsevi.py:70-74); work_dev = 2048*S doubles
  *   select : arg-max_n vecs[n].resid / ||vecs[n]|| / S (sparsevi.py:49-51) -> result_dev = {double, int64};
  *            work_dev = 2048 doubles + 2048 int64 */
