@@ -43,12 +43,9 @@ struct ProjArgs {
 };
 
 // gammaln(y + 1) of the Poisson likelihood as a real call: inlined, its polynomial tables and temporaries land in the
-// epilogue's register budget (WRITE spilled 166 VGPRs, 20 with the call: 9.8 -> 12.3 TFLOP/s at D=300; COLSUM 102 -> 0).
-// SELECT measured faster with the inlined form (17.8 against 14.3) and keeps it.
+// epilogue's register budget (WRITE spilled 166 VGPRs, none with the call; SELECT 175 -> 6).
 __device__ __attribute__((noinline)) double pj_lgamma1p_call(double y) { return lgamma(y + 1.0); }
-template <int MODE> __device__ __forceinline__ double pj_lgamma1p(double y) {
-  return MODE == PMODE_SELECT ? lgamma(y + 1.0) : pj_lgamma1p_call(y);
-}
+template <int MODE> __device__ __forceinline__ double pj_lgamma1p(double y) { return pj_lgamma1p_call(y); }
 
 // log1p(u) for 0 <= u <= 1 (u = exp(-|t|) of a softplus): 2 atanh(s) with s = u / (2 + u) <= 1/3 as the odd series
 // s (1 + s^2/3 + s^4/5 + ...) up to s^32/33 (truncation < 2e-17 relative), Horner in fp64: 2-3 ulp, 32 VALU instructions.
@@ -66,14 +63,24 @@ __device__ __forceinline__ double pj_log1p01(double u) {
 // log(1 + exp(t)) = max(t, 0) + log1p(exp(-|t|))
 __device__ __forceinline__ double pj_softplus(double t) { return fmax(t, 0.0) + pj_log1p01(exp(-fabs(t))); }
 
+// (a real call: inlined, the three routines' temporaries spill registers inside the k loop -- 24.8 against 28.3 TFLOP/s at
+// D = 300 although the epilogue got shorter)
+__device__ __attribute__((noinline)) double pj_poisson_call(double m, double y, double c0) {
+  const double lam = fmax(m, 0.0) + pj_log1p01(exp(-fabs(m)));
+  const double sl = m > -100.0 ? log(lam) : m;
+  return y * sl - c0 - lam;
+}
+
 template <int FAM> __device__ __forceinline__ double loglik(double m, double y, double param, double c0) {
   if (FAM == FAM_LOGISTIC) {
     const double t = -m;                                   // model_lr.py:28
     return t < 100.0 ? -pj_softplus(t) : -t;               // model_lr.py:29-31  (-log1p(exp(t)) below 100)
   } else if (FAM == FAM_POISSON) {
-    double s = m;                                          // model_poiss.py:25-30
-    if (s > -100.0) s = log(fmax(s, 0.0) + log1p(exp(-fabs(s))));   // (pj_log1p01 here measured slower: 23.8 against 27.0 TFLOP/s)
-    return y * s - c0 - exp(s);                            // model_poiss.py:38  (c0 = gammaln(y+1))
+    // model_poiss.py:25-38: s' = log(lam) with the rate lam = log(1 + e^s) = max(s, 0) + log1p(exp(-|s|)) where s > -100,
+    // s' = s below (there lam = e^s to every bit: log1p(e) = e for e < 4e-44); log-likelihood y s' - gammaln(y + 1) - exp(s').
+    // exp(s') IS lam: the rate is used as computed instead of exponentiating its logarithm again (one 42-instruction exp
+    // less per element, and a few ulp closer to the exact value than the reference's exp(log(.))).
+    return pj_poisson_call(m, y, c0);                      // (c0 = gammaln(y+1))
   } else {
     // model_linreg.py:10 (c0 = -0.5 log(2 pi sigsq)); param = 1 / (2 sigsq), formed once per kernel: the quotient by the
     // common divisor as a product (<= 1 ulp from the division; an fp64 division is ~25 instructions on the unit the
