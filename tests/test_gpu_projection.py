@@ -453,3 +453,44 @@ def test_host_solver_behind_device_projector(bc):
     c2.build(30)
     assert np.array_equal(c2.get()[2], idcs)
     np.testing.assert_allclose(c2.error(), c.error(), rtol=1e-9)
+
+
+def test_colsum_tile_and_team_variants_agree():
+    """The column sums come out of three block -> tile arrangements (128-column tile on XCD teams: the default for this
+    shape; 64-column tile on teams; 64-column tile with every workgroup walking its own column groups: the fallback for
+    grids that do not cover the XCDs evenly).  They differ only in summation order: same result to rounding, and each
+    against NumPy.  One subprocess per arrangement (the knobs are read once per process)."""
+    import json
+    import subprocess
+    import sys
+    code = r'''
+import json, os, sys
+import numpy as np
+sys.path.insert(0, os.path.join(%r, "bayesian-coresets_amd"))
+sys.path.insert(0, %r)
+import bayesiancoresets_amd as bc
+rs = np.random.RandomState(5)
+N, D, S = 70000, 40, 256                      # 547 row blocks: the full 512-workgroup grid
+Z = np.hstack((rs.randn(N, D) * 0.6, rs.randn(N, 1)))
+theta = rs.randn(S, D) * 0.4
+prj = bc.DeviceProjector("linreg", lambda n, w, p: theta, S, sigsq=0.8)
+print(json.dumps([float(v) for v in prj.project_colsum(Z)]))
+''' % (ROOT, ROOT)
+    outs = []
+    for env in ({}, {"BCX_PROJ_NCT": "4"}, {"BCX_PROJ_NCT": "4", "BCX_PROJ_NO_TEAM": "1"}):
+        e = dict(os.environ)
+        e.update(env)
+        r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=e)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs.append(np.array(json.loads(r.stdout.strip().splitlines()[-1])))
+    rs = np.random.RandomState(5)
+    N, D, S = 70000, 40, 256
+    Z = np.hstack((rs.randn(N, D) * 0.6, rs.randn(N, 1)))
+    theta = rs.randn(S, D) * 0.4
+    ll = linreg_log_likelihood(Z, theta, 0.8)
+    want = (ll - ll.mean(axis=1)[:, None]).sum(axis=0)
+    scale = np.abs(want).max()
+    for got in outs:
+        np.testing.assert_allclose(got, want, rtol=1e-9, atol=1e-11 * scale)
+    np.testing.assert_allclose(outs[1], outs[0], rtol=1e-10, atol=1e-12 * scale)
+    np.testing.assert_allclose(outs[2], outs[0], rtol=1e-10, atol=1e-12 * scale)
