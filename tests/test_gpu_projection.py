@@ -365,10 +365,11 @@ def test_linear_regression_example_cli(tmp_path, alg):
 
 @pytest.mark.parametrize("family", ("logistic", "poisson", "linreg"))
 @pytest.mark.parametrize("N,D,S", ((1, 1, 1), (2, 3, 5), (127, 2, 16), (129, 16, 64), (257, 17, 65), (300, 33, 130), (1031, 48, 200),
-                                   (140, 20, 100), (515, 40, 256)))
+                                   (140, 20, 100), (515, 40, 256), (700, 24, 1100)))
 def test_projection_tile_edges(bc, family, N, D, S):
     """Shapes around the kernel's tile sizes (128 rows x 64 or -- linreg column sums when S pads to a multiple of 128: S =
-    65, 100, 200, 256 here -- 128 columns x 16 features per stage), odd and even leading
+    65, 100, 200, 256, 1100 here -- 128 columns x 16 features per stage; S = 1100 also takes the column-sum accumulators past
+    the LDS budget of two workgroups per CU), odd and even leading
     dimensions (16-byte and 8-byte operand loads), single row / column / feature: values, column sums and the
     correlation arg-max against NumPy for every consumer."""
     rs = np.random.RandomState(N * 1000 + D * 10 + S)
