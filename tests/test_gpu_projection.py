@@ -495,3 +495,21 @@ print(json.dumps([float(v) for v in prj.project_colsum(Z)]))
         np.testing.assert_allclose(got, want, rtol=1e-9, atol=1e-11 * scale)
     np.testing.assert_allclose(outs[1], outs[0], rtol=1e-10, atol=1e-12 * scale)
     np.testing.assert_allclose(outs[2], outs[0], rtol=1e-10, atol=1e-12 * scale)
+
+
+@pytest.mark.parametrize("family,S", (("linreg", 256), ("logistic", 640)))
+def test_write_on_teams_matches_numpy(bc, family, S):
+    """project() on a full 512-workgroup grid: the column groups of a row block are written by different workgroups (XCD
+    teams; S = 640 leaves four workgroups per XCD idle) and the centring pass forms the row means from the stored values."""
+    rs = np.random.RandomState(11)
+    N, D = 70000, 24
+    X = rs.randn(N, D) * 0.6
+    theta = rs.randn(S, D) * 0.4
+    if family == "linreg":
+        Z, ll = np.hstack((X, rs.randn(N, 1))), (lambda z, th: linreg_log_likelihood(z, th, 0.8))
+    else:
+        Z, ll = X, logistic_log_likelihood
+    want = ll(Z.copy(), theta)
+    want -= want.mean(axis=1)[:, None]
+    got = bc.DeviceProjector(family, lambda n, w, p: theta, S, sigsq=0.8).project(Z).cpu().numpy()
+    np.testing.assert_allclose(got, want, rtol=1e-10, atol=1e-11 * np.abs(want).max())
