@@ -437,8 +437,9 @@ def run_sparsevi(args, torch, dist, nat, world, rank, local_rank):
                         % (D, N, S, args.opt_itrs, world, args.steps),
             "name": "c5", "baseline_config": args.what, "rows": N, "features": D, "dim": S, "rows_per_gpu": hi - lo,
             "opt_itrs": args.opt_itrs, "projections_per_step": 1 + args.opt_itrs,
-            "sampler": "weighted conjugate posterior on the device (examples/common/model_linreg.py; torch.linalg Cholesky of a "
-                       "%d x %d matrix per ADAM step: the user-callback side of the Projector interface)" % (D, D),
+            "sampler": "weighted conjugate posterior on the device (examples/common/model_linreg.py: rank-k update of the "
+                       "prior's %d x %d factor per ADAM step, k = coreset size: the user-callback side of the Projector "
+                       "interface)" % (D, D),
             "coreset_size": int(alg.size()), "coreset_idcs": [int(i) for i in alg.idcs],
             "projection_ms_per_step_kernels": kms / args.steps,
         },
