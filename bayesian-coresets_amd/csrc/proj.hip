@@ -205,10 +205,6 @@ __global__ __launch_bounds__(256, 2) void proj_kernel(ProjArgs p) {
   const int ngc = (S + COLS - 1) / COLS;
   const int nst = (D + PJ_KC - 1) / PJ_KC;
   const int64_t nblk = (p.N + PJ_ROWS - 1) / PJ_ROWS;
-  double* colacc = (double*)(pj_lds + PJ_STAGING_BYTES(NCT)) + (size_t)wave * S;
-  if (MODE == PMODE_COLSUM) {
-    for (int c = lane; c < S; c += 64) colacc[c] = 0.0;
-  }
   double bestv = -INFINITY;
   long long besti = 0x7fffffffffffffffLL;
   const double clin = (FAM == FAM_LINREG) ? -0.5 * log(2.0 * 3.14159265358979323846 * p.param) : 0.0;
@@ -231,6 +227,13 @@ __global__ __launch_bounds__(256, 2) void proj_kernel(ProjArgs p) {
     cg0 = j % ngc;
     br0 = j < per * ngc ? (int64_t)xcd * per + j / ngc : nblk;      // the (gridDim / 8) % ngc left-over workgroups of an XCD idle
     brstep = 8 * per;
+  }
+  // COLSUM: per-wave column-sum accumulators in LDS -- S of them, or only the COLS of the workgroup's own column group
+  // when it is a member of a team (S = 1024 then costs 4 KiB instead of 32: two workgroups per CU stay resident)
+  const int cacc_n = teamed ? COLS : S, cacc_0 = teamed ? cg0 * COLS : 0;
+  double* colacc = (double*)(pj_lds + PJ_STAGING_BYTES(NCT)) + (size_t)wave * cacc_n;
+  if (MODE == PMODE_COLSUM) {
+    for (int c = lane; c < cacc_n; c += 64) colacc[c] = 0.0;
   }
   if (br0 >= nblk) {
     if (MODE == PMODE_COLSUM) {
@@ -536,7 +539,7 @@ __global__ __launch_bounds__(256, 2) void proj_kernel(ProjArgs p) {
             for (int e = 0; e < 2; ++e) c2[e] = pj_fold<0x4E>(c4[e], c4[e + 2], (li & 2) != 0);
             const double tot = pj_fold<0xB1>(c2[0], c2[1], (li & 1) != 0);
             const int col = cg * COLS + 64 * h + 16 * (li >> 2) + lk + 4 * (li & 3);
-            if (col < S) colacc[col] += tot;
+            if (col < S) colacc[col - cacc_0] += tot;
           }
           if (NCT > 4) __builtin_amdgcn_sched_barrier(0);
         }
@@ -579,8 +582,10 @@ __global__ __launch_bounds__(256, 2) void proj_kernel(ProjArgs p) {
     __syncthreads();
     double* outp = p.colpart + (size_t)blockIdx.x * S;
     const double* ca = (const double*)(pj_lds + PJ_STAGING_BYTES(NCT));
-    for (int c = tid; c < S; c += blockDim.x)
-      outp[c] = ((ca[c] + ca[(size_t)S + c]) + ca[2 * (size_t)S + c]) + ca[3 * (size_t)S + c];
+    for (int c = tid; c < S; c += blockDim.x) {
+      const int k = c - cacc_0;                    // (columns of other team members: zero)
+      outp[c] = (k >= 0 && k < cacc_n) ? ((ca[k] + ca[(size_t)cacc_n + k]) + ca[2 * (size_t)cacc_n + k]) + ca[3 * (size_t)cacc_n + k] : 0.0;
+    }
   }
   if (MODE == PMODE_SELECT) {
     // arg-max over the workgroup (the staging area is free after the last stage)
@@ -859,7 +864,8 @@ extern "C" int bcx_project_colsum(void* stream, int32_t family, const void* Z_de
   const int grid = proj_grid(N);
   p.colpart = (double*)work_dev;
   p.team = proj_team(PMODE_COLSUM, family, S, grid);
-  if ((rc = launch_family<PMODE_COLSUM>(family, dim3(grid), 4 * (size_t)S * sizeof(double), st, p))) return rc;
+  const size_t cacc = p.team ? (size_t)16 * proj_nct(PMODE_COLSUM, family, S) : (size_t)S;   // accumulators per wave
+  if ((rc = launch_family<PMODE_COLSUM>(family, dim3(grid), 4 * cacc * sizeof(double), st, p))) return rc;
   hipLaunchKernelGGL(colsum_reduce_kernel, dim3((S + 63) / 64), dim3(256), 0, st, p.colpart, grid, S, (double*)colsum_dev);
   hipLaunchKernelGGL(colsum_center_kernel, dim3(1), dim3(256), 0, st, S, (double*)colsum_dev);
   PROJ_HIP(hipGetLastError());
