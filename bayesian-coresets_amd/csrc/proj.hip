@@ -37,7 +37,8 @@ struct ProjArgs {
   double* colpart;      // COLSUM: gridDim.x x S partial column sums
   const double* resid;  // SELECT: S
   double resid_sum;     // SELECT: sum_s resid[s]
-  int team;             // COLSUM: column groups of a row block spread over `team` workgroups of one XCD (0: one workgroup)
+  int team;             // column groups of a row block spread over `team` workgroups of one XCD (0: one workgroup walks them)
+  double* part;         // SELECT on teams: ngc x N records {shift, s1, s2, sd} of partial row moments (select_combine_kernel)
   double* best_val;     // SELECT: gridDim.x
   int64_t* best_idx;    // SELECT: gridDim.x
 };
@@ -215,11 +216,12 @@ __global__ __launch_bounds__(256, 2) void proj_kernel(ProjArgs p) {
 
   // Block -> tile sequence.  Default: workgroup b takes row blocks b, b + gridDim, ... and walks their column groups
   // itself -- Z is then streamed from HBM once per column group (the 64 workgroups of an XCD push ~20 MB through its 4 MB
-  // L2 between two passes of one of them).  COLSUM's and WRITE's tiles are independent, so there (p.team = number of column groups)
+  // L2 between two passes of one of them).  With p.team = number of column groups (COLSUM and WRITE: independent tiles;
+  // SELECT: the members leave partial row moments in p.part for select_combine_kernel)
   // the column groups of a row block go to workgroups that sit on the SAME XCD and run in step: blocks b and b + 8 share
   // an XCD (dispatch is round-robin over the 8 XCDs: a speed assumption, not a correctness one), team = (b / 8) / ngc,
   // member = column group = (b / 8) % ngc; the second reader of a Z line finds it in L2.
-  const bool teamed = MODE != PMODE_SELECT && p.team > 1;
+  const bool teamed = p.team > 1;
   int cg0 = 0;
   int64_t br0 = blockIdx.x, brstep = gridDim.x;
   if (teamed) {
@@ -241,7 +243,7 @@ __global__ __launch_bounds__(256, 2) void proj_kernel(ProjArgs p) {
       double* outp = p.colpart + (size_t)blockIdx.x * S;
       for (int c = tid; c < S; c += blockDim.x) outp[c] = 0.0;
     }
-    if (MODE == PMODE_SELECT && tid == 0) { p.best_val[blockIdx.x] = -INFINITY; p.best_idx[blockIdx.x] = besti; }
+    if (MODE == PMODE_SELECT && !teamed && tid == 0) { p.best_val[blockIdx.x] = -INFINITY; p.best_idx[blockIdx.x] = besti; }
     return;
   }
   // ---- the prefetch stream -------------------------------------------------------------------------------------
@@ -543,7 +545,7 @@ __global__ __launch_bounds__(256, 2) void proj_kernel(ProjArgs p) {
           }
           if (NCT > 4) __builtin_amdgcn_sched_barrier(0);
         }
-        if (MODE == PMODE_SELECT && cg == ngc - 1) {
+        if (MODE == PMODE_SELECT && (cg == ngc - 1 || teamed)) {
 #pragma unroll
           for (int tr = 0; tr < 2; ++tr) {
             // the four lane groups hold disjoint columns of the same row
@@ -552,6 +554,15 @@ __global__ __launch_bounds__(256, 2) void proj_kernel(ProjArgs p) {
             s2 += bcx_xor16_f64(s2); s2 += bcx_xor32_f64(s2);
             sd += bcx_xor16_f64(sd); sd += bcx_xor32_f64(sd);
             const long long row = r0 + 16 * tr + li;
+            if (teamed) {
+              // this column group's share of the row's moments, about the group's own shift (its first column)
+              if (lk == 0 && row < p.N) {
+                double* rec = p.part + ((size_t)cg * (size_t)p.N + (size_t)row) * 4;
+                *(pv2d*)rec = (pv2d){piv[tr], s1};
+                *(pv2d*)(rec + 2) = (pv2d){s2, sd};
+              }
+              continue;
+            }
             const double mean = s1 / (double)S;                         // mean of (ll - shift)
             const double dot = sd - mean * p.resid_sum;                 // (ll - mean ll) . resid
             const double nrm2 = s2 - (double)S * mean * mean;           // ||ll - mean ll||^2
@@ -587,7 +598,7 @@ __global__ __launch_bounds__(256, 2) void proj_kernel(ProjArgs p) {
       outp[c] = (k >= 0 && k < cacc_n) ? ((ca[k] + ca[(size_t)cacc_n + k]) + ca[2 * (size_t)cacc_n + k]) + ca[3 * (size_t)cacc_n + k] : 0.0;
     }
   }
-  if (MODE == PMODE_SELECT) {
+  if (MODE == PMODE_SELECT && !teamed) {
     // arg-max over the workgroup (the staging area is free after the last stage)
     double* sv = (double*)pj_lds;
     long long* si = (long long*)(pj_lds + 64);
@@ -672,6 +683,60 @@ __global__ __launch_bounds__(256) void colsum_center_kernel(int S, double* colsu
   block_allsum<1>(tot, scratch);
   const double corr = tot[0] / (double)S;
   for (int c = threadIdx.x; c < S; c += blockDim.x) colsum[c] -= corr;
+}
+
+// SELECT on teams: the column groups of a row were processed by different workgroups, each leaving {shift p_g, s1_g, s2_g,
+// sd_g} = its first column's value and the sums of (ll - p_g), (ll - p_g)^2, (ll - p_g) resid over its n_g columns.  With
+// delta_g = mean - p_g (differences of close numbers: every p_g is a value of the row, so the cancellation stays on the scale
+// of the row's spread):   mean - p_0 = sum_g (n_g (p_g - p_0) + s1_g) / S,
+//   ||ll - mean||^2 = sum_g (s2_g - 2 delta_g s1_g + n_g delta_g^2),    (ll - mean) . resid = sum_g (sd_g - delta_g R_g)
+// with R_g the group's residual sum -- the one-group case is the formula of the projection kernel's own epilogue.
+__global__ __launch_bounds__(256) void select_combine_kernel(const double* part, int64_t N, int ngc, int cols, int S, const double* resid,
+                                                             double* best_val, int64_t* best_idx) {
+  __shared__ double Rg[64];
+  __shared__ double sv[4];
+  __shared__ long long si[4];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  for (int g = wave; g < ngc; g += 4) {                 // residual sum of each column group, fixed order
+    double a = 0.0;
+    for (int c = g * cols + lane; c < min(S, (g + 1) * cols); c += 64) a += resid[c];
+    a = wave_allsum(a);
+    if (lane == 0) Rg[g] = a;
+  }
+  __syncthreads();
+  double bestv = -INFINITY;
+  long long besti = 0x7fffffffffffffffLL;
+  for (int64_t row = (int64_t)blockIdx.x * 256 + tid; row < N; row += (int64_t)gridDim.x * 256) {
+    const double p0 = part[(size_t)row * 4];
+    double msum = 0.0;
+    for (int g = 0; g < ngc; ++g) {
+      const double* rec = part + ((size_t)g * (size_t)N + (size_t)row) * 4;
+      msum += (double)min(cols, S - g * cols) * (rec[0] - p0) + rec[1];
+    }
+    const double mrel = msum / (double)S;               // mean - p_0
+    double nrm2 = 0.0, dot = 0.0;
+    for (int g = 0; g < ngc; ++g) {
+      const double* rec = part + ((size_t)g * (size_t)N + (size_t)row) * 4;
+      const double dl = mrel - (rec[0] - p0);
+      nrm2 += rec[2] - 2.0 * dl * rec[1] + (double)min(cols, S - g * cols) * dl * dl;
+      dot += rec[3] - dl * Rg[g];
+    }
+    const double corr = nrm2 > 0.0 ? dot / sqrt(nrm2) / (double)S : __builtin_nan("");
+    if (corr_better(corr, row, bestv, besti)) { bestv = corr; besti = row; }
+  }
+  for (int off = 32; off >= 1; off >>= 1) {
+    const double ov = __shfl_xor(bestv, off, BCX_WAVE);
+    const long long oi = __shfl_xor(besti, off, BCX_WAVE);
+    if (corr_better(ov, oi, bestv, besti)) { bestv = ov; besti = oi; }
+  }
+  if (lane == 0) { sv[wave] = bestv; si[wave] = besti; }
+  __syncthreads();
+  if (tid == 0) {
+    for (int w = 1; w < 4; ++w)
+      if (corr_better(sv[w], si[w], bestv, besti)) { bestv = sv[w]; besti = si[w]; }
+    best_val[blockIdx.x] = bestv;
+    best_idx[blockIdx.x] = besti;
+  }
 }
 
 __global__ __launch_bounds__(256) void select_final_kernel(const double* bv, const int64_t* bi, int nparts, double* out_val, int64_t* out_idx) {
@@ -825,7 +890,7 @@ static int fill(ProjArgs& p, int family, const void* Z, int64_t N, int64_t ldz, 
   p.Z = (const double*)Z; p.theta = (const double*)theta; p.N = N; p.ldz = ldz; p.ldt = ldt; p.D = D; p.S = S;
   p.ycol = family == FAM_LOGISTIC ? -1 : ycol; p.param = param;
   p.out = nullptr; p.ldo = 0; p.rowsum = nullptr; p.colpart = nullptr; p.resid = nullptr; p.resid_sum = 0.0;
-  p.best_val = nullptr; p.best_idx = nullptr; p.team = 0;
+  p.best_val = nullptr; p.best_idx = nullptr; p.team = 0; p.part = nullptr;
   return BCX_OK;
 }
 
@@ -885,9 +950,25 @@ extern "C" int bcx_project_select(void* stream, int32_t family, const void* Z_de
   const int grid = proj_grid(N);
   p.resid = (const double*)resid_dev; p.resid_sum = resid_sum;
   p.best_val = (double*)work_dev; p.best_idx = (int64_t*)((double*)work_dev + 2048);
-  if ((rc = launch_family<PMODE_SELECT>(family, dim3(grid), 0, st, p))) return rc;
-  hipLaunchKernelGGL(select_final_kernel, dim3(1), dim3(256), 0, st, p.best_val, p.best_idx, grid, (double*)result_dev,
+  // XCD teams (Z streamed once instead of once per column group) need room for the members' partial row moments:
+  // 32 bytes per row and column group, stream-ordered scratch; without it the one-workgroup walk is used.
+  int nparts = grid;
+  const int team = proj_team(PMODE_SELECT, family, S, grid);
+  void* part = nullptr;
+  if (team > 1 && N > 0 && hipMallocAsync(&part, (size_t)team * (size_t)N * 4 * sizeof(double), st) != hipSuccess) {
+    (void)hipGetLastError();
+    part = nullptr;
+  }
+  if (part) { p.team = team; p.part = (double*)part; }
+  if ((rc = launch_family<PMODE_SELECT>(family, dim3(grid), 0, st, p))) { if (part) (void)hipFreeAsync(part, st); return rc; }
+  if (part) {
+    nparts = (int)std::min<int64_t>((N + 255) / 256, 512);
+    hipLaunchKernelGGL(select_combine_kernel, dim3(nparts), dim3(256), 0, st, (const double*)part, N, team, 16 * proj_nct(PMODE_SELECT, family, S), S,
+                       p.resid, p.best_val, p.best_idx);
+  }
+  hipLaunchKernelGGL(select_final_kernel, dim3(1), dim3(256), 0, st, p.best_val, p.best_idx, nparts, (double*)result_dev,
                      (int64_t*)((double*)result_dev + 1));
   PROJ_HIP(hipGetLastError());
+  if (part) PROJ_HIP(hipFreeAsync(part, st));
   return BCX_OK;
 }
