@@ -158,12 +158,14 @@ def _reference_select(vecs, resid):
     return corrs, int(np.argmax(corrs))
 
 
-def test_select_rows_with_huge_mean_and_tiny_spread(bc):
+@pytest.mark.parametrize("N", (20000, 70000))
+def test_select_rows_with_huge_mean_and_tiny_spread(bc, N):
     """|mean| >> spread: a concentrated posterior (samples theta_0 + 1e-7 noise) and large responses give log-likelihoods
     ~ -1e9 whose variation across samples is ~1e-3.  The one-pass moments s2 - S mean^2 of the raw values would lose
-    every digit (round 1); the shifted accumulation must name the reference's row and value."""
+    every digit (round 1); the shifted accumulation must name the reference's row and value.  N = 70000 fills the grid:
+    the two column groups of a row are then handled by different workgroups and merged from moments about two shifts."""
     rs = np.random.RandomState(31)
-    N, D, S, sigsq = 20000, 12, 96, 1e-4
+    D, S, sigsq = 12, 96, 1e-4
     X = rs.randn(N, D)
     th0 = rs.randn(D)
     y = X.dot(th0) + 400.0 + rs.randn(N)          # residual ~400 => ll ~ -400^2 / 2e-4 = -8e8
@@ -183,12 +185,13 @@ def test_select_rows_with_huge_mean_and_tiny_spread(bc):
     np.testing.assert_allclose(got_col, vecs.sum(axis=0), rtol=1e-6, atol=1e-6 * np.abs(vecs).sum() / S)
 
 
-def test_select_logistic_rows_over_sixteen_decades(bc):
+@pytest.mark.parametrize("N", (30000, 70000))
+def test_select_logistic_rows_over_sixteen_decades(bc, N):
     """Saturated logistic rows: projected-vector norms from ~1e-16 (log-likelihood ~ -exp(-m), m ~ 37) to O(1), the
     range real Laplace-projected vectors show.  Tiny-norm rows must neither win through a
-    cancelled norm nor turn into NaN."""
+    cancelled norm nor turn into NaN.  (N = 70000: on XCD teams, see above.)"""
     rs = np.random.RandomState(33)
-    N, D, S = 30000, 8, 128
+    D, S = 8, 128
     scale = 10.0 ** rs.uniform(-1.0, 1.62, size=N)               # |z.theta| from ~0.1 to ~42
     Zdir = rs.randn(N, D)
     th0 = rs.randn(D)
@@ -214,21 +217,29 @@ def test_select_logistic_rows_over_sixteen_decades(bc):
     assert np.isfinite(b2) and abs(b2) <= 1.0 / np.sqrt(S) * np.abs(resid).sum()
 
 
-def test_select_zero_vector_is_numpys_nan_pick(bc):
+@pytest.mark.parametrize("N,S", ((5000, 64), (70000, 128)))
+def test_select_zero_vector_is_numpys_nan_pick(bc, N, S):
     """A data row whose log-likelihood is the same for every sample projects to the zero vector: corrs is 0/0 = NaN
-    there and ``corrs.argmax()`` returns the first NaN (sparsevi.py:51-55).  Same pick on the device."""
+    there and ``corrs.argmax()`` returns the first NaN (sparsevi.py:51-55).  Same pick on the device -- also when the row's
+    two column groups are merged from two workgroups' partial moments (N = 70000, S = 128: a power of two keeps the
+    reference's own row mean exact)."""
     rs = np.random.RandomState(35)
-    N, D, S = 5000, 6, 64
+    D = 6
     Z = np.hstack((rs.randn(N, D), rs.randn(N, 1)))
     Z[1234, :D] = 0.0                                             # x = 0: the likelihood does not depend on theta
     Z[4000, :D] = 0.0
     theta = rs.randn(S, D)
     vecs = linreg_log_likelihood(Z, theta, 1.0)
     vecs = vecs - vecs.mean(axis=1)[:, None]
-    assert np.all(vecs[1234] == 0.0)
     resid = rs.randn(S)
-    corrs, want = _reference_select(vecs, resid)
-    assert want == 1234 and np.isnan(corrs[want])
+    if N == 5000:
+        assert np.all(vecs[1234] == 0.0)
+        corrs, want = _reference_select(vecs, resid)
+        assert want == 1234 and np.isnan(corrs[want])
+    else:
+        # (NumPy's own row mean of 128 equal values may be one ulp off the value, which turns its 0/0 into noise; the
+        #  device forms the moments about a value of the row itself, so a constant row is exactly zero there)
+        assert np.abs(vecs[1234]).max() < 1e-15
     prj = bc.DeviceProjector("linreg", lambda n, w, p: theta, S, sigsq=1.0)
     best, row = prj.project_select(Z, resid)
     assert row == 1234 and np.isnan(best)
@@ -457,7 +468,7 @@ def test_host_solver_behind_device_projector(bc):
 
 
 def test_colsum_tile_and_team_variants_agree():
-    """The column sums come out of three block -> tile arrangements (128-column tile on XCD teams: the default for this
+    """The column sums (and the correlation arg-max) come out of three block -> tile arrangements (128-column tile on XCD teams: the default for this
     shape; 64-column tile on teams; 64-column tile with every workgroup walking its own column groups: the fallback for
     grids that do not cover the XCDs evenly).  They differ only in summation order: same result to rounding, and each
     against NumPy.  One subprocess per arrangement (the knobs are read once per process)."""
@@ -475,15 +486,18 @@ N, D, S = 70000, 40, 256                      # 547 row blocks: the full 512-wor
 Z = np.hstack((rs.randn(N, D) * 0.6, rs.randn(N, 1)))
 theta = rs.randn(S, D) * 0.4
 prj = bc.DeviceProjector("linreg", lambda n, w, p: theta, S, sigsq=0.8)
-print(json.dumps([float(v) for v in prj.project_colsum(Z)]))
+best, row = prj.project_select(Z, np.random.RandomState(6).randn(S))
+print(json.dumps({"colsum": [float(v) for v in prj.project_colsum(Z)], "select": [float(best), int(row)]}))
 ''' % (ROOT, ROOT)
-    outs = []
+    outs, sels = [], []
     for env in ({}, {"BCX_PROJ_NCT": "4"}, {"BCX_PROJ_NCT": "4", "BCX_PROJ_NO_TEAM": "1"}):
         e = dict(os.environ)
         e.update(env)
         r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=e)
         assert r.returncode == 0, r.stderr[-2000:]
-        outs.append(np.array(json.loads(r.stdout.strip().splitlines()[-1])))
+        rec = json.loads(r.stdout.strip().splitlines()[-1])
+        outs.append(np.array(rec["colsum"]))
+        sels.append(rec["select"])
     rs = np.random.RandomState(5)
     N, D, S = 70000, 40, 256
     Z = np.hstack((rs.randn(N, D) * 0.6, rs.randn(N, 1)))
@@ -495,6 +509,14 @@ print(json.dumps([float(v) for v in prj.project_colsum(Z)]))
         np.testing.assert_allclose(got, want, rtol=1e-9, atol=1e-11 * scale)
     np.testing.assert_allclose(outs[1], outs[0], rtol=1e-10, atol=1e-12 * scale)
     np.testing.assert_allclose(outs[2], outs[0], rtol=1e-10, atol=1e-12 * scale)
+    # the correlation arg-max: on teams (partial row moments about per-group shifts, merged by select_combine_kernel) and
+    # with the one-workgroup walk, against NumPy
+    vecs = ll - ll.mean(axis=1)[:, None]
+    corrs, arg = _reference_select(vecs, np.random.RandomState(6).randn(S))
+    for best, row in sels:
+        assert row == arg
+        np.testing.assert_allclose(best, corrs[arg], rtol=1e-9)
+    assert sels[2][1] == sels[0][1] and abs(sels[2][0] - sels[0][0]) <= 1e-12 * abs(sels[0][0])
 
 
 @pytest.mark.parametrize("family,S", (("linreg", 256), ("logistic", 640)))
