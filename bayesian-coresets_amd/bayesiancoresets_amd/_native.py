@@ -14,6 +14,7 @@ F32, F64, F16 = 0, 1, 2
 OK, ERR_ARG, ERR_HIP, ERR_ZERO_ROW, ERR_ZERO_B, ERR_NOMEM, ERR_STATE = 0, -1, -2, -3, -4, -5, -6
 IT_OK, IT_FAIL_SELECT, IT_FAIL_REWEIGHT, IT_FAIL_MONOTONE = 0, 1, 2, 3
 REC_HDR = 4
+LOAD_CENTER_ROWS = 1
 CHUNK_ROWS = 1024
 
 # every symbol include/bcx.h declares (checked by tests/test_abi.py)
@@ -25,7 +26,7 @@ SYMBOLS = (
     "bcx_stats", "bcx_profile_scan", "bcx_profile_read", "bcx_version",
     "bcx_project_write", "bcx_project_colsum", "bcx_project_select", "bcx_project_last_error",
     "bcx_build_enqueue_exact", "bcx_exchange_export", "bcx_exchange_attach", "bcx_exchange_probe", "bcx_exchange_disable", "bcx_exchange_set_timeout",
-    "bcx_set_check_monotone", "bcx_project_profile", "bcx_project_profile_read",
+    "bcx_set_check_monotone", "bcx_project_profile", "bcx_project_profile_read", "bcx_exchange_stats", "bcx_load_rows_flags", "bcx_project_write_raw",
 )
 
 
@@ -71,6 +72,7 @@ def load():
         "bcx_destroy": [vp],
         "bcx_set_stream": [vp, vp],
         "bcx_load_rows": [vp, vp, i32, i32, i64, i64, i64],
+        "bcx_load_rows_flags": [vp, vp, i32, i32, i64, i64, i64, i32],
         "bcx_chunk_sums": [vp, P(vp), P(i64), P(i64)],
         "bcx_export_chunk_sums": [vp, vp, i64],
         "bcx_finalize": [vp, vp, vp, i64],
@@ -101,9 +103,11 @@ def load():
         "bcx_exchange_probe": [vp, P(i32)],
         "bcx_exchange_disable": [vp],
         "bcx_exchange_set_timeout": [vp, dbl],
+        "bcx_exchange_stats": [vp, P(i64), P(dbl), P(dbl), P(dbl), P(dbl), i32],
     }
     proj_common = [vp, i32, vp, i64, i64, i32, i32, vp, i32, i32, dbl]
     sigs["bcx_project_write"] = proj_common + [vp, i64, vp]
+    sigs["bcx_project_write_raw"] = proj_common + [vp, i64]
     sigs["bcx_project_colsum"] = proj_common + [vp, vp]
     sigs["bcx_project_select"] = proj_common + [vp, dbl, vp, vp]
     sigs["bcx_project_profile"] = [i32]
@@ -176,16 +180,18 @@ class Engine(object):
         self._check(self.lib.bcx_set_stream(self.h, ctypes.c_void_p(_current_stream_ptr())))
 
     # -- ingest -----------------------------------------------------------
-    def load_host_rows(self, rows, row_begin=0):
-        """rows: C-contiguous (n, >=d) float32/float64 ndarray view (row stride in elements = ld)."""
+    def load_host_rows(self, rows, row_begin=0, center=False):
+        """rows: C-contiguous (n, >=d) float32/float64 ndarray view (row stride in elements = ld).
+        center: the rows are raw log-likelihoods, subtract each row's mean during the pass (projector.py:21)."""
         assert rows.ndim == 2 and rows.strides[1] == rows.itemsize
         dt = F64 if rows.dtype == np.float64 else F32
         ld = rows.strides[0] // rows.itemsize
-        self._check(self.lib.bcx_load_rows(self.h, ctypes.c_void_p(rows.ctypes.data), 0, dt, row_begin,
-                                           rows.shape[0], ld))
+        self._check(self.lib.bcx_load_rows_flags(self.h, ctypes.c_void_p(rows.ctypes.data), 0, dt, row_begin,
+                                                 rows.shape[0], ld, LOAD_CENTER_ROWS if center else 0))
 
-    def load_device_rows(self, ptr, n, ld, is_f64, row_begin=0):
-        self._check(self.lib.bcx_load_rows(self.h, ctypes.c_void_p(ptr), 1, F64 if is_f64 else F32, row_begin, n, ld))
+    def load_device_rows(self, ptr, n, ld, is_f64, row_begin=0, center=False):
+        self._check(self.lib.bcx_load_rows_flags(self.h, ctypes.c_void_p(ptr), 1, F64 if is_f64 else F32, row_begin, n, ld,
+                                                 LOAD_CENTER_ROWS if center else 0))
 
     def chunk_sums_info(self):
         p, n, r = ctypes.c_void_p(), ctypes.c_int64(), ctypes.c_int64()
@@ -209,19 +215,19 @@ class Engine(object):
         import torch
         return torch.device("cuda", self.cfg.device)
 
-    def load_rows_any(self, rows, row_begin=0):
+    def load_rows_any(self, rows, row_begin=0, center=False):
         try:
             import torch
             if isinstance(rows, torch.Tensor):
                 if rows.device.type == "cuda":
                     assert rows.stride(1) == 1
                     self.load_device_rows(rows.data_ptr(), rows.shape[0], rows.stride(0),
-                                          rows.element_size() == 8, row_begin)
+                                          rows.element_size() == 8, row_begin, center)
                     return
                 rows = rows.numpy()
         except ImportError:
             pass
-        self.load_host_rows(np.ascontiguousarray(rows), row_begin)
+        self.load_host_rows(np.ascontiguousarray(rows), row_begin, center)
 
     def export_chunk_sums_tensor(self, t, cap_chunks):
         self.export_chunk_sums(t.data_ptr(), cap_chunks)
@@ -274,6 +280,14 @@ class Engine(object):
 
     def exchange_set_timeout(self, timeout_s):
         self._check(self.lib.bcx_exchange_set_timeout(self.h, float(timeout_s)))
+
+    def exchange_stats(self, reset=False):
+        """Device-side timing of the record exchanges since the last reset (microseconds)."""
+        n = ctypes.c_int64()
+        v = [ctypes.c_double() for _ in range(4)]
+        self._check(self.lib.bcx_exchange_stats(self.h, ctypes.byref(n), *[ctypes.byref(x) for x in v], int(bool(reset))))
+        return {"exchanges": n.value, "wait_us_mean": v[0].value, "wait_us_max": v[1].value,
+                "total_us_mean": v[2].value, "total_us_max": v[3].value}
 
     def exchange_disable(self):
         self._check(self.lib.bcx_exchange_disable(self.h))

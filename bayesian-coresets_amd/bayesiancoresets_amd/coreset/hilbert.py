@@ -20,7 +20,14 @@ def _is_torch(x):
 class HilbertCoreset(Coreset):
     def __init__(self, data, ll_projector, n_subsample=None, snnls=GIGA, **kw):
         rows = None if n_subsample is None else self._draw_subsample(data.shape[0], n_subsample)
-        vecs = ll_projector.project(data if rows is None else data[rows])
+        # a device projector feeding a device solver on the full data: take the raw log-likelihoods and let the solver's
+        # constructor pass subtract the row means (projector.py:21) -- one pass over N x S less (csrc/ingest.hip)
+        fold = (rows is None and hasattr(ll_projector, "project_uncentred")
+                and isinstance(snnls, type) and issubclass(snnls, _DeviceSolver))
+        if fold:
+            vecs = ll_projector.project_uncentred(data)
+        else:
+            vecs = ll_projector.project(data if rows is None else data[rows])
         if rows is None:
             rows = np.arange(data.shape[0])
         else:
@@ -30,7 +37,7 @@ class HilbertCoreset(Coreset):
             if not keep.all():
                 vecs = self._take_rows(vecs, keep)
             rows = rows[keep]
-        self.snnls = self._make_solver(snnls, vecs)
+        self.snnls = self._make_solver(snnls, vecs, center_rows=fold)
         self.sub_idcs = rows
         self.data = data
         super().__init__(**kw)
@@ -55,12 +62,14 @@ class HilbertCoreset(Coreset):
         return vecs[keep, :]
 
     @staticmethod
-    def _make_solver(snnls, vecs):
+    def _make_solver(snnls, vecs, center_rows=False):
         """Solver on A = vecs^T with b = the column sums of vecs (hilbert.py:24).  The device solvers form b
         themselves during ingest (fp64 chunked column sums, csrc/ingest.hip) when handed ``b=None``; host-only
         solver classes (the sampling baselines) get the NumPy sum as in the reference."""
         on_device = isinstance(snnls, type) and issubclass(snnls, _DeviceSolver)
         if on_device:
+            if center_rows:
+                return snnls(vecs.t(), None, center_rows=True)
             return snnls(vecs.t() if _is_torch(vecs) else vecs.T, None)
         if _is_torch(vecs):
             vecs = vecs.detach().cpu().numpy()      # a device projector's output, for a host-side solver class

@@ -53,8 +53,10 @@ class ShardedHilbertCoreset(Coreset):
                              % (lo, hi, int(local_data.shape[0])))
         self.data, self.group = local_data, group
         self.row_begin, self.row_end = lo, hi
+        fold = n_subsample is None and hasattr(ll_projector, "project_uncentred")
         if n_subsample is None:
-            vecs = ll_projector.project(local_data)
+            # a device projector: raw log-likelihoods, centred by the solver's constructor pass (one pass over N x S less)
+            vecs = ll_projector.project_uncentred(local_data) if fold else ll_projector.project(local_data)
             n_rows, self.sub_idcs = n_global, None
         else:
             drawn = np.unique(np.random.randint(n_global, size=n_subsample))      # hilbert.py:16, same on every rank
@@ -65,7 +67,7 @@ class ShardedHilbertCoreset(Coreset):
         self.snnls = ShardedSolver(snnls._ALG, n_rows, d, group=group, engine_factory=engine_factory)
         assert int(vecs.shape[0]) == self.snnls.n_local
         if self.snnls.n_local:
-            self.snnls.load_local(vecs)
+            self.snnls.load_local(vecs, center=fold)
         rc = self.snnls.finalize(None)                     # b = column sums over all shards (hilbert.py:24)
         if rc == nat.ERR_ZERO_ROW:
             raise ValueError("ShardedHilbertCoreset.__init__(): A must not have any 0 columns")   # giga.py:11-12

@@ -181,6 +181,20 @@ class DeviceProjector(Projector):
             self._launch(self._lib.bcx_project_write, self._common(Z) + [out.data_ptr(), S, None], Z)
         return out
 
+    def project_uncentred(self, pts):
+        """The raw log-likelihoods ``loglikelihood(pts, samples)`` (N x S device tensor) WITHOUT the row-mean
+        subtraction of projector.py:21 -- for a consumer that centres while it reads: ``HilbertCoreset`` hands them to
+        the solver's constructor pass with ``center_rows=True`` (csrc/ingest.hip: the row is in registers between the
+        norm and the stores), so the N x S matrix is written once and read once and the separate centring pass
+        (another read + write of N x S) disappears.  ``project()`` is this followed by that pass."""
+        torch = self._torch
+        Z = self._dev(pts)
+        N, S = Z.shape[0], self.theta.shape[0]
+        out = torch.empty((N, S), dtype=torch.float64, device=self.device)
+        if N:
+            self._launch(self._lib.bcx_project_write_raw, self._common(Z) + [out.data_ptr(), S], Z)
+        return out
+
     # -- fused consumers (SparseVI) -------------------------------------------------
     def _workspace(self, S):
         torch = self._torch

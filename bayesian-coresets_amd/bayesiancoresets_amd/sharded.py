@@ -145,10 +145,14 @@ class ShardedSolver(object):
         self.dist.all_gather(views, send, group=self.group)
 
     # ---- construction ------------------------------------------------------
-    def load_local(self, rows, local_row_begin=0):
+    def load_local(self, rows, local_row_begin=0, center=False):
         """rows: torch tensor (device or cpu) or ndarray holding local rows
-        [local_row_begin, local_row_begin + len(rows))."""
-        self.engine.load_rows_any(rows, local_row_begin)
+        [local_row_begin, local_row_begin + len(rows)).  center: the rows are raw log-likelihoods
+        (``DeviceProjector.project_uncentred``); the ingest pass subtracts the row means (projector.py:21)."""
+        if center:
+            self.engine.load_rows_any(rows, local_row_begin, center=True)
+        else:
+            self.engine.load_rows_any(rows, local_row_begin)
 
     def finalize(self, b=None):
         torch, dist = self.torch, self.dist

@@ -152,9 +152,12 @@ class DeviceSparseNNLS(SparseNNLS):
     used -- build(), error(), optimize(), reset() and the weights all live in libbcx.so."""
     _ALG = None  # set by subclasses
 
-    def __init__(self, A, b, check_error_monotone=True, *, device=0, dtype="float32", keep_exact_rows=True):
+    def __init__(self, A, b, check_error_monotone=True, *, device=0, dtype="float32", keep_exact_rows=True,
+                 center_rows=False):
+        """center_rows: the columns of ``A`` are raw log-likelihood vectors; the constructor pass subtracts each one's
+        mean over the d samples (projector.py:21) while it forms the norms -- ``.A`` then reads as the centred matrix."""
         self.alg_name, self.log = object_logger(self)
-        self.A = A
+        self._A_arg, self._A_centred, self._center_rows = A, None, bool(center_rows)
         self._b_arg = b
         self._w_cache = None
         self._eng = None
@@ -173,12 +176,12 @@ class DeviceSparseNNLS(SparseNNLS):
         if self._N:
             if kind == "torch":
                 if rows.device.type != "cuda":
-                    eng.load_host_rows(rows.numpy())
+                    eng.load_host_rows(rows.numpy(), center=self._center_rows)
                 else:
                     eng.load_device_rows(rows.data_ptr(), self._N, rows.stride(0),
-                                         rows.element_size() == 8)
+                                         rows.element_size() == 8, center=self._center_rows)
             else:
-                eng.load_host_rows(rows)
+                eng.load_host_rows(rows, center=self._center_rows)
         bb = None if b is None else np.asarray(b, dtype=np.float64)
         rc = eng.finalize(bb)
         if rc == nat.ERR_ZERO_ROW:
@@ -189,6 +192,16 @@ class DeviceSparseNNLS(SparseNNLS):
             raise nat.EngineError(rc, eng.lib.bcx_last_error(eng.h).decode())
         self.reached_numeric_limit = False
         self.last_trace = None
+
+    @property
+    def A(self):
+        """The d x N matrix the solver works on (with ``center_rows`` the centred one, formed on first use)."""
+        if not self._center_rows:
+            return self._A_arg
+        if self._A_centred is None:
+            A = self._A_arg
+            self._A_centred = A - (A.mean(dim=0, keepdim=True) if hasattr(A, "dim") else A.mean(axis=0, keepdims=True))
+        return self._A_centred
 
     @property
     def check_error_monotone(self):

@@ -183,9 +183,24 @@ static int upload_host_rows(bcx_solver* s, void* dst_dev, size_t dpitch, const v
 }
 
 
+static int load_rows(bcx_solver* s, const void* src, int32_t src_is_device, int32_t src_dtype, int64_t row_begin,
+                     int64_t rows, int64_t ld, int32_t flags);
+
 extern "C" int bcx_load_rows(bcx_solver* s, const void* src, int32_t src_is_device, int32_t src_dtype,
                              int64_t row_begin, int64_t rows, int64_t ld) {
+  return load_rows(s, src, src_is_device, src_dtype, row_begin, rows, ld, 0);
+}
+
+extern "C" int bcx_load_rows_flags(bcx_solver* s, const void* src, int32_t src_is_device, int32_t src_dtype,
+                                   int64_t row_begin, int64_t rows, int64_t ld, int32_t flags) {
+  if (flags & ~BCX_LOAD_CENTER_ROWS) { if (s) s->err = "bcx_load_rows_flags: unknown flag"; return BCX_ERR_ARG; }
+  return load_rows(s, src, src_is_device, src_dtype, row_begin, rows, ld, flags);
+}
+
+static int load_rows(bcx_solver* s, const void* src, int32_t src_is_device, int32_t src_dtype, int64_t row_begin,
+                     int64_t rows, int64_t ld, int32_t flags) {
   if (!s || (!src && rows > 0)) return BCX_ERR_ARG;
+  const int center = (flags & BCX_LOAD_CENTER_ROWS) ? 1 : 0;
   const int d = s->cfg.d;
   if (rows == 0) return BCX_OK;
   if (row_begin < 0 || rows < 0 || row_begin + rows > s->cfg.n_local || ld < d ||
@@ -214,14 +229,14 @@ extern "C" int bcx_load_rows(bcx_solver* s, const void* src, int32_t src_is_devi
   }
   const size_t esz = src_dtype == BCX_F64 ? 8 : 4;
   if (src_is_device) {
-    int rc = bcx_launch_ingest(s, src, src_dtype, ld, row_begin, rows);
+    int rc = bcx_launch_ingest(s, src, src_dtype, ld, row_begin, rows, center);
     if (rc != BCX_OK) return rc;
   } else if (s->A64 && src_dtype == BCX_F64) {
     // host fp64 rows go straight to their final place; the ingest kernel then works in place
     double* dst = s->A64 + (size_t)row_begin * s->ld64;
     int rc = upload_host_rows(s, dst, (size_t)s->ld64 * 8, src, (size_t)ld * 8, (size_t)d * 8, rows);
     if (rc != BCX_OK) return rc;
-    rc = bcx_launch_ingest(s, dst, BCX_F64, s->ld64, row_begin, rows);
+    rc = bcx_launch_ingest(s, dst, BCX_F64, s->ld64, row_begin, rows, center);
     if (rc != BCX_OK) return rc;
   } else {
     // stage through a device buffer in pieces of <= 256 MiB
@@ -239,7 +254,7 @@ extern "C" int bcx_load_rows(bcx_solver* s, const void* src, int32_t src_is_devi
       int rc = upload_host_rows(s, s->staging, (size_t)d * esz, (const char*)src + (size_t)r * ld * esz, (size_t)ld * esz,
                                 (size_t)d * esz, m);
       if (rc != BCX_OK) return rc;
-      rc = bcx_launch_ingest(s, s->staging, src_dtype, d, row_begin + r, m);
+      rc = bcx_launch_ingest(s, s->staging, src_dtype, d, row_begin + r, m, center);
       if (rc != BCX_OK) return rc;
       BCX_HIP(hipStreamSynchronize(s->stream));  // staging buffer is reused
     }
@@ -510,7 +525,7 @@ extern "C" int bcx_exchange_attach(bcx_solver* s, const void* handles, int32_t h
     }
   }
   hipError_t e;
-  if ((e = dev_alloc(&s->peer_tab, (size_t)world)) != hipSuccess || (e = dev_alloc(&s->xseq, 1)) != hipSuccess ||
+  if ((e = dev_alloc(&s->peer_tab, (size_t)world)) != hipSuccess || (e = dev_alloc(&s->xseq, 8)) != hipSuccess ||
       (e = dev_alloc(&s->xprobe, 1)) != hipSuccess ||
       (e = dev_alloc(&s->rec_gather, (size_t)world * (s->cfg.d + BCX_REC_HDR))) != hipSuccess) {
     s->err = std::string("peer mailbox: ") + hipGetErrorString(e);
@@ -536,6 +551,27 @@ extern "C" int bcx_exchange_probe(bcx_solver* s, int32_t* result) {
 extern "C" int bcx_exchange_set_timeout(bcx_solver* s, double timeout_s) {
   if (!s || !(timeout_s > 0.0)) return BCX_ERR_ARG;
   s->exchange_timeout_s = timeout_s;
+  return BCX_OK;
+}
+
+// Device-side timing of the record exchange since the last reset: n exchanges, mean / max (microseconds) of the wait for
+// the slowest peer's record after this shard posted its own, and of the whole exchange step.
+extern "C" int bcx_exchange_stats(bcx_solver* s, int64_t* n, double* wait_us_mean, double* wait_us_max, double* total_us_mean,
+                                  double* total_us_max, int32_t reset) {
+  if (!s) return BCX_ERR_ARG;
+  unsigned long long h[5] = {0, 0, 0, 0, 0};
+  if (s->xseq) {
+    BCX_HIP(hipSetDevice(s->cfg.device));
+    BCX_HIP(hipStreamSynchronize(s->stream));
+    BCX_HIP(hipMemcpy(h, s->xseq + 1, sizeof h, hipMemcpyDeviceToHost));
+    if (reset) BCX_HIP(hipMemset(s->xseq + 1, 0, sizeof h));
+  }
+  const double per = h[0] ? 1.0 / (double)h[0] : 0.0, us = 1.0 / 100.0;   // wall_clock64: 100 MHz
+  if (n) *n = (int64_t)h[0];
+  if (wait_us_mean) *wait_us_mean = (double)h[1] * per * us;
+  if (wait_us_max) *wait_us_max = (double)h[2] * us;
+  if (total_us_mean) *total_us_mean = (double)h[3] * per * us;
+  if (total_us_max) *total_us_max = (double)h[4] * us;
   return BCX_OK;
 }
 

@@ -48,6 +48,8 @@ struct Mailbox {
   void* const* peers;          // world mailbox base addresses (device array; [rank] is this shard's own)
   unsigned long long* seq;     // exchanges completed so far (device word; identical on every shard)
   int32_t* probe;              // result of bcx_exchange_probe: 1 ok, -1 timeout, -2 payload mismatch
+  unsigned long long* stat;    // [0] exchanges timed, [1] sum / [2] max of the wait for the peers' records, [3] sum / [4] max
+                               // of the whole exchange (own stores + wait), wall_clock64 ticks (100 MHz); bcx_exchange_stats
   int world, rank, recw;
   unsigned off_slots;
   long long timeout_ticks;     // wall_clock64 ticks (100 MHz) before a wait gives up
@@ -121,7 +123,7 @@ struct bcx_solver {
   size_t mbox_bytes = 0;
   std::vector<void*> peer_mbox;  // mapped mailboxes by rank ([rank] == mbox)
   void** peer_tab = nullptr;     // device copy of peer_mbox
-  unsigned long long* xseq = nullptr;
+  unsigned long long* xseq = nullptr;   // [0] exchanges completed; [1..5] timing statistics (Mailbox::stat)
   int32_t* xprobe = nullptr;
   double* rec_gather = nullptr;  // world x (d+4): records of the last exchange (input of the OMP apply kernels)
   bool exchange_ready = false;
@@ -168,7 +170,8 @@ struct bcx_solver {
 };
 
 // ---- kernel launchers (defined in the .hip files) ------------------------
-int bcx_launch_ingest(bcx_solver* s, const void* src, int src_dtype, int64_t ld_src, int64_t row_begin, int64_t rows);
+int bcx_launch_ingest(bcx_solver* s, const void* src, int src_dtype, int64_t ld_src, int64_t row_begin, int64_t rows,
+                      int center);
 int bcx_launch_finalize(bcx_solver* s, int have_b, const double* gathered, int64_t n_gathered);
 int bcx_launch_scan(bcx_solver* s, int exact);
 int bcx_launch_resolve(bcx_solver* s, double* send_dev, int exact);

@@ -8,6 +8,11 @@
 #include "dev_util.h"
 
 template <typename TD> __device__ __forceinline__ TD to_store(double v) { return (TD)v; }
+// sum of one 16-byte piece, in the association the projection's former centring pass used ((x + y) per piece)
+template <int EPS> __device__ __forceinline__ double piece_sum(const double* v) {
+  if constexpr (EPS == 2) return v[0] + v[1];
+  else return (v[0] + v[1]) + (v[2] + v[3]);
+}
 template <> __device__ __forceinline__ __half to_store<__half>(double v) { return __float2half_rn((float)v); }
 
 // One workgroup per chunk of BCX_CHUNK_ROWS rows; one wave per row, lanes stride the columns
@@ -18,7 +23,7 @@ template <typename TS, typename TD>
 __global__ __launch_bounds__(1024) void ingest_kernel(const TS* src, int64_t ld_src, int64_t row_begin,
                                                       int64_t rows, int d, TD* __restrict__ An, int ld, int ld64,
                                                       double* A64, double* __restrict__ norms,
-                                                      double* __restrict__ chunk_sums, DevState* st) {
+                                                      double* __restrict__ chunk_sums, DevState* st, int center) {
   extern __shared__ double lds[];  // nw * d column accumulators + nw norm accumulators
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
   double* colacc = lds + (size_t)wave * d;
@@ -32,11 +37,24 @@ __global__ __launch_bounds__(1024) void ingest_kernel(const TS* src, int64_t ld_
     // squares are summed in the order of the vectorised kernel below (a lane owns the 16-byte pieces
     // lane, lane + 64, ... of the row), so both kernels give the same norm bit for bit
     constexpr int EPS = 16 / (int)sizeof(TS);
+    // center: subtract the row mean first (projector.py:21 folded into the constructor pass); the mean is summed in
+    // the piece order of the vectorised kernel, so both kernels centre alike
+    double mean = 0.0;
+    if (center) {
+      double acc = 0.0;
+      for (int c0 = lane * EPS; c0 < d; c0 += 64 * EPS) {
+        double pv[EPS];
+#pragma unroll
+        for (int e = 0; e < EPS; ++e) pv[e] = c0 + e < d ? (double)x[c0 + e] : 0.0;
+        acc += piece_sum<EPS>(pv);
+      }
+      mean = wave_allsum(acc) / (double)d;
+    }
     double ss = 0.0;
     for (int c0 = lane * EPS; c0 < d; c0 += 64 * EPS) {
 #pragma unroll
       for (int e = 0; e < EPS; ++e) {
-        if (c0 + e < d) { const double v = (double)x[c0 + e]; ss = fma(v, v, ss); }   // (explicit: both kernels contract alike)
+        if (c0 + e < d) { const double v = (double)x[c0 + e] - mean; ss = fma(v, v, ss); }   // (explicit: both kernels contract alike)
       }
     }
     ss = wave_allsum(ss);
@@ -58,9 +76,9 @@ __global__ __launch_bounds__(1024) void ingest_kernel(const TS* src, int64_t ld_
     normacc += nrm;
     TD* y = An + lr * (int64_t)ld;
     double* raw = A64 ? A64 + lr * (int64_t)ld64 : nullptr;
-    const bool copy_raw = raw && (const void*)raw != (const void*)x;
+    const bool copy_raw = raw && ((const void*)raw != (const void*)x || center);
     for (int c = lane; c < d; c += 64) {
-      double v = (double)x[c];  // second touch hits L1/L2
+      double v = (double)x[c] - mean;  // second touch hits L1/L2
       colacc[c] += v;
       y[c] = to_store<TD>(v / nrm);
       if (copy_raw) raw[c] = v;
@@ -112,7 +130,7 @@ template <typename TS, typename TD, int CHI>
 __global__ __launch_bounds__(1024) void ingest_vec_kernel(const TS* src, int64_t ld_src, int64_t row_begin,
                                                           int64_t rows, int d, TD* __restrict__ An, int ld, int ld64,
                                                           double* A64, double* __restrict__ norms,
-                                                          double* __restrict__ chunk_sums, DevState* st) {
+                                                          double* __restrict__ chunk_sums, DevState* st, int center) {
   typedef typename SrcVec<TS>::V V;
   constexpr int EPS = SrcVec<TS>::EPS;
   extern __shared__ double lds[];  // nw * d column sums + nw norm sums
@@ -136,10 +154,25 @@ __global__ __launch_bounds__(1024) void ingest_vec_kernel(const TS* src, int64_t
       xv[t] = x[pc < npieces ? pc : 0];
     }
     double v[CHI][EPS];
+#pragma unroll
+    for (int t = 0; t < CHI; ++t) unpack(xv[t], v[t]);
+    if (center) {
+      // row mean subtracted here (projector.py:21): the row is in registers anyway, one more wave sum -- the separate
+      // centring pass over the N x S matrix (read + write) is gone.  Same lane -> column ownership and association as
+      // that pass had, so the centred values are the same bits.
+      double acc = 0.0;
+#pragma unroll
+      for (int t = 0; t < CHI; ++t)
+        if (lane + 64 * t < npieces) acc += piece_sum<EPS>(v[t]);
+      const double mean = wave_allsum(acc) / (double)d;
+#pragma unroll
+      for (int t = 0; t < CHI; ++t)
+#pragma unroll
+        for (int e = 0; e < EPS; ++e) v[t][e] -= mean;
+    }
     double ss = 0.0;
 #pragma unroll
     for (int t = 0; t < CHI; ++t) {
-      unpack(xv[t], v[t]);
       if (lane + 64 * t < npieces) {
 #pragma unroll
         for (int e = 0; e < EPS; ++e) ss = fma(v[t][e], v[t][e], ss);
@@ -163,7 +196,7 @@ __global__ __launch_bounds__(1024) void ingest_vec_kernel(const TS* src, int64_t
     normacc += nrm;
     TD* y = An + lr * (int64_t)ld;
     double* raw = A64 ? A64 + lr * (int64_t)ld64 : nullptr;
-    const bool copy_raw = raw && (const void*)raw != (const void*)x;
+    const bool copy_raw = raw && ((const void*)raw != (const void*)x || center);
 #pragma unroll
     for (int t = 0; t < CHI; ++t) {
       const int pc = lane + 64 * t;
@@ -203,7 +236,8 @@ __global__ __launch_bounds__(1024) void ingest_vec_kernel(const TS* src, int64_t
   }
 }
 
-int bcx_launch_ingest(bcx_solver* s, const void* src, int src_dtype, int64_t ld_src, int64_t row_begin, int64_t rows) {
+int bcx_launch_ingest(bcx_solver* s, const void* src, int src_dtype, int64_t ld_src, int64_t row_begin, int64_t rows,
+                      int center) {
   const int d = s->cfg.d;
   const int64_t nblk = (rows + BCX_CHUNK_ROWS - 1) / BCX_CHUNK_ROWS;
   int nw = (int)((144 * 1024) / ((size_t)d * 8));   // column accumulators must fit the 160 KiB LDS
@@ -222,7 +256,7 @@ int bcx_launch_ingest(bcx_solver* s, const void* src, int src_dtype, int64_t ld_
     if (shmem > 48 * 1024)                                                                                    \
       BCX_HIP(hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));  \
     hipLaunchKernelGGL(kfn, grid, block, shmem, s->stream, (const TS_*)src, ld_src, row_begin, rows, d,       \
-                       (TD_*)s->An, s->ld, s->ld64, s->A64, s->norms, s->chunk_sums, s->st);                  \
+                       (TD_*)s->An, s->ld, s->ld64, s->A64, s->norms, s->chunk_sums, s->st, center);          \
   } while (0)
 #define LAUNCH(TS, TD)                                                                                        \
   do {                                                                                                        \

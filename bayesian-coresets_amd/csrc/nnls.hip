@@ -17,6 +17,12 @@
 #include "apply_common.h"
 #include "nnls_common.h"
 
+#ifdef BCX_TIMING
+#define NN_COUNT(st, i) do { if (threadIdx.x == 0) (st)->dbg_t[12 + (i)] += 1; } while (0)
+#else
+#define NN_COUNT(st, i) do {} while (0)
+#endif
+
 // y[a] = sum_b M[b*ld + a] * v[b], a < p  (M symmetric: reading column a as row entries is coalesced).
 // 8 independent loads per step so the L2 latencies overlap; fixed summation order.
 static __device__ void mv_sym(const double* M, int64_t ld, int p, const double* v, double* y) {
@@ -136,6 +142,7 @@ static __device__ void passive_solve(const NnlsArgs& n, double* scratch) {
   // ill-conditioned ones (omp_ill): refine until the residual is at rounding level
   const int max_it = n.a.st->omp_ill ? 4 : 1;
   for (int it = 0; it < max_it; ++it) {
+    NN_COUNT(n.a.st, 2);
     mv_gram(n, p, n.z, n.t1);
     double rmax = 0.0;
     for (int a = threadIdx.x; a < p; a += blockDim.x) { const double r = n.t0[a] - n.t1[a]; n.t1[a] = r; rmax = fmax(rmax, fabs(r)); }
@@ -181,6 +188,7 @@ static __device__ void nnls_run(const NnlsArgs& n, int k, double tolscale, doubl
     }
     const ArgBest best = block_argbest(bv, bi, scratch);
     if (best.i < 0) break;
+    NN_COUNT(st, 0);
     if (!border_add(n, best.i, scratch)) {
       if (threadIdx.x == 0) n.flag[best.i] |= FLAG_REJ;
       __syncthreads();
@@ -189,6 +197,7 @@ static __device__ void nnls_run(const NnlsArgs& n, int k, double tolscale, doubl
     if (threadIdx.x == 0) n.x[best.i] = 0.0;
     __syncthreads();
     for (int inner = 0; inner < max_outer; ++inner) {
+      NN_COUNT(st, 1);
       passive_solve(n, scratch);
       const int pp = st->np;
       // feasibility: all z > 0 ?  else step length alpha = min x/(x - z) over z <= 0
@@ -232,6 +241,7 @@ static __device__ void nnls_run(const NnlsArgs& n, int k, double tolscale, doubl
           if (slot == best.i && inner == 0) n.flag[slot] |= FLAG_REJ;   // LH safeguard: do not re-pick at once
         }
         __syncthreads();
+        NN_COUNT(st, 3);
         border_del(n, top.i);
       }
       if (st->np == 0) break;
@@ -619,6 +629,15 @@ __global__ __launch_bounds__(BCX_APPLY_THREADS) void omp_finish_kernel(NnlsArgs 
 #define OMPF_MAX_K 4096      // LDS per position: g / x (8) + u (8) + slot (4) bytes, next to 3 d-vectors
 
 #define OMPF_STAMP(i) do { if (blockIdx.x == 0) BCX_STAMP(st, i); } while (0)
+#ifdef BCX_TIMING
+// dev builds: one record per fused step (tools/omp_hist.py): it, k, p, mode before / after the step phase, status, and
+// the stamps 0..11 of workgroup 0 as offsets from stamp 0
+#define OMP_LOG_MAX 4096
+__device__ long long g_omp_log[OMP_LOG_MAX][24];
+extern "C" int bcx_debug_omp_log(long long* out, int n) {
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_omp_log), (size_t)n * 24 * sizeof(long long)) == hipSuccess ? 0 : -2;
+}
+#endif
 
 // (value desc, global index asc) arg-max over the workgroup; carries the slot of the winner.  idx < 0: no entry.
 struct NegBest { double v; long long idx; int slot; };
@@ -754,6 +773,7 @@ __global__ __launch_bounds__(NN_THREADS) void omp_fused_kernel(NnlsArgs n, GridS
   else if (ill0) mode = OMP_GENERAL;
   else if ((since0 % OMP_RESOLVE_EVERY) == OMP_RESOLVE_EVERY - 1) mode = OMP_GENERAL;
   else mode = OMP_FAST_TRY;
+  const int mode0 = mode; (void)mode0;
   OMPF_STAMP(3);
   // ---- phase 3: u = H g on this workgroup's 64-column blocks ------------------------------------------
   if (mode == OMP_FAST_TRY) {
@@ -964,9 +984,20 @@ __global__ __launch_bounds__(NN_THREADS) void omp_fused_kernel(NnlsArgs n, GridS
   }
   __syncthreads();
   OMPF_STAMP(10);
-  if (!st->active) return;
-  prepare_next(a, scratch);
+#ifdef BCX_TIMING
+  const int64_t log_it = st->it - 1;
+#endif
+  if (st->active) prepare_next(a, scratch);
   OMPF_STAMP(11);
+#ifdef BCX_TIMING
+  __syncthreads();
+  if (tid == 0 && log_it >= 0 && log_it < OMP_LOG_MAX) {
+    long long* L = g_omp_log[log_it];
+    L[0] = log_it; L[1] = k; L[2] = p; L[3] = mode0; L[4] = mode; L[5] = status; L[6] = st->np; L[7] = st->omp_ill;
+    for (int i = 0; i < 12; ++i) L[8 + i] = st->dbg_t[i] - st->dbg_t[0];
+    for (int i = 0; i < 4; ++i) { L[20 + i] = st->dbg_t[12 + i]; st->dbg_t[12 + i] = 0; }
+  }
+#endif
 }
 
 void fill_nnls_args(bcx_solver* s, NnlsArgs& n, const double* recs) {

@@ -894,10 +894,10 @@ static int fill(ProjArgs& p, int family, const void* Z, int64_t N, int64_t ldz, 
   return BCX_OK;
 }
 
-// vecs (N x S, centred) into out_dev; rowsum_dev (N doubles) is no longer used: the centring pass forms the means.
-extern "C" int bcx_project_write(void* stream, int32_t family, const void* Z_dev, int64_t N, int64_t ldz, int32_t D,
-                                 int32_t ycol, const void* theta_dev, int32_t S, int32_t ldt, double param,
-                                 void* out_dev, int64_t ldo, void* rowsum_dev) {
+// vecs (N x S) into out_dev, centred by a second pass over the rows (center != 0) or left as the raw log-likelihoods
+static int project_write(void* stream, int32_t family, const void* Z_dev, int64_t N, int64_t ldz, int32_t D,
+                         int32_t ycol, const void* theta_dev, int32_t S, int32_t ldt, double param,
+                         void* out_dev, int64_t ldo, void* rowsum_dev, bool center) {
   ProjArgs p;
   int rc = fill(p, family, Z_dev, N, ldz, D, ycol, theta_dev, S, ldt, param);
   if (rc) return rc;
@@ -908,6 +908,7 @@ extern "C" int bcx_project_write(void* stream, int32_t family, const void* Z_dev
   const int wgrid = proj_grid(N);
   p.team = proj_team(PMODE_WRITE, family, S, wgrid);
   if ((rc = launch_family<PMODE_WRITE>(family, dim3(wgrid), 0, st, p))) return rc;
+  if (!center) return BCX_OK;
   const int g = (int)std::min<int64_t>((N + 3) / 4, 8192);
   if (S % 2 == 0 && ldo % 2 == 0 && (uintptr_t)p.out % 16 == 0)
     hipLaunchKernelGGL(center_kernel<true>, dim3(g), dim3(256), 0, st, p.out, ldo, N, S);
@@ -915,6 +916,20 @@ extern "C" int bcx_project_write(void* stream, int32_t family, const void* Z_dev
     hipLaunchKernelGGL(center_kernel<false>, dim3(g), dim3(256), 0, st, p.out, ldo, N, S);
   PROJ_HIP(hipGetLastError());
   return BCX_OK;
+}
+
+// rowsum_dev (N doubles) is no longer used: the centring pass forms the means.
+extern "C" int bcx_project_write(void* stream, int32_t family, const void* Z_dev, int64_t N, int64_t ldz, int32_t D,
+                                 int32_t ycol, const void* theta_dev, int32_t S, int32_t ldt, double param,
+                                 void* out_dev, int64_t ldo, void* rowsum_dev) {
+  return project_write(stream, family, Z_dev, N, ldz, D, ycol, theta_dev, S, ldt, param, out_dev, ldo, rowsum_dev, true);
+}
+// The raw log-likelihoods loglik(z_n, theta_s), NOT centred: for a consumer that centres the rows itself while it reads
+// them (bcx_load_rows_flags with BCX_LOAD_CENTER_ROWS) -- the N x S matrix is then written once and read once.
+extern "C" int bcx_project_write_raw(void* stream, int32_t family, const void* Z_dev, int64_t N, int64_t ldz, int32_t D,
+                                     int32_t ycol, const void* theta_dev, int32_t S, int32_t ldt, double param,
+                                     void* out_dev, int64_t ldo) {
+  return project_write(stream, family, Z_dev, N, ldz, D, ycol, theta_dev, S, ldt, param, out_dev, ldo, nullptr, false);
 }
 
 // colsum_dev[s] = sum_n vecs[n][s] without materialising vecs.  work_dev: 2048 * S doubles.

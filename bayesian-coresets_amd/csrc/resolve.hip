@@ -134,8 +134,13 @@ static __device__ void resolve_core(const ResolveArgs& a, Winner* win, double* x
   const double* q0 = a.q64;
   const double* q1 = a.q64 + a.ld64;
   const bool dual = a.alg == BCX_ALG_GIGA;
-  const bool unscored = !a.need_score && nc == 1;       // (the usual case: 1.00-1.01 candidates per iteration)
-  if (unscored && tid == 0) cscore[0] = 0.0;
+  // No re-score when (a) the scan was exact: every candidate's score IS Lstar, the maximum of the scan's own fp64
+  // scores -- comparing shards by that value (and rows by index) is what makes the pick independent of the shard
+  // count; a re-score in this kernel's summation order could split rows the scan tied and name a different winner on
+  // one shard than on four (found by the 4-rank exact-fallback test on rows duplicated up to scaling) -- or (b) a
+  // single candidate on a single shard, whose score nobody reads (the usual case: 1.00-1.01 candidates per iteration).
+  const bool unscored = exact || (!a.need_score && nc == 1);
+  if (unscored && tid < nc) cscore[tid] = exact ? Lstar : 0.0;
   for (int c = wave; c < nc && !unscored; c += nwaves) {
     const int64_t i = cand[c];
     const double nrm = a.norms[i];
@@ -487,6 +492,7 @@ static __device__ const double* mailbox_exchange(const Mailbox& m, const double*
   const int tid = threadIdx.x;
   const unsigned long long seq = *m.seq + 1;
   const int par = (int)(seq & 1ull);
+  const long long t_in = tid == 0 ? wall_clock64() : 0;
   const size_t my_slot = m.off_slots + ((size_t)par * m.world + m.rank) * m.recw * sizeof(double);
   for (int w = 0; w < m.world; ++w) {
     double* dst = (double*)((char*)m.peers[w] + my_slot);
@@ -496,6 +502,7 @@ static __device__ const double* mailbox_exchange(const Mailbox& m, const double*
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (explicit: ROCm 7.2 can drop the wait that belongs to a fence)
   if (tid == 0) *s_flag = 0;
   __syncthreads();
+  const long long t_posted = tid == 0 ? wall_clock64() : 0;
   if (tid < m.world) {
     unsigned long long* out = (unsigned long long*)m.peers[tid] + (par * m.world + m.rank);
     __hip_atomic_store(out, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -509,7 +516,16 @@ static __device__ const double* mailbox_exchange(const Mailbox& m, const double*
   __syncthreads();
   __threadfence_system();
   if (*s_flag) return nullptr;
-  if (tid == 0) *m.seq = seq;
+  if (tid == 0) {
+    *m.seq = seq;
+    // device-side timing of the exchange step (bench.py: config.exchange_wait_us): how long this shard waited for
+    // the slowest peer's record after posting its own, and the whole step including its own G stores
+    const unsigned long long now = (unsigned long long)wall_clock64();
+    const unsigned long long wait = now - (unsigned long long)t_posted, all = now - (unsigned long long)t_in;
+    m.stat[0] += 1ull;
+    m.stat[1] += wait; if (wait > m.stat[2]) m.stat[2] = wait;
+    m.stat[3] += all;  if (all > m.stat[4]) m.stat[4] = all;
+  }
   return (const double*)((const char*)m.peers[m.rank] + m.off_slots + (size_t)par * m.world * m.recw * sizeof(double));
 }
 
@@ -718,6 +734,7 @@ Mailbox bcx_mailbox(const bcx_solver* s) {
   Mailbox m;
   m.peers = s->peer_tab;
   m.seq = s->xseq;
+  m.stat = s->xseq + 1;
   m.probe = s->xprobe;
   m.world = s->cfg.world_size;
   m.rank = s->cfg.rank;

@@ -185,14 +185,17 @@ def load_logistic(args, torch, dist, world, solver, info):
     t1 = time.perf_counter()
     prj = bc.DeviceProjector("logistic", lambda n, w, p: samples[:n], args.dim, device=torch.cuda.current_device())
     prj.profile(True)
-    vecs = prj.project(Z)
+    # as HilbertCoreset does behind a device projector: raw log-likelihoods out of the projection kernel, the row means
+    # (projector.py:21) subtracted by the solver's constructor pass -- N x S written once, read once
+    vecs = prj.project_uncentred(Z)
     torch.cuda.synchronize()
     t2 = time.perf_counter()
     pms, pl, pfl = prj.profile_read()
     prj.profile(False)
-    solver.load_local(vecs)
+    solver.load_local(vecs, center=True)
     torch.cuda.synchronize()
     t3 = time.perf_counter()
+    vecs -= vecs.mean(dim=1, keepdim=True)          # (for the row-norm report and the CPU sample below; outside the timings)
     nrm = torch.linalg.vector_norm(vecs, dim=1)
     info.update({"laplace_fit_s": t1 - t0, "projection_s": t2 - t1, "ingest_s": t3 - t2, "features": args.features,
                  "projection_kernel_ms": pms, "projection_kernel_gelem_per_s": (hi - lo) * args.dim / max(pms, 1e-9) / 1e6,
@@ -251,6 +254,8 @@ def run_snnls(args, torch, dist, nat, world, rank, local_rank):
         every = 1 if steps < 64 else 8
         if not os.environ.get("BENCH_NO_EVENTS"):
             s.engine.profile(every)
+        if s.exchange == "mailbox":
+            s.engine.exchange_stats(reset=True)       # device-side wait stamps of the timed region only
         sync()
         t0 = time.perf_counter()
         tr = build(s, steps)
@@ -268,6 +273,16 @@ def run_snnls(args, torch, dist, nat, world, rank, local_rank):
     sel, err, status = tr
     steps_done = len(sel)
     out = None
+    # device-stamped exchange step of the timed region (mailbox mode): every rank's own view, worst rank reported
+    xstat = None
+    if world > 1 and solver.exchange == "mailbox":
+        xs = solver.engine.exchange_stats()
+        t = torch.tensor([xs["wait_us_mean"], xs["wait_us_max"], xs["total_us_mean"], xs["total_us_max"]],
+                         dtype=torch.float64, device="cuda")
+        lo_t = t.clone()
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dist.all_reduce(lo_t, op=dist.ReduceOp.MIN)
+        xstat = {"n": xs["exchanges"], "max": [float(v) for v in t.tolist()], "min": [float(v) for v in lo_t.tolist()]}
     if rank == 0:
         bytes_per_launch = float(solver.n_local) * args.dim * elem
         avg_ms = scan_ms / max(scan_launches, 1)
@@ -292,6 +307,15 @@ def run_snnls(args, torch, dist, nat, world, rank, local_rank):
                 "alg": args.alg, "rows": args.rows, "dim": args.dim, "rows_per_gpu": solver.n_local,
                 "exchange": solver.exchange if world > 1 else None,   # mailbox = device-side P2P stores; collective = all-gather
                 "exchange_probe": solver.probe_info,
+                # wall_clock64 stamps inside the tail kernel (csrc/resolve.hip mailbox_exchange), timed region only:
+                # wait = from this shard's record being posted to the slowest peer's record arriving (load imbalance +
+                # xGMI latency); exchange = wait + this shard's own G record stores.  Worst / best rank.
+                "exchange_wait_us": xstat["max"][0] if xstat else None,
+                "exchange_wait_us_max": xstat["max"][1] if xstat else None,
+                "exchange_wait_us_best_rank": xstat["min"][0] if xstat else None,
+                "exchange_us": xstat["max"][2] if xstat else None,
+                "exchange_us_max": xstat["max"][3] if xstat else None,
+                "exchanges_timed": xstat["n"] if xstat else None,
                 "exact_rows_resident": not args.no_exact_rows,
                 "iterations_run": int(steps_done), "reached_numeric_limit": bool(solver.reached_numeric_limit),
                 "steps_accepted": int((status == 0).sum()), "final_error": float(err[-1]) if len(err) else None,

@@ -82,6 +82,13 @@ int bcx_set_stream(bcx_solver* s, void* hip_stream);
  * streaming upload).  A zero-norm row is reported by bcx_finalize (BCX_ERR_ZERO_ROW). */
 int bcx_load_rows(bcx_solver* s, const void* src, int32_t src_is_device, int32_t src_dtype,
                   int64_t row_begin, int64_t rows, int64_t ld);
+/* The same with options.  BCX_LOAD_CENTER_ROWS: subtract every row's mean before anything else, i.e. the rows are
+ * raw log-likelihoods and the constructor pass applies the projector's centring (projector.py:21) itself -- the row
+ * is in registers between the norm and the stores, so a projection that feeds HilbertCoreset is written once and read
+ * once instead of taking a separate centring pass.  The caller's buffer is left as it is (uncentred). */
+#define BCX_LOAD_CENTER_ROWS 1
+int bcx_load_rows_flags(bcx_solver* s, const void* src, int32_t src_is_device, int32_t src_dtype,
+                        int64_t row_begin, int64_t rows, int64_t ld, int32_t flags);
 /* Number of row chunks on this shard and rows per chunk; chunk sums are (d+1) doubles each:
  * d column sums followed by the sum of row norms.  Device pointer for the all-gather across shards. */
 int bcx_chunk_sums(bcx_solver* s, const void** dev_ptr, int64_t* n_chunks, int64_t* chunk_rows);
@@ -128,12 +135,17 @@ int bcx_build_enqueue_exact(bcx_solver* s);
  *                        record arrived intact, -1 timeout, -2 payload mismatch;
  *   bcx_exchange_set_timeout  change the bound on every later wait;
  *   bcx_exchange_disable go back to the host-driven exchange (e.g. after a failed probe).
+ *   bcx_exchange_stats   device-side time stamps of the exchanges since the last reset: how many, mean / max microseconds
+ *                        this shard waited for the slowest peer's record after posting its own, mean / max of the whole
+ *                        exchange step (own stores + wait); any output may be NULL; reset != 0 clears the counters.
  * All shards must issue the same sequence of exchanges (they do: the solver state is replicated). */
 int bcx_exchange_export(bcx_solver* s, void* handle_out, int32_t handle_bytes);
 int bcx_exchange_attach(bcx_solver* s, const void* handles, int32_t handle_bytes, double timeout_s);
 int bcx_exchange_probe(bcx_solver* s, int32_t* result);
 int bcx_exchange_set_timeout(bcx_solver* s, double timeout_s);
 int bcx_exchange_disable(bcx_solver* s);
+int bcx_exchange_stats(bcx_solver* s, int64_t* n, double* wait_us_mean, double* wait_us_max, double* total_us_mean,
+                       double* total_us_max, int32_t reset);
 /* Synchronise and report.  *n_done = loop iterations consumed so far in this build() call;
  * *need_exact = 1 if the engine stopped before an iteration because the fp32 candidate window
  * overflowed (tie-heavy data) -- call bcx_step_scan_exact for that iteration and continue;
@@ -188,6 +200,11 @@ int bcx_profile_read(bcx_solver* s, double* scan_ms_total, int64_t* scan_launche
 int bcx_project_write(void* stream, int32_t family, const void* Z_dev, int64_t N, int64_t ldz, int32_t D,
                       int32_t ycol, const void* theta_dev, int32_t S, int32_t ldt, double param,
                       void* out_dev, int64_t ldo, void* rowsum_dev);
+ /* write_raw: the log-likelihoods WITHOUT the centring (one pass less); the rows are centred by whoever reads them, e.g.
+  * bcx_load_rows_flags(..., BCX_LOAD_CENTER_ROWS) -- HilbertCoreset behind a device projector. */
+int bcx_project_write_raw(void* stream, int32_t family, const void* Z_dev, int64_t N, int64_t ldz, int32_t D,
+                          int32_t ycol, const void* theta_dev, int32_t S, int32_t ldt, double param,
+                          void* out_dev, int64_t ldo);
 int bcx_project_colsum(void* stream, int32_t family, const void* Z_dev, int64_t N, int64_t ldz, int32_t D,
                        int32_t ycol, const void* theta_dev, int32_t S, int32_t ldt, double param,
                        void* colsum_dev, void* work_dev);

@@ -25,8 +25,10 @@ class FakeEngine(object):
     def tensor_device(self):
         return torch.device("cpu")
 
-    def load_rows_any(self, rows, row_begin=0):
+    def load_rows_any(self, rows, row_begin=0, center=False):
         rows = rows.numpy() if isinstance(rows, torch.Tensor) else np.asarray(rows)
+        if center:
+            rows = rows - rows.mean(axis=1)[:, None]
         self.rows[row_begin:row_begin + rows.shape[0]] = rows
 
     def export_chunk_sums_tensor(self, t, cap_chunks):

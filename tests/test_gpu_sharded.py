@@ -330,6 +330,106 @@ def test_two_level_column_sums_are_shard_count_independent(tmp_path):
                 assert np.array_equal(ref[k], r[k]), (world, rank, k)
 
 
+# ---- "identical for G in {1, 2, 4, 8}" -- world sizes 4 and 8, ranks sharing cuda:0 ---------------------------
+@pytest.mark.parametrize("exchange", ("collective", "mailbox"))
+@pytest.mark.parametrize("alg", (0, 1, 2))
+def test_four_and_eight_shards_match_one_shard(tmp_path, alg, exchange):
+    """Every rank of a 4- and an 8-way split (mailbox flags [2][G], G spinning lanes, 8 records per exchange; or the
+    all-gather) records the trace, weights and b of the single-shard run, bit for bit.  N = 40000 = 40 chunks: every one of
+    the 8 shards owns rows (the last one a ragged 4160)."""
+    import torch.multiprocessing as mp
+    N, d, itrs = 40000, 48, 50
+    mp.spawn(_worker, args=(1, _free_port(), alg, itrs, N, d, str(tmp_path)), nprocs=1, join=True)
+    ref = np.load(tmp_path / "w1_r0.npz")
+    assert len(ref["sel"]) == itrs
+    for world in (4, 8):
+        mp.spawn(_worker, args=(world, _free_port(), alg, itrs, N, d, str(tmp_path), exchange, "g_"), nprocs=world, join=True)
+        for rank in range(world):
+            r = np.load(tmp_path / ("g_w%d_r%d.npz" % (world, rank)))
+            for k in ("sel", "err", "status", "idx", "w", "b"):
+                assert np.array_equal(ref[k], r[k]), (world, rank, k)
+
+
+def test_peer_mailbox_exact_fallback_four_shards(tmp_path):
+    """the exact-scan fallback (candidate window overflow on tie-heavy rows) taken by FOUR ranks together"""
+    import torch.multiprocessing as mp
+    for world in (1, 4):
+        mp.spawn(_mailbox_storm_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    ref = np.load(tmp_path / "storm_w1_r0.npz")
+    for rank in range(4):
+        r = np.load(tmp_path / ("storm_w4_r%d.npz" % rank))
+        for k in ("sel", "err", "status", "idx", "w"):
+            assert np.array_equal(ref[k], r[k]), (rank, k)
+    assert int(np.load(tmp_path / "storm_w4_r0.npz")["ex"]) > 0
+
+
+def _c4_worker(rank, world, port, itrs, out_dir):
+    """configs[3] geometry (N = 10M, d = 512, Frank-Wolfe) with bench.py's own generator (seeded per 8192-row block, so
+    the matrix does not depend on the shard count); `world` ranks share cuda:0."""
+    for p in (ROOT, os.path.join(ROOT, "bayesian-coresets_amd")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    import argparse
+    import torch
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ["BCX_EXCHANGE"] = "mailbox"
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import bench
+    from bayesiancoresets_amd.sharded import ShardedSolver
+    args = argparse.Namespace(rows=10_000_000, dim=512, seed=1)
+    s = ShardedSolver(1, args.rows, args.dim, device=0)
+    bench.load_synthetic(args, torch, s)
+    assert s.finalize(None) == 0
+    tr = s.build(itrs)
+    idx, w = s.sparse_weights()
+    xs = s.engine.exchange_stats() if world > 1 else {}
+    assert world == 1 or (s.exchange == "mailbox" and xs["exchanges"] >= itrs)
+    np.savez(os.path.join(out_dir, "c4_w%d_r%d.npz" % (world, rank)), sel=tr[0], err=tr[1], status=tr[2], idx=idx, w=w,
+             b=s.engine.vector(0), n_local=s.n_local)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_config4_geometry_as_eight_shards(tmp_path):
+    """The FULL configs[3] problem as the 8 row shards of the 8-GPU run (1,250,304 rows x 512 each, ~9 GB per rank, all on
+    this one GPU): trace, weights and b equal the one-shard run of the same matrix bit for bit (the one-shard selects are
+    checked against a torch-fp64 restatement over all rows in test_gpu_fullsize.py::test_config4_fw_10m_x_512)."""
+    import torch.multiprocessing as mp
+    itrs = 48
+    mp.spawn(_c4_worker, args=(1, _free_port(), itrs, str(tmp_path)), nprocs=1, join=True)
+    ref = np.load(tmp_path / "c4_w1_r0.npz")
+    assert len(ref["sel"]) == itrs and (ref["status"] == 0).all()
+    mp.spawn(_c4_worker, args=(8, _free_port(), itrs, str(tmp_path)), nprocs=8, join=True)
+    rows = 0
+    for rank in range(8):
+        r = np.load(tmp_path / ("c4_w8_r%d.npz" % rank))
+        rows += int(r["n_local"])
+        for k in ("sel", "err", "status", "idx", "w", "b"):
+            assert np.array_equal(ref[k], r[k]), (rank, k)
+    assert rows == 10_000_000 and int(np.load(tmp_path / "c4_w8_r0.npz")["n_local"]) == 1_250_304
+    # the selections come from all over the matrix, i.e. from every shard
+    assert len(set(int(i) // 1_250_304 for i in ref["sel"])) == 8
+
+
+def test_bench_contract_eight_ranks():
+    """bench.py --gpus 8 under torchrun (ranks sharing the GPU): the SCALE contract end to end -- n_gpus, rows_per_gpu,
+    exchange mode + probe, the device-stamped exchange wait -- and the same bits as one rank."""
+    args = ["--rows", "400000", "--dim", "64", "--steps", "40", "--warmup", "5", "--no-cpu-baseline"]
+    one, _ = _run_bench({}, 1, args)
+    eight, _ = _run_bench({"BENCH_SHARE_GPU": "1"}, 8, args)
+    assert eight["n_gpus"] == 8 and eight["config"]["exchange"] == "mailbox"
+    assert eight["config"]["rows_per_gpu"] == 50176                      # 49 chunks of 1024 rows on rank 0
+    assert eight["config"]["final_error"] == one["config"]["final_error"]
+    assert eight["config"]["steps_accepted"] == one["config"]["steps_accepted"]
+    assert eight["config"]["exchanges_timed"] == 40
+    assert 0.0 < eight["config"]["exchange_wait_us"] <= eight["config"]["exchange_wait_us_max"]
+    assert eight["config"]["exchange_us"] >= eight["config"]["exchange_wait_us_best_rank"]
+    assert eight["config"]["exchange_probe"]["result"] == 1
+
+
 # ---- one rank per DEVICE over RCCL: runs only where the box has >= 2 GPUs (the 1-GPU test boxes skip it) ------------
 def _multi_device_worker(rank, world, port, alg, itrs, N, d, out_dir, exchange):
     os.environ["BCX_EXCHANGE"] = exchange

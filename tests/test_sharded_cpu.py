@@ -72,6 +72,19 @@ def test_two_shards_match_single_process(tmp_path, alg, name, explicit_b):
     np.testing.assert_allclose(w, ow, rtol=1e-12, atol=0)
 
 
+@pytest.mark.parametrize("alg", (0, 1, 2))
+def test_four_shards_match_two_shards(tmp_path, alg):
+    """world size 4 under gloo: the replicated state is the same on all four ranks and equals the 2-rank run bit for bit"""
+    N, d, itrs = 9000, 16, 12
+    mp.spawn(_worker, args=(2, _free_port(), alg, itrs, N, d, str(tmp_path), False), nprocs=2, join=True)
+    two = {k: np.load(tmp_path / "r0.npz")[k] for k in ("sel", "err", "idx", "w", "b")}
+    mp.spawn(_worker, args=(4, _free_port(), alg, itrs, N, d, str(tmp_path), False), nprocs=4, join=True)
+    for rank in range(4):
+        r = np.load(tmp_path / ("r%d.npz" % rank))
+        for k in ("sel", "err", "idx", "w", "b"):
+            assert np.array_equal(two[k], r[k]), (rank, k)
+
+
 def test_shard_bounds_properties():
     sys.path.insert(0, os.path.join(ROOT, "bayesian-coresets_amd"))
     from bayesiancoresets_amd.sharded import shard_bounds
