@@ -26,7 +26,7 @@ SYMBOLS = (
     "bcx_stats", "bcx_profile_scan", "bcx_profile_read", "bcx_version",
     "bcx_project_write", "bcx_project_colsum", "bcx_project_select", "bcx_project_last_error",
     "bcx_build_enqueue_exact", "bcx_exchange_export", "bcx_exchange_attach", "bcx_exchange_probe", "bcx_exchange_disable", "bcx_exchange_set_timeout",
-    "bcx_set_check_monotone", "bcx_project_profile", "bcx_project_profile_read", "bcx_exchange_stats", "bcx_load_rows_flags", "bcx_project_write_raw",
+    "bcx_set_check_monotone", "bcx_project_profile", "bcx_project_profile_read", "bcx_exchange_stats", "bcx_load_rows_flags", "bcx_project_write_raw", "bcx_omp_stats", "bcx_project_select_ws", "bcx_project_select_scratch_bytes",
 )
 
 
@@ -95,6 +95,7 @@ def load():
         "bcx_argmax_correlation": [vp, vp, P(i64), P(dbl)],
         "bcx_time_scan": [vp, i32, i32, P(dbl), P(dbl)],
         "bcx_stats": [vp, P(i64), P(i64), P(i64)],
+        "bcx_omp_stats": [vp, vp],
         "bcx_profile_scan": [vp, i32],
         "bcx_profile_read": [vp, P(dbl), P(i64)],
         "bcx_build_enqueue_exact": [vp],
@@ -110,11 +111,16 @@ def load():
     sigs["bcx_project_write_raw"] = proj_common + [vp, i64]
     sigs["bcx_project_colsum"] = proj_common + [vp, vp]
     sigs["bcx_project_select"] = proj_common + [vp, dbl, vp, vp]
+    sigs["bcx_project_select_ws"] = proj_common + [vp, dbl, vp, vp, i64]
     sigs["bcx_project_profile"] = [i32]
     sigs["bcx_project_profile_read"] = [P(dbl), P(i64), P(dbl)]
+    lib.bcx_project_select_scratch_bytes.restype = ctypes.c_int64
+    lib.bcx_project_select_scratch_bytes.argtypes = [i32, i64, i32]
     lib.bcx_project_last_error.restype = ctypes.c_char_p
     lib.bcx_project_last_error.argtypes = []
     for name, args in sigs.items():
+        if name == "bcx_project_select_scratch_bytes":
+            continue
         fn = getattr(lib, name)
         fn.argtypes = args
         fn.restype = ctypes.c_int
@@ -386,6 +392,11 @@ class Engine(object):
         a, b, c = ctypes.c_int64(), ctypes.c_int64(), ctypes.c_int64()
         self._check(self.lib.bcx_stats(self.h, ctypes.byref(a), ctypes.byref(b), ctypes.byref(c)))
         return {"exact_fallbacks": a.value, "candidates": b.value, "resolves": c.value}
+
+    def omp_stats(self):
+        out = (ctypes.c_int64 * 4)()
+        self._check(self.lib.bcx_omp_stats(self.h, out))
+        return {"steps": out[0], "columns_left": out[1], "resolves": out[2], "extra_entered": out[3]}
 
     def profile(self, on):
         self._check(self.lib.bcx_profile_scan(self.h, int(on)))

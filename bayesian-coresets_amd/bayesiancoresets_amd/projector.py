@@ -202,6 +202,15 @@ class DeviceProjector(Projector):
             self._work = torch.empty(2048 * max(S, 2), dtype=torch.float64, device=self.device)
         return self._work
 
+    def _select_scratch(self, N, S):
+        """Caller-owned scratch of the select step (arg-max reduction + 32 bytes per row and 64-column group of partial row
+        moments): kept between calls, so the step never goes to the stream-ordered allocator (whose pool would compete
+        with torch's caching allocator: ~0.6 GB per call at N = 5M, S = 256)."""
+        need = int(self._lib.bcx_project_select_scratch_bytes(self._fam, int(N), int(S)))
+        if getattr(self, "_sel_work", None) is None or self._sel_work.numel() * 8 < need:
+            self._sel_work = self._torch.empty((need + 7) // 8, dtype=self._torch.float64, device=self.device)
+        return self._sel_work
+
     def project_colsum(self, pts):
         """sum_n vecs[n, :] as a length-S ndarray, without forming vecs."""
         torch = self._torch
@@ -229,8 +238,9 @@ class DeviceProjector(Projector):
         r = torch.from_numpy(np.ascontiguousarray(resid, dtype=np.float64)).to(self.device)
         res = torch.empty(2, dtype=torch.float64, device=self.device)
         if Z.shape[0]:
-            self._launch(self._lib.bcx_project_select, self._common(Z) + [r.data_ptr(), float(np.sum(resid)), res.data_ptr(),
-                                                                  self._workspace(S).data_ptr()], Z)
+            work = self._select_scratch(Z.shape[0], S)
+            self._launch(self._lib.bcx_project_select_ws, self._common(Z) + [r.data_ptr(), float(np.sum(resid)), res.data_ptr(),
+                                                                     work.data_ptr(), work.numel() * 8], Z)
             h = res.cpu()
             best, row = float(h[0]), int(h[1:2].view(torch.int64)[0])
             row = int(row_ids[row]) if row_ids is not None else row + self.row_offset

@@ -25,7 +25,7 @@ static int round_up(int x, int m) { return (x + m - 1) / m * m; }
 static void free_all(bcx_solver* s) {
   void* ptrs[] = {s->An, s->A64, s->norms, s->chunk_sums, s->staging, s->st, s->b, s->bn, s->xw, s->q64, s->qst,
                   s->tmp, s->partials, s->rec_local, s->act_idx, s->act_w, s->act_rows, s->act_norm, s->gram,
-                  s->hinv, s->cvec, s->plist, s->ppos, s->nn_x, s->nn_z, s->nn_wv, s->nn_tmp, s->nn_flag, s->nn_wbak, s->tr_sel, s->tr_err,
+                  s->hinv, s->hinv_lo, s->cvec, s->plist, s->ppos, s->nn_x, s->nn_z, s->nn_wv, s->nn_tmp, s->nn_flag, s->nn_wbak, s->nn_xr, s->tr_sel, s->tr_err,
                   s->tr_status};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
@@ -333,16 +333,19 @@ int bcx_ensure_gram(bcx_solver* s, int64_t need) {
   const int64_t ncap = std::max<int64_t>((need + 63) / 64 * 64, std::max<int64_t>(256, s->gram_cap * 2));
   const size_t oc = (size_t)s->gram_cap, nc = (size_t)ncap;
   // gram / hinv change their leading dimension: copy row by row
-  double* g2 = nullptr; double* h2 = nullptr;
+  double* g2 = nullptr; double* h2 = nullptr; double* l2 = nullptr;
   BCX_HIP(dev_alloc(&g2, nc * nc));
   BCX_HIP(dev_alloc(&h2, nc * nc));
+  BCX_HIP(dev_alloc(&l2, nc * nc));
   if (oc) {
     BCX_HIP(hipMemcpy2D(g2, nc * 8, s->gram, oc * 8, oc * 8, oc, hipMemcpyDeviceToDevice));
     BCX_HIP(hipMemcpy2D(h2, nc * 8, s->hinv, oc * 8, oc * 8, oc, hipMemcpyDeviceToDevice));
+    BCX_HIP(hipMemcpy2D(l2, nc * 8, s->hinv_lo, oc * 8, oc * 8, oc, hipMemcpyDeviceToDevice));
     BCX_HIP(hipFree(s->gram));
     BCX_HIP(hipFree(s->hinv));
+    BCX_HIP(hipFree(s->hinv_lo));
   }
-  s->gram = g2; s->hinv = h2;
+  s->gram = g2; s->hinv = h2; s->hinv_lo = l2;
   int rc;
   if ((rc = grow(s, &s->cvec, oc, nc))) return rc;
   if ((rc = grow(s, &s->plist, oc, nc))) return rc;
@@ -350,9 +353,10 @@ int bcx_ensure_gram(bcx_solver* s, int64_t need) {
   if ((rc = grow(s, &s->nn_x, oc, nc))) return rc;
   if ((rc = grow(s, &s->nn_z, 0, nc))) return rc;
   if ((rc = grow(s, &s->nn_wv, 0, nc))) return rc;
-  if ((rc = grow(s, &s->nn_tmp, 0, 4 * nc))) return rc;
+  if ((rc = grow(s, &s->nn_tmp, 0, 8 * nc))) return rc;   // t0..t3 + the exchange ring of grid_lh.h (8 buffers)
   if ((rc = grow(s, &s->nn_flag, 0, nc))) return rc;
   if ((rc = grow(s, &s->nn_wbak, 0, nc))) return rc;
+  if ((rc = grow(s, &s->nn_xr, 0, 2 * nc))) return rc;
   s->gram_cap = ncap;
   return BCX_OK;
 }
@@ -382,8 +386,8 @@ extern "C" int bcx_build_begin(bcx_solver* s, int64_t itrs, double tol, int32_t*
   if ((rc = ensure_slots(s, (int64_t)h.k + itrs))) return rc;
   if (s->cfg.alg == BCX_ALG_OMP) {
     if ((rc = bcx_ensure_gram(s, (int64_t)h.k + itrs))) return rc;
-    if (!s->grid_counter && dev_alloc(&s->grid_counter, 1) != hipSuccess) { s->err = "grid counter allocation failed"; return BCX_ERR_NOMEM; }
-    BCX_HIP(hipMemsetAsync(s->grid_counter, 0, sizeof(unsigned long long), s->stream));
+    if (!s->grid_counter && dev_alloc(&s->grid_counter, 2) != hipSuccess) { s->err = "grid counter allocation failed"; return BCX_ERR_NOMEM; }
+    BCX_HIP(hipMemsetAsync(s->grid_counter, 0, 2 * sizeof(unsigned long long), s->stream));
     s->grid_epoch = 0;
   }
   if ((rc = ensure_trace(s, itrs))) return rc;
@@ -820,6 +824,17 @@ extern "C" int bcx_stats(bcx_solver* s, int64_t* exact_fallbacks, int64_t* candi
   if (exact_fallbacks) *exact_fallbacks = h.n_exact;
   if (candidates) *candidates = h.n_cand;
   if (resolves) *resolves = h.n_resolved;
+  return BCX_OK;
+}
+
+// OMP step diagnostics since construction: out4 = {steps, columns that left the passive set, from-scratch re-solves,
+// columns that entered beyond the selected one}
+extern "C" int bcx_omp_stats(bcx_solver* s, int64_t* out4) {
+  if (!s || !out4) return BCX_ERR_ARG;
+  DevState h;
+  int rc = read_state(s, &h);
+  if (rc != BCX_OK) return rc;
+  for (int i = 0; i < 4; ++i) out4[i] = h.n_omp[i];
   return BCX_OK;
 }
 

@@ -72,6 +72,8 @@ struct DevState {
   int32_t no_monotone; // check_error_monotone=False (snnls.py:9,45,56): no error comparison, no revert, retry flag never cleared
   int32_t np;          // size of the passive set P (OMP / optimize)
   int32_t hvalid;      // hinv == inverse of gram[P,P] and P == {slots with weight > 0}
+  int32_t hlo_valid;   // hinv_lo holds the low words of that inverse (omp_lh.hip keeps it in double-double); 0 after any
+                       // kernel that rewrote hinv in plain doubles
   // multi-kernel OMP step (nnls.hip): decisions handed from kernel to kernel
   int32_t omp_mode;    // OMP_* below
   int32_t omp_slot, omp_fresh, omp_checked, omp_p;
@@ -87,6 +89,7 @@ struct DevState {
   int64_t n_exact;     // diagnostics: iterations that needed the exact fp64 scan (candidate window overflow)
   int64_t n_cand;      // diagnostics: candidate rows re-scored in fp64, summed over iterations
   int64_t n_resolved;  // diagnostics: resolve passes
+  int64_t n_omp[4];    // diagnostics (omp_lh.hip): OMP steps, columns that left, from-scratch re-solves, extra columns entered
   double qscale;       // norm of the query vector (error bound of the fp32 scan scales with it)
   long long dbg_t[32]; // phase time stamps of the last tail (dev builds with -DBCX_TIMING, tools/tail_timing.py)
 };
@@ -137,18 +140,20 @@ struct bcx_solver {
   // OMP / optimize(): Gram system over the slots
   double* gram = nullptr;        // cap x cap
   double* hinv = nullptr;        // cap x cap inverse of the passive block
+  double* hinv_lo = nullptr;     // its low words (double-double inverse of the OMP step, omp_lh.hip)
   double* cvec = nullptr;        // cap : a_j . b
   int32_t* plist = nullptr;      // passive list (slot ids)
   int32_t* ppos = nullptr;       // slot -> position in plist or -1
   double* nn_x = nullptr;        // cap
   double* nn_z = nullptr;        // cap
   double* nn_wv = nullptr;       // cap
-  double* nn_tmp = nullptr;      // 4*cap position scratch
+  double* nn_tmp = nullptr;      // 8*cap: position scratch t0..t3 = the first half of the exchange ring (grid_lh.h)
   int32_t* nn_flag = nullptr;    // cap: bit0 in problem set S, bit1 rejected, bit2 remove
   double* nn_wbak = nullptr;     // cap: weights before the step (revert on monotone failure)
+  double* nn_xr = nullptr;       // 2*cap: row-phase exchange of the OMP step (omp_lh.hip)
   int64_t gram_cap = 0;
   int64_t k_ub = 0;              // host upper bound of the slot count (grid sizing of the multi-kernel OMP step)
-  unsigned long long* grid_counter = nullptr;   // arrival counter of the fused OMP step's grid barriers
+  unsigned long long* grid_counter = nullptr;   // [0] arrival counter of the grid barriers, [1] barrier base of the next OMP step
   uint64_t grid_epoch = 0;       // fused OMP launches since the counter was reset (bcx_build_begin)
   size_t omp_lds_allowed = 0;
   // trace of the current build() call

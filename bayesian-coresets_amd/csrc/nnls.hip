@@ -308,21 +308,6 @@ static __device__ void rebuild_passive(const NnlsArgs& n, int k, double* scratch
 //   general (1 WG)  full active-set solve (rare)
 //   combine (grid)  xw' = sum_P x_j row_j; extra workgroups apply the bordered update of H
 //   finish  (1 WG)  error, monotone check, commit / revert, trace, next query
-static __device__ int omp_pick_record(const ApplyArgs& a, int* overflow) {
-  const int recw = a.d + BCX_REC_HDR;
-  int win = -1, ovf = 0;
-  for (int r = 0; r < a.world; ++r) {
-    const double* rec = a.recs + (size_t)r * recw;
-    if (rec[3] == BCX_REC_OVERFLOW) ovf = 1;
-    if (rec[3] != BCX_REC_VALID) continue;
-    if (win < 0) { win = r; continue; }
-    const double* best = a.recs + (size_t)win * recw;
-    if (rec[0] > best[0] || (rec[0] == best[0] && rec[1] < best[1])) win = r;
-  }
-  *overflow = ovf;
-  return win;
-}
-
 __global__ __launch_bounds__(256) void omp_rows_kernel(NnlsArgs n) {
   const ApplyArgs& a = n.a;
   DevState* st = a.st;
@@ -601,6 +586,7 @@ __global__ __launch_bounds__(BCX_APPLY_THREADS) void omp_finish_kernel(NnlsArgs 
     st->it = it + 1;
     st->exact_mode = 0;
     st->omp_mode = OMP_IDLE;
+    st->hlo_valid = 0;
     if (status != BCX_IT_OK) {
       if (st->retried) { st->limit = 1; st->active = 0; st->halt = HALT_LIMIT; }
       else st->retried = 1;
@@ -629,21 +615,6 @@ __global__ __launch_bounds__(BCX_APPLY_THREADS) void omp_finish_kernel(NnlsArgs 
 #define OMPF_MAX_K 4096      // LDS per position: g / x (8) + u (8) + slot (4) bytes, next to 3 d-vectors
 
 #define OMPF_STAMP(i) do { if (blockIdx.x == 0) BCX_STAMP(st, i); } while (0)
-#ifdef BCX_TIMING
-// dev builds: one record per fused step (tools/omp_hist.py): it, k, p, mode before / after the step phase, status, and
-// the stamps 0..11 of workgroup 0 as offsets from stamp 0
-#define OMP_LOG_MAX 4096
-__device__ long long g_omp_log[OMP_LOG_MAX][24];
-extern "C" int bcx_debug_omp_log(long long* out, int n) {
-  return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_omp_log), (size_t)n * 24 * sizeof(long long)) == hipSuccess ? 0 : -2;
-}
-#endif
-
-// (value desc, global index asc) arg-max over the workgroup; carries the slot of the winner.  idx < 0: no entry.
-struct NegBest { double v; long long idx; int slot; };
-static __device__ __forceinline__ bool negbest_better(double v, long long i, double ov, long long oi) {
-  return oi >= 0 && (i < 0 || ov > v || (ov == v && oi < i));
-}
 
 // data of a newly selected slot: row, Gram row / column (from the rows phase), c = row . b.  One workgroup.
 static __device__ void omp_store_new_slot(const NnlsArgs& n, int slot, int k, const double* xfs, int64_t f, double nf,
@@ -977,6 +948,7 @@ __global__ __launch_bounds__(NN_THREADS) void omp_fused_kernel(NnlsArgs n, GridS
     st->it = it + 1;
     st->exact_mode = 0;
     st->omp_mode = OMP_IDLE;
+    st->hlo_valid = 0;
     if (status != BCX_IT_OK) {
       if (st->retried) { st->limit = 1; st->active = 0; st->halt = HALT_LIMIT; }
       else st->retried = 1;
@@ -984,31 +956,20 @@ __global__ __launch_bounds__(NN_THREADS) void omp_fused_kernel(NnlsArgs n, GridS
   }
   __syncthreads();
   OMPF_STAMP(10);
-#ifdef BCX_TIMING
-  const int64_t log_it = st->it - 1;
-#endif
   if (st->active) prepare_next(a, scratch);
   OMPF_STAMP(11);
-#ifdef BCX_TIMING
-  __syncthreads();
-  if (tid == 0 && log_it >= 0 && log_it < OMP_LOG_MAX) {
-    long long* L = g_omp_log[log_it];
-    L[0] = log_it; L[1] = k; L[2] = p; L[3] = mode0; L[4] = mode; L[5] = status; L[6] = st->np; L[7] = st->omp_ill;
-    for (int i = 0; i < 12; ++i) L[8 + i] = st->dbg_t[i] - st->dbg_t[0];
-    for (int i = 0; i < 4; ++i) { L[20 + i] = st->dbg_t[12 + i]; st->dbg_t[12 + i] = 0; }
-  }
-#endif
 }
 
 void fill_nnls_args(bcx_solver* s, NnlsArgs& n, const double* recs) {
   fill_apply_args(s, n.a, recs);
   n.a.refresh_every = 0;   // OMP recomputes xw from the passive set on every step
-  n.gram = s->gram; n.hinv = s->hinv; n.ldg = s->gram_cap;
+  n.gram = s->gram; n.hinv = s->hinv; n.hlo = s->hinv_lo; n.ldg = s->gram_cap;
   n.cvec = s->cvec; n.plist = s->plist; n.ppos = s->ppos;
   n.x = s->nn_x; n.z = s->nn_z;
   n.t0 = s->nn_tmp; n.t1 = s->nn_tmp + s->gram_cap; n.t2 = s->nn_tmp + 2 * s->gram_cap;
   n.t3 = s->nn_tmp + 3 * s->gram_cap;
   n.flag = s->nn_flag; n.wbak = s->nn_wbak;
+  n.xr = s->nn_xr;
 }
 
 int bcx_launch_apply_omp(bcx_solver* s, const double* recv_dev) {
@@ -1016,8 +977,17 @@ int bcx_launch_apply_omp(bcx_solver* s, const double* recv_dev) {
   fill_nnls_args(s, n, recv_dev);
   s->k_ub += 1;                               // this step may add one slot
   const int64_t kub = s->k_ub;
-  static const bool legacy = getenv("BCX_OMP_MULTI") != nullptr;   // dev: force the multi-kernel form
-  if (!legacy && s->grid_counter && kub < OMPF_MAX_K) {
+  // dev: BCX_OMP_FORM=fused (round 2's kernel: closed form until the first small Schur complement, then one workgroup
+  // solving from scratch) or =multi (one kernel per phase); default: the incremental multi-workgroup step of omp_lh.hip,
+  // multi-kernel form beyond its LDS budget
+  static const char* form = getenv("BCX_OMP_FORM");
+  static const bool legacy = getenv("BCX_OMP_MULTI") != nullptr || (form && form[0] == 'm');
+  const bool old_fused = form && form[0] == 'f';
+  if (!legacy && !old_fused && s->grid_counter) {
+    const int rc = bcx_launch_omp_lh(s, n);
+    if (rc <= 0) return rc;
+  }
+  if (old_fused && s->grid_counter && kub < OMPF_MAX_K) {
     const int kcap = (int)((kub + 1 + 63) / 64 * 64);
     const int dpad = (s->cfg.d + 63) / 64 * 64;
     const size_t lds = (2 * (size_t)kcap + 3 * (size_t)dpad) * sizeof(double) + (size_t)kcap * sizeof(int);
@@ -1159,6 +1129,7 @@ __global__ __launch_bounds__(NN_THREADS) void optimize_kernel(NnlsArgs n, double
     if (tid == 0) { st->limit = 1; st->hvalid = 0; }
   } else if (tid == 0) {
     st->hvalid = 1;
+    st->hlo_valid = 0;
     st->since_refresh = 0;
   }
 }

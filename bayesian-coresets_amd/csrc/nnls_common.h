@@ -13,6 +13,7 @@ struct NnlsArgs {
   ApplyArgs a;
   double* gram;
   double* hinv;
+  double* hlo;     // low words of hinv (double-double), same layout; only omp_lh.hip reads / writes it
   int64_t ldg;
   double* cvec;
   int32_t* plist;
@@ -25,6 +26,7 @@ struct NnlsArgs {
   double* t3;      // per slot: Gram-row candidate
   int32_t* flag;   // per slot
   double* wbak;    // per slot
+  double* xr;      // 2 * ldg doubles: row-phase exchange of the OMP step (row_j . x_f, row_j . residual), by slot
 };
 
 // ---- small workgroup-wide helpers ---------------------------------------------------------------
@@ -109,6 +111,30 @@ static __device__ bool grid_barrier(const GridSync& g, int index, int* s_flag) {
   return *s_flag != 0;
 }
 
+// ---- shared by the OMP step kernels (nnls.hip legacy forms, omp_lh.hip) -------------------------------------------------
+// winner over the shards' records: (score desc, global index asc); -1 if none is valid.  One thread.
+static __device__ int omp_pick_record(const ApplyArgs& a, int* overflow) {
+  const int recw = a.d + BCX_REC_HDR;
+  int win = -1, ovf = 0;
+  for (int r = 0; r < a.world; ++r) {
+    const double* rec = a.recs + (size_t)r * recw;
+    if (rec[3] == BCX_REC_OVERFLOW) ovf = 1;
+    if (rec[3] != BCX_REC_VALID) continue;
+    if (win < 0) { win = r; continue; }
+    const double* best = a.recs + (size_t)win * recw;
+    if (rec[0] > best[0] || (rec[0] == best[0] && rec[1] < best[1])) win = r;
+  }
+  *overflow = ovf;
+  return win;
+}
+
+// (value desc, global index asc) arg-max over the workgroup; carries the slot of the winner.  idx < 0: no entry.
+struct NegBest { double v; long long idx; int slot; };
+static __device__ __forceinline__ bool negbest_better(double v, long long i, double ov, long long oi) {
+  return oi >= 0 && (i < 0 || ov > v || (ov == v && oi < i));
+}
+
 
 void fill_nnls_args(bcx_solver* s, NnlsArgs& n, const double* recs);   // nnls.hip
+int bcx_launch_omp_lh(bcx_solver* s, NnlsArgs& n);                      // omp_lh.hip; 1 = not applicable (LDS budget)
 int bcx_launch_optimize_grid(bcx_solver* s, double tol, int k);         // nnls_grid.hip

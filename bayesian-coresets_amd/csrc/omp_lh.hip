@@ -1,0 +1,691 @@
+// omp_lh.hip -- the OMP re-weight step  w[f] = 1; w[active] = nnls(A[:, active], b)  (orthopursuit.py:37-42) as ONE launch
+// of 16 co-resident workgroups that keeps the Lawson-Hanson iteration incremental from end to end.
+//
+// The active set of the call is S = P u {f}: P = the columns that carry weight (the previous step's optimum: their duals
+// are zero) and the newly selected column f.  So Lawson-Hanson's first pick is f, and every later change of the passive
+// set is a single column entering or leaving.  Both have closed forms on the inverse H of the passive Gram block:
+//   enter f :  u = H g, s = G_ff - g.u, t = (c_f - g.x) / s,   z = [x - t u ; t],   H <- bordered inverse
+//   leave q :  h = H[:, q],                                    z <- z - (z_q / h_qq) h,   H <- rank-1 downdate
+// so no step solves from scratch: the least-squares solution z of the current passive set is carried along with H, and
+// the error of a closed-form update is proportional to the CHANGE it makes.
+//
+// What that needs is an H that does not drift.  In plain doubles it does: a nearly dependent column enters with a Schur
+// complement s ~ 1e-10 G_ff, the entries of H grow to 1/s, and when the column leaves again the downdate cancels them to
+// eps / s absolute -- on the Laplace-projected vectors of configs[2] (numerical rank ~100) H was good to four digits after
+// a hundred steps, and a NumPy model of this step (tools/omp_lh_proto.py) against the CPU oracle needed 2-5 refinement
+// iterations after EVERY change to keep the selections (round 2's kernel: four per solve, in one workgroup: 67-218 us per
+// step from the first small Schur complement on, against 26 us for the closed form).  H is therefore kept in
+// DOUBLE-DOUBLE (hinv + hinv_lo, ~32 digits): the mat-vec u = H g, the Schur complement, the bordered update and the
+// downdate run on (hi, lo) pairs (error-free products by FMA, ~20-40 flops per element of a p x p matrix: nothing beside
+// the memory latency that bounds this kernel), everything else -- weights, Gram entries, duals -- stays double.  H is then
+// the exact inverse of the stored Gram block to working precision, the closed forms reproduce what the reference's
+// solver computes from scratch (scipy.optimize.nnls solves the same normal equations G[P,P] z = c[P]) and no refinement
+// pass exists: the model matched the oracle's 250 selections and its error to 8e-13 on every data set tried, where the
+// best plain-double policy reached 7e-11 at 2.5 refinement iterations per change.
+// A drift monitor costs nothing: the rows phase forms row_j . r for every passive row anyway (OMP's negative-direction
+// select, orthopursuit.py:27-30), which is the gradient of the carried solution; dz = H_hi (V_P r) rides along in the pass
+// that forms u = H g.  It stays at the Gram-vs-data discrepancy (<= 1e-7 of the weights on configs[2]); above 1e-4 -- or
+// after a reverted step / a rejected optimize() -- the step first re-solves on P from scratch with the data-space
+// refinement of optimize() (g_passive_solve).
+//
+// Cost: the usual step (f enters, every weight stays positive) is 3 grid barriers; every column that leaves adds 1-2
+// (publish its row of H, move the last position into the hole).
+//
+// Replicated control: every workgroup holds the O(k) state in LDS (passive list, weights, z, feasible point) and takes the
+// same decisions from the same data in the same order, so all workgroups -- and all shards of a row-sharded run -- stay
+// bit-identical; H is owner-computes by rows and everything that crosses workgroups is an exchange vector (grid_lh.h).
+// The number of barriers of a launch depends on the data, so the barrier base lives in device memory: workgroup 0 advances
+// it at the end of the launch by what the launch used.
+#include <stdlib.h>
+#include "grid_lh.h"
+
+#define OMPL_WGS 16
+#define OMPL_LDS_MAX (150 * 1024)
+#ifdef BCX_TIMING
+// dev builds: one record per step (tools/omp_hist.py)
+__device__ long long g_omp_log[4096][24];
+extern "C" int bcx_debug_omp_log(long long* out, int n) {
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_omp_log), (size_t)n * 24 * sizeof(long long)) == hipSuccess ? 0 : -2;
+}
+#endif
+
+// ---- double-double arithmetic (error-free transformations; explicit _rn intrinsics: no contraction across them) ----------
+struct dd { double h, l; };
+static __device__ __forceinline__ dd dd_make(double h, double l) { dd r; r.h = h; r.l = l; return r; }
+static __device__ __forceinline__ dd two_sum(double a, double b) {
+  const double s = __dadd_rn(a, b), bb = __dsub_rn(s, a);
+  return dd_make(s, __dadd_rn(__dsub_rn(a, __dsub_rn(s, bb)), __dsub_rn(b, bb)));
+}
+static __device__ __forceinline__ dd quick_two_sum(double a, double b) {   // |a| >= |b|
+  const double s = __dadd_rn(a, b);
+  return dd_make(s, __dsub_rn(b, __dsub_rn(s, a)));
+}
+static __device__ __forceinline__ dd two_prod(double a, double b) {
+  const double p = __dmul_rn(a, b);
+  return dd_make(p, __fma_rn(a, b, -p));
+}
+static __device__ __forceinline__ dd dd_add(dd a, dd b) {
+  dd s = two_sum(a.h, b.h);
+  const dd t = two_sum(a.l, b.l);
+  s.l = __dadd_rn(s.l, t.h);
+  s = quick_two_sum(s.h, s.l);
+  s.l = __dadd_rn(s.l, t.l);
+  return quick_two_sum(s.h, s.l);
+}
+static __device__ __forceinline__ dd dd_neg(dd a) { return dd_make(-a.h, -a.l); }
+static __device__ __forceinline__ dd dd_mul_d(dd a, double b) {
+  dd p = two_prod(a.h, b);
+  p.l = __fma_rn(a.l, b, p.l);
+  return quick_two_sum(p.h, p.l);
+}
+static __device__ __forceinline__ dd dd_mul(dd a, dd b) {
+  dd p = two_prod(a.h, b.h);
+  p.l = __dadd_rn(p.l, __fma_rn(a.h, b.l, __dmul_rn(a.l, b.h)));
+  return quick_two_sum(p.h, p.l);
+}
+static __device__ __forceinline__ dd dd_recip(dd a) {      // one Newton step on the double reciprocal: ~31 digits
+  const double x = 1.0 / a.h;
+  const dd r = dd_add(dd_make(1.0, 0.0), dd_neg(dd_mul_d(a, x)));
+  return dd_add(dd_make(x, 0.0), dd_mul_d(r, x));
+}
+// butterfly all-reduce of a double-double over the wave (fixed association order; every lane ends with the total)
+static __device__ __forceinline__ dd dd_wave_allsum(dd v) {
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const dd o = dd_make(__shfl_xor(v.h, off, BCX_WAVE), __shfl_xor(v.l, off, BCX_WAVE));
+    v = dd_add(v, o);
+  }
+  return v;
+}
+
+struct OmpLds {
+  double *g, *gl, *u, *ul, *x, *z, *xs;   // g / u (hi, lo) / z / xs by position, x by slot
+  double *xfs, *qs, *bs;                  // winner's row, residual query (later: refinement scratch), b
+  int *cs, *pos, *fl;                     // position -> slot, slot -> position (-1), flags by slot
+};
+
+// (u, mon)[rr] = (H[rr] . v in double-double, H_hi[rr] . m in double) for the rows this wave owns; m may be null
+static __device__ void ompl_mv_rows(const NnlsArgs& n, int p, const double* v, const double* m, double* Uh, double* Ul, double* M) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  for (int rr = blockIdx.x * nw + wave; rr < p; rr += gridDim.x * nw) {
+    const double* hh = n.hinv + (size_t)rr * n.ldg;
+    const double* hl = n.hlo + (size_t)rr * n.ldg;
+    dd acc = dd_make(0.0, 0.0);
+    double mon = 0.0;
+    for (int c0 = 0; c0 < p; c0 += 256) {
+      double a[4], b[4];
+#pragma unroll
+      for (int t = 0; t < 4; ++t) { const int c = c0 + t * 64 + lane; a[t] = c < p ? hh[c] : 0.0; b[t] = c < p ? hl[c] : 0.0; }
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const int c = c0 + t * 64 + lane;
+        if (c < p) {
+          acc = dd_add(acc, dd_mul_d(dd_make(a[t], b[t]), v[c]));
+          if (m) mon += a[t] * m[c];
+        }
+      }
+    }
+    acc = dd_wave_allsum(acc);
+    if (m) mon = wave_allsum(mon);
+    if (lane == 0) { xst(&Uh[rr], acc.h); xst(&Ul[rr], acc.l); if (m) xst(&M[rr], mon); }
+  }
+}
+
+// H <- [[H + u u^T / s, -u/s], [-u^T/s, 1/s]] for the column entering at position p (inv = 1/s): every wave updates the rows
+// it owns, in double-double
+static __device__ void ompl_border_apply(const NnlsArgs& n, const OmpLds& L, int p, dd inv) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  const int64_t ld = n.ldg;
+  for (int rr = blockIdx.x * nw + wave; rr < p; rr += gridDim.x * nw) {
+    const dd wr = dd_mul(dd_make(L.u[rr], L.ul[rr]), inv);
+    double* hh = n.hinv + (size_t)rr * ld;
+    double* hl = n.hlo + (size_t)rr * ld;
+    for (int cc = lane; cc < p; cc += 64) {
+      const dd v = dd_add(dd_make(hh[cc], hl[cc]), dd_mul(wr, dd_make(L.u[cc], L.ul[cc])));
+      hh[cc] = v.h; hl[cc] = v.l;
+    }
+    if (lane == 0) { hh[p] = -wr.h; hl[p] = -wr.l; }
+  }
+  if (owns_row(p)) {
+    double* hh = n.hinv + (size_t)p * ld;
+    double* hl = n.hlo + (size_t)p * ld;
+    for (int cc = lane; cc < p; cc += 64) {
+      const dd w = dd_mul(dd_make(L.u[cc], L.ul[cc]), inv);
+      hh[cc] = -w.h; hl[cc] = -w.l;
+    }
+    if (lane == 0) { hh[p] = inv.h; hl[p] = inv.l; }
+  }
+}
+
+// Position q leaves the passive set: closed-form update of the carried solution z, rank-1 downdate of H (double-double),
+// the last position moves into the hole (z, the feasible point xs and the lists move with it).  1-2 barriers.
+static __device__ void ompl_remove(const NnlsArgs& n, const OmpLds& L, int& p, int q, Grid& G) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = blockDim.x >> 6;
+  const int64_t ld = n.ldg;
+  const int last = p - 1;
+  double* Xh = xbuf(n, G);
+  double* Xl = xbuf(n, G);
+  if (owns_row(q)) {                                // row q == column q (symmetric): its owner publishes it
+    const double* hh = n.hinv + (size_t)q * ld;
+    const double* hl = n.hlo + (size_t)q * ld;
+    for (int cc = lane; cc < p; cc += 64) { xst(&Xh[cc], hh[cc]); xst(&Xl[cc], hl[cc]); }
+  }
+  gsync(G);
+  for (int a = tid; a < p; a += blockDim.x) { L.g[a] = xld(&Xh[a]); L.gl[a] = xld(&Xl[a]); }   // h = H[:, q] (g is free by now)
+  __syncthreads();
+  const dd hqq = dd_make(L.g[q], L.gl[q]);
+  const dd iq = dd_recip(hqq);
+  const double f = L.z[q] / hqq.h;
+  for (int a = tid; a < p; a += blockDim.x) L.z[a] -= f * L.g[a];    // least-squares solution on P \ {q}
+  for (int rr = blockIdx.x * nw + wave; rr < p; rr += gridDim.x * nw) {
+    const dd fr = dd_mul(dd_make(L.g[rr], L.gl[rr]), iq);
+    double* hh = n.hinv + (size_t)rr * ld;
+    double* hl = n.hlo + (size_t)rr * ld;
+    for (int cc = lane; cc < p; cc += 64) {
+      const dd v = dd_add(dd_make(hh[cc], hl[cc]), dd_neg(dd_mul(fr, dd_make(L.g[cc], L.gl[cc]))));
+      hh[cc] = v.h; hl[cc] = v.l;
+    }
+  }
+  const int gone = L.cs[q];
+  if (q != last) {
+    double* Yh = xbuf(n, G);
+    double* Yl = xbuf(n, G);
+    if (owns_row(last)) {                           // (the same wave just finished the downdate of this row)
+      const double* hh = n.hinv + (size_t)last * ld;
+      const double* hl = n.hlo + (size_t)last * ld;
+      for (int cc = lane; cc < p; cc += 64) { xst(&Yh[cc], hh[cc]); xst(&Yl[cc], hl[cc]); }
+    }
+    gsync(G);
+    for (int a = tid; a < p; a += blockDim.x) { L.u[a] = xld(&Yh[a]); L.ul[a] = xld(&Yl[a]); }
+    __syncthreads();
+    for (int rr = blockIdx.x * nw + wave; rr < last; rr += gridDim.x * nw)   // column q of the rows this wave owns
+      if (rr != q && lane == 0) { n.hinv[(size_t)rr * ld + q] = L.u[rr]; n.hlo[(size_t)rr * ld + q] = L.ul[rr]; }
+    if (owns_row(q)) {
+      double* hh = n.hinv + (size_t)q * ld;
+      double* hl = n.hlo + (size_t)q * ld;
+      for (int cc = lane; cc < last; cc += 64) if (cc != q) { hh[cc] = L.u[cc]; hl[cc] = L.ul[cc]; }
+      if (lane == 0) { hh[q] = L.u[last]; hl[q] = L.ul[last]; }
+    }
+    __syncthreads();
+    if (tid == 0) {
+      const int moved = L.cs[last];
+      L.cs[q] = moved; L.pos[moved] = q;
+      L.z[q] = L.z[last]; L.xs[q] = L.xs[last];
+    }
+  }
+  __syncthreads();
+  if (tid == 0) { L.pos[gone] = -1; L.x[gone] = 0.0; }
+  p = last;
+  __syncthreads();
+}
+
+// Lawson-Hanson inner loop on the carried data: z = least-squares solution on the passive set, xs = a feasible point.
+// Columns leave until z > 0; then x <- z.  `entered`: the slot that just entered (left again at once => never re-picked).
+// n_out: members of the call's active set that are outside P and may still be picked (kept by every workgroup alike).
+static __device__ int ompl_inner(const NnlsArgs& n, const OmpLds& L, int& p, int entered, int max_it, int& n_out, Grid& G,
+                                 double* scratch) {
+  const int tid = threadIdx.x;
+  int removed = 0;
+  for (int inner = 0; inner < max_it && G.ok && p > 0; ++inner) {
+    double amin = INFINITY; int apos = -1;
+    for (int a = tid; a < p; a += blockDim.x) {
+      const double za = L.z[a];
+      if (!(za > 0.0)) {
+        const double xa = L.xs[a];
+        double al = xa / (xa - za);
+        if (!(al == al)) al = 0.0;                 // 0/0: a zero weight asked to go further down
+        if (apos < 0 || al < amin) { amin = al; apos = a; }
+      }
+    }
+    const ArgBest worst = block_argbest(-amin, apos, scratch);   // smallest alpha, lowest position
+    if (worst.i < 0) break;
+    const double alpha = -worst.v;
+    for (int a = tid; a < p; a += blockDim.x) {
+      const double xa = L.xs[a];
+      const double xn = xa + alpha * (L.z[a] - xa);
+      const bool rm = (a == worst.i) || !(xn > 0.0);
+      L.xs[a] = rm ? 0.0 : xn;
+      if (rm) L.fl[L.cs[a]] |= FLAG_RM;
+    }
+    __syncthreads();
+    for (;;) {                                     // highest position first: the one moved into a hole was already checked
+      int cand = -1;
+      for (int a = tid; a < p; a += blockDim.x)
+        if (L.fl[L.cs[a]] & FLAG_RM) cand = a > cand ? a : cand;
+      const ArgBest top = block_argbest((double)cand, cand, scratch);
+      if (top.i < 0) break;
+      const int slot = L.cs[top.i];
+      const bool rej = slot == entered && inner == 0;              // LH safeguard: do not re-pick at once
+      if (tid == 0) {
+        L.fl[slot] &= ~FLAG_RM;
+        if (rej) L.fl[slot] |= FLAG_REJ;
+      }
+      if (!rej) ++n_out;
+      __syncthreads();
+      ompl_remove(n, L, p, top.i, G);
+      ++removed;
+      if (!G.ok) break;
+    }
+  }
+  for (int a = tid; a < p; a += blockDim.x) L.x[L.cs[a]] = L.z[a];
+  __syncthreads();
+  return removed;
+}
+
+__global__ __launch_bounds__(NN_THREADS) void omp_lh_kernel(NnlsArgs n, GridSync gs, unsigned long long* base_ptr, int kcap, int dpad,
+                                                            int force_resolve) {
+  const ApplyArgs& a = n.a;
+  DevState* st = a.st;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = blockDim.x >> 6, d = a.d;
+  const int wg = blockIdx.x, nwg = gridDim.x;
+  if (!st->active) return;
+  extern __shared__ double dyn[];
+  OmpLds L;
+  L.g = dyn; L.gl = dyn + kcap; L.u = dyn + 2 * (size_t)kcap; L.ul = dyn + 3 * (size_t)kcap;
+  L.x = dyn + 4 * (size_t)kcap; L.z = dyn + 5 * (size_t)kcap; L.xs = dyn + 6 * (size_t)kcap;
+  L.xfs = dyn + 7 * (size_t)kcap; L.qs = L.xfs + dpad; L.bs = L.qs + dpad;
+  L.cs = (int*)(L.bs + dpad); L.pos = L.cs + kcap; L.fl = L.pos + kcap;
+  __shared__ double scratch[BCX_SCRATCH];
+  __shared__ double seg[NN_THREADS / 64][64];
+  __shared__ double w_v[NN_THREADS / 64];
+  __shared__ long long w_i[NN_THREADS / 64];
+  __shared__ int w_s[NN_THREADS / 64], w_np[NN_THREADS / 64], w_m[NN_THREADS / 64];
+  __shared__ int s_win, s_ovf, s_flag;
+  BCX_STAMP(st, 0);
+  if (tid == 0) { int o; s_win = omp_pick_record(a, &o); s_ovf = o; }
+  __syncthreads();
+  if (s_ovf || s_win < 0) {
+    if (wg == 0 && tid == 0) { st->active = 0; st->halt = s_ovf ? HALT_NEED_EXACT : HALT_DONE; }
+    return;
+  }
+  Grid G;
+  G.gs = gs; G.gs.base = *base_ptr; G.bi = 0; G.xi = 0; G.s_flag = &s_flag; G.ok = true;
+  const double* rec = a.recs + (size_t)s_win * (d + BCX_REC_HDR);
+  const double* xf = rec + BCX_REC_HDR;
+  const int k = st->k;
+  int p = st->np;
+  const double err0 = st->err, bnorm0 = st->bnorm;
+  const int hvalid0 = st->hvalid, hlo0 = st->hlo_valid;
+  for (int i = tid; i < d; i += blockDim.x) { L.xfs[i] = xf[i]; L.qs[i] = a.q64[i]; L.bs[i] = a.b[i]; }
+  for (int q = tid; q < p; q += blockDim.x) L.cs[q] = n.plist[q];
+  for (int j = tid; j <= k; j += blockDim.x) {
+    const int pj = (j < k && hvalid0) ? n.ppos[j] : -1;
+    L.pos[j] = pj;
+    L.x[j] = pj >= 0 ? n.x[j] : 0.0;
+    L.fl[j] = 0;
+  }
+  __syncthreads();
+  BCX_STAMP(st, 12);
+  Rep R;
+  R.t0 = L.g; R.t1 = L.u; R.x = L.x; R.z = L.z; R.rv = L.qs; R.cs = L.cs; R.pos = L.pos; R.fl = L.fl;
+  bool resolve = force_resolve != 0;
+  // ---- rows phase: row_j . x_f and row_j . r for every slot; one wave per row, all loads of a 512-element stretch in
+  // flight together ----------------------------------------------------------------------------------------------------
+  double* T3 = n.xr;                 // row_j . x_f  (the Gram row of a new slot)
+  double* T2 = n.xr + n.ldg;         // row_j . r    (select of the negative direction; gradient of the carried solution)
+  for (int j = wg * nw + wave; j < k; j += nwg * nw) {
+    const double* row = a.act_rows + (size_t)j * d;
+    double a0 = 0.0, a1 = 0.0;
+    for (int i0 = 0; i0 < d; i0 += 512) {
+      double rv[8];
+#pragma unroll
+      for (int t = 0; t < 8; ++t) { const int i = i0 + t * 64 + lane; rv[t] = i < d ? row[i] : 0.0; }
+#pragma unroll
+      for (int t = 0; t < 8; ++t) { const int i = i0 + t * 64 + lane; if (i < d) { a0 += rv[t] * L.xfs[i]; a1 += rv[t] * L.qs[i]; } }
+    }
+    a0 = wave_allsum(a0);
+    a1 = wave_allsum(a1);
+    if (lane == 0) { xst(&T3[j], a0); xst(&T2[j], a1); }
+  }
+  BCX_STAMP(st, 13);
+  // a stale passive set (a reverted step, a rejected optimize()): P = {slots with weight > 0}, H by successive bordering
+  if (!hvalid0) {
+    p = 0;
+    for (int j = tid; j < k; j += blockDim.x) L.x[j] = a.act_w[j] > 0.0 ? a.act_w[j] : 0.0;
+    __syncthreads();
+    int ill = 0;
+    for (int j = 0; j < k && G.ok; ++j) {
+      if (!(L.x[j] > 0.0)) continue;
+      if (!g_border_add(n, R, p, ill, j, G, scratch)) { __syncthreads(); if (tid == 0) L.x[j] = 0.0; __syncthreads(); }
+    }
+    resolve = true;
+  }
+  if (!hvalid0 || !hlo0) {
+    // H was (re)written in plain doubles (the rebuild above, optimize(), the multi-kernel form): its low words are zero
+    for (int rr = wg * nw + wave; rr < p; rr += nwg * nw)
+      for (int cc = lane; cc < p; cc += 64) n.hlo[(size_t)rr * n.ldg + cc] = 0.0;
+  }
+  BCX_STAMP(st, 1);
+  gsync(G);                                                                                   // ---- B1
+  BCX_STAMP(st, 2);
+  // ---- decide (every workgroup, one pass over the slots) -----------------------------------------------------------------
+  const int64_t fpos = (int64_t)rec[1];
+  const double nf = rec[2];
+  int npos = 0, match = 0x7fffffff;
+  double bv = -INFINITY; long long bidx = -1; int bslot = -1;
+  for (int j = tid; j < k; j += blockDim.x) {
+    const long long gj = a.act_idx[j];
+    if (gj == fpos && j < match) match = j;
+    if (L.x[j] > 0.0) {
+      ++npos;
+      const double vv = -(xld(&T2[j]) / a.act_norm[j]);
+      if (negbest_better(bv, bidx, vv, gj)) { bv = vv; bidx = gj; bslot = j; }
+    }
+  }
+  double g2[2] = {0.0, 0.0};                                   // xf . xf, xf . b
+  for (int i = tid; i < d; i += blockDim.x) { g2[0] += L.xfs[i] * L.xfs[i]; g2[1] += L.xfs[i] * L.bs[i]; }
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) {
+    const double ov = __shfl_xor(bv, off, BCX_WAVE);
+    const long long oi = __shfl_xor(bidx, off, BCX_WAVE);
+    const int os = __shfl_xor(bslot, off, BCX_WAVE);
+    if (negbest_better(bv, bidx, ov, oi)) { bv = ov; bidx = oi; bslot = os; }
+    npos += __shfl_xor(npos, off, BCX_WAVE);
+    match = min(match, __shfl_xor(match, off, BCX_WAVE));
+  }
+  g2[0] = wave_allsum(g2[0]);
+  g2[1] = wave_allsum(g2[1]);
+  if (lane == 0) { w_v[wave] = bv; w_i[wave] = bidx; w_s[wave] = bslot; w_np[wave] = npos; w_m[wave] = match; seg[0][wave] = g2[0]; seg[1][wave] = g2[1]; }
+  __syncthreads();
+  bv = w_v[0]; bidx = w_i[0]; bslot = w_s[0]; npos = w_np[0]; match = w_m[0];
+  double xfxf = seg[0][0], xfb = seg[1][0];
+  for (int w = 1; w < nw; ++w) {
+    if (negbest_better(bv, bidx, w_v[w], w_i[w])) { bv = w_v[w]; bidx = w_i[w]; bslot = w_s[w]; }
+    npos += w_np[w];
+    match = min(match, w_m[w]);
+    xfxf += seg[0][w]; xfb += seg[1][w];
+  }
+  __syncthreads();
+  const bool checked = npos > 0;
+  int64_t f = fpos;
+  int slot = match == 0x7fffffff ? -1 : match;
+  if (checked && !(rec[0] >= bv)) { f = bidx; slot = bslot; }   // orthopursuit.py:32-35
+  const bool fresh = slot < 0;
+  if (fresh) slot = k;
+  const int k1 = fresh ? k + 1 : k;
+  const double gff = fresh ? xfxf : n.gram[(size_t)slot * n.ldg + slot];
+  const double cf = fresh ? xfb : n.cvec[slot];
+  const double nslot = fresh ? nf : a.act_norm[slot];
+  const bool done = !fresh && L.pos[slot] >= 0;               // f already carries weight: the NNLS problem is unchanged
+  const double eps = 2.220446049250313e-16;
+  const double tolscale = 10.0 * eps * (double)(d > k1 ? d : k1) * bnorm0;
+  // a new slot's data: row, Gram row / column (from the rows phase), c = row . b -- one workgroup, for later launches
+  // (inside this launch the new Gram entries are read from T3)
+  if (fresh && wg == nwg - 1) {
+    for (int i = tid; i < d; i += blockDim.x) a.act_rows[(size_t)slot * d + i] = L.xfs[i];
+    for (int j = tid; j < k; j += blockDim.x) {
+      const double gv = xld(&T3[j]);
+      n.gram[(size_t)slot * n.ldg + j] = gv;
+      n.gram[(size_t)j * n.ldg + slot] = gv;
+    }
+    if (tid == 0) {
+      a.act_idx[slot] = f; a.act_norm[slot] = nf;       // (weight, position: workgroup 0 at the commit)
+      n.gram[(size_t)slot * n.ldg + slot] = gff;
+      n.cvec[slot] = cf;
+    }
+  }
+  BCX_STAMP(st, 3);
+  int n_removed = 0, n_entered = 0, did_resolve = 0;
+  if (!done) {
+    // members of the call's active set S = P u {f}
+    for (int q = tid; q < p; q += blockDim.x) L.fl[L.cs[q]] = FLAG_INS;
+    if (tid == 0) L.fl[slot] |= FLAG_INS;
+    // ---- u = H g (double-double) and the drift monitor dz = H_hi (V_P r) in one pass over the rows this wave owns ---------
+    for (int q = tid; q < p; q += blockDim.x) {
+      L.g[q] = fresh ? xld(&T3[L.cs[q]]) : n.gram[(size_t)slot * n.ldg + L.cs[q]];
+      L.xs[q] = xld(&T2[L.cs[q]]);                       // gradient of the carried solution (xs is free until the step)
+    }
+    __syncthreads();
+    double* Uh = xbuf(n, G);
+    double* Ul = xbuf(n, G);
+    double* DZ = xbuf(n, G);
+    ompl_mv_rows(n, p, L.g, L.xs, Uh, Ul, DZ);
+    BCX_STAMP(st, 4);
+    gsync(G);                                                                                 // ---- B2
+    BCX_STAMP(st, 5);
+    // ---- the carried solution: z = x on P, feasible point xs = x; drift check ---------------------------------------------
+    double cm = 0.0, xm = 0.0;
+    for (int q = tid; q < p; q += blockDim.x) {
+      const double dq = xld(&DZ[q]), xq = L.x[L.cs[q]];
+      L.u[q] = xld(&Uh[q]); L.ul[q] = xld(&Ul[q]);
+      L.xs[q] = xq;
+      L.z[q] = xq;
+      cm = fmax(cm, fabs(dq)); xm = fmax(xm, fabs(xq));
+    }
+    cm = block_allmax(cm, scratch);
+    xm = block_allmax(xm, scratch);
+    if (!(cm <= 1e-4 * xm) && p > 0) resolve = true;      // H no longer a good inverse of G_PP (NaN fails the '<=' too)
+    BCX_STAMP(st, 14);
+    int cand = slot, n_out = 1;
+    bool have_u = true;
+    if (resolve && p > 0) {
+      // from scratch on P: z = H c_P refined in data space until the gradient is at rounding level (as optimize() does),
+      // columns leave if that asks for it; then f enters from the re-solved state
+      did_resolve = 1;
+      g_passive_solve(n, R, p, 1, G, seg, scratch);       // (uses g / u / qs as scratch; H's high words)
+      n_removed += ompl_inner(n, L, p, -1, 3 * k1 + 16, n_out, G, scratch);
+      for (int q = tid; q < p; q += blockDim.x) { L.xs[q] = L.x[L.cs[q]]; L.z[q] = L.xs[q]; }
+      __syncthreads();
+      have_u = false;
+    }
+    // ---- Lawson-Hanson outer loop: one column enters per pass (the first one is f) --------------------------------------
+    for (int outer = 0; outer < 3 * k1 + 16 && G.ok && cand >= 0; ++outer) {
+      const bool cfresh = fresh && cand == slot;
+      if (!have_u) {
+        for (int q = tid; q < p; q += blockDim.x) {
+          const int c = L.cs[q];
+          L.g[q] = cfresh ? xld(&T3[c]) : ((fresh && c == slot) ? xld(&T3[cand]) : n.gram[(size_t)cand * n.ldg + c]);
+        }
+        __syncthreads();
+        double* U2h = xbuf(n, G);
+        double* U2l = xbuf(n, G);
+        ompl_mv_rows(n, p, L.g, nullptr, U2h, U2l, nullptr);
+        gsync(G);
+        for (int q = tid; q < p; q += blockDim.x) { L.u[q] = xld(&U2h[q]); L.ul[q] = xld(&U2l[q]); }
+        __syncthreads();
+      }
+      have_u = false;
+      // Schur complement s = G_cc - g.u in double-double (g.u agrees with G_cc to all but the last digits when the column
+      // is nearly dependent), dual w = c_c - g.z in double as the reference forms it
+      dd gu = dd_make(0.0, 0.0);
+      double r1[1] = {0.0};
+      for (int q = tid; q < p; q += blockDim.x) {
+        gu = dd_add(gu, dd_mul_d(dd_make(L.u[q], L.ul[q]), L.g[q]));
+        r1[0] += L.g[q] * L.z[q];
+      }
+      gu = dd_wave_allsum(gu);
+      if (lane == 0) { seg[0][wave] = gu.h; seg[1][wave] = gu.l; }
+      block_allsum<1>(r1, scratch);                       // (its barriers also publish seg)
+      gu = dd_make(seg[0][0], seg[1][0]);
+      for (int w = 1; w < nw; ++w) gu = dd_add(gu, dd_make(seg[0][w], seg[1][w]));
+      __syncthreads();
+      const double gcc = cand == slot ? gff : n.gram[(size_t)cand * n.ldg + cand];
+      const double ccand = cand == slot ? cf : n.cvec[cand];
+      const double ncand = cand == slot ? nslot : a.act_norm[cand];
+      const dd sc = dd_add(dd_make(gcc, 0.0), dd_neg(gu));
+      const double wv = ccand - r1[0];
+      if (outer == 0) BCX_STAMP(st, 15);
+      bool entered = false;
+      if (!(wv > tolscale * ncand)) {
+        // dual not positive: the column stays at weight 0 (and no other candidate can have a larger dual: it was the arg-max)
+        cand = -1;
+      } else if (!(sc.h > 1e-12 * gcc)) {
+        if (tid == 0) L.fl[cand] |= FLAG_REJ;             // numerically dependent on P
+        --n_out;
+        __syncthreads();
+      } else {
+        const double t = wv / sc.h;
+        const dd inv = dd_recip(sc);
+        for (int q = tid; q < p; q += blockDim.x) L.z[q] -= t * L.u[q];
+        ompl_border_apply(n, L, p, inv);
+        if (tid == 0) { L.z[p] = t; L.xs[p] = 0.0; L.cs[p] = cand; L.pos[cand] = p; }
+        p += 1;
+        ++n_entered;
+        --n_out;
+        entered = true;
+        __syncthreads();
+      }
+      if (outer == 0) BCX_STAMP(st, 16);
+      if (cand < 0) break;                                // nothing entered, nothing can leave: x stays as it is, bit for bit
+      n_removed += ompl_inner(n, L, p, entered ? cand : -1, 3 * k1 + 16, n_out, G, scratch);
+      for (int q = tid; q < p; q += blockDim.x) { L.xs[q] = L.x[L.cs[q]]; L.z[q] = L.xs[q]; }
+      __syncthreads();
+      if (outer == 0) BCX_STAMP(st, 17);
+      // next candidate: the member of S without weight that has the largest positive dual (only columns that left in this
+      // call can qualify); duals c_j - G[j, P] x are formed by every workgroup, one wave per candidate
+      cand = -1;
+      if (n_out <= 0) break;
+      for (int j = wave; j < k1; j += nw) {
+        const int fl = L.fl[j];
+        if (!(fl & FLAG_INS) || (fl & FLAG_REJ) || L.pos[j] >= 0) continue;
+        const bool jf = fresh && j == slot;
+        double acc = 0.0;
+        for (int q = lane; q < p; q += 64) {
+          const int c = L.cs[q];
+          const double gv = jf ? xld(&T3[c]) : ((fresh && c == slot) ? xld(&T3[j]) : n.gram[(size_t)j * n.ldg + c]);
+          acc += gv * L.x[c];
+        }
+        acc = wave_allsum(acc);
+        if (lane == 0) L.g[j] = (j == slot ? cf : n.cvec[j]) - acc;      // (g by SLOT here; refilled by position above)
+      }
+      __syncthreads();
+      double dbv = -INFINITY; int dbi = -1;
+      for (int j = tid; j < k1; j += blockDim.x) {
+        const int fl = L.fl[j];
+        if (!(fl & FLAG_INS) || (fl & FLAG_REJ) || L.pos[j] >= 0) continue;
+        const double wvj = L.g[j];
+        const double nj = j == slot ? nslot : a.act_norm[j];
+        if (wvj > tolscale * nj && (dbi < 0 || wvj > dbv)) { dbv = wvj; dbi = j; }
+      }
+      const ArgBest pick = block_argbest(dbv, dbi, scratch);
+      cand = pick.i;
+    }
+  }
+  BCX_STAMP(st, 6);
+  // ---- xw' = sum_P x_j row_j on 64-column blocks ------------------------------------------------------------------------
+  for (int q = tid; q < p; q += blockDim.x) L.z[q] = L.x[L.cs[q]];
+  __syncthreads();
+  const int pf = (fresh && L.pos[slot] >= 0) ? L.pos[slot] : -1;      // the new slot's row is in LDS, not in act_rows yet
+  for (int cb = wg; cb * 64 < d; cb += nwg) {
+    const int col = cb * 64 + lane;
+    double acc = 0.0;
+    if (col < d) {
+      int q = wave;
+      for (; q + 7 * nw < p; q += 8 * nw) {
+        double m[8];
+#pragma unroll
+        for (int t = 0; t < 8; ++t) { const int qq = q + t * nw; m[t] = qq == pf ? L.xfs[col] : a.act_rows[(size_t)L.cs[qq] * d + col]; }
+#pragma unroll
+        for (int t = 0; t < 8; ++t) acc += L.z[q + t * nw] * m[t];
+      }
+      for (; q < p; q += nw) acc += L.z[q] * (q == pf ? L.xfs[col] : a.act_rows[(size_t)L.cs[q] * d + col]);
+    }
+    seg[wave][lane] = acc;
+    __syncthreads();
+    if (wave == 0 && col < d) {
+      double t = seg[0][lane];
+      for (int w = 1; w < nw; ++w) t += seg[w][lane];
+      xst(&a.tmp[col], t);
+    }
+    __syncthreads();
+  }
+  BCX_STAMP(st, 7);
+  if (wg != 0) { if (G.ok) grid_arrive(G.gs, 1); return; }
+  gsync(G);                                                                                   // ---- last barrier
+  BCX_STAMP(st, 8);
+  if (!G.ok) { if (tid == 0) { st->active = 0; st->halt = HALT_GRID_TIMEOUT; st->hvalid = 0; } return; }
+  // ---- workgroup 0: error, monotone check, commit or revert, trace, next query ----------------------------------------------
+  double v[2] = {0.0, 0.0};
+  for (int j = tid; j < d; j += blockDim.x) {
+    const double x = xld(&a.tmp[j]), rr = x - L.bs[j];
+    L.qs[j] = x;
+    v[0] += rr * rr; v[1] += x * x;
+  }
+  block_allsum<2>(v, scratch);
+  const double new_err = sqrt(v[0]);
+  int status = BCX_IT_OK;
+  if (checked && !st->no_monotone && new_err > err0) status = BCX_IT_FAIL_MONOTONE;      // snnls.py:56-58
+  if (status == BCX_IT_OK) {
+    for (int q = tid; q < p; q += blockDim.x) n.plist[q] = L.cs[q];
+    for (int j = tid; j < k1; j += blockDim.x) {
+      const int pj = L.pos[j];
+      n.ppos[j] = pj;
+      n.x[j] = pj >= 0 ? L.x[j] : 0.0;
+      a.act_w[j] = pj >= 0 ? L.x[j] : 0.0;
+    }
+    for (int j = tid; j < d; j += blockDim.x) a.xw[j] = L.qs[j];
+    if (tid == 0) {
+      st->k = k1;
+      st->np = p;
+      st->hvalid = 1;
+      st->hlo_valid = 1;
+      st->err = new_err;
+      const double nwn = sqrt(v[1]);
+      st->nw = nwn == 0.0 ? 1.0 : nwn;
+      st->since_refresh += 1;
+      if (checked && !st->no_monotone) st->retried = 0;
+    }
+  } else if (tid == 0) {
+    st->hvalid = 0;        // weights were not touched; H and the lists changed: rebuilt from the weights next time
+  }
+  __syncthreads();
+  if (tid == 0) {
+    *base_ptr = G.gs.base + (unsigned long long)G.bi * (unsigned long long)nwg;
+    const int64_t it = st->it;
+    a.tr_sel[it] = f; a.tr_err[it] = st->err; a.tr_status[it] = status;
+    st->it = it + 1;
+    st->exact_mode = 0;
+    st->omp_mode = OMP_IDLE;
+    st->n_omp[0] += 1;
+    st->n_omp[1] += n_removed;
+    st->n_omp[2] += did_resolve;
+    st->n_omp[3] += (n_entered > 1) ? n_entered - 1 : 0;
+    if (status != BCX_IT_OK) {
+      if (st->retried) { st->limit = 1; st->active = 0; st->halt = HALT_LIMIT; }
+      else st->retried = 1;
+    }
+  }
+  __syncthreads();
+  BCX_STAMP(st, 9);
+#ifdef BCX_TIMING
+  const int64_t log_it = st->it - 1;
+#endif
+  if (st->active) prepare_next(a, scratch);
+  BCX_STAMP(st, 10);
+#ifdef BCX_TIMING
+  __syncthreads();
+  if (tid == 0 && log_it >= 0 && log_it < 4096) {
+    long long* Lg = g_omp_log[log_it];
+    Lg[0] = log_it; Lg[1] = k; Lg[2] = st->np; Lg[3] = done ? 1 : 2; Lg[4] = did_resolve ? 4 : 3; Lg[5] = status; Lg[6] = st->np; Lg[7] = G.bi;
+    for (int i = 0; i < 12; ++i) Lg[8 + i] = i <= 10 ? st->dbg_t[i] - st->dbg_t[0] : 0;
+    // finer stamps, packed: init | rows loop | B2 -> monitor | -> Schur scalars | -> bordered | -> inner loop   (ticks, 3 digits each)
+    long long pk = 0;
+    const int seq[7] = {0, 12, 13, 5, 14, 15, 16};
+    for (int i = 1; i < 7; ++i) { long long dt = st->dbg_t[seq[i]] - st->dbg_t[seq[i - 1]]; if (i == 3) dt = 0; pk = pk * 10000 + (dt < 0 ? 0 : (dt > 9999 ? 9999 : dt)); }
+    Lg[19] = pk;
+    Lg[20] = n_entered; Lg[21] = n_removed; Lg[22] = (st->dbg_t[17] - st->dbg_t[16]); Lg[23] = G.bi;
+  }
+#endif
+}
+
+int bcx_launch_omp_lh(bcx_solver* s, NnlsArgs& n) {
+  static const int force = getenv("BCX_OMP_FORCE_RESOLVE") ? atoi(getenv("BCX_OMP_FORCE_RESOLVE")) : 0;   // tests: re-solve every N-th step
+  const int64_t kub = s->k_ub;
+  const int kcap = (int)((kub + 1 + 63) / 64 * 64);
+  const int dpad = (s->cfg.d + 63) / 64 * 64;
+  const size_t lds = (size_t)kcap * (7 * sizeof(double) + 3 * sizeof(int)) + 3 * (size_t)dpad * sizeof(double);
+  if (lds > OMPL_LDS_MAX) return 1;
+  if (lds > s->omp_lds_allowed) {
+    BCX_HIP(hipFuncSetAttribute((const void*)omp_lh_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)OMPL_LDS_MAX));
+    s->omp_lds_allowed = OMPL_LDS_MAX;
+  }
+  GridSync gs;
+  gs.counter = s->grid_counter;
+  gs.base = 0;                         // (read from device memory by the kernel: s->grid_counter[1])
+  gs.timeout_ticks = 1000000000LL;     // 10 s
+  s->grid_epoch += 1;
+  const int fr = (force > 0 && (s->grid_epoch % force) == 0) ? 1 : 0;
+  hipLaunchKernelGGL(omp_lh_kernel, dim3(OMPL_WGS), dim3(NN_THREADS), lds, s->stream, n, gs, s->grid_counter + 1, kcap, dpad, fr);
+  BCX_HIP(hipGetLastError());
+  return BCX_OK;
+}

@@ -64,16 +64,45 @@ __device__ __forceinline__ double pj_log1p01(double u) {
 // log(1 + exp(t)) = max(t, 0) + log1p(exp(-|t|))
 __device__ __forceinline__ double pj_softplus(double t) { return fmax(t, 0.0) + pj_log1p01(exp(-fabs(t))); }
 
-// (a real call: inlined, the three routines' temporaries spill registers inside the k loop -- 24.8 against 28.3 TFLOP/s at
-// D = 300 although the epilogue got shorter)
-__device__ __attribute__((noinline)) double pj_poisson_call(double m, double y, double c0) {
-  const double lam = fmax(m, 0.0) + pj_log1p01(exp(-fabs(m)));
-  const double sl = m > -100.0 ? log(lam) : m;
+// log(x) for a positive normal x (the Poisson rate: >= log1p(e^-100) = 3.7e-44): x = 2^e m with m in [sqrt(1/2), sqrt(2)),
+// log m = 2 atanh(s), s = (m - 1) / (m + 1), |s| <= 0.172 -- the odd series up to s^22 / 23 (truncation < 1e-18 relative)
+// in Horner form, e ln 2 added in two pieces: <= 3 ulp (checked against long double over 4e6 arguments), ~35 VALU
+// instructions.  The library log is a double-double routine of 98, and it was the last library transcendental of the
+// Poisson epilogue beside exp.
+__device__ __forceinline__ double pj_log_pos(double x) {
+  const long long bits = __double_as_longlong(x);
+  int e = (int)((bits >> 52) & 0x7ff) - 1023;
+  double m = __longlong_as_double((bits & 0x000fffffffffffffLL) | 0x3ff0000000000000LL);   // [1, 2)
+  if (m > 1.4142135623730951) { m *= 0.5; e += 1; }
+  const double s = (m - 1.0) / (m + 1.0), q = s * s;
+  double p = 1.0 / 23.0;
+  p = p * q + 1.0 / 21.0; p = p * q + 1.0 / 19.0; p = p * q + 1.0 / 17.0; p = p * q + 1.0 / 15.0; p = p * q + 1.0 / 13.0;
+  p = p * q + 1.0 / 11.0; p = p * q + 1.0 / 9.0;  p = p * q + 1.0 / 7.0;  p = p * q + 1.0 / 5.0;  p = p * q + 1.0 / 3.0;
+  p = p * q + 1.0;
+  const double ed = (double)e;
+  return ed * 6.93147180369123816490e-01 + (2.0 * s * p + ed * 1.90821492927058770002e-10);
+}
+
+// The Poisson likelihood as two real calls in sequence (rate, then its logarithm): inlined, the series' temporaries spill
+// registers inside the k loop (24.8 against 28.3 TFLOP/s at D = 300 although the epilogue got shorter); as ONE call the
+// two series interleave and cost the SELECT caller registers; nested, the outer call needs a stack frame.
+__device__ __attribute__((noinline)) double pj_rate_call(double m) { return fmax(m, 0.0) + pj_log1p01(exp(-fabs(m))); }
+__device__ __attribute__((noinline)) double pj_lograte_call(double lam) { return pj_log_pos(lam); }
+__device__ __forceinline__ double pj_poisson_call(double m, double y, double c0) {
+  const double lam = pj_rate_call(m);
+  const double sl = m > -100.0 ? pj_lograte_call(lam) : m;
   return y * sl - c0 - lam;
 }
 
-template <int FAM> __device__ __forceinline__ double loglik(double m, double y, double param, double c0) {
+// the logistic likelihood as a real call (SELECT: inlined beside the per-row moments its exp / log1p series spill registers)
+__device__ __attribute__((noinline)) double pj_logistic_call(double m) {
+  const double t = -m;
+  return t < 100.0 ? -pj_softplus(t) : -t;
+}
+
+template <int FAM, bool CALL = false> __device__ __forceinline__ double loglik(double m, double y, double param, double c0) {
   if (FAM == FAM_LOGISTIC) {
+    if (CALL) return pj_logistic_call(m);
     const double t = -m;                                   // model_lr.py:28
     return t < 100.0 ? -pj_softplus(t) : -t;               // model_lr.py:29-31  (-log1p(exp(t)) below 100)
   } else if (FAM == FAM_POISSON) {
@@ -96,7 +125,7 @@ template <int FAM> __device__ __forceinline__ double loglik(double m, double y, 
 // -- three operations instead of seven per element, and more accurate than forming both terms.
 template <int FAM, int MODE> __device__ __forceinline__ double loglik_shifted(double m, double y, double param, double c0, double shift) {
   if (FAM == FAM_LINREG && MODE == PMODE_COLSUM) return (2.0 * y - m) * m * param;
-  return loglik<FAM>(m, y, param, c0) - shift;
+  return loglik<FAM, MODE == PMODE_SELECT>(m, y, param, c0) - shift;
 }
 
 // sum over the 16 lanes of a DPP row (lanes that share l >> 4)
@@ -206,8 +235,6 @@ __global__ __launch_bounds__(256, 2) void proj_kernel(ProjArgs p) {
   const int ngc = (S + COLS - 1) / COLS;
   const int nst = (D + PJ_KC - 1) / PJ_KC;
   const int64_t nblk = (p.N + PJ_ROWS - 1) / PJ_ROWS;
-  double bestv = -INFINITY;
-  long long besti = 0x7fffffffffffffffLL;
   const double clin = (FAM == FAM_LINREG) ? -0.5 * log(2.0 * 3.14159265358979323846 * p.param) : 0.0;
   const double parg = (FAM == FAM_LINREG) ? 1.0 / (2.0 * p.param) : p.param;
 
@@ -243,7 +270,6 @@ __global__ __launch_bounds__(256, 2) void proj_kernel(ProjArgs p) {
       double* outp = p.colpart + (size_t)blockIdx.x * S;
       for (int c = tid; c < S; c += blockDim.x) outp[c] = 0.0;
     }
-    if (MODE == PMODE_SELECT && !teamed && tid == 0) { p.best_val[blockIdx.x] = -INFINITY; p.best_idx[blockIdx.x] = besti; }
     return;
   }
   // ---- the prefetch stream -------------------------------------------------------------------------------------
@@ -362,7 +388,7 @@ __global__ __launch_bounds__(256, 2) void proj_kernel(ProjArgs p) {
   // of 8: what makes the kernel fit 256 registers at two waves per SIMD.
   pv4d acc[2][NCT];                  // [row tile][column tile]
   double yv[TRP ? 2 : 8], cp[TRP ? 2 : 8];
-  double piv[2], rs[2], rq[2], rd[2];
+  double piv[2];
   while (true) {
     const int s = cur.s, cg = cur.cg;
     const int64_t br = cur.br;
@@ -482,24 +508,35 @@ __global__ __launch_bounds__(256, 2) void proj_kernel(ProjArgs p) {
         }
       } else {
         // i = column (lk + 4 reg within column tile tc), j = data row (li within row tile tr)
-        if (cg == 0 || teamed) {
+        // SELECT: every column group of a row stands alone -- shift = the group's first column, moments about it -- and
+        // leaves {shift, sum, sum of squares, dot with the residual} in p.part; select_combine_kernel forms the row's
+        // correlation from the groups' records.  Nothing is carried from one column group to the next and the kernel has
+        // no arg-max of its own: the per-row state held in registers across the MFMA loop (24 VGPRs) and the in-kernel
+        // correlation code are what made the transcendental instantiations spill (logistic 56 VGPRs, Poisson 12).
+        // COLSUM keeps its three loop-carried values (response, constant, shift).
+        constexpr bool SEL = MODE == PMODE_SELECT;
+        double syv[2], scp[2], spiv[2], rs[2], rq[2], rd[2];
+        double* const yq = SEL ? syv : yv;
+        double* const cq = SEL ? scp : cp;
+        double* const pq = SEL ? spiv : piv;
+        if (SEL || cg == 0 || teamed) {
 #pragma unroll
           for (int tr = 0; tr < 2; ++tr) {
             const int64_t row = r0 + 16 * tr + li;
             const double y = (p.ycol >= 0 && row < p.N) ? p.Z[row * p.ldz + p.ycol] : 0.0;
-            yv[tr] = y;
-            cp[tr] = (FAM == FAM_POISSON) ? pj_lgamma1p<MODE>(y) : clin;
+            yq[tr] = y;
+            cq[tr] = (FAM == FAM_POISSON) ? pj_lgamma1p<MODE>(y) : clin;
             rs[tr] = 0.0; rq[tr] = 0.0; rd[tr] = 0.0;
-            // per-row shift: the row's value in column 0 (lane group lk == 0, register 0 of column tile 0), handed to
-            // the four lanes that share the row.  Sums, squares and dot products are accumulated on (ll - shift): the
-            // one-pass moments then cancel on the scale of the row's SPREAD, not of |ll| (rows with |mean| >> spread:
-            // a concentrated posterior, saturated logistic rows) -- the accuracy of the reference's centre-then-norm
-            // order (sparsevi.py:49-51) without a second pass.
+            // per-row shift: the row's value in the group's first column (lane group lk == 0, register 0 of column tile
+            // 0), handed to the four lanes that share the row.  Sums, squares and dot products are accumulated on
+            // (ll - shift): the one-pass moments then cancel on the scale of the row's SPREAD, not of |ll| (rows with
+            // |mean| >> spread: a concentrated posterior, saturated logistic rows) -- the accuracy of the reference's
+            // centre-then-norm order (sparsevi.py:49-51) without a second pass.
             // COLSUM only needs SOME shift that is constant along the row (the centring correction removes it); its
             // column groups may sit in different workgroups, so it takes one every workgroup can form from the row
             // alone: the likelihood at a zero linear predictor.
-            const double l0 = loglik<FAM>(MODE == PMODE_COLSUM ? 0.0 : acc[tr][0][0], yv[tr], parg, cp[tr]);
-            piv[tr] = MODE == PMODE_COLSUM ? l0 : __shfl(l0, li, BCX_WAVE);
+            const double l0 = loglik<FAM, SEL>(MODE == PMODE_COLSUM ? 0.0 : acc[tr][0][0], yq[tr], parg, cq[tr]);
+            pq[tr] = MODE == PMODE_COLSUM ? l0 : __shfl(l0, li, BCX_WAVE);
           }
         }
         // 64 columns at a time, fenced: with all NCT column tiles in one scheduling region the compiler keeps every
@@ -519,11 +556,14 @@ __global__ __launch_bounds__(256, 2) void proj_kernel(ProjArgs p) {
 #pragma unroll
               for (int tr = 0; tr < 2; ++tr) {
                 const bool ok = cvalid && r0 + 16 * tr + li < p.N;
-                const double v = ok ? loglik_shifted<FAM, MODE>(acc[tr][tc][r], yv[tr], parg, cp[tr], piv[tr]) : 0.0;
+                const double v = ok ? loglik_shifted<FAM, MODE>(acc[tr][tc][r], yq[tr], parg, cq[tr], pq[tr]) : 0.0;
                 if (MODE == PMODE_COLSUM) csum += v;
                 else { rs[tr] += v; rq[tr] += v * v; rd[tr] += v * rsd; }
               }
               cs[4 * t4 + r] = csum;
+              // SELECT with a transcendental epilogue: two likelihood values (one column, the lane's two rows) per
+              // scheduling region -- given the whole tile the compiler interleaves the exp / log series of many values
+              if (MODE == PMODE_SELECT && FAM != FAM_LINREG) __builtin_amdgcn_sched_barrier(0);
             }
           }
           if (MODE == PMODE_COLSUM) {
@@ -545,7 +585,7 @@ __global__ __launch_bounds__(256, 2) void proj_kernel(ProjArgs p) {
           }
           if (NCT > 4) __builtin_amdgcn_sched_barrier(0);
         }
-        if (MODE == PMODE_SELECT && (cg == ngc - 1 || teamed)) {
+        if (MODE == PMODE_SELECT) {
 #pragma unroll
           for (int tr = 0; tr < 2; ++tr) {
             // the four lane groups hold disjoint columns of the same row
@@ -554,21 +594,12 @@ __global__ __launch_bounds__(256, 2) void proj_kernel(ProjArgs p) {
             s2 += bcx_xor16_f64(s2); s2 += bcx_xor32_f64(s2);
             sd += bcx_xor16_f64(sd); sd += bcx_xor32_f64(sd);
             const long long row = r0 + 16 * tr + li;
-            if (teamed) {
-              // this column group's share of the row's moments, about the group's own shift (its first column)
-              if (lk == 0 && row < p.N) {
-                double* rec = p.part + ((size_t)cg * (size_t)p.N + (size_t)row) * 4;
-                *(pv2d*)rec = (pv2d){piv[tr], s1};
-                *(pv2d*)(rec + 2) = (pv2d){s2, sd};
-              }
-              continue;
+            // this column group's share of the row's moments, about the group's own shift (its first column)
+            if (lk == 0 && row < p.N) {
+              double* rec = p.part + ((size_t)cg * (size_t)p.N + (size_t)row) * 4;
+              *(pv2d*)rec = (pv2d){pq[tr], s1};
+              *(pv2d*)(rec + 2) = (pv2d){s2, sd};
             }
-            const double mean = s1 / (double)S;                         // mean of (ll - shift)
-            const double dot = sd - mean * p.resid_sum;                 // (ll - mean ll) . resid
-            const double nrm2 = s2 - (double)S * mean * mean;           // ||ll - mean ll||^2
-            // a row that is constant over the samples has shifted values 0 exactly: 0/0 = NaN as in NumPy
-            const double corr = nrm2 > 0.0 ? dot / sqrt(nrm2) / (double)S : __builtin_nan("");
-            if (row < p.N && corr_better(corr, row, bestv, besti)) { bestv = corr; besti = row; }
           }
         }
       }
@@ -596,25 +627,6 @@ __global__ __launch_bounds__(256, 2) void proj_kernel(ProjArgs p) {
     for (int c = tid; c < S; c += blockDim.x) {
       const int k = c - cacc_0;                    // (columns of other team members: zero)
       outp[c] = (k >= 0 && k < cacc_n) ? ((ca[k] + ca[(size_t)cacc_n + k]) + ca[2 * (size_t)cacc_n + k]) + ca[3 * (size_t)cacc_n + k] : 0.0;
-    }
-  }
-  if (MODE == PMODE_SELECT && !teamed) {
-    // arg-max over the workgroup (the staging area is free after the last stage)
-    double* sv = (double*)pj_lds;
-    long long* si = (long long*)(pj_lds + 64);
-    for (int off = 32; off >= 1; off >>= 1) {
-      const double ov = __shfl_xor(bestv, off, BCX_WAVE);
-      const long long oi = __shfl_xor(besti, off, BCX_WAVE);
-      if (corr_better(ov, oi, bestv, besti)) { bestv = ov; besti = oi; }
-    }
-    __syncthreads();
-    if (lane == 0) { sv[wave] = bestv; si[wave] = besti; }
-    __syncthreads();
-    if (tid == 0) {
-      for (int w = 1; w < 4; ++w)
-        if (corr_better(sv[w], si[w], bestv, besti)) { bestv = sv[w]; besti = si[w]; }
-      p.best_val[blockIdx.x] = bestv;
-      p.best_idx[blockIdx.x] = besti;
     }
   }
 }
@@ -804,7 +816,7 @@ template <int FAM, int MODE, int NCT> static int launch_one(bool aligned, dim3 g
     }
     PROJ_HIP(hipEventRecord(g_prof.ev[g_prof.used].first, st));
   }
-  if (aligned) {
+if (aligned) {
     PROJ_HIP(hipFuncSetAttribute((const void*)proj_kernel<FAM, MODE, true, NCT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
     hipLaunchKernelGGL((proj_kernel<FAM, MODE, true, NCT>), grid, dim3(256), shmem, st, p);
   } else {
@@ -954,9 +966,17 @@ extern "C" int bcx_project_colsum(void* stream, int32_t family, const void* Z_de
 
 // arg-max_n of vecs[n].resid / ||vecs[n]|| / S  (first maximum), result to result_dev = {double value, int64 row}.
 // work_dev: 2048 doubles + 2048 int64.
-extern "C" int bcx_project_select(void* stream, int32_t family, const void* Z_dev, int64_t N, int64_t ldz, int32_t D,
-                                  int32_t ycol, const void* theta_dev, int32_t S, int32_t ldt, double param,
-                                  const void* resid_dev, double resid_sum, void* result_dev, void* work_dev) {
+// Scratch of the select step: per row and column group four doubles {shift, sum, sum of squares, dot with the residual},
+// after 2048 doubles + 2048 int64 for the reduction of the arg-max.
+extern "C" int64_t bcx_project_select_scratch_bytes(int32_t family, int64_t N, int32_t S) {
+  if (N < 0 || S < 1) return -1;
+  const int cols = 16 * proj_nct(PMODE_SELECT, family, S), ngc = (S + cols - 1) / cols;
+  return (int64_t)(4096 * sizeof(double)) + (int64_t)ngc * N * 4 * (int64_t)sizeof(double);
+}
+
+static int project_select(void* stream, int32_t family, const void* Z_dev, int64_t N, int64_t ldz, int32_t D,
+                          int32_t ycol, const void* theta_dev, int32_t S, int32_t ldt, double param,
+                          const void* resid_dev, double resid_sum, void* result_dev, void* work_dev, void* part_dev) {
   ProjArgs p;
   int rc = fill(p, family, Z_dev, N, ldz, D, ycol, theta_dev, S, ldt, param);
   if (rc) return rc;
@@ -965,25 +985,48 @@ extern "C" int bcx_project_select(void* stream, int32_t family, const void* Z_de
   const int grid = proj_grid(N);
   p.resid = (const double*)resid_dev; p.resid_sum = resid_sum;
   p.best_val = (double*)work_dev; p.best_idx = (int64_t*)((double*)work_dev + 2048);
-  // XCD teams (Z streamed once instead of once per column group) need room for the members' partial row moments:
-  // 32 bytes per row and column group, stream-ordered scratch; without it the one-workgroup walk is used.
-  int nparts = grid;
-  const int team = proj_team(PMODE_SELECT, family, S, grid);
-  void* part = nullptr;
-  if (team > 1 && N > 0 && hipMallocAsync(&part, (size_t)team * (size_t)N * 4 * sizeof(double), st) != hipSuccess) {
-    (void)hipGetLastError();
-    part = nullptr;
+  // The kernel leaves every column group's share of the row moments (32 bytes per row and group); the arg-max is taken
+  // by select_combine_kernel.  On XCD teams the column groups of a row block run side by side (Z streamed once instead
+  // of once per column group), otherwise one workgroup walks them; the records are the same.
+  const int cols = 16 * proj_nct(PMODE_SELECT, family, S), ngc = (S + cols - 1) / cols;
+  void* part = part_dev;
+  bool own = false;
+  if (!part && N > 0) {
+    // (callers of the round-2 entry point: stream-ordered scratch; a caller-owned buffer does not compete with the
+    // framework's allocator -- bcx_project_select_ws)
+    if (hipMallocAsync(&part, (size_t)ngc * (size_t)N * 4 * sizeof(double), st) != hipSuccess) {
+      (void)hipGetLastError();
+      g_proj_err = "bcx_project_select: no scratch for the row moments (" + std::to_string((size_t)ngc * (size_t)N * 32) + " bytes)";
+      return BCX_ERR_NOMEM;
+    }
+    own = true;
   }
-  if (part) { p.team = team; p.part = (double*)part; }
-  if ((rc = launch_family<PMODE_SELECT>(family, dim3(grid), 0, st, p))) { if (part) (void)hipFreeAsync(part, st); return rc; }
-  if (part) {
-    nparts = (int)std::min<int64_t>((N + 255) / 256, 512);
-    hipLaunchKernelGGL(select_combine_kernel, dim3(nparts), dim3(256), 0, st, (const double*)part, N, team, 16 * proj_nct(PMODE_SELECT, family, S), S,
-                       p.resid, p.best_val, p.best_idx);
-  }
+  p.team = proj_team(PMODE_SELECT, family, S, grid);
+  p.part = (double*)part;
+  if (N > 0 && (rc = launch_family<PMODE_SELECT>(family, dim3(grid), 0, st, p))) { if (own) (void)hipFreeAsync(part, st); return rc; }
+  const int nparts = (int)std::max<int64_t>(1, std::min<int64_t>((N + 255) / 256, 512));
+  hipLaunchKernelGGL(select_combine_kernel, dim3(nparts), dim3(256), 0, st, (const double*)part, N, ngc, cols, S, p.resid, p.best_val,
+                     p.best_idx);
   hipLaunchKernelGGL(select_final_kernel, dim3(1), dim3(256), 0, st, p.best_val, p.best_idx, nparts, (double*)result_dev,
                      (int64_t*)((double*)result_dev + 1));
   PROJ_HIP(hipGetLastError());
-  if (part) PROJ_HIP(hipFreeAsync(part, st));
+  if (own) PROJ_HIP(hipFreeAsync(part, st));
   return BCX_OK;
+}
+
+// arg-max_n of vecs[n].resid / ||vecs[n]|| / S  (first maximum), result to result_dev = {double value, int64 row}.
+// work_dev: 2048 doubles + 2048 int64 (the row-moment scratch is taken from the stream-ordered allocator).
+extern "C" int bcx_project_select(void* stream, int32_t family, const void* Z_dev, int64_t N, int64_t ldz, int32_t D,
+                                  int32_t ycol, const void* theta_dev, int32_t S, int32_t ldt, double param,
+                                  const void* resid_dev, double resid_sum, void* result_dev, void* work_dev) {
+  return project_select(stream, family, Z_dev, N, ldz, D, ycol, theta_dev, S, ldt, param, resid_dev, resid_sum, result_dev, work_dev,
+                        nullptr);
+}
+// The same with ALL scratch supplied by the caller: work_dev holds bcx_project_select_scratch_bytes(family, N, S) bytes.
+extern "C" int bcx_project_select_ws(void* stream, int32_t family, const void* Z_dev, int64_t N, int64_t ldz, int32_t D,
+                                     int32_t ycol, const void* theta_dev, int32_t S, int32_t ldt, double param,
+                                     const void* resid_dev, double resid_sum, void* result_dev, void* work_dev, int64_t work_bytes) {
+  if (work_bytes < bcx_project_select_scratch_bytes(family, N, S)) { g_proj_err = "bcx_project_select_ws: scratch too small"; return BCX_ERR_ARG; }
+  return project_select(stream, family, Z_dev, N, ldz, D, ycol, theta_dev, S, ldt, param, resid_dev, resid_sum, result_dev, work_dev,
+                        work_dev ? (char*)work_dev + 4096 * sizeof(double) : nullptr);
 }

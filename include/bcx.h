@@ -186,6 +186,9 @@ int bcx_time_scan(bcx_solver* s, int32_t reps, int32_t exact, double* ms_per_lau
 int bcx_stats(bcx_solver* s, int64_t* exact_fallbacks, int64_t* candidates, int64_t* resolves);
 /* Sum of scan-kernel time recorded by hipEvents during bcx_build_enqueue: on = 1 times every scan launch,
  * on = N > 1 every N-th one (an event pair costs several microseconds of stream time), on = 0 stops. */
+/* OMP step diagnostics since construction: out4 = {steps taken, columns that left the passive set, from-scratch re-solves
+ * (the incremental inverse had drifted, or a reverted step), columns that entered beyond the selected one}. */
+int bcx_omp_stats(bcx_solver* s, int64_t* out4);
 int bcx_profile_scan(bcx_solver* s, int32_t on);
 int bcx_profile_read(bcx_solver* s, double* scan_ms_total, int64_t* scan_launches);
 /* ---- device-native projection (projector.py:19-21 with the example likelihoods) --------------------
@@ -211,6 +214,13 @@ int bcx_project_colsum(void* stream, int32_t family, const void* Z_dev, int64_t 
 int bcx_project_select(void* stream, int32_t family, const void* Z_dev, int64_t N, int64_t ldz, int32_t D,
                        int32_t ycol, const void* theta_dev, int32_t S, int32_t ldt, double param,
                        const void* resid_dev, double resid_sum, void* result_dev, void* work_dev);
+/* The select step with ALL of its scratch supplied by the caller (it then never touches the stream-ordered allocator):
+ * work_dev holds bcx_project_select_scratch_bytes(family, N, S) bytes = 2048 doubles + 2048 int64 for the arg-max
+ * reduction, then 32 bytes per row and 64-column group for the partial row moments. */
+int64_t bcx_project_select_scratch_bytes(int32_t family, int64_t N, int32_t S);
+int bcx_project_select_ws(void* stream, int32_t family, const void* Z_dev, int64_t N, int64_t ldz, int32_t D,
+                          int32_t ycol, const void* theta_dev, int32_t S, int32_t ldt, double param,
+                          const void* resid_dev, double resid_sum, void* result_dev, void* work_dev, int64_t work_bytes);
 const char* bcx_project_last_error(void);
 /* Measurement: hipEvents around the projection kernel alone, recorded on the stream the kernel is launched on.
  * bcx_project_profile(1) starts timing every later projection launch of the calling host thread, (0) stops;

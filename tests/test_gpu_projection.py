@@ -67,6 +67,57 @@ def test_hilbert_coreset_with_device_projector(bc):
         np.testing.assert_allclose(c.error(), float(g[alg + "_err"]), rtol=1e-7)
 
 
+@pytest.mark.parametrize("family,S", (("logistic", 128), ("linreg", 37), ("poisson", 600)))
+def test_centring_folded_into_ingest_equals_the_centring_pass(bc, family, S):
+    """projector.py:21 inside the solver's constructor pass (csrc/ingest.hip, BCX_LOAD_CENTER_ROWS): HilbertCoreset
+    behind a DeviceProjector takes the RAW log-likelihoods and centres them while it reads them.  The solver must end up
+    with the state it gets from the centred projection -- norms, b, trace, weights: bit for bit for S <= 512 on 16-byte
+    rows (same lane -> column ownership and association as the former centring pass), to rounding otherwise (odd S: the
+    scalar ingest kernel; S > 512) -- and project_uncentred() minus its row means is project()."""
+    import torch
+    Z, theta0, ll, sigsq = _cases()[family]
+    theta = np.random.RandomState(S).randn(S, theta0.shape[1]) * (0.3 if family == "poisson" else 1.0)
+    prj = bc.DeviceProjector(family, lambda n, w, p: theta, S, sigsq=sigsq)
+    centred = prj.project(Z)
+    raw = prj.project_uncentred(Z)
+    torch.testing.assert_close(raw - raw.mean(dim=1, keepdim=True), centred, rtol=1e-12, atol=1e-12 * float(centred.abs().max()))
+    assert float((raw.mean(dim=1).abs()).max()) > 1e-3          # (the raw rows really are uncentred)
+    for cls in (bc.snnls.GIGA, bc.snnls.OrthoPursuit):
+        two_pass = cls(centred.t(), None)
+        folded = bc.HilbertCoreset(Z, prj, snnls=cls)
+        assert folded.snnls._center_rows
+        exact = S <= 512 and S % 2 == 0
+        cmp = np.testing.assert_array_equal if exact else (lambda a, b: np.testing.assert_allclose(a, b, rtol=1e-12, atol=1e-300))
+        cmp(folded.snnls.Anorms, two_pass.Anorms)
+        np.testing.assert_allclose(folded.snnls.b, two_pass.b, rtol=1e-10, atol=1e-10 * np.abs(two_pass.b).max())
+        if exact:
+            np.testing.assert_array_equal(folded.snnls.b, two_pass.b)
+        two_pass.build(25)
+        folded.build(25)
+        assert np.array_equal(folded.snnls.last_trace[0], two_pass.last_trace[0])
+        cmp(folded.snnls.weights(), two_pass.weights())
+        # .A of the folded solver reads as the centred matrix
+        torch.testing.assert_close(folded.snnls.A, centred.t(), rtol=1e-12, atol=1e-12 * float(centred.abs().max()))
+
+
+def test_center_rows_flag_on_host_and_fp32_sources(bc):
+    """BCX_LOAD_CENTER_ROWS through every upload path: host fp64 (in place in the resident raw copy), host fp32 (staged),
+    fp64 storage without raw rows; all against the explicitly centred matrix."""
+    rs = np.random.RandomState(12)
+    V = rs.randn(5000, 24) * np.exp(rs.randn(5000, 1)) + 3.0 * rs.randn(5000, 1)      # large row means
+    C = V - V.mean(axis=1)[:, None]
+    for src, kw in ((V, {}), (V.astype(np.float32), {}), (V, {"dtype": "float64"}), (V, {"keep_exact_rows": False})):
+        want = bc.snnls.FrankWolfe((src.astype(np.float64) - src.astype(np.float64).mean(axis=1)[:, None]).T, None, **kw)
+        got = bc.snnls.FrankWolfe(src.T, None, center_rows=True, **kw)
+        np.testing.assert_allclose(got.Anorms, want.Anorms, rtol=1e-6 if src.dtype == np.float32 else 1e-13)
+        np.testing.assert_allclose(got.b, want.b, rtol=1e-6 if src.dtype == np.float32 else 1e-11,
+                                   atol=(1e-5 if src.dtype == np.float32 else 1e-11) * np.abs(want.b).max())
+        got.build(20)
+        want.build(20)
+        assert np.array_equal(got.last_trace[0], want.last_trace[0])
+    np.testing.assert_allclose(np.asarray(bc.snnls.FrankWolfe(V.T, None, center_rows=True).A), C.T, rtol=1e-13, atol=1e-13)
+
+
 @pytest.mark.parametrize("kind", ("device", "blackbox"))
 def test_sparsevi_matches_reference(bc, kind):
     """F6: 5 greedy steps x 20 ADAM steps; same points in the same order, weights to 1e-5."""

@@ -40,22 +40,26 @@ lib = nat.load()
 lib.bcx_debug_omp_log.argtypes = [C.c_void_p, C.c_int]
 buf = np.zeros((n, 24), dtype=np.int64)
 assert lib.bcx_debug_omp_log(buf.ctypes.data, n) == 0
-MODE = {0: "idle", 1: "done", 2: "fast_try", 3: "fast_accept", 4: "general"}
-NAMES = ["entry", "rows", "B1", "decide", "u=Hg", "B2", "step", "gen+comb", "rank-1", "B5", "finish", "next"]
+NAMES = ["entry", "rows", "B1", "decide", "u,dz=H[g,grad]", "B2", "LH step", "combine", "B-last", "finish", "next"]
 tot = {}
 for r in buf:
-    it, k, p, m0, m1, st_, np1, ill = r[:8]
+    it, k, p, m0, m1, st_, np1, nbar = r[:8]
     t = r[8:20] / 100.0
-    key = (MODE.get(int(m0)), MODE.get(int(m1)))
-    tot.setdefault(key, []).append((t[11] if t[11] > 0 else t[10], int(k), int(p), t[7] - t[6], r[20], r[21], r[22], r[23]))
+    ent, rem, res = int(r[20]), int(r[21]), 0
+    pk = int(r[19]); fine = []
+    for _ in range(6):
+        fine.append((pk % 10000) / 100.0); pk //= 10000
+    fine = fine[::-1] + [int(r[22]) / 100.0]       # init, rows loop, -, monitor, schur, border, inner
+    key = ("done" if m0 == 1 else "step", "resolve" if res else ("left %d" % min(rem, 3) if rem else "closed form"))
+    tot.setdefault(key, []).append((t[10], int(k), int(p), t[6] - t[5], ent, rem, res, int(nbar)))
     if not a.quiet:
-        print("it %3d k %3d p %3d %-8s -> %-11s st %d np %3d ill %d | total %6.1f us: " % (it, k, p, MODE.get(int(m0)), MODE.get(int(m1)), st_, np1, ill, t[11] if t[11] > 0 else t[10])
-              + " ".join("%s %.1f" % (NAMES[i], t[i] - t[i - 1]) for i in range(1, 12))
-              + " | outer %d inner %d refine %d del %d" % tuple(r[20:24]))
-print("size %d error %.6g limit %s; statuses %s" % (s.size(), s.error(), s.reached_numeric_limit, {int(k): int((status == k).sum()) for k in set(status)}))
+        print("it %3d k %3d np %3d %-5s st %d barriers %2d entered %d left %d resolve %d | total %6.1f us: " % (it, k, p, key[0], st_, nbar, ent, rem, res, t[10])
+              + " ".join("%s %.1f" % (NAMES[i], t[i] - t[i - 1]) for i in range(1, 11))
+              + " || init %.1f rowsloop %.1f | monitor %.1f schur %.1f border %.1f inner %.1f" % (fine[0], fine[1], fine[3], fine[4], fine[5], fine[6]))
+print("size %d error %.6g limit %s; statuses %s; omp stats %s" % (s.size(), s.error(), s.reached_numeric_limit,
+      {int(k): int((status == k).sum()) for k in set(status)}, s._eng.omp_stats()))
 for key, v in sorted(tot.items(), key=lambda kv: -sum(x[0] for x in kv[1])):
     v = np.array(v, dtype=float)
-    print("%-10s -> %-12s n %3d  in-kernel mean %6.1f us max %6.1f  (gen+comb mean %6.1f)  k %3d..%3d  outer %.2f inner %.2f refine %.2f del %.2f"
-          % (key[0], key[1], len(v), v[:, 0].mean(), v[:, 0].max(), v[:, 3].mean(), v[:, 1].min(), v[:, 1].max(),
-             v[:, 4].mean(), v[:, 5].mean(), v[:, 6].mean(), v[:, 7].mean()))
+    print("%-5s %-12s n %3d  in-kernel mean %6.1f us max %6.1f  (LH step mean %6.1f)  k %3d..%3d  barriers %.2f"
+          % (key[0], key[1], len(v), v[:, 0].mean(), v[:, 0].max(), v[:, 3].mean(), v[:, 1].min(), v[:, 1].max(), v[:, 7].mean()))
 print("all steps: mean %.1f us in-kernel" % np.mean([x[0] for v in tot.values() for x in v]))

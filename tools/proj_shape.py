@@ -21,12 +21,14 @@ if a.family == "poisson":
     Z[:, -1] = torch.poisson(torch.ones(a.rows, dtype=torch.float64, device="cuda"))
 theta = 0.1 * rs.randn(a.samples, a.dim)
 prj = bc.DeviceProjector(a.family, lambda n, w, p: theta, a.samples, sigsq=1.0)
+prj.profile(True)
 resid = rs.randn(a.samples)
 lib, S = prj._lib, a.samples
 col = torch.empty(S, dtype=torch.float64, device="cuda")
 res = torch.empty(2, dtype=torch.float64, device="cuda")
 r = torch.from_numpy(resid).cuda()
-out = torch.empty((a.rows, S), dtype=torch.float64, device="cuda") if a.mode == "write" else None
+out = torch.empty((a.rows, S), dtype=torch.float64, device="cuda") if a.mode.startswith("write") else None
+swork = prj._select_scratch(a.rows, S)
 rowsum = torch.empty(a.rows, dtype=torch.float64, device="cuda")
 work = prj._workspace(S)
 
@@ -35,7 +37,10 @@ def launch():
     if a.mode == "colsum":
         prj._check(lib.bcx_project_colsum(*prj._common(Z), col.data_ptr(), work.data_ptr()))
     elif a.mode == "select":
-        prj._check(lib.bcx_project_select(*prj._common(Z), r.data_ptr(), float(resid.sum()), res.data_ptr(), work.data_ptr()))
+        prj._check(lib.bcx_project_select_ws(*prj._common(Z), r.data_ptr(), float(resid.sum()), res.data_ptr(), swork.data_ptr(),
+                                             swork.numel() * 8))
+    elif a.mode == "write_raw":
+        prj._check(lib.bcx_project_write_raw(*prj._common(Z), out.data_ptr(), S))
     else:
         prj._check(lib.bcx_project_write(*prj._common(Z), out.data_ptr(), S, rowsum.data_ptr()))
 
@@ -51,4 +56,6 @@ e1.record()
 torch.cuda.synchronize()
 ms = e0.elapsed_time(e1) / a.reps
 fl = 2.0 * a.rows * a.dim * S
-print("%s %s N=%d D=%d S=%d: %.3f ms per call (all kernels of the call), %.1f TFLOP/s fp64" % (a.family, a.mode, a.rows, a.dim, S, ms, fl / ms / 1e9), flush=True)
+kms, kn, kfl = prj.profile_read()          # hipEvents around proj_kernel alone (3 warm-up + reps launches)
+print("%s %s N=%d D=%d S=%d: %.3f ms per call (all kernels of the call) = %.1f TFLOP/s; proj_kernel alone %.3f ms = %.1f TFLOP/s fp64"
+      % (a.family, a.mode, a.rows, a.dim, S, ms, fl / ms / 1e9, kms / max(kn, 1), kfl / max(kms, 1e-9) / 1e9), flush=True)

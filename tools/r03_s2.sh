@@ -1,0 +1,18 @@
+#!/bin/bash
+# round-3 GPU session 2: incremental OMP step (omp_lh.hip), centring folded into ingest, exact-mode shard independence
+cd "$(dirname "$0")/.." || exit 1
+O=gpurun_out/s2; mkdir -p $O
+run() { local name=$1; shift; timeout 1500 "$@" > $O/$name.log 2>&1; echo "$name rc=$? :: $(tail -n 1 $O/$name.log)" | tee -a $O/summary.txt; }
+run parity python -m pytest tests/test_gpu_parity.py -q -p no:cacheprovider
+run parity_resolve env BCX_OMP_FORCE_RESOLVE=3 python -m pytest tests/test_gpu_parity.py -q -p no:cacheprovider -k "omp or OMP or F7 or optimize or repeated or wide or incremental or reset"
+run omp_hist_c3 python tools/omp_hist.py --rows 1000000 --itrs 140
+tail -8 $O/omp_hist_c3.log
+run omp_hist_randn python tools/omp_hist.py --rows 1000000 --itrs 140 --randn --quiet
+tail -5 $O/omp_hist_randn.log
+run proj python -m pytest tests/test_gpu_projection.py -q -p no:cacheprovider -k "centring or center_rows or hilbert_coreset_with_device or host_solver"
+run sharded python -m pytest tests/test_gpu_sharded.py -q -p no:cacheprovider -k "exact_fallback or four_and_eight or config4_geometry or bench_contract_eight or two_shards_on_one or peer_mailbox_exchange"
+run c3check python tools/c3_check.py --rows 200000 --itrs 200
+tail -6 $O/c3check.log
+run fullsize3 python -m pytest tests/test_gpu_fullsize.py -q -p no:cacheprovider -k "config3"
+python bench.py --config c3 --no-cpu-baseline > $O/bench_c3.json 2> $O/bench_c3.err; echo "bench c3 rc=$?" | tee -a $O/summary.txt
+tail -c 1200 $O/bench_c3.json
