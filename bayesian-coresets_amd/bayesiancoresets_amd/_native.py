@@ -15,6 +15,7 @@ OK, ERR_ARG, ERR_HIP, ERR_ZERO_ROW, ERR_ZERO_B, ERR_NOMEM, ERR_STATE = 0, -1, -2
 IT_OK, IT_FAIL_SELECT, IT_FAIL_REWEIGHT, IT_FAIL_MONOTONE = 0, 1, 2, 3
 REC_HDR = 4
 LOAD_CENTER_ROWS = 1
+MAX_ROW_LENGTH = 8192      # BCX_MAX_ROW_LENGTH of include/bcx.h (tests/test_abi.py keeps the two equal)
 CHUNK_ROWS = 1024
 
 # every symbol include/bcx.h declares (checked by tests/test_abi.py)
@@ -42,6 +43,32 @@ class Config(ctypes.Structure):
 _lib = None
 
 
+def ensure_ipc_mode():
+    """The ONE place that sets the IPC mode: multi-process GPU work on this platform (RCCL, the peer mailbox's
+    hipIpcGetMemHandle) needs dmabuf IPC, i.e. HSA_ENABLE_IPC_MODE_LEGACY=0 in the environment BEFORE the HSA runtime
+    initialises.  Called by load(), tests/conftest.py, bench.py and __graft_entry__.py.  A different value chosen by the
+    user is respected (BCX_KEEP_IPC_MODE=1) and a setting that can no longer take effect is reported."""
+    import logging
+    cur = os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY")
+    if cur == "0":
+        return True
+    if os.environ.get("BCX_KEEP_IPC_MODE"):
+        return False
+    initialised = False
+    try:
+        import sys
+        t = sys.modules.get("torch")
+        initialised = bool(t is not None and t.cuda.is_initialized())
+    except Exception:
+        pass
+    os.environ["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
+    if initialised:
+        logging.getLogger().warning("bayesiancoresets_amd: the HIP runtime was initialised before HSA_ENABLE_IPC_MODE_LEGACY=0 "
+                                    "could be set (it was %r); peer mailboxes / RCCL between processes may fail -- export it "
+                                    "before the first GPU call", cur)
+    return not initialised
+
+
 def load():
     """Load libbcx.so once; raise (never fall back) when it is absent."""
     global _lib
@@ -51,16 +78,16 @@ def load():
         raise RuntimeError(
             "libbcx.so not found at %s -- build it with `make -C bayesian-coresets_amd` "
             "(or python -c 'import __graft_entry__ as g; g.build()'). There is no CPU fallback." % LIB_PATH)
-    # the HSA runtime reads this when the first HIP call initialises it; default to the dmabuf IPC mode the peer
-    # mailbox (hipIpcGetMemHandle) and RCCL need unless the user chose otherwise
-    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    ensure_ipc_mode()
     # PyTorch-ROCm bundles its own HIP / HSA runtime; libbcx.so must bind to THAT copy (same SONAME, already loaded),
     # not pull the system one in next to it -- two HIP runtimes in one process fight over the device ("No HIP GPUs are
-    # available" in whichever initialises second).  So torch is imported before the library is opened.
-    try:
-        import torch  # noqa: F401
-    except ImportError:
-        pass
+    # available" in whichever initialises second).  So torch is imported before the library is opened
+    # (BCX_NO_TORCH_PRELOAD=1 skips this for embedders without torch).
+    if not os.environ.get("BCX_NO_TORCH_PRELOAD"):
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
     lib = ctypes.CDLL(LIB_PATH)
     vp, i32, i64, dbl = ctypes.c_void_p, ctypes.c_int32, ctypes.c_int64, ctypes.c_double
     P = ctypes.POINTER

@@ -64,8 +64,12 @@ class ShardedHilbertCoreset(Coreset):
             vecs, self.sub_idcs = self._deal_subsample(ll_projector.project(local_data[mine - lo]), mine, world, rank)
             n_rows = int(self.sub_idcs.shape[0])
         d = int(vecs.shape[1])
+        if n_rows == 0:
+            raise ValueError("ShardedHilbertCoreset.__init__(): every drawn vector is zero -- nothing to build a coreset from")
         self.snnls = ShardedSolver(snnls._ALG, n_rows, d, group=group, engine_factory=engine_factory)
-        assert int(vecs.shape[0]) == self.snnls.n_local
+        if int(vecs.shape[0]) != self.snnls.n_local:
+            raise ValueError("ShardedHilbertCoreset.__init__(): this rank holds %d projected rows, its solver shard %d"
+                             % (int(vecs.shape[0]), self.snnls.n_local))
         if self.snnls.n_local:
             self.snnls.load_local(vecs, center=fold)
         rc = self.snnls.finalize(None)                     # b = column sums over all shards (hilbert.py:24)
@@ -85,6 +89,8 @@ class ShardedHilbertCoreset(Coreset):
         import torch.distributed as dist
         is_t = isinstance(vecs, torch.Tensor)
         v = vecs if is_t else torch.from_numpy(np.ascontiguousarray(vecs, dtype=np.float64))
+        if world > 1 and v.device.type == "cpu" and dist.get_backend(self.group) == "nccl":
+            v = v.to(torch.device("cuda", torch.cuda.current_device()))     # RCCL moves device tensors only
         keep = (v * v).sum(dim=1) > 0.0
         v, mine = v[keep], mine[keep.cpu().numpy()]
         if world == 1:

@@ -166,6 +166,9 @@ class DeviceSparseNNLS(SparseNNLS):
             raise NotImplementedError("DeviceSparseNNLS is abstract; use GIGA, FrankWolfe or OrthoPursuit")
         kind, rows = _as_row_matrix(A)
         self._N, self._d = int(rows.shape[0]), int(rows.shape[1])
+        if self._d > nat.MAX_ROW_LENGTH:
+            raise ValueError(self.alg_name + ".__init__(): vectors of length %d exceed the engine's row-length limit of %d "
+                             "(BCX_MAX_ROW_LENGTH, include/bcx.h); reduce the projection dimension" % (self._d, nat.MAX_ROW_LENGTH))
         dt = str(dtype)
         store = nat.F64 if dt in ("float64", "f64", "double") else (nat.F16 if dt in ("float16", "f16", "half") else nat.F32)
         eng = nat.Engine(self._ALG, self._N, self._d, device=device, store_dtype=store,

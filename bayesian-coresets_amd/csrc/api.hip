@@ -6,6 +6,10 @@
 #include "bcx_internal.h"
 
 static thread_local std::string g_create_err;
+namespace {   // pinned upload buffers, one pair per device (defined with the upload code below)
+void bounce_acquire(int device);
+void bounce_release(int device);
+}
 
 extern "C" const char* bcx_version(void) { return "bcx 0.1 gfx950"; }
 
@@ -47,7 +51,7 @@ extern "C" int bcx_create(const bcx_config* cfg, bcx_solver** out) {
     return BCX_ERR_ARG;
   }
   const int maxd = BCX_MAX_D;
-  if (cfg->d > maxd) { g_create_err = "bcx_create: d exceeds the supported row length"; return BCX_ERR_ARG; }
+  if (cfg->d > maxd) { g_create_err = "bcx_create: d exceeds the supported row length (" + std::to_string(maxd) + ")"; return BCX_ERR_ARG; }
   if (cfg->n_local >= (int64_t)0x7fffffff) { g_create_err = "bcx_create: n_local must be < 2^31 per shard"; return BCX_ERR_ARG; }
   if (cfg->row_offset % BCX_CHUNK_ROWS != 0) {
     g_create_err = "bcx_create: row_offset must be a multiple of the chunk size (1024 rows)";
@@ -82,6 +86,7 @@ extern "C" int bcx_create(const bcx_config* cfg, bcx_solver** out) {
   chk(dev_alloc((char**)&s->partials, (size_t)bcx_scan_grid(s) * BCX_PARTIAL_BYTES));
   chk(dev_alloc(&s->rec_local, (size_t)(d + BCX_REC_HDR)));
   if (!ok) { free_all(s); delete s; return BCX_ERR_NOMEM; }
+  bounce_acquire(cfg->device);
   *out = s;
   return BCX_OK;
 }
@@ -91,6 +96,7 @@ extern "C" int bcx_destroy(bcx_solver* s) {
   (void)hipSetDevice(s->cfg.device);
   (void)hipDeviceSynchronize();
   free_all(s);
+  bounce_release(s->cfg.device);
   delete s;
   return BCX_OK;
 }
@@ -114,11 +120,31 @@ static int read_state(bcx_solver* s, DevState* h);
 #include <thread>
 namespace {
 constexpr size_t kBounceBytes = (size_t)32 << 20;
+constexpr int kMaxDevices = 64;
+// One pair of pinned buffers and one lock PER DEVICE: uploads to different GPUs of one process run side by side (round 2
+// had a single process-wide pair: solvers on different devices queued behind each other); the pair is freed when the
+// last solver of its device is destroyed.
 struct Bounce {
   std::mutex mu;
   void* buf[2] = {nullptr, nullptr};
+  int users = 0;
 };
-Bounce g_bounce;
+Bounce g_bounce[kMaxDevices];
+Bounce& bounce_of(int device) { return g_bounce[(device >= 0 && device < kMaxDevices) ? device : 0]; }
+void bounce_acquire(int device) {
+  Bounce& b = bounce_of(device);
+  std::lock_guard<std::mutex> lock(b.mu);
+  b.users += 1;
+}
+void bounce_release(int device) {
+  Bounce& b = bounce_of(device);
+  std::lock_guard<std::mutex> lock(b.mu);
+  if (--b.users <= 0) {
+    b.users = 0;
+    for (int i = 0; i < 2; ++i)
+      if (b.buf[i]) { (void)hipHostFree(b.buf[i]); b.buf[i] = nullptr; }
+  }
+}
 
 void copy_rows_mt(char* dst, size_t dpitch, const char* src, size_t spitch, size_t width, int64_t rows) {
   const size_t bytes = (size_t)rows * width;
@@ -144,9 +170,10 @@ void copy_rows_mt(char* dst, size_t dpitch, const char* src, size_t spitch, size
 static int upload_host_rows(bcx_solver* s, void* dst_dev, size_t dpitch, const void* src, size_t spitch, size_t width,
                             int64_t rows) {
   if (rows <= 0) return BCX_OK;
-  std::lock_guard<std::mutex> lock(g_bounce.mu);
+  Bounce& g_b = bounce_of(s->cfg.device);
+  std::lock_guard<std::mutex> lock(g_b.mu);
   for (int i = 0; i < 2; ++i)
-    if (!g_bounce.buf[i]) BCX_HIP(hipHostMalloc(&g_bounce.buf[i], kBounceBytes, hipHostMallocPortable));
+    if (!g_b.buf[i]) BCX_HIP(hipHostMalloc(&g_b.buf[i], kBounceBytes, hipHostMallocPortable));
   if (width > kBounceBytes) { s->err = "bcx_load_rows: a row exceeds the upload buffer"; return BCX_ERR_ARG; }
   hipEvent_t done[2] = {nullptr, nullptr};     // (per call: events belong to the device that is current now)
   bool busy[2] = {false, false};
@@ -167,14 +194,14 @@ static int upload_host_rows(bcx_solver* s, void* dst_dev, size_t dpitch, const v
       if (hipEventSynchronize(done[which]) != hipSuccess) { s->err = "upload: event wait failed"; rc = BCX_ERR_HIP; break; }
       busy[which] = false;
     }
-    copy_rows_mt((char*)g_bounce.buf[which], width, (const char*)src + (size_t)r * spitch, spitch, width, m);
-    hipError_t e = hipMemcpy2DAsync((char*)dst_dev + (size_t)r * dpitch, dpitch, g_bounce.buf[which], width, width, (size_t)m,
+    copy_rows_mt((char*)g_b.buf[which], width, (const char*)src + (size_t)r * spitch, spitch, width, m);
+    hipError_t e = hipMemcpy2DAsync((char*)dst_dev + (size_t)r * dpitch, dpitch, g_b.buf[which], width, width, (size_t)m,
                                     hipMemcpyHostToDevice, s->stream);
     if (e == hipSuccess) e = hipEventRecord(done[which], s->stream);
     if (e != hipSuccess) { s->err = std::string("upload: ") + hipGetErrorString(e); rc = BCX_ERR_HIP; break; }
     busy[which] = true;
   }
-  // the bounce buffers are shared by every solver of the process: leave them idle
+  // the bounce buffers are shared by every solver of the device: leave them idle
   for (int i = 0; i < 2; ++i) {
     if (busy[i]) (void)hipEventSynchronize(done[i]);
     (void)hipEventDestroy(done[i]);

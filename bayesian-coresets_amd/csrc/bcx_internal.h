@@ -13,7 +13,7 @@
 #define BCX_REC_HDR 4            // record header doubles: score, global index, norm, flags
 #define BCX_REC_VALID 1.0
 #define BCX_REC_OVERFLOW 2.0
-#define BCX_MAX_D 2048          // 5 LDS vectors of d doubles in the apply kernels
+#define BCX_MAX_D BCX_MAX_ROW_LENGTH   // include/bcx.h
 #define BCX_SCAN_THREADS 256
 #define BCX_APPLY_THREADS 256
 

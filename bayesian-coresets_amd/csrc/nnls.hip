@@ -987,12 +987,13 @@ int bcx_launch_apply_omp(bcx_solver* s, const double* recv_dev) {
     const int rc = bcx_launch_omp_lh(s, n);
     if (rc <= 0) return rc;
   }
-  if (old_fused && s->grid_counter && kub < OMPF_MAX_K) {
+  if (old_fused && s->grid_counter && kub < OMPF_MAX_K &&
+      (2 * (size_t)((kub + 1 + 63) / 64 * 64) + 3 * (size_t)((s->cfg.d + 63) / 64 * 64)) * 8 + (size_t)((kub + 1 + 63) / 64 * 64) * 4 <= 150 * 1024) {
     const int kcap = (int)((kub + 1 + 63) / 64 * 64);
     const int dpad = (s->cfg.d + 63) / 64 * 64;
     const size_t lds = (2 * (size_t)kcap + 3 * (size_t)dpad) * sizeof(double) + (size_t)kcap * sizeof(int);
     if (lds > s->omp_lds_allowed) {
-      const size_t mx = (2 * (size_t)OMPF_MAX_K + 3 * (size_t)BCX_MAX_D) * sizeof(double) + (size_t)OMPF_MAX_K * sizeof(int);
+      const size_t mx = 150 * 1024;
       BCX_HIP(hipFuncSetAttribute((const void*)omp_fused_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)mx));
       s->omp_lds_allowed = mx;
     }

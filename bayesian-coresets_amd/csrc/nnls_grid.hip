@@ -232,12 +232,9 @@ int bcx_launch_optimize_grid(bcx_solver* s, double tol, int k) {
   const int kcap = (k + 1 + 63) / 64 * 64;
   const int dpad = (s->cfg.d + 63) / 64 * 64;
   const size_t lds = (size_t)kcap * (4 * sizeof(double) + 3 * sizeof(int)) + (size_t)dpad * sizeof(double);
-  static bool allowed = false;
-  if (!allowed) {
-    BCX_HIP(hipFuncSetAttribute((const void*)optimize_grid_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                (int)((size_t)OPT_MAX_K * (4 * sizeof(double) + 3 * sizeof(int)) + (size_t)BCX_MAX_D * sizeof(double))));
-    allowed = true;
-  }
+  if (lds > 150 * 1024) return 1;      // (long rows with a large support: the single-workgroup kernel)
+  if (lds > 48 * 1024)
+    BCX_HIP(hipFuncSetAttribute((const void*)optimize_grid_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   GridSync gs;
   gs.counter = s->grid_counter;
   gs.base = 0;

@@ -40,6 +40,7 @@
 #include "grid_lh.h"
 
 #define OMPL_WGS 16
+#define OMPL_STAMP(st, i) do { if (blockIdx.x == 0) BCX_STAMP(st, i); } while (0)
 #define OMPL_LDS_MAX (150 * 1024)
 #ifdef BCX_TIMING
 // dev builds: one record per step (tools/omp_hist.py)
@@ -158,17 +159,25 @@ static __device__ void ompl_border_apply(const NnlsArgs& n, const OmpLds& L, int
 }
 
 // Position q leaves the passive set: closed-form update of the carried solution z, rank-1 downdate of H (double-double),
-// the last position moves into the hole (z, the feasible point xs and the lists move with it).  1-2 barriers.
+// the last position moves into the hole (z, the feasible point xs and the lists move with it).  ONE barrier: the owners
+// publish row q and the not yet downdated row `last` together, every workgroup downdates its copy of the latter itself.
 static __device__ void ompl_remove(const NnlsArgs& n, const OmpLds& L, int& p, int q, Grid& G) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = blockDim.x >> 6;
   const int64_t ld = n.ldg;
   const int last = p - 1;
   double* Xh = xbuf(n, G);
   double* Xl = xbuf(n, G);
+  double* Yh = xbuf(n, G);
+  double* Yl = xbuf(n, G);
   if (owns_row(q)) {                                // row q == column q (symmetric): its owner publishes it
     const double* hh = n.hinv + (size_t)q * ld;
     const double* hl = n.hlo + (size_t)q * ld;
     for (int cc = lane; cc < p; cc += 64) { xst(&Xh[cc], hh[cc]); xst(&Xl[cc], hl[cc]); }
+  }
+  if (q != last && owns_row(last)) {
+    const double* hh = n.hinv + (size_t)last * ld;
+    const double* hl = n.hlo + (size_t)last * ld;
+    for (int cc = lane; cc < p; cc += 64) { xst(&Yh[cc], hh[cc]); xst(&Yl[cc], hl[cc]); }
   }
   gsync(G);
   for (int a = tid; a < p; a += blockDim.x) { L.g[a] = xld(&Xh[a]); L.gl[a] = xld(&Xl[a]); }   // h = H[:, q] (g is free by now)
@@ -176,45 +185,44 @@ static __device__ void ompl_remove(const NnlsArgs& n, const OmpLds& L, int& p, i
   const dd hqq = dd_make(L.g[q], L.gl[q]);
   const dd iq = dd_recip(hqq);
   const double f = L.z[q] / hqq.h;
+  if (q != last) {
+    // the downdated row `last` (what moves into the hole), formed by everybody from the two published rows
+    const dd fl = dd_mul(dd_make(L.g[last], L.gl[last]), iq);
+    for (int a = tid; a < p; a += blockDim.x) {
+      const dd v = dd_add(dd_make(xld(&Yh[a]), xld(&Yl[a])), dd_neg(dd_mul(fl, dd_make(L.g[a], L.gl[a]))));
+      L.u[a] = v.h; L.ul[a] = v.l;
+    }
+  }
   for (int a = tid; a < p; a += blockDim.x) L.z[a] -= f * L.g[a];    // least-squares solution on P \ {q}
-  for (int rr = blockIdx.x * nw + wave; rr < p; rr += gridDim.x * nw) {
-    const dd fr = dd_mul(dd_make(L.g[rr], L.gl[rr]), iq);
+  __syncthreads();
+  for (int rr = blockIdx.x * nw + wave; rr < last; rr += gridDim.x * nw) {
+    // rows that stay: downdate; row q takes the downdated row `last`, column q of every row its entry of it
     double* hh = n.hinv + (size_t)rr * ld;
     double* hl = n.hlo + (size_t)rr * ld;
-    for (int cc = lane; cc < p; cc += 64) {
-      const dd v = dd_add(dd_make(hh[cc], hl[cc]), dd_neg(dd_mul(fr, dd_make(L.g[cc], L.gl[cc]))));
-      hh[cc] = v.h; hl[cc] = v.l;
+    if (rr == q) {
+      for (int cc = lane; cc < last; cc += 64) {
+        const int src = cc == q ? last : cc;
+        hh[cc] = L.u[src]; hl[cc] = L.ul[src];
+      }
+    } else {
+      const dd fr = dd_mul(dd_make(L.g[rr], L.gl[rr]), iq);
+      for (int cc = lane; cc < last; cc += 64) {
+        if (cc == q && q != last) { hh[cc] = L.u[rr]; hl[cc] = L.ul[rr]; continue; }
+        const dd v = dd_add(dd_make(hh[cc], hl[cc]), dd_neg(dd_mul(fr, dd_make(L.g[cc], L.gl[cc]))));
+        hh[cc] = v.h; hl[cc] = v.l;
+      }
     }
   }
   const int gone = L.cs[q];
-  if (q != last) {
-    double* Yh = xbuf(n, G);
-    double* Yl = xbuf(n, G);
-    if (owns_row(last)) {                           // (the same wave just finished the downdate of this row)
-      const double* hh = n.hinv + (size_t)last * ld;
-      const double* hl = n.hlo + (size_t)last * ld;
-      for (int cc = lane; cc < p; cc += 64) { xst(&Yh[cc], hh[cc]); xst(&Yl[cc], hl[cc]); }
-    }
-    gsync(G);
-    for (int a = tid; a < p; a += blockDim.x) { L.u[a] = xld(&Yh[a]); L.ul[a] = xld(&Yl[a]); }
-    __syncthreads();
-    for (int rr = blockIdx.x * nw + wave; rr < last; rr += gridDim.x * nw)   // column q of the rows this wave owns
-      if (rr != q && lane == 0) { n.hinv[(size_t)rr * ld + q] = L.u[rr]; n.hlo[(size_t)rr * ld + q] = L.ul[rr]; }
-    if (owns_row(q)) {
-      double* hh = n.hinv + (size_t)q * ld;
-      double* hl = n.hlo + (size_t)q * ld;
-      for (int cc = lane; cc < last; cc += 64) if (cc != q) { hh[cc] = L.u[cc]; hl[cc] = L.ul[cc]; }
-      if (lane == 0) { hh[q] = L.u[last]; hl[q] = L.ul[last]; }
-    }
-    __syncthreads();
-    if (tid == 0) {
+  __syncthreads();
+  if (tid == 0) {
+    if (q != last) {
       const int moved = L.cs[last];
       L.cs[q] = moved; L.pos[moved] = q;
       L.z[q] = L.z[last]; L.xs[q] = L.xs[last];
     }
+    L.pos[gone] = -1; L.x[gone] = 0.0;
   }
-  __syncthreads();
-  if (tid == 0) { L.pos[gone] = -1; L.x[gone] = 0.0; }
   p = last;
   __syncthreads();
 }
@@ -291,7 +299,7 @@ __global__ __launch_bounds__(NN_THREADS) void omp_lh_kernel(NnlsArgs n, GridSync
   __shared__ long long w_i[NN_THREADS / 64];
   __shared__ int w_s[NN_THREADS / 64], w_np[NN_THREADS / 64], w_m[NN_THREADS / 64];
   __shared__ int s_win, s_ovf, s_flag;
-  BCX_STAMP(st, 0);
+  OMPL_STAMP(st, 0);
   if (tid == 0) { int o; s_win = omp_pick_record(a, &o); s_ovf = o; }
   __syncthreads();
   if (s_ovf || s_win < 0) {
@@ -315,7 +323,6 @@ __global__ __launch_bounds__(NN_THREADS) void omp_lh_kernel(NnlsArgs n, GridSync
     L.fl[j] = 0;
   }
   __syncthreads();
-  BCX_STAMP(st, 12);
   Rep R;
   R.t0 = L.g; R.t1 = L.u; R.x = L.x; R.z = L.z; R.rv = L.qs; R.cs = L.cs; R.pos = L.pos; R.fl = L.fl;
   bool resolve = force_resolve != 0;
@@ -337,7 +344,6 @@ __global__ __launch_bounds__(NN_THREADS) void omp_lh_kernel(NnlsArgs n, GridSync
     a1 = wave_allsum(a1);
     if (lane == 0) { xst(&T3[j], a0); xst(&T2[j], a1); }
   }
-  BCX_STAMP(st, 13);
   // a stale passive set (a reverted step, a rejected optimize()): P = {slots with weight > 0}, H by successive bordering
   if (!hvalid0) {
     p = 0;
@@ -355,9 +361,9 @@ __global__ __launch_bounds__(NN_THREADS) void omp_lh_kernel(NnlsArgs n, GridSync
     for (int rr = wg * nw + wave; rr < p; rr += nwg * nw)
       for (int cc = lane; cc < p; cc += 64) n.hlo[(size_t)rr * n.ldg + cc] = 0.0;
   }
-  BCX_STAMP(st, 1);
+  OMPL_STAMP(st, 1);
   gsync(G);                                                                                   // ---- B1
-  BCX_STAMP(st, 2);
+  OMPL_STAMP(st, 2);
   // ---- decide (every workgroup, one pass over the slots) -----------------------------------------------------------------
   const int64_t fpos = (int64_t)rec[1];
   const double nf = rec[2];
@@ -424,7 +430,7 @@ __global__ __launch_bounds__(NN_THREADS) void omp_lh_kernel(NnlsArgs n, GridSync
       n.cvec[slot] = cf;
     }
   }
-  BCX_STAMP(st, 3);
+  OMPL_STAMP(st, 3);
   int n_removed = 0, n_entered = 0, did_resolve = 0;
   if (!done) {
     // members of the call's active set S = P u {f}
@@ -440,9 +446,9 @@ __global__ __launch_bounds__(NN_THREADS) void omp_lh_kernel(NnlsArgs n, GridSync
     double* Ul = xbuf(n, G);
     double* DZ = xbuf(n, G);
     ompl_mv_rows(n, p, L.g, L.xs, Uh, Ul, DZ);
-    BCX_STAMP(st, 4);
+    OMPL_STAMP(st, 4);
     gsync(G);                                                                                 // ---- B2
-    BCX_STAMP(st, 5);
+    OMPL_STAMP(st, 5);
     // ---- the carried solution: z = x on P, feasible point xs = x; drift check ---------------------------------------------
     double cm = 0.0, xm = 0.0;
     for (int q = tid; q < p; q += blockDim.x) {
@@ -455,8 +461,7 @@ __global__ __launch_bounds__(NN_THREADS) void omp_lh_kernel(NnlsArgs n, GridSync
     cm = block_allmax(cm, scratch);
     xm = block_allmax(xm, scratch);
     if (!(cm <= 1e-4 * xm) && p > 0) resolve = true;      // H no longer a good inverse of G_PP (NaN fails the '<=' too)
-    BCX_STAMP(st, 14);
-    int cand = slot, n_out = 1;
+      int cand = slot, n_out = 1;
     bool have_u = true;
     if (resolve && p > 0) {
       // from scratch on P: z = H c_P refined in data space until the gradient is at rounding level (as optimize() does),
@@ -504,7 +509,6 @@ __global__ __launch_bounds__(NN_THREADS) void omp_lh_kernel(NnlsArgs n, GridSync
       const double ncand = cand == slot ? nslot : a.act_norm[cand];
       const dd sc = dd_add(dd_make(gcc, 0.0), dd_neg(gu));
       const double wv = ccand - r1[0];
-      if (outer == 0) BCX_STAMP(st, 15);
       bool entered = false;
       if (!(wv > tolscale * ncand)) {
         // dual not positive: the column stays at weight 0 (and no other candidate can have a larger dual: it was the arg-max)
@@ -525,12 +529,10 @@ __global__ __launch_bounds__(NN_THREADS) void omp_lh_kernel(NnlsArgs n, GridSync
         entered = true;
         __syncthreads();
       }
-      if (outer == 0) BCX_STAMP(st, 16);
       if (cand < 0) break;                                // nothing entered, nothing can leave: x stays as it is, bit for bit
       n_removed += ompl_inner(n, L, p, entered ? cand : -1, 3 * k1 + 16, n_out, G, scratch);
       for (int q = tid; q < p; q += blockDim.x) { L.xs[q] = L.x[L.cs[q]]; L.z[q] = L.xs[q]; }
       __syncthreads();
-      if (outer == 0) BCX_STAMP(st, 17);
       // next candidate: the member of S without weight that has the largest positive dual (only columns that left in this
       // call can qualify); duals c_j - G[j, P] x are formed by every workgroup, one wave per candidate
       cand = -1;
@@ -561,7 +563,7 @@ __global__ __launch_bounds__(NN_THREADS) void omp_lh_kernel(NnlsArgs n, GridSync
       cand = pick.i;
     }
   }
-  BCX_STAMP(st, 6);
+  OMPL_STAMP(st, 6);
   // ---- xw' = sum_P x_j row_j on 64-column blocks ------------------------------------------------------------------------
   for (int q = tid; q < p; q += blockDim.x) L.z[q] = L.x[L.cs[q]];
   __syncthreads();
@@ -589,10 +591,10 @@ __global__ __launch_bounds__(NN_THREADS) void omp_lh_kernel(NnlsArgs n, GridSync
     }
     __syncthreads();
   }
-  BCX_STAMP(st, 7);
+  OMPL_STAMP(st, 7);
   if (wg != 0) { if (G.ok) grid_arrive(G.gs, 1); return; }
   gsync(G);                                                                                   // ---- last barrier
-  BCX_STAMP(st, 8);
+  OMPL_STAMP(st, 8);
   if (!G.ok) { if (tid == 0) { st->active = 0; st->halt = HALT_GRID_TIMEOUT; st->hvalid = 0; } return; }
   // ---- workgroup 0: error, monotone check, commit or revert, trace, next query ----------------------------------------------
   double v[2] = {0.0, 0.0};
@@ -646,24 +648,19 @@ __global__ __launch_bounds__(NN_THREADS) void omp_lh_kernel(NnlsArgs n, GridSync
     }
   }
   __syncthreads();
-  BCX_STAMP(st, 9);
+  OMPL_STAMP(st, 9);
 #ifdef BCX_TIMING
   const int64_t log_it = st->it - 1;
 #endif
   if (st->active) prepare_next(a, scratch);
-  BCX_STAMP(st, 10);
+  OMPL_STAMP(st, 10);
 #ifdef BCX_TIMING
   __syncthreads();
   if (tid == 0 && log_it >= 0 && log_it < 4096) {
     long long* Lg = g_omp_log[log_it];
     Lg[0] = log_it; Lg[1] = k; Lg[2] = st->np; Lg[3] = done ? 1 : 2; Lg[4] = did_resolve ? 4 : 3; Lg[5] = status; Lg[6] = st->np; Lg[7] = G.bi;
     for (int i = 0; i < 12; ++i) Lg[8 + i] = i <= 10 ? st->dbg_t[i] - st->dbg_t[0] : 0;
-    // finer stamps, packed: init | rows loop | B2 -> monitor | -> Schur scalars | -> bordered | -> inner loop   (ticks, 3 digits each)
-    long long pk = 0;
-    const int seq[7] = {0, 12, 13, 5, 14, 15, 16};
-    for (int i = 1; i < 7; ++i) { long long dt = st->dbg_t[seq[i]] - st->dbg_t[seq[i - 1]]; if (i == 3) dt = 0; pk = pk * 10000 + (dt < 0 ? 0 : (dt > 9999 ? 9999 : dt)); }
-    Lg[19] = pk;
-    Lg[20] = n_entered; Lg[21] = n_removed; Lg[22] = (st->dbg_t[17] - st->dbg_t[16]); Lg[23] = G.bi;
+    Lg[19] = blockDim.x; Lg[20] = n_entered; Lg[21] = n_removed; Lg[22] = did_resolve; Lg[23] = G.bi;
   }
 #endif
 }
@@ -685,7 +682,13 @@ int bcx_launch_omp_lh(bcx_solver* s, NnlsArgs& n) {
   gs.timeout_ticks = 1000000000LL;     // 10 s
   s->grid_epoch += 1;
   const int fr = (force > 0 && (s->grid_epoch % force) == 0) ? 1 : 0;
-  hipLaunchKernelGGL(omp_lh_kernel, dim3(OMPL_WGS), dim3(NN_THREADS), lds, s->stream, n, gs, s->grid_counter + 1, kcap, dpad, fr);
+  // Workgroup width.  The step is a chain of short latency-bound phases separated by workgroup barriers and block
+  // reductions, whose cost grows with the number of waves; the parallel work (one wave per slot row / per row of H) is
+  // 16 workgroups x waves.  Measured on the configs[2] vectors (tools/omp_hist.py, k <= 140): closed-form step 43.6 us
+  // with 1024 threads, 30.2 with 512, 28.8 with 256.  Wider workgroups once a wave would own more than ~3 rows.
+  static const int forced_threads = getenv("BCX_OMP_THREADS") ? atoi(getenv("BCX_OMP_THREADS")) : 0;   // dev: 256 / 512 / 1024
+  const int threads = forced_threads ? forced_threads : (kub <= 192 ? 256 : (kub <= 448 ? 512 : NN_THREADS));
+  hipLaunchKernelGGL(omp_lh_kernel, dim3(OMPL_WGS), dim3(threads), lds, s->stream, n, gs, s->grid_counter + 1, kcap, dpad, fr);
   BCX_HIP(hipGetLastError());
   return BCX_OK;
 }

@@ -12,6 +12,7 @@
 //   SELECT  : per row  corr_n = vecs[n].resid / ||vecs[n]|| / S  and its arg-max   (sparsevi.py:44-55)
 // Arithmetic is fp64 throughout (the selection compares correlations to ~1e-7).
 #include <algorithm>
+#include <atomic>
 #include <cstdlib>
 #include <string>
 #include <utility>
@@ -782,12 +783,16 @@ extern "C" const char* bcx_project_last_error(void) { return g_proj_err.c_str();
 // Persistent launch: as many workgroups as are resident at once (2 per CU: 64 KiB of staging LDS each), every one
 // striding over the 128-row blocks -- with more workgroups than that the last wave of blocks leaves most CUs idle.
 static int proj_grid(int64_t N) {
-  static int resident = 0;
+  // resident workgroups of the CURRENT device (looked up per device id, once; races write the same value)
+  static std::atomic<int> resident_of[64];
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+  int resident = resident_of[dev].load(std::memory_order_relaxed);
   if (!resident) {
-    int dev = 0, cus = 0;
-    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
-      cus = 256;
+    int cus = 0;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
     resident = std::min(2 * cus, 2048);
+    resident_of[dev].store(resident, std::memory_order_relaxed);
   }
   const int64_t blocks = (N + PJ_ROWS - 1) / PJ_ROWS;
   return (int)std::max<int64_t>(1, std::min<int64_t>(blocks, resident));

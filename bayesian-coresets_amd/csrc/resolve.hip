@@ -193,6 +193,11 @@ struct StateVecs {   // LDS copies, d doubles each
   double *xw, *b, *bn, *xf, *tx;
 };
 
+// BIG (5 d doubles beyond the LDS budget, d > BCX_LDS_VEC_MAX_D): the five vectors live in the solver's global scratch
+// (a.tmp + 8 d ...) instead -- one workgroup on one CU: its waves share the L1, and __syncthreads() orders the accesses
+template <bool BIG> static __device__ __forceinline__ double* vec_base(const ApplyArgs& a, double* dyn) {
+  return BIG ? a.tmp + 8 * (size_t)a.d : dyn;
+}
 static __device__ __forceinline__ StateVecs carve(double* dyn, int d) {
   StateVecs v;
   v.xw = dyn; v.b = dyn + d; v.bn = dyn + 2 * (size_t)d; v.xf = dyn + 3 * (size_t)d; v.tx = dyn + 4 * (size_t)d;
@@ -420,14 +425,14 @@ __global__ __launch_bounds__(256) void resolve_kernel(ResolveArgs a) {
   resolve_core(a, &win, nullptr, scratch);
 }
 
-template <int ALG>
+template <int ALG, bool BIG>
 __global__ __launch_bounds__(BCX_APPLY_THREADS) void apply_kernel(ApplyArgs a) {
   DevState* st = a.st;
   if (!st->active) return;
   extern __shared__ double dyn[];
   __shared__ double scratch[BCX_SCRATCH];
   __shared__ int s_win, s_overflow;
-  const StateVecs v = carve(dyn, a.d);
+  const StateVecs v = carve(vec_base<BIG>(a, dyn), a.d);
   const SlotPre pre = slot_prefetch(a);
   stage_state(a, v);
   const int tid = threadIdx.x, d = a.d;
@@ -456,7 +461,7 @@ __global__ __launch_bounds__(BCX_APPLY_THREADS) void apply_kernel(ApplyArgs a) {
 }
 
 // single shard: resolve + apply in one launch
-template <int ALG>
+template <int ALG, bool BIG>
 __global__ __launch_bounds__(BCX_APPLY_THREADS) void tail_kernel(ResolveArgs r, ApplyArgs a) {
   DevState* st = a.st;
   if (!st->active) return;
@@ -464,7 +469,7 @@ __global__ __launch_bounds__(BCX_APPLY_THREADS) void tail_kernel(ResolveArgs r, 
   __shared__ double scratch[BCX_SCRATCH];
   __shared__ Winner win;
   BCX_STAMP(st, 0);
-  const StateVecs v = carve(dyn, a.d);
+  const StateVecs v = carve(vec_base<BIG>(a, dyn), a.d);
   const SlotPre pre = slot_prefetch(a);
   stage_state(a, v);
   resolve_core(r, &win, v.xf, scratch);
@@ -546,7 +551,7 @@ static __device__ int pick_record(const double* recs, int world, int recw, int* 
 }
 
 // row-sharded GIGA / FW iteration tail in one launch: resolve, exchange records with the peers, apply
-template <int ALG>
+template <int ALG, bool BIG>
 __global__ __launch_bounds__(BCX_APPLY_THREADS) void tail_exchange_kernel(ResolveArgs r, ApplyArgs a, Mailbox m) {
   DevState* st = a.st;
   if (!st->active) return;
@@ -556,7 +561,7 @@ __global__ __launch_bounds__(BCX_APPLY_THREADS) void tail_exchange_kernel(Resolv
   __shared__ double s_hdr[BCX_REC_HDR];
   __shared__ int s_flag, s_win, s_overflow;
   const int tid = threadIdx.x;
-  const StateVecs v = carve(dyn, a.d);
+  const StateVecs v = carve(vec_base<BIG>(a, dyn), a.d);
   const SlotPre pre = slot_prefetch(a);
   stage_state(a, v);
   resolve_core(r, &win, v.xf, scratch);
@@ -662,7 +667,9 @@ static void fill_resolve_args(bcx_solver* s, ResolveArgs& a, double* send_dev, i
   a.rec = send_dev;
 }
 
-static size_t vec_lds_bytes(const bcx_solver* s) { return 5 * (size_t)s->cfg.d * sizeof(double); }
+#define BCX_LDS_VEC_MAX_D 3584    // 5 d doubles = 140 KiB of the CU's 160 KiB
+static bool vec_big(const bcx_solver* s) { return s->cfg.d > BCX_LDS_VEC_MAX_D; }
+static size_t vec_lds_bytes(const bcx_solver* s) { return vec_big(s) ? 0 : 5 * (size_t)s->cfg.d * sizeof(double); }
 
 template <typename K> static int allow_lds(bcx_solver* s, K kfn, size_t bytes) {
   if (bytes > 48 * 1024) BCX_HIP(hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
@@ -700,11 +707,17 @@ int bcx_launch_apply(bcx_solver* s, const double* recv_dev) {
   const size_t lds = vec_lds_bytes(s);
   int rc;
   if (s->cfg.alg == BCX_ALG_GIGA) {
-    if ((rc = allow_lds(s, apply_kernel<BCX_ALG_GIGA>, lds))) return rc;
-    hipLaunchKernelGGL((apply_kernel<BCX_ALG_GIGA>), dim3(1), dim3(BCX_APPLY_THREADS), lds, s->stream, a);
+    if (vec_big(s)) hipLaunchKernelGGL((apply_kernel<BCX_ALG_GIGA, true>), dim3(1), dim3(BCX_APPLY_THREADS), 0, s->stream, a);
+    else {
+      if ((rc = allow_lds(s, apply_kernel<BCX_ALG_GIGA, false>, lds))) return rc;
+      hipLaunchKernelGGL((apply_kernel<BCX_ALG_GIGA, false>), dim3(1), dim3(BCX_APPLY_THREADS), lds, s->stream, a);
+    }
   } else {
-    if ((rc = allow_lds(s, apply_kernel<BCX_ALG_FW>, lds))) return rc;
-    hipLaunchKernelGGL((apply_kernel<BCX_ALG_FW>), dim3(1), dim3(BCX_APPLY_THREADS), lds, s->stream, a);
+    if (vec_big(s)) hipLaunchKernelGGL((apply_kernel<BCX_ALG_FW, true>), dim3(1), dim3(BCX_APPLY_THREADS), 0, s->stream, a);
+    else {
+      if ((rc = allow_lds(s, apply_kernel<BCX_ALG_FW, false>, lds))) return rc;
+      hipLaunchKernelGGL((apply_kernel<BCX_ALG_FW, false>), dim3(1), dim3(BCX_APPLY_THREADS), lds, s->stream, a);
+    }
   }
   BCX_HIP(hipGetLastError());
   return BCX_OK;
@@ -720,11 +733,17 @@ int bcx_launch_tail(bcx_solver* s, int exact) {
   const size_t lds = vec_lds_bytes(s);
   int rc;
   if (s->cfg.alg == BCX_ALG_GIGA) {
-    if ((rc = allow_lds(s, tail_kernel<BCX_ALG_GIGA>, lds))) return rc;
-    hipLaunchKernelGGL((tail_kernel<BCX_ALG_GIGA>), dim3(1), dim3(BCX_APPLY_THREADS), lds, s->stream, r, a);
+    if (vec_big(s)) hipLaunchKernelGGL((tail_kernel<BCX_ALG_GIGA, true>), dim3(1), dim3(BCX_APPLY_THREADS), 0, s->stream, r, a);
+    else {
+      if ((rc = allow_lds(s, tail_kernel<BCX_ALG_GIGA, false>, lds))) return rc;
+      hipLaunchKernelGGL((tail_kernel<BCX_ALG_GIGA, false>), dim3(1), dim3(BCX_APPLY_THREADS), lds, s->stream, r, a);
+    }
   } else {
-    if ((rc = allow_lds(s, tail_kernel<BCX_ALG_FW>, lds))) return rc;
-    hipLaunchKernelGGL((tail_kernel<BCX_ALG_FW>), dim3(1), dim3(BCX_APPLY_THREADS), lds, s->stream, r, a);
+    if (vec_big(s)) hipLaunchKernelGGL((tail_kernel<BCX_ALG_FW, true>), dim3(1), dim3(BCX_APPLY_THREADS), 0, s->stream, r, a);
+    else {
+      if ((rc = allow_lds(s, tail_kernel<BCX_ALG_FW, false>, lds))) return rc;
+      hipLaunchKernelGGL((tail_kernel<BCX_ALG_FW, false>), dim3(1), dim3(BCX_APPLY_THREADS), lds, s->stream, r, a);
+    }
   }
   BCX_HIP(hipGetLastError());
   return BCX_OK;
@@ -752,6 +771,7 @@ int bcx_launch_tail_exchange(bcx_solver* s, int exact) {
   int rc;
   if (s->cfg.alg == BCX_ALG_OMP) {
     const size_t lds = (size_t)s->cfg.d * sizeof(double);
+    if ((rc = allow_lds(s, resolve_exchange_kernel, lds))) return rc;
     hipLaunchKernelGGL(resolve_exchange_kernel, dim3(1), dim3(BCX_APPLY_THREADS), lds, s->stream, r, m, s->rec_gather);
     BCX_HIP(hipGetLastError());
     return bcx_launch_apply_omp(s, s->rec_gather);
@@ -760,11 +780,17 @@ int bcx_launch_tail_exchange(bcx_solver* s, int exact) {
   fill_apply_args(s, a, nullptr);
   const size_t lds = vec_lds_bytes(s);
   if (s->cfg.alg == BCX_ALG_GIGA) {
-    if ((rc = allow_lds(s, tail_exchange_kernel<BCX_ALG_GIGA>, lds))) return rc;
-    hipLaunchKernelGGL((tail_exchange_kernel<BCX_ALG_GIGA>), dim3(1), dim3(BCX_APPLY_THREADS), lds, s->stream, r, a, m);
+    if (vec_big(s)) hipLaunchKernelGGL((tail_exchange_kernel<BCX_ALG_GIGA, true>), dim3(1), dim3(BCX_APPLY_THREADS), 0, s->stream, r, a, m);
+    else {
+      if ((rc = allow_lds(s, tail_exchange_kernel<BCX_ALG_GIGA, false>, lds))) return rc;
+      hipLaunchKernelGGL((tail_exchange_kernel<BCX_ALG_GIGA, false>), dim3(1), dim3(BCX_APPLY_THREADS), lds, s->stream, r, a, m);
+    }
   } else {
-    if ((rc = allow_lds(s, tail_exchange_kernel<BCX_ALG_FW>, lds))) return rc;
-    hipLaunchKernelGGL((tail_exchange_kernel<BCX_ALG_FW>), dim3(1), dim3(BCX_APPLY_THREADS), lds, s->stream, r, a, m);
+    if (vec_big(s)) hipLaunchKernelGGL((tail_exchange_kernel<BCX_ALG_FW, true>), dim3(1), dim3(BCX_APPLY_THREADS), 0, s->stream, r, a, m);
+    else {
+      if ((rc = allow_lds(s, tail_exchange_kernel<BCX_ALG_FW, false>, lds))) return rc;
+      hipLaunchKernelGGL((tail_exchange_kernel<BCX_ALG_FW, false>), dim3(1), dim3(BCX_APPLY_THREADS), lds, s->stream, r, a, m);
+    }
   }
   BCX_HIP(hipGetLastError());
   return BCX_OK;
@@ -772,6 +798,8 @@ int bcx_launch_tail_exchange(bcx_solver* s, int exact) {
 
 int bcx_launch_exchange_probe(bcx_solver* s) {
   const Mailbox m = bcx_mailbox(s);
+  int rc;
+  if ((rc = allow_lds(s, exchange_probe_kernel, (size_t)s->cfg.d * sizeof(double)))) return rc;
   hipLaunchKernelGGL(exchange_probe_kernel, dim3(1), dim3(BCX_APPLY_THREADS), (size_t)s->cfg.d * sizeof(double), s->stream, m);
   BCX_HIP(hipGetLastError());
   return BCX_OK;

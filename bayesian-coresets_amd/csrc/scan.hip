@@ -377,6 +377,18 @@ __global__ __launch_bounds__(BCX_SCAN_THREADS) void scan_kernel(ScanArgs a) {
         const T s0 = reduce4_pack<G, T>(a0[0], a0[1], a0[2], a0[3]);
         const T s1 = DUAL ? reduce4_pack<G, T>(a1[0], a1[1], a1[2], a1[3]) : (T)0;
         const int64_t myrow = r0 + (int64_t)((g4 * 4 + myu) * WAVES + wave) * RPW + myrs;
+        if constexpr (sizeof(T) == 4 && DUAL && G < 64) {
+          // Short rows are VALU-bound on the interval arithmetic (two rsq, the slack terms and the top-2 update per row):
+          // once the lane group's best lower bound tr.L is positive, a row can only matter if its upper bound reaches it,
+          //   U = (s0 + e) / sqrt((1 - ah)(1 + ah)) >= tr.L   <=>   (s0 + e)^2 >= tr.L^2 (1 - ah)(1 + ah)   (s0 + e > 0),
+          // four multiplications and a compare.  A row below that can neither be a candidate (candidates reach the
+          // global max L >= tr.L) nor raise tr.L (its L <= U < tr.L) nor trip the overflow test (U3 >= max L): the wave
+          // skips interval and update when none of its rows passes (1e-5 head room for the roundings of the test itself).
+          const float hi = (float)s0 + (float)e, ah = fabsf((float)s1) + (float)e;
+          const float Lc = (float)tr.L;
+          const bool maybe = !(Lc > 0.0f) || !(ah < 1.0f) || (hi > 0.0f && hi * hi >= Lc * Lc * (1.0f - ah) * (1.0f + ah) * 0.99999f);
+          if (!__builtin_amdgcn_ballot_w64(maybe)) continue;
+        }
         T U, L;
         if constexpr (sizeof(T) == 4) {
           float Uf, Lf;
@@ -443,6 +455,101 @@ __global__ __launch_bounds__(BCX_SCAN_THREADS) void scan_kernel(ScanArgs a) {
     a.out.U1[b] = (double)r.U1; a.out.U2[b] = (double)r.U2; a.out.U3[b] = (double)r.U3; a.out.L[b] = (double)r.L;
     a.out.i1[b] = r.i1; a.out.i2[b] = r.i2;
   }
+}
+
+// ---- rows longer than 16 pieces per lane (nvec > 1024: d > 4096 floats / 2048 doubles) ----------------------------------
+// The query no longer fits the register file beside the loads, so it rests in LDS (16 bytes per piece and query) and a
+// wave walks ONE row in trips of 8 wave-wide loads (8 KiB of contiguous row data in flight per wave), multiplying each
+// piece with its query piece read from LDS; one wave-wide reduction, interval and arg-max update per row (at >= 64 KiB a
+// row that is noise).  Same scores to the last bit as the register form would give for the same row length?  No: the
+// summation order differs (trip by trip instead of chunk-major), which only matters to the interval's error coefficient
+// -- computed from the same chunk count -- and to exact-mode ties between different rows, which stay lowest-index-first.
+#define BCX_LONG_LCH 8
+template <typename ST, bool DUAL>
+__global__ __launch_bounds__(BCX_SCAN_THREADS) void scan_long_kernel(ScanArgs a) {
+  if (!a.st->active) return;
+  typedef typename Stor<ST>::V V;
+  typedef typename Stor<ST>::Q Q;
+  typedef typename Stor<ST>::T T;
+  constexpr int WAVES = BCX_SCAN_THREADS / 64;
+  extern __shared__ __attribute__((aligned(16))) unsigned char scan_qlds[];
+  Q* ql0 = (Q*)scan_qlds;
+  Q* ql1 = ql0 + a.nvec;
+  for (int v = threadIdx.x; v < a.nvec; v += blockDim.x) {
+    ql0[v] = load_q<ST>(a.q, v, true);
+    if (DUAL) ql1[v] = load_q<ST>(a.q, a.qstride + v, true);
+  }
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const T e = (T)(a.err_coef * (float)a.st->qscale);
+  Track<T> tr;
+  tr.U1 = tr.U2 = tr.U3 = tr.L = -INFINITY;
+  tr.i1 = tr.i2 = 0x7fffffff;
+  const V* base = (const V*)a.An;
+  const int64_t n = a.n;
+  const int nvec = a.nvec;
+  for (int64_t row = (int64_t)blockIdx.x * WAVES + wave; row < n; row += (int64_t)gridDim.x * WAVES) {
+    const V* p = base + row * a.ldv;
+    double nr = 1.0;
+    if constexpr (sizeof(T) == 8) { if (a.norms) nr = a.norms[row]; }
+    T s0 = 0, s1 = 0;
+    for (int v0 = 0; v0 < nvec; v0 += 64 * BCX_LONG_LCH) {
+      V x[BCX_LONG_LCH];
+#pragma unroll
+      for (int c = 0; c < BCX_LONG_LCH; ++c) {
+        const int v = v0 + c * 64 + lane;
+        x[c] = stream_load(p + (v < nvec ? v : 0));
+      }
+      __builtin_amdgcn_sched_barrier(0);       // all loads of the trip in flight before the first use
+#pragma unroll
+      for (int c = 0; c < BCX_LONG_LCH; ++c) {
+        const int v = v0 + c * 64 + lane;
+        if (v < nvec) {
+          if constexpr (sizeof(T) == 8) {
+            if (a.norms) { x[c].x /= nr; x[c].y /= nr; }     // raw fp64 rows: An = A / Anorms element by element (giga.py:13)
+          }
+          s0 = vdot(x[c], ql0[v], s0);
+          if (DUAL) s1 = vdot(x[c], ql1[v], s1);
+        }
+      }
+    }
+    s0 = group_allsum<T, 64>(s0);
+    if (DUAL) s1 = group_allsum<T, 64>(s1);
+    T U, L;
+    if (sizeof(T) == 4) {
+      if (DUAL) {
+        float Uf, Lf;
+        giga_interval((float)s0, (float)s1, (float)e, Uf, Lf);
+        U = Uf; L = Lf;
+      } else {
+        const T ee = e + fabsf((float)s0) * 2e-7f;
+        U = s0 + ee; L = s0 - ee;
+      }
+    } else {
+      U = L = DUAL ? (T)giga_score((double)s0, (double)s1) : s0;
+    }
+    track_update<T>(tr, U, L, (int)row);
+  }
+  __shared__ Track<T> wtr[WAVES];            // (every lane of a wave holds the same track)
+  if (lane == 0) wtr[wave] = tr;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    Track<T> r = wtr[0];
+#pragma unroll
+    for (int w = 1; w < WAVES; ++w) r = merge<T>(r, wtr[w]);
+    const int b = blockIdx.x;
+    a.out.U1[b] = (double)r.U1; a.out.U2[b] = (double)r.U2; a.out.U3[b] = (double)r.U3; a.out.L[b] = (double)r.L;
+    a.out.i1[b] = r.i1; a.out.i2[b] = r.i2;
+  }
+}
+
+template <typename ST, bool DUAL> static int launch_long(bcx_solver* s, const ScanArgs& a, int grid) {
+  const size_t lds = (size_t)a.nvec * sizeof(typename Stor<ST>::Q) * (DUAL ? 2 : 1);
+  if (lds > 150 * 1024) { s->err = "scan: row too long for the query staging"; return BCX_ERR_ARG; }
+  if (lds > 48 * 1024)
+    BCX_HIP(hipFuncSetAttribute((const void*)scan_long_kernel<ST, DUAL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  hipLaunchKernelGGL((scan_long_kernel<ST, DUAL>), dim3(grid), dim3(BCX_SCAN_THREADS), lds, s->stream, a);
+  return BCX_OK;
 }
 
 // ---- host side ----------------------------------------------------------------------------
@@ -561,10 +668,19 @@ int bcx_launch_scan(bcx_solver* s, int exact) {
     const int64_t want = (a.n + rpb - 1) / rpb;
     grid = (int)(want < 512 ? (want < 1 ? 1 : want) : 512);
   }
+  const bool long_rows = nvec > 64 * 16;     // beyond the (G, CH) menu: one wave per row, query in LDS
+  if (long_rows) {
+    const int64_t want = (a.n + 3) / 4;
+    grid = (int)(want < 512 ? (want < 1 ? 1 : want) : 512);
+  }
   s->n_partials = grid;                     // resolve reads exactly this launch's partials
   a.out = partial_view(s->partials, grid);
   int rc;
-  if (f64) rc = dual ? launch_t<double, true>(s, a, G, CH, ur, grid) : launch_t<double, false>(s, a, G, CH, ur, grid);
+  if (long_rows) {
+    if (f64) rc = dual ? launch_long<double, true>(s, a, grid) : launch_long<double, false>(s, a, grid);
+    else if (f16) rc = dual ? launch_long<half_t, true>(s, a, grid) : launch_long<half_t, false>(s, a, grid);
+    else rc = dual ? launch_long<float, true>(s, a, grid) : launch_long<float, false>(s, a, grid);
+  } else if (f64) rc = dual ? launch_t<double, true>(s, a, G, CH, ur, grid) : launch_t<double, false>(s, a, G, CH, ur, grid);
   else if (f16) rc = dual ? launch_t<half_t, true>(s, a, G, CH, ur, grid) : launch_t<half_t, false>(s, a, G, CH, ur, grid);
   else rc = dual ? launch_t<float, true>(s, a, G, CH, ur, grid) : launch_t<float, false>(s, a, G, CH, ur, grid);
   if (rc != BCX_OK) return rc;

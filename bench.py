@@ -63,7 +63,9 @@ def parse():
     ap.add_argument("--no-exact-rows", action="store_true", help="do not keep the raw fp64 rows resident")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-exact-mode", action="store_true", help="skip the fp64-stored-rows figure of the c4 line")
-    ap.add_argument("--cpu-rows", type=int, default=200_000, help="rows of the CPU-baseline sample")
+    ap.add_argument("--cpu-rows", type=int, default=1_000_000,
+                    help="rows of the CPU-baseline sample (SURVEY 8d: N = 1e6 when host memory allows; halved until "
+                         "three copies of the fp64 sample fit the free memory)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--opt-itrs", type=int, default=100, help="c5: ADAM steps per greedy step (sparsevi.py:7)")
     ap.add_argument("--features", type=int, default=10, help="c3: regression features D (simple_lr/main.py:24)")
@@ -102,6 +104,18 @@ def host_threads():
         return os.cpu_count() or 1
 
 
+def blas_info():
+    """'<library> <version> (<threads> threads, <threading layer>)' of the BLAS behind ndarray.dot, and the host's core count."""
+    try:
+        from threadpoolctl import threadpool_info
+        pools = [p for p in threadpool_info() if p.get("user_api") == "blas"] or threadpool_info()
+        p0 = max(pools, key=lambda p: p.get("num_threads", 0))
+        return "%s %s (%d threads, %s)" % (p0.get("internal_api", "?"), p0.get("version", "?"), p0.get("num_threads", 0),
+                                           p0.get("threading_layer", "?")), os.cpu_count() or 0
+    except Exception:
+        return "unknown", os.cpu_count() or 0
+
+
 def cpu_baseline_snnls(args, X, what):
     """The oracle's faithful mode (reference op sequence: 5 passes of OpenBLAS dgemv/dgemm per iteration, fp64) timed on
     this box's host cores on a bounded sample X (n_s x d) of the same workload, scaled linearly in N."""
@@ -118,11 +132,24 @@ def cpu_baseline_snnls(args, X, what):
             break
     its_sample = done / el
     scale = n_s / float(args.rows)   # cost per iteration is linear in N
+    # the fairer CPU number: the same arithmetic with A.dot(w) maintained incrementally -- one pass over the
+    # matrix per iteration instead of the reference's five
+    o1 = SnnlsOracle(X.T, X.sum(axis=0), alg=args.alg, mode="onepass")
+    o1.build(3)
+    done1, t1 = 0, time.perf_counter()
+    while True:
+        o1.build(4)
+        done1 += 4
+        el1 = time.perf_counter() - t1
+        if el1 > args.cpu_seconds / 2 or done1 >= 200:
+            break
+    blas, ncpu = blas_info()
     return {
         "value": its_sample * scale, "unit": "iterations/s", "cores": int(host_threads()), "kind": "port",
         "sample": "oracle faithful mode (NumPy/OpenBLAS fp64, reference op sequence), %s, %s, first %d of %d rows, d=%d, "
                   "%d iterations in %.1f s = %.2f it/s on the sample, scaled linearly in N (x%.4f)"
                   % (args.alg, what, n_s, args.rows, X.shape[1], done, el, its_sample, scale),
+        "onepass_value": done1 / el1 * scale, "blas": blas, "host_cpus": ncpu, "sample_rows": int(n_s),
     }
 
 
@@ -288,13 +315,15 @@ def run_snnls(args, torch, dist, nat, world, rank, local_rank):
         avg_ms = scan_ms / max(scan_launches, 1)
         achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
         names = {"fw": "Frank-Wolfe", "giga": "GIGA", "omp": "OMP"}
+        ran = ("M=%d greedy iterations" % steps_done if steps_done == args.steps else
+               "%d of the requested M=%d greedy iterations (numeric limit reached, as in the reference)" % (steps_done, args.steps))
         if args.kind == "logistic":
             workload = ("Laplace-projected logistic-regression vectors (simple_lr pipeline, projection on the device) N=%d "
-                        "features=%d S=d=%d, %s, %d row shard(s), M=%d greedy iterations"
-                        % (args.rows, args.features, args.dim, names[args.alg], world, args.steps))
+                        "features=%d S=d=%d, %s, %d row shard(s), %s"
+                        % (args.rows, args.features, args.dim, names[args.alg], world, ran))
         else:
-            workload = ("synthetic randn N=%d d=%d, %s, %d row shard(s), M=%d greedy iterations"
-                        % (args.rows, args.dim, names[args.alg], world, args.steps))
+            workload = ("synthetic randn N=%d d=%d, %s, %d row shard(s), %s"
+                        % (args.rows, args.dim, names[args.alg], world, ran))
         out = {
             "metric": "greedy coreset iterations/sec (N=%d, d=%d)" % (args.rows, args.dim),
             "value": steps_done / elapsed, "unit": "iterations/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -320,7 +349,10 @@ def run_snnls(args, torch, dist, nat, world, rank, local_rank):
                 "iterations_run": int(steps_done), "reached_numeric_limit": bool(solver.reached_numeric_limit),
                 "steps_accepted": int((status == 0).sum()), "final_error": float(err[-1]) if len(err) else None,
                 "rescue": solver.engine.stats(),   # fp64 re-scored candidates / exact-scan fallbacks since construction
-            }, **info),
+                # the same, flat (nested objects do not survive every consumer of this line)
+                "rescue_exact_fallbacks": int(solver.engine.stats()["exact_fallbacks"]),
+                "rescue_candidates_per_iteration": solver.engine.stats()["candidates"] / max(1.0, float(solver.engine.stats()["resolves"])),
+            }, **info, **omp_fields(args, solver)),
             "roofline": {
                 "bound": "hbm", "kernel": "scan_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS, "traffic": measured_traffic(args, solver.n_local),
@@ -346,6 +378,10 @@ def run_snnls(args, torch, dist, nat, world, rank, local_rank):
                 "iterations_per_s": len(tr2[0]) / el, "ms_per_step": el / max(len(tr2[0]), 1) * 1e3, "steps": n_ex,
                 "scan_GBps": a2, "scan_frac_of_hbm_peak": a2 / HBM_PEAK_GBS, "algorithmic_bytes_per_launch": b64,
             }
+            # the same figures flat, at the top level and in config: the reference's own arithmetic end to end (fp64 rows)
+            out["exact_mode_its"] = out["config"]["exact_mode_its"] = len(tr2[0]) / el
+            out["exact_mode_frac"] = out["config"]["exact_mode_frac"] = a2 / HBM_PEAK_GBS
+            out["config"]["exact_mode_ms_per_step"] = el / max(len(tr2[0]), 1) * 1e3
         del ex
     if rank == 0 and not args.no_cpu_baseline and world == 1:
         if args.kind == "logistic":
@@ -353,13 +389,29 @@ def run_snnls(args, torch, dist, nat, world, rank, local_rank):
             what = "Laplace-projected logistic vectors"
         else:
             n_s = min(args.cpu_rows, args.rows)
+            try:      # the oracle holds A, An and temporaries: three copies of the fp64 sample
+                import psutil
+                while n_s > 8 * GEN_BLOCK and 3.5 * n_s * args.dim * 8 > 0.6 * psutil.virtual_memory().available:
+                    n_s //= 2
+            except ImportError:
+                n_s = min(n_s, 200_000)
             n_s = (n_s // GEN_BLOCK) * GEN_BLOCK or n_s
             parts = [gen_block(torch, args.seed, blk, min(GEN_BLOCK, n_s - blk * GEN_BLOCK), args.dim, "cuda").cpu().numpy()
                      for blk in range((n_s + GEN_BLOCK - 1) // GEN_BLOCK)]
             X = np.concatenate(parts, axis=0)
             what = "synthetic randn"
         out["cpu_baseline"] = cpu_baseline_snnls(args, X, what)
+        out["cpu_baseline_onepass"] = out["cpu_baseline"]["onepass_value"]      # flat: it/s, scaled to N like `value`
     return out
+
+
+def omp_fields(args, solver):
+    """OMP step diagnostics of csrc/omp_lh.hip, flat: how many steps ran, columns that left the passive set, from-scratch
+    re-solves (none expected: the inverse is kept in double-double)."""
+    if args.alg != "omp" or not hasattr(solver.engine, "omp_stats"):
+        return {}
+    st = solver.engine.omp_stats()
+    return {"omp_steps": int(st["steps"]), "omp_columns_left": int(st["columns_left"]), "omp_resolves": int(st["resolves"])}
 
 
 def measured_traffic(args, n_local):

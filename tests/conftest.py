@@ -8,7 +8,7 @@ import time
 # legacy mode and died in it (profiles/README.md, "round-1 GPUTEST abort"); BCX_KEEP_IPC_MODE=1 keeps the caller's
 # value for crash hunts.
 if not os.environ.get("BCX_KEEP_IPC_MODE"):
-    os.environ["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
+    os.environ["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"     # (same rule as bayesiancoresets_amd._native.ensure_ipc_mode, before anything loads)
 if not os.environ.get("BCX_NO_FAULTHANDLER"):   # (crash hunts preload tools/probe/abort_trace.so instead)
     faulthandler.enable(all_threads=True)
 

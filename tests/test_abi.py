@@ -37,6 +37,13 @@ def test_config_struct_layout():
     assert _native.Config.n_local.offset == 32
 
 
+def test_row_length_limit_matches_header():
+    from bayesiancoresets_amd import _native
+    text = open(os.path.join(ROOT, "include", "bcx.h")).read()
+    assert int(re.search(r"#define\s+BCX_MAX_ROW_LENGTH\s+(\d+)", text).group(1)) == _native.MAX_ROW_LENGTH
+    assert int(re.search(r"#define\s+BCX_LOAD_CENTER_ROWS\s+(\d+)", text).group(1)) == _native.LOAD_CENTER_ROWS
+
+
 def test_no_cpu_fallback():
     """Without a GPU the solver constructors raise; they never fall back to host arithmetic."""
     import torch

@@ -1,5 +1,7 @@
 """Pin the CPU oracle (oracle/snnls_oracle.py) against golden vectors produced by
 the reference itself (tests/golden/make_golden.py).  CPU only."""
+import os
+
 import numpy as np
 import pytest
 
@@ -100,6 +102,32 @@ def test_F3_harness_trial1(golden, normal_inputs, alg):
     assert np.array_equal(np.array(csize, dtype=float), golden[k + "csize"])
     assert np.array_equal(np.array(err), golden[k + "err"])
     assert o.reached_numeric_limit == bool(golden[k + "limit"])
+
+
+@pytest.mark.parametrize("trial", (4, 5))
+@pytest.mark.parametrize("alg", ALGS)
+def test_F3_harness_trials_4_and_5(trial, alg):
+    """seeds 1-5 of the config-1 harness; seeds 4 and 5 live in harness45_golden.npz (reference outputs)."""
+    import hashlib
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "harness45_golden.npz"))
+    np.random.seed(trial)
+    X = np.random.randn(10000, 100)
+    assert hashlib.sha256(np.ascontiguousarray(X).tobytes()).hexdigest() == str(g["F3_t%d_input_sha256" % trial])
+    Ms = harness_sizes()
+    assert np.array_equal(Ms, g["F3_Ms"])
+    o = SnnlsOracle(X.T, X.sum(axis=0), alg=alg, mode="faithful")
+    csize, err = [], []
+    for m in range(len(Ms)):
+        o.build(int(Ms[m] if m == 0 else Ms[m] - Ms[m - 1]))
+        csize.append(o.size())
+        err.append(o.error())
+    k = "F3_t%d_%s_" % (trial, alg)
+    assert np.array_equal(np.array(csize, dtype=float), g[k + "csize"])
+    assert np.array_equal(np.array(err), g[k + "err"])
+    assert o.reached_numeric_limit == bool(g[k + "limit"])
+    w = o.weights()
+    assert np.array_equal(np.flatnonzero(w > 0), g[k + "idcs"])
+    assert np.array_equal(w[w > 0], g[k + "wts"])
 
 
 def test_F8_error_paths():

@@ -45,17 +45,12 @@ tot = {}
 for r in buf:
     it, k, p, m0, m1, st_, np1, nbar = r[:8]
     t = r[8:20] / 100.0
-    ent, rem, res = int(r[20]), int(r[21]), 0
-    pk = int(r[19]); fine = []
-    for _ in range(6):
-        fine.append((pk % 10000) / 100.0); pk //= 10000
-    fine = fine[::-1] + [int(r[22]) / 100.0]       # init, rows loop, -, monitor, schur, border, inner
+    ent, rem, res = int(r[20]), int(r[21]), int(r[22])
     key = ("done" if m0 == 1 else "step", "resolve" if res else ("left %d" % min(rem, 3) if rem else "closed form"))
     tot.setdefault(key, []).append((t[10], int(k), int(p), t[6] - t[5], ent, rem, res, int(nbar)))
     if not a.quiet:
         print("it %3d k %3d np %3d %-5s st %d barriers %2d entered %d left %d resolve %d | total %6.1f us: " % (it, k, p, key[0], st_, nbar, ent, rem, res, t[10])
-              + " ".join("%s %.1f" % (NAMES[i], t[i] - t[i - 1]) for i in range(1, 11))
-              + " || init %.1f rowsloop %.1f | monitor %.1f schur %.1f border %.1f inner %.1f" % (fine[0], fine[1], fine[3], fine[4], fine[5], fine[6]))
+              + " ".join("%s %.1f" % (NAMES[i], t[i] - t[i - 1]) for i in range(1, 11)) + " | threads %d" % r[19])
 print("size %d error %.6g limit %s; statuses %s; omp stats %s" % (s.size(), s.error(), s.reached_numeric_limit,
       {int(k): int((status == k).sum()) for k in set(status)}, s._eng.omp_stats()))
 for key, v in sorted(tot.items(), key=lambda kv: -sum(x[0] for x in kv[1])):
