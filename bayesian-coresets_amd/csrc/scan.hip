@@ -377,18 +377,6 @@ __global__ __launch_bounds__(BCX_SCAN_THREADS) void scan_kernel(ScanArgs a) {
         const T s0 = reduce4_pack<G, T>(a0[0], a0[1], a0[2], a0[3]);
         const T s1 = DUAL ? reduce4_pack<G, T>(a1[0], a1[1], a1[2], a1[3]) : (T)0;
         const int64_t myrow = r0 + (int64_t)((g4 * 4 + myu) * WAVES + wave) * RPW + myrs;
-        if constexpr (sizeof(T) == 4 && DUAL && G < 64) {
-          // Short rows are VALU-bound on the interval arithmetic (two rsq, the slack terms and the top-2 update per row):
-          // once the lane group's best lower bound tr.L is positive, a row can only matter if its upper bound reaches it,
-          //   U = (s0 + e) / sqrt((1 - ah)(1 + ah)) >= tr.L   <=>   (s0 + e)^2 >= tr.L^2 (1 - ah)(1 + ah)   (s0 + e > 0),
-          // four multiplications and a compare.  A row below that can neither be a candidate (candidates reach the
-          // global max L >= tr.L) nor raise tr.L (its L <= U < tr.L) nor trip the overflow test (U3 >= max L): the wave
-          // skips interval and update when none of its rows passes (1e-5 head room for the roundings of the test itself).
-          const float hi = (float)s0 + (float)e, ah = fabsf((float)s1) + (float)e;
-          const float Lc = (float)tr.L;
-          const bool maybe = !(Lc > 0.0f) || !(ah < 1.0f) || (hi > 0.0f && hi * hi >= Lc * Lc * (1.0f - ah) * (1.0f + ah) * 0.99999f);
-          if (!__builtin_amdgcn_ballot_w64(maybe)) continue;
-        }
         T U, L;
         if constexpr (sizeof(T) == 4) {
           float Uf, Lf;

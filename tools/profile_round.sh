@@ -3,8 +3,8 @@
 # binary in this tree.  Output: gpurun_out/prof_$TAG/*.txt|json (summaries to copy into profiles/).
 # usage: tools/profile_round.sh TAG [part ...]      parts: c4 c4pmc c2 c3 c5 c5pmc opt probe shards
 R=$(cd "$(dirname "$0")/.." && pwd)
-TAG=${1:-r02}; shift
-PARTS=${@:-c4 c4pmc c2 c3 c5 c5pmc opt probe shards}
+TAG=${1:-r03}; shift
+PARTS=${@:-c4 c4pmc c2 c3 c5 c5pmc fam opt probe shards}
 O=$R/gpurun_out/prof_$TAG
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
@@ -50,6 +50,11 @@ c5pmc) pmc proj_c5shard_mfma "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_A
        kt proj_c5shard python $R/tools/proj_shape.py --mode colsum --reps 30
        kt proj_c5shard_select python $R/tools/proj_shape.py --mode select --reps 30
        kt proj_c5shard_write python $R/tools/proj_shape.py --mode write --reps 30 ;;
+fam) # the other two likelihood families at the shard shape (N=625k, D=300, S=256): kernel trace + MFMA-busy pass per mode
+     for fam in logistic poisson; do for mode in colsum select write; do
+       kt proj_${fam}_${mode} python $R/tools/proj_shape.py --family $fam --mode $mode --dim 300 --reps 30
+       pmc proj_${fam}_${mode}_mfma "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_INSTS_VALU" python $R/tools/proj_shape.py --family $fam --mode $mode --dim 300 --reps 8
+     done; done ;;
 opt) kt optimize python $R/tools/optimize_bench.py
      pmc optimize_mfma "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE" python $R/tools/optimize_bench.py ;;
 probe) [ -x $R/tools/probe/mfma_f64_peak ] || /opt/rocm/bin/hipcc -O3 --offload-arch=gfx950 -o $R/tools/probe/mfma_f64_peak $R/tools/probe/mfma_f64_peak.hip
