@@ -51,7 +51,7 @@ c5pmc) pmc proj_c5shard_mfma "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_A
        kt proj_c5shard_select python $R/tools/proj_shape.py --mode select --reps 30
        kt proj_c5shard_write python $R/tools/proj_shape.py --mode write --reps 30 ;;
 fam) # the other two likelihood families at the shard shape (N=625k, D=300, S=256): kernel trace + MFMA-busy pass per mode
-     for fam in logistic poisson; do for mode in colsum select write; do
+     for fam in ${FAMS:-logistic poisson}; do for mode in colsum select write; do
        kt proj_${fam}_${mode} python $R/tools/proj_shape.py --family $fam --mode $mode --dim 300 --reps 30
        pmc proj_${fam}_${mode}_mfma "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_INSTS_VALU" python $R/tools/proj_shape.py --family $fam --mode $mode --dim 300 --reps 8
      done; done ;;

@@ -16,7 +16,8 @@ ap.add_argument("--reps", type=int, default=30)
 a = ap.parse_args()
 rs = np.random.RandomState(0)
 cols = a.dim if a.family == "logistic" else a.dim + 1
-Z = torch.randn(a.rows, cols, dtype=torch.float64, device="cuda")
+# even leading dimension (16-byte aligned rows), as DeviceProjector._dev lays host arrays out
+Z = torch.randn(a.rows, cols + (cols % 2), dtype=torch.float64, device="cuda")[:, :cols]
 if a.family == "poisson":
     Z[:, -1] = torch.poisson(torch.ones(a.rows, dtype=torch.float64, device="cuda"))
 theta = 0.1 * rs.randn(a.samples, a.dim)
