@@ -53,17 +53,58 @@ template <int MODE> __device__ __forceinline__ double pj_lgamma1p(double y) { re
 // s (1 + s^2/3 + s^4/5 + ...) up to s^32/33 (truncation < 2e-17 relative), Horner in fp64: 2-3 ulp, 32 VALU instructions.
 // The library log1p is a double-double routine of 135 instructions (75 dependent v_add_f64): with exp (42) it made the
 // logistic epilogue 177 instructions per element on the unit the fp64 MFMAs run on -- a third of the kernel at D = 300.
+// a * b + C with the constant C held in a scalar register pair.  hipcc materialises every fp64 literal of a Horner chain
+// with two v_mov_b32 into a VGPR pair (v_fmac_f64 takes no 64-bit literal): 46 of the 104 VALU instructions of the
+// logistic likelihood were such moves -- paid on the port the fp64 MFMAs issue from.  As an SGPR operand of v_fma_f64 the
+// constant costs two s_mov_b32 on the scalar unit instead.
+__device__ __forceinline__ double pj_fma_c(double a, double b, double c) {
+  double r;
+  asm("v_fma_f64 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "s"(c));
+  return r;
+}
+__device__ __forceinline__ double pj_fma_k(double a, double k, double b) {   // a * K + b, K scalar
+  double r;
+  asm("v_fma_f64 %0, %1, %2, %3" : "=v"(r) : "v"(a), "s"(k), "v"(b));
+  return r;
+}
+// u / d for d in [1.7, 3]: hardware reciprocal + two Newton steps + one correction of the quotient (8 instructions, <= 1
+// ulp; the compiler's fp64 division is 14 with its scaling and fix-up steps, which a bounded divisor does not need)
+__device__ __forceinline__ double pj_div_bounded(double u, double d) {
+  double x = __builtin_amdgcn_rcp(d);
+  x = fma(fma(-d, x, 1.0), x, x);
+  x = fma(fma(-d, x, 1.0), x, x);
+  const double q = u * x;
+  return fma(fma(-d, q, u), x, q);
+}
+// exp(x) for x <= 0 (the softplus argument -|t|): x = k ln 2 + r with |r| <= 0.347 (Cody-Waite, ln 2 in two pieces), the
+// Taylor polynomial of degree 13 in Horner form (truncation 4e-18), ldexp: 20 instructions, 1 ulp against long double over
+// 2.3e6 arguments.  The library exp is ~45 VALU instructions here, most of them 32-bit moves and selects around its
+// double-double arithmetic; on this kernel they are paid on the unit the fp64 MFMAs issue from (profiles/r03_proj_*_mfma.txt:
+// MFMA busy + VALU busy = 97 % of the SIMD cycles for the logistic family).
+__device__ __forceinline__ double pj_exp_nonpos(double x) {
+  x = fmax(x, -800.0);
+  const double kf = __builtin_rint(x * 1.4426950408889634);
+  double r = pj_fma_k(kf, -6.93147180369123816490e-01, x);
+  r = pj_fma_k(kf, -1.90821492927058770002e-10, r);
+  double p = 1.0 / 6227020800.0;
+  p = pj_fma_c(p, r, 1.0 / 479001600.0); p = pj_fma_c(p, r, 1.0 / 39916800.0); p = pj_fma_c(p, r, 1.0 / 3628800.0);
+  p = pj_fma_c(p, r, 1.0 / 362880.0);    p = pj_fma_c(p, r, 1.0 / 40320.0);    p = pj_fma_c(p, r, 1.0 / 5040.0);
+  p = pj_fma_c(p, r, 1.0 / 720.0);       p = pj_fma_c(p, r, 1.0 / 120.0);      p = pj_fma_c(p, r, 1.0 / 24.0);
+  p = pj_fma_c(p, r, 1.0 / 6.0);         p = fma(p, r, 0.5);                   p = fma(p, r, 1.0);
+  p = fma(p, r, 1.0);
+  return ldexp(p, (int)kf);
+}
 __device__ __forceinline__ double pj_log1p01(double u) {
-  const double s = u / (2.0 + u), q = s * s;
+  const double s = pj_div_bounded(u, 2.0 + u), q = s * s;
   double p = 1.0 / 33.0;
-  p = p * q + 1.0 / 31.0; p = p * q + 1.0 / 29.0; p = p * q + 1.0 / 27.0; p = p * q + 1.0 / 25.0;
-  p = p * q + 1.0 / 23.0; p = p * q + 1.0 / 21.0; p = p * q + 1.0 / 19.0; p = p * q + 1.0 / 17.0;
-  p = p * q + 1.0 / 15.0; p = p * q + 1.0 / 13.0; p = p * q + 1.0 / 11.0; p = p * q + 1.0 / 9.0;
-  p = p * q + 1.0 / 7.0;  p = p * q + 1.0 / 5.0;  p = p * q + 1.0 / 3.0;  p = p * q + 1.0;
+  p = pj_fma_c(p, q, 1.0 / 31.0); p = pj_fma_c(p, q, 1.0 / 29.0); p = pj_fma_c(p, q, 1.0 / 27.0); p = pj_fma_c(p, q, 1.0 / 25.0);
+  p = pj_fma_c(p, q, 1.0 / 23.0); p = pj_fma_c(p, q, 1.0 / 21.0); p = pj_fma_c(p, q, 1.0 / 19.0); p = pj_fma_c(p, q, 1.0 / 17.0);
+  p = pj_fma_c(p, q, 1.0 / 15.0); p = pj_fma_c(p, q, 1.0 / 13.0); p = pj_fma_c(p, q, 1.0 / 11.0); p = pj_fma_c(p, q, 1.0 / 9.0);
+  p = pj_fma_c(p, q, 1.0 / 7.0);  p = pj_fma_c(p, q, 1.0 / 5.0);  p = pj_fma_c(p, q, 1.0 / 3.0);  p = fma(p, q, 1.0);
   return 2.0 * s * p;
 }
 // log(1 + exp(t)) = max(t, 0) + log1p(exp(-|t|))
-__device__ __forceinline__ double pj_softplus(double t) { return fmax(t, 0.0) + pj_log1p01(exp(-fabs(t))); }
+__device__ __forceinline__ double pj_softplus(double t) { return fmax(t, 0.0) + pj_log1p01(pj_exp_nonpos(-fabs(t))); }
 
 // log(x) for a positive normal x (the Poisson rate: >= log1p(e^-100) = 3.7e-44): x = 2^e m with m in [sqrt(1/2), sqrt(2)),
 // log m = 2 atanh(s), s = (m - 1) / (m + 1), |s| <= 0.172 -- the odd series up to s^22 / 23 (truncation < 1e-18 relative)
@@ -75,11 +116,11 @@ __device__ __forceinline__ double pj_log_pos(double x) {
   int e = (int)((bits >> 52) & 0x7ff) - 1023;
   double m = __longlong_as_double((bits & 0x000fffffffffffffLL) | 0x3ff0000000000000LL);   // [1, 2)
   if (m > 1.4142135623730951) { m *= 0.5; e += 1; }
-  const double s = (m - 1.0) / (m + 1.0), q = s * s;
+  const double s = pj_div_bounded(m - 1.0, m + 1.0), q = s * s;
   double p = 1.0 / 23.0;
-  p = p * q + 1.0 / 21.0; p = p * q + 1.0 / 19.0; p = p * q + 1.0 / 17.0; p = p * q + 1.0 / 15.0; p = p * q + 1.0 / 13.0;
-  p = p * q + 1.0 / 11.0; p = p * q + 1.0 / 9.0;  p = p * q + 1.0 / 7.0;  p = p * q + 1.0 / 5.0;  p = p * q + 1.0 / 3.0;
-  p = p * q + 1.0;
+  p = pj_fma_c(p, q, 1.0 / 21.0); p = pj_fma_c(p, q, 1.0 / 19.0); p = pj_fma_c(p, q, 1.0 / 17.0); p = pj_fma_c(p, q, 1.0 / 15.0);
+  p = pj_fma_c(p, q, 1.0 / 13.0); p = pj_fma_c(p, q, 1.0 / 11.0); p = pj_fma_c(p, q, 1.0 / 9.0);  p = pj_fma_c(p, q, 1.0 / 7.0);
+  p = pj_fma_c(p, q, 1.0 / 5.0);  p = pj_fma_c(p, q, 1.0 / 3.0);  p = fma(p, q, 1.0);
   const double ed = (double)e;
   return ed * 6.93147180369123816490e-01 + (2.0 * s * p + ed * 1.90821492927058770002e-10);
 }
@@ -87,7 +128,7 @@ __device__ __forceinline__ double pj_log_pos(double x) {
 // The Poisson likelihood as two real calls in sequence (rate, then its logarithm): inlined, the series' temporaries spill
 // registers inside the k loop (24.8 against 28.3 TFLOP/s at D = 300 although the epilogue got shorter); as ONE call the
 // two series interleave and cost the SELECT caller registers; nested, the outer call needs a stack frame.
-__device__ __attribute__((noinline)) double pj_rate_call(double m) { return fmax(m, 0.0) + pj_log1p01(exp(-fabs(m))); }
+__device__ __attribute__((noinline)) double pj_rate_call(double m) { return fmax(m, 0.0) + pj_log1p01(pj_exp_nonpos(-fabs(m))); }
 __device__ __attribute__((noinline)) double pj_lograte_call(double lam) { return pj_log_pos(lam); }
 __device__ __forceinline__ double pj_poisson_call(double m, double y, double c0) {
   const double lam = pj_rate_call(m);
@@ -124,9 +165,9 @@ template <int FAM, bool CALL = false> __device__ __forceinline__ double loglik(d
 // predictor (see the epilogue), and the difference has a closed form without the cancellation:
 //   [c0 - (y^2 - 2 m y + m^2) / (2 sigsq)] - [c0 - y^2 / (2 sigsq)] = (2 y - m) m / (2 sigsq)
 // -- three operations instead of seven per element, and more accurate than forming both terms.
-template <int FAM, int MODE> __device__ __forceinline__ double loglik_shifted(double m, double y, double param, double c0, double shift) {
+template <int FAM, int MODE, bool CALL> __device__ __forceinline__ double loglik_shifted(double m, double y, double param, double c0, double shift) {
   if (FAM == FAM_LINREG && MODE == PMODE_COLSUM) return (2.0 * y - m) * m * param;
-  return loglik<FAM, MODE == PMODE_SELECT>(m, y, param, c0) - shift;
+  return loglik<FAM, CALL>(m, y, param, c0) - shift;
 }
 
 // sum over the 16 lanes of a DPP row (lanes that share l >> 4)
@@ -278,7 +319,8 @@ __global__ __launch_bounds__(256, 2) void proj_kernel(ProjArgs p) {
   // 2 wave + j (columns 16 wave + 8 j + fr), piece fq of the row's 128-byte line
   const int fr = lane >> 3, fq = ((lane & 7) - 2 * ((fr >> 1) & 3)) & 7;
   const double* zp[4];                       // row pointers of the Z tile being requested (they change once per row block)
-  const double* tp[TCH];                     // column pointers of the Theta tile being requested (once per column group)
+  int tp[TCH];                               // element offsets (into Theta: S x ldt < 2^31) of the columns being requested --
+                                             // one VGPR each instead of a pointer pair: what the 128-column transcendental tiles lacked
   int64_t zp_br = -1;
   int tp_cg = -1;
   const int kmax = ALIGNED ? ((D - 1) & ~1) : (D - 1);
@@ -295,7 +337,7 @@ __global__ __launch_bounds__(256, 2) void proj_kernel(ProjArgs p) {
 #pragma unroll
     for (int j = 0; j < TCH; ++j) {
       const int col = fcg * COLS + 8 * (TCH * wave + j) + fr;
-      tp[j] = p.theta + (size_t)(col < S ? col : S - 1) * p.ldt;
+      tp[j] = (col < S ? col : S - 1) * p.ldt;
     }
   };
   auto advance = [&](PjPos a) {
@@ -324,7 +366,7 @@ __global__ __launch_bounds__(256, 2) void proj_kernel(ProjArgs p) {
     const int kc = min(a.s * PJ_KC + 2 * fq, kmax);
 #pragma unroll
     for (int j = 0; j < TCH; ++j)
-      pj_glds16(tp[j] + kc, lds0 + (unsigned)(TBASE + tslot * TBYTES + (TCH * wave + j) * 1024));
+      pj_glds16(p.theta + (tp[j] + kc), lds0 + (unsigned)(TBASE + tslot * TBYTES + (TCH * wave + j) * 1024));
   };
   // zero-fill of this lane's own slots of a stage that is not plain (after its DMA has landed)
   auto zero_fill = [&](const PjPos& a, int zslot, int tslot) {
@@ -347,7 +389,7 @@ __global__ __launch_bounds__(256, 2) void proj_kernel(ProjArgs p) {
     const int k0 = min(k, D - 1), k1 = min(k + 1, D - 1);
 #pragma unroll
     for (int j = 0; j < 4 + TCH; ++j) {
-      const double* src = j < 4 ? zp[j] : tp[j - 4];
+      const double* src = j < 4 ? zp[j] : p.theta + tp[j < 4 ? 0 : j - 4];
       sreg[ALIGNED ? 0 : j].x = src[k0];
       sreg[ALIGNED ? 0 : j].y = src[k1];
     }
@@ -458,7 +500,7 @@ __global__ __launch_bounds__(256, 2) void proj_kernel(ProjArgs p) {
 #pragma unroll
           for (int q = 0; q < TCH + 4; ++q) {
             if ((NG >= 8 ? q : q * NG / 8) != g) continue;
-            if (q < TCH) { if (more) pj_glds16(tp[q] + kct, lds0 + (unsigned)(TBASE + ts1 * TBYTES + (TCH * wave + q) * 1024)); }
+            if (q < TCH) { if (more) pj_glds16(p.theta + (tp[q] + kct), lds0 + (unsigned)(TBASE + ts1 * TBYTES + (TCH * wave + q) * 1024)); }
             else if (ZRING == 3 ? more2 : more)
               pj_glds16(zp[q - TCH] + kcz, lds0 + (unsigned)((ZRING == 3 ? zs2 : zs1) * PJ_ZBYTES + (4 * wave + q - TCH) * 1024));
           }
@@ -557,7 +599,7 @@ __global__ __launch_bounds__(256, 2) void proj_kernel(ProjArgs p) {
 #pragma unroll
               for (int tr = 0; tr < 2; ++tr) {
                 const bool ok = cvalid && r0 + 16 * tr + li < p.N;
-                const double v = ok ? loglik_shifted<FAM, MODE>(acc[tr][tc][r], yq[tr], parg, cq[tr], pq[tr]) : 0.0;
+                const double v = ok ? loglik_shifted<FAM, MODE, SEL>(acc[tr][tc][r], yq[tr], parg, cq[tr], pq[tr]) : 0.0;
                 if (MODE == PMODE_COLSUM) csum += v;
                 else { rs[tr] += v; rq[tr] += v * v; rd[tr] += v * rsd; }
               }
@@ -810,7 +852,7 @@ struct ProjProfile {
 thread_local ProjProfile g_prof;
 }  // namespace
 
-template <int FAM, int MODE, int NCT> static int launch_one(bool aligned, dim3 grid, size_t shmem, hipStream_t st, const ProjArgs& p) {
+template <int FAM, int MODE, int NCT, bool ALIGNED_ONLY = false> static int launch_one(bool aligned, dim3 grid, size_t shmem, hipStream_t st, const ProjArgs& p) {
   const bool timed = g_prof.on;
   if (timed) {
     if (g_prof.used == g_prof.ev.size()) {
@@ -824,7 +866,7 @@ template <int FAM, int MODE, int NCT> static int launch_one(bool aligned, dim3 g
 if (aligned) {
     PROJ_HIP(hipFuncSetAttribute((const void*)proj_kernel<FAM, MODE, true, NCT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
     hipLaunchKernelGGL((proj_kernel<FAM, MODE, true, NCT>), grid, dim3(256), shmem, st, p);
-  } else {
+  } else if constexpr (!ALIGNED_ONLY) {
     PROJ_HIP(hipFuncSetAttribute((const void*)proj_kernel<FAM, MODE, false, NCT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
     hipLaunchKernelGGL((proj_kernel<FAM, MODE, false, NCT>), grid, dim3(256), shmem, st, p);
   }
@@ -864,17 +906,21 @@ extern "C" int bcx_project_profile_read(double* ms_total, int64_t* launches, dou
 // padded columns over 64-wide groups (54 against 50 TFLOP/s at the configs[4] shard shape).  Everything else keeps 64:
 // SELECT's per-row moments and the transcendental epilogues (logistic, Poisson) spill with 128 accumulator VGPRs and
 // measured slower (logistic D=300: 29 against 35 TFLOP/s), WRITE holds eight rows per lane.
-static int proj_nct(int mode, int family, int S) {
-  if (mode != PMODE_COLSUM || family != FAM_LINREG) return 4;
+static int proj_nct(int mode, int family, int S, bool aligned = true) {
+  if (mode != PMODE_COLSUM) return 4;
+  // the 128-column tile exists for the column sums of the linear-regression family and, on 16-byte aligned rows, of the
+  // logistic one (round 3: with the series' constants in scalar registers and 32-bit Theta offsets it fits 255 VGPRs;
+  // +8 % at D = 300); the unaligned logistic and the Poisson instantiations would spill and are not built
+  if (family == FAM_POISSON || (family == FAM_LOGISTIC && !aligned)) return 4;
   static const int forced = [] { const char* e = getenv("BCX_PROJ_NCT"); return e ? atoi(e) : 0; }();   // dev knob
   if (forced == 4 || forced == 8) return forced;
   return (S + 127) / 128 * 128 == (S + 63) / 64 * 64 ? 8 : 4;
 }
 // XCD teams (COLSUM, WRITE) need a grid that covers the 8 XCDs evenly; workgroups of an XCD that do not fill a team stay
 // idle (at most a fifth of them).  Returns the team size = number of column groups, 0 for the one-workgroup walk.
-static int proj_team(int mode, int family, int S, int grid) {
+static int proj_team(int mode, int family, int S, int grid, bool aligned = true) {
   static const bool no_team = getenv("BCX_PROJ_NO_TEAM") != nullptr;   // dev knob
-  const int cols = 16 * proj_nct(mode, family, S), ngc = (S + cols - 1) / cols;
+  const int cols = 16 * proj_nct(mode, family, S, aligned), ngc = (S + cols - 1) / cols;
   return (!no_team && ngc > 1 && grid % 8 == 0 && grid / 8 >= 4 * ngc) ? ngc : 0;
 }
 static bool proj_aligned(const ProjArgs& p) {
@@ -882,12 +928,13 @@ static bool proj_aligned(const ProjArgs& p) {
   return ((uintptr_t)p.Z % 16 == 0) && ((uintptr_t)p.theta % 16 == 0) && p.ldz % 2 == 0 && p.ldt % 2 == 0;
 }
 template <int MODE> static int launch_family(int family, dim3 grid, size_t extra_lds, hipStream_t st, const ProjArgs& p) {
-  const int nct = proj_nct(MODE, family, p.S);
+  const int nct = proj_nct(MODE, family, p.S, proj_aligned(p));
   const size_t shmem = (nct == 8 ? PJ_STAGING_BYTES(8) : PJ_STAGING_BYTES(4)) + extra_lds;
   if (shmem > 160 * 1024) { g_proj_err = "bcx_project: S too large for the column-sum accumulators (S <= 3072)"; return BCX_ERR_ARG; }
   const bool aligned = proj_aligned(p);
   if constexpr (MODE == PMODE_COLSUM) {
-    if (nct == 8) return launch_one<FAM_LINREG, MODE, 8>(aligned, grid, shmem, st, p);
+    if (nct == 8 && family == FAM_LINREG) return launch_one<FAM_LINREG, MODE, 8>(aligned, grid, shmem, st, p);
+    if (nct == 8 && family == FAM_LOGISTIC) return launch_one<FAM_LOGISTIC, MODE, 8, true>(true, grid, shmem, st, p);
   }
   switch (family) {
     case FAM_LOGISTIC: return launch_one<FAM_LOGISTIC, MODE, 4>(aligned, grid, shmem, st, p);
@@ -960,8 +1007,8 @@ extern "C" int bcx_project_colsum(void* stream, int32_t family, const void* Z_de
   hipStream_t st = (hipStream_t)stream;
   const int grid = proj_grid(N);
   p.colpart = (double*)work_dev;
-  p.team = proj_team(PMODE_COLSUM, family, S, grid);
-  const size_t cacc = p.team ? (size_t)16 * proj_nct(PMODE_COLSUM, family, S) : (size_t)S;   // accumulators per wave
+  p.team = proj_team(PMODE_COLSUM, family, S, grid, proj_aligned(p));
+  const size_t cacc = p.team ? (size_t)16 * proj_nct(PMODE_COLSUM, family, S, proj_aligned(p)) : (size_t)S;   // accumulators per wave
   if ((rc = launch_family<PMODE_COLSUM>(family, dim3(grid), 4 * cacc * sizeof(double), st, p))) return rc;
   hipLaunchKernelGGL(colsum_reduce_kernel, dim3((S + 63) / 64), dim3(256), 0, st, p.colpart, grid, S, (double*)colsum_dev);
   hipLaunchKernelGGL(colsum_center_kernel, dim3(1), dim3(256), 0, st, S, (double*)colsum_dev);
