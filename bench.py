@@ -97,9 +97,12 @@ def gen_block(torch, seed, block_id, rows, d, device):
 
 
 def host_threads():
+    """threads the NumPy restatement actually computes on: the BLAS pool behind ndarray.dot (OpenBLAS caps at 64)"""
     try:
         from threadpoolctl import threadpool_info
-        return max([p.get("num_threads", 1) for p in threadpool_info()] or [1])
+        pools = threadpool_info()
+        blas = [p.get("num_threads", 1) for p in pools if p.get("user_api") == "blas"]
+        return max(blas or [p.get("num_threads", 1) for p in pools] or [1])
     except Exception:
         return os.cpu_count() or 1
 

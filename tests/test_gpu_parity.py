@@ -157,6 +157,25 @@ def test_long_rows_against_oracle(bc, alg, d, dtype):
     np.testing.assert_allclose(s.error(), o.error(), rtol=1e-6)
 
 
+def test_omp_large_active_set_crosses_workgroup_widths(bc):
+    """OMP for 520 iterations on Gaussian rows (d = 640): the active set grows through the step kernel's three workgroup
+    widths (256 threads up to k = 192, 512 up to 448, 1024 beyond: the rows of the double-double inverse change owners
+    between launches) -- selections, weights and error against the CPU oracle throughout."""
+    from oracle.snnls_oracle import SnnlsOracle
+    N, d, itrs = 12000, 640, 520
+    X = np.random.RandomState(77).randn(N, d)
+    o = SnnlsOracle(X.T, X.sum(axis=0), alg="omp", mode="onepass")
+    o.build(itrs)
+    s = _run(bc, X, "omp", itrs)
+    assert np.array_equal(s.last_trace[0], np.array([t[0] for t in o.trace]))
+    w, ow = s.weights(), o.weights()
+    assert np.array_equal(np.flatnonzero(w > 0), np.flatnonzero(ow > 0)) and (w > 0).sum() > 450
+    np.testing.assert_allclose(w[w > 0], ow[ow > 0], rtol=WEIGHT_RTOL)
+    np.testing.assert_allclose(s.error(), o.error(), rtol=ERR_RTOL)
+    st = s._eng.omp_stats()
+    assert st["steps"] == itrs and st["resolves"] == 0
+
+
 def test_row_length_limit_is_a_value_error(bc):
     X = np.zeros((4, 8193))
     with pytest.raises(ValueError, match="8192"):
