@@ -330,6 +330,49 @@ def test_two_level_column_sums_are_shard_count_independent(tmp_path):
                 assert np.array_equal(ref[k], r[k]), (world, rank, k)
 
 
+def _devproj_worker(rank, world, port, out_dir):
+    for p in (ROOT, os.path.join(ROOT, "bayesian-coresets_amd"), os.path.join(ROOT, "tests")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    import torch
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import bayesiancoresets_amd as bc
+    from lr_workload import make_data
+    N, D, S = 9000, 10, 128
+    Z = make_data(5, N, D)
+    samples = np.random.RandomState(6).randn(S, D)
+    prj = bc.DeviceProjector("logistic", lambda n, w, p: samples, S)
+    if world == 1:
+        cs = bc.HilbertCoreset(Z, prj, snnls=bc.snnls.OrthoPursuit)
+        assert cs.snnls._center_rows                          # raw log-likelihoods, centred by the ingest pass
+    else:
+        lo, hi = bc.ShardedHilbertCoreset.local_rows(N)
+        cs = bc.ShardedHilbertCoreset(Z[lo:hi], prj, N, snnls=bc.snnls.OrthoPursuit)
+    cs.build(30)
+    wts, pts, idcs = cs.get()
+    np.savez(os.path.join(out_dir, "dp_w%d_r%d.npz" % (world, rank)), wts=wts, pts=pts, idcs=idcs, err=cs.error())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_sharded_hilbert_behind_device_projector(tmp_path):
+    """HilbertCoreset behind a DeviceProjector takes the raw log-likelihoods and lets the solver's constructor pass centre
+    them (projector.py:21 folded into the ingest); row-sharded on two ranks the same must come out, bit for bit."""
+    import torch.multiprocessing as mp
+    for world in (1, 2):
+        mp.spawn(_devproj_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    ref = np.load(tmp_path / "dp_w1_r0.npz")
+    assert len(ref["idcs"]) >= 20
+    for rank in range(2):
+        r = np.load(tmp_path / ("dp_w2_r%d.npz" % rank))
+        for k in ("idcs", "wts", "pts", "err"):
+            assert np.array_equal(ref[k], r[k]), (rank, k)
+
+
 # ---- SURVEY 8e: "identical for G in {1, 2, 4, 8}" -- world sizes 4 and 8, ranks sharing cuda:0 ---------------------------
 @pytest.mark.parametrize("exchange", ("collective", "mailbox"))
 @pytest.mark.parametrize("alg", (0, 1, 2))
