@@ -259,6 +259,17 @@ def test_hilbert_coreset_api(bc, golden, normal_inputs):
 
 
 # ---- numeric-limit regime and the config-1 harness (F3) -------------------------------
+def _graded_error_trace(err, ref):
+    """The whole error trace on the way into the numeric floor, at the accuracy the arithmetic allows: the error is a
+    difference of vectors of size ||b||, so its absolute rounding noise is ~1e-16 ||b|| whatever its own size -- 1e-9
+    relative plus 2e-14 of the first error (||b||-sized) absolute, i.e. 1e-9 relative while the error is above 1e-5 of its
+    start and proportionally looser below (a flat rtol = 1e-4, which the floor regime needs, would let the first three
+    hundred iterations drift by five digits)."""
+    n = min(len(err), len(ref))
+    assert n >= len(ref) - 2
+    np.testing.assert_allclose(err[:n], ref[:n], rtol=1e-9, atol=2e-14 * ref[0])
+
+
 def test_F4_giga_latch(bc, golden, normal_inputs):
     """GIGA driven to the numeric limit: same 429 selections, then select fails twice in a row
     (cdirnrm < TOL, giga.py:28) and the solver latches (snnls.py:63-72) at the same place."""
@@ -270,6 +281,7 @@ def test_F4_giga_latch(bc, golden, normal_inputs):
     assert s.reached_numeric_limit is True and bool(golden["F4_giga_limit"])
     assert s.size() == int(golden["F4_giga_size"])
     np.testing.assert_allclose(s.error(), float(golden["F4_giga_final_err"]), rtol=1e-3)
+    _graded_error_trace(err[status == 0], golden["F4_giga_err"])
     w = s.weights()
     assert np.array_equal(np.flatnonzero(w > 0), golden["F4_giga_idx"])
     gw = golden["F4_giga_w"]   # at the numeric limit weights ~1e-10 of the largest carry only rounding noise
@@ -287,6 +299,7 @@ def test_F4_fw_400(bc, golden, normal_inputs):
     assert s.size() == int(golden["F4_fw_size"]) and not s.reached_numeric_limit
     np.testing.assert_allclose(s.error(), float(golden["F4_fw_final_err"]), rtol=1e-4)
     np.testing.assert_allclose(err, golden["F4_fw_err"], rtol=1e-4)
+    _graded_error_trace(err, golden["F4_fw_err"])
 
 
 def test_F4_omp_past_k_equals_d(bc, golden, normal_inputs):
