@@ -300,7 +300,7 @@ static __device__ void rebuild_passive(const NnlsArgs& n, int k, double* scratch
 
 // ---- OMP apply, multi-kernel form ----------------------------------------------------------------
 // The step split into phases that use many CUs, chained by ordinary kernel boundaries (decisions travel in
-// DevState).  Fallback of the fused form below for active sets beyond its LDS budget (k >= OMPF_MAX_K):
+// DevState).  Fallback of the incremental step (omp_lh.hip) for active sets beyond its LDS budget:
 //   rows    (grid)  -An[j].r for the active rows and row_j . xf for all slots (+ xf.xf, xf.b)
 //   decide  (1 WG)  f, slot, new-slot data, g = G[slot, P]; chooses DONE / FAST_TRY / GENERAL
 //   matvec  (grid)  u = H g
@@ -597,369 +597,6 @@ __global__ __launch_bounds__(BCX_APPLY_THREADS) void omp_finish_kernel(NnlsArgs 
   prepare_next(a, scratch);
 }
 
-// ---- OMP apply, fused multi-workgroup form ----------------------------------------------------------
-// The phases of the multi-kernel form above in ONE launch of OMPF_WGS co-resident workgroups, separated by
-// grid barriers (an arrival counter in device memory) instead of kernel boundaries.  The single-workgroup
-// phases (decide, step) are computed REDUNDANTLY by every workgroup from the same data in the same order,
-// so each one knows the decision without another barrier; only workgroup 0 writes the shared state.
-// Fast path: 3 barriers
-//   rows | B1 | decide, u = H g | B2 | step, xw' = sum x_j row_j, bordered update of H | B5 | finish (WG 0)
-// (B3 / B4 only around the general active-set solve on WG 0: everybody done with the fast step's data | solve |
-// result visible).  Every workgroup arrives exactly
-// OMPF_NBAR times per launch whatever path it takes, so barrier `i` of launch `e` is "counter >=
-// (e * OMPF_NBAR + i) * OMPF_WGS"; the host resets the counter at build_begin.
-#ifndef OMPF_WGS
-#define OMPF_WGS 16
-#endif
-#define OMPF_NBAR 5
-#define OMPF_MAX_K 4096      // LDS per position: g / x (8) + u (8) + slot (4) bytes, next to 3 d-vectors
-
-#define OMPF_STAMP(i) do { if (blockIdx.x == 0) BCX_STAMP(st, i); } while (0)
-
-// data of a newly selected slot: row, Gram row / column (from the rows phase), c = row . b.  One workgroup.
-static __device__ void omp_store_new_slot(const NnlsArgs& n, int slot, int k, const double* xfs, int64_t f, double nf,
-                                          double gff, double cf) {
-  const ApplyArgs& a = n.a;
-  const int tid = threadIdx.x, d = a.d;
-  for (int i = tid; i < d; i += blockDim.x) a.act_rows[(size_t)slot * d + i] = xfs[i];
-  for (int j = tid; j < k; j += blockDim.x) {
-    const double g = n.t3[j];
-    n.gram[(size_t)slot * n.ldg + j] = g;
-    n.gram[(size_t)j * n.ldg + slot] = g;
-  }
-  if (tid == 0) {
-    a.act_idx[slot] = f; a.act_norm[slot] = nf; a.act_w[slot] = 0.0; n.ppos[slot] = -1; n.x[slot] = 0.0;
-    n.gram[(size_t)slot * n.ldg + slot] = gff;
-    n.cvec[slot] = cf;
-  }
-}
-
-__global__ __launch_bounds__(NN_THREADS) void omp_fused_kernel(NnlsArgs n, GridSync gs, int kcap, int dpad) {
-  const ApplyArgs& a = n.a;
-  DevState* st = a.st;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = blockDim.x >> 6, d = a.d;
-  const int wg = blockIdx.x, nwg = gridDim.x;
-  if (!st->active) { grid_arrive(gs, OMPF_NBAR); return; }
-  extern __shared__ double dyn[];
-  double* t0s = dyn;                     // g = G[slot, P] by position; later the new x by position
-  double* t1s = dyn + kcap;              // u = H g
-  double* xfs = dyn + 2 * (size_t)kcap;  // the winner's row
-  double* qs = xfs + dpad;               // current residual query
-  double* bs = qs + dpad;                // b
-  int* cs = (int*)(bs + dpad);           // passive list: slot by position
-  __shared__ double scratch[BCX_SCRATCH];
-  __shared__ double seg[NN_THREADS / 64][64];
-  __shared__ double w_v[NN_THREADS / 64];
-  __shared__ long long w_i[NN_THREADS / 64];
-  __shared__ int w_s[NN_THREADS / 64], w_np[NN_THREADS / 64], w_m[NN_THREADS / 64];
-  __shared__ int s_win, s_ovf, s_bad, s_flag;
-  OMPF_STAMP(0);
-  if (tid == 0) { int o; s_win = omp_pick_record(a, &o); s_ovf = o; s_bad = 0; }
-  __syncthreads();
-  if (s_ovf || s_win < 0) {
-    grid_arrive(gs, OMPF_NBAR);
-    if (wg == 0 && tid == 0) { st->active = 0; st->halt = s_ovf ? HALT_NEED_EXACT : HALT_DONE; }
-    return;
-  }
-  const double* rec = a.recs + (size_t)s_win * (d + BCX_REC_HDR);
-  const double* xf = rec + BCX_REC_HDR;
-  const int k = st->k, p = st->np;
-  const double err0 = st->err, bnorm0 = st->bnorm;
-  const int hvalid0 = st->hvalid, ill0 = st->omp_ill, since0 = st->since_refresh;   // fetched with the first round trip
-  for (int i = tid; i < d; i += blockDim.x) { xfs[i] = xf[i]; qs[i] = a.q64[i]; bs[i] = a.b[i]; }
-  for (int q = tid; q < p; q += blockDim.x) cs[q] = n.plist[q];
-  __syncthreads();
-  // ---- phase 1: -An[j].r for the active rows and row_j . xf for all slots; one wave per row, all loads of a
-  // 512-element stretch in flight together ------------------------------------------------------------------
-  for (int j = wg * nw + wave; j < k; j += nwg * nw) {
-    const double* row = a.act_rows + (size_t)j * d;
-    double a0 = 0.0, a1 = 0.0;
-    for (int i0 = 0; i0 < d; i0 += 512) {
-      double rv[8];
-#pragma unroll
-      for (int t = 0; t < 8; ++t) { const int i = i0 + t * 64 + lane; rv[t] = i < d ? row[i] : 0.0; }
-#pragma unroll
-      for (int t = 0; t < 8; ++t) { const int i = i0 + t * 64 + lane; if (i < d) { a0 += rv[t] * xfs[i]; a1 += rv[t] * qs[i]; } }
-    }
-    a0 = wave_allsum(a0);
-    a1 = wave_allsum(a1);
-    if (lane == 0) { n.t3[j] = a0; n.t2[j] = -(a1 / a.act_norm[j]); }
-  }
-  OMPF_STAMP(1);
-  if (!grid_barrier(gs, 1, &s_flag)) { if (wg == 0 && tid == 0) { st->active = 0; st->halt = HALT_GRID_TIMEOUT; } return; }
-  OMPF_STAMP(2);
-  // ---- phase 2: decide (every workgroup, one pass over the slots; workgroup 0 writes) --------------------------
-  const int64_t fpos = (int64_t)rec[1];
-  const double nf = rec[2];
-  int npos = 0, match = 0x7fffffff;
-  double bv = -INFINITY; long long bidx = -1; int bslot = -1;
-  for (int j = tid; j < k; j += blockDim.x) {
-    const double wj = a.act_w[j];
-    const long long gj = a.act_idx[j];
-    if (gj == fpos && j < match) match = j;
-    if (wj > 0.0) {
-      ++npos;
-      const double vv = n.t2[j];
-      if (negbest_better(bv, bidx, vv, gj)) { bv = vv; bidx = gj; bslot = j; }
-    }
-  }
-  double g2[2] = {0.0, 0.0};                                   // xf . xf, xf . b
-  for (int i = tid; i < d; i += blockDim.x) { g2[0] += xfs[i] * xfs[i]; g2[1] += xfs[i] * bs[i]; }
-#pragma unroll
-  for (int off = 32; off >= 1; off >>= 1) {
-    const double ov = __shfl_xor(bv, off, BCX_WAVE);
-    const long long oi = __shfl_xor(bidx, off, BCX_WAVE);
-    const int os = __shfl_xor(bslot, off, BCX_WAVE);
-    if (negbest_better(bv, bidx, ov, oi)) { bv = ov; bidx = oi; bslot = os; }
-    npos += __shfl_xor(npos, off, BCX_WAVE);
-    match = min(match, __shfl_xor(match, off, BCX_WAVE));
-  }
-  g2[0] = wave_allsum(g2[0]);
-  g2[1] = wave_allsum(g2[1]);
-  if (lane == 0) { w_v[wave] = bv; w_i[wave] = bidx; w_s[wave] = bslot; w_np[wave] = npos; w_m[wave] = match; seg[0][wave] = g2[0]; seg[1][wave] = g2[1]; }
-  __syncthreads();
-  bv = w_v[0]; bidx = w_i[0]; bslot = w_s[0]; npos = w_np[0]; match = w_m[0];
-  double xfxf = seg[0][0], xfb = seg[1][0];
-  for (int w = 1; w < nw; ++w) {
-    if (negbest_better(bv, bidx, w_v[w], w_i[w])) { bv = w_v[w]; bidx = w_i[w]; bslot = w_s[w]; }
-    npos += w_np[w];
-    match = min(match, w_m[w]);
-    xfxf += seg[0][w]; xfb += seg[1][w];
-  }
-  __syncthreads();
-  const bool checked = npos > 0;
-  int64_t f = fpos;
-  int slot = match == 0x7fffffff ? -1 : match;
-  if (checked && !(rec[0] >= bv)) { f = bidx; slot = bslot; }   // orthopursuit.py:32-35
-  const bool fresh = slot < 0;
-  if (fresh) slot = k;
-  const int k1 = fresh ? k + 1 : k;
-  const double gff = fresh ? xfxf : n.gram[(size_t)slot * n.ldg + slot];
-  const double cf = fresh ? xfb : n.cvec[slot];
-  const double nslot = fresh ? nf : a.act_norm[slot];
-  const int pos_slot = fresh ? -1 : n.ppos[slot];
-  int mode;
-  if (!hvalid0) mode = OMP_GENERAL;
-  else if (pos_slot >= 0) mode = OMP_DONE;                // f already carries weight: nothing changes
-  else if (ill0) mode = OMP_GENERAL;
-  else if ((since0 % OMP_RESOLVE_EVERY) == OMP_RESOLVE_EVERY - 1) mode = OMP_GENERAL;
-  else mode = OMP_FAST_TRY;
-  const int mode0 = mode; (void)mode0;
-  OMPF_STAMP(3);
-  // ---- phase 3: u = H g on this workgroup's 64-column blocks ------------------------------------------
-  if (mode == OMP_FAST_TRY) {
-    for (int q = tid; q < p; q += blockDim.x)
-      t0s[q] = fresh ? n.t3[cs[q]] : n.gram[(size_t)slot * n.ldg + cs[q]];
-    __syncthreads();
-    for (int cb = wg; cb * 64 < p; cb += nwg) {
-      const int col = cb * 64 + lane;
-      double acc = 0.0;
-      if (col < p) {
-        int b = wave;
-        for (; b + 7 * nw < p; b += 8 * nw) {
-          double m[8];
-#pragma unroll
-          for (int t = 0; t < 8; ++t) m[t] = n.hinv[(size_t)(b + t * nw) * n.ldg + col];
-#pragma unroll
-          for (int t = 0; t < 8; ++t) acc += m[t] * t0s[b + t * nw];
-        }
-        for (; b < p; b += nw) acc += n.hinv[(size_t)b * n.ldg + col] * t0s[b];
-      }
-      seg[wave][lane] = acc;
-      __syncthreads();
-      if (wave == 0 && col < p) {
-        double t = seg[0][lane];
-        for (int w = 1; w < nw; ++w) t += seg[w][lane];
-        n.t1[col] = t;
-      }
-      __syncthreads();
-    }
-  }
-  OMPF_STAMP(4);
-  if (!grid_barrier(gs, 2, &s_flag)) { if (wg == 0 && tid == 0) { st->active = 0; st->halt = HALT_GRID_TIMEOUT; } return; }
-  OMPF_STAMP(5);
-  // ---- phase 4: step (every workgroup) -------------------------------------------------------------------
-  const double eps = 2.220446049250313e-16;
-  const double tolscale = 10.0 * eps * (double)(d > k1 ? d : k1) * bnorm0;
-  double tstep = 0.0, inv = 0.0;
-  if (mode == OMP_FAST_TRY) {
-    double r[2] = {0.0, 0.0};
-    double xo[OMPF_MAX_K / NN_THREADS];
-#pragma unroll
-    for (int t = 0; t < OMPF_MAX_K / NN_THREADS; ++t) {
-      const int q = tid + t * NN_THREADS;
-      xo[t] = 0.0;
-      if (q < p) {
-        const double u = n.t1[q];
-        xo[t] = n.x[cs[q]];
-        t1s[q] = u;
-        r[0] += t0s[q] * u; r[1] += t0s[q] * xo[t];
-      }
-    }
-    block_allsum<2>(r, scratch);
-    const double sc = gff - r[0];
-    const double wvf = cf - r[1];
-    mode = OMP_GENERAL;
-    if (!(wvf > tolscale * nslot)) {
-      mode = OMP_DONE;                                      // dual not positive: f gets weight 0
-    } else if (!(sc > 1e-4 * gff)) {
-      if (wg == 0 && tid == 0) st->omp_ill = 1;             // nearly dependent column: refined general solve
-    } else {
-      tstep = wvf / sc;
-      int bad = 0;
-#pragma unroll
-      for (int t = 0; t < OMPF_MAX_K / NN_THREADS; ++t) {
-        const int q = tid + t * NN_THREADS;
-        if (q < p) {
-          const double xn = xo[t] - tstep * t1s[q];
-          t0s[q] = xn;                                      // candidate x by position (g is no longer needed)
-          if (!(xn > 0.0)) bad = 1;
-        }
-      }
-      if (bad) s_bad = 1;
-      __syncthreads();
-      if (!s_bad && tstep > 0.0) { mode = OMP_FAST_ACCEPT; inv = 1.0 / sc; }
-    }
-    __syncthreads();
-  }
-  OMPF_STAMP(6);
-  // ---- general active-set solve (rare): workgroup 0 alone, the others wait at barrier 3 -------------------
-  if (mode == OMP_GENERAL) {
-    // every workgroup must be done with x / u of the failed fast step before workgroup 0 starts rewriting them
-    if (!grid_barrier(gs, 3, &s_flag)) { if (wg == 0 && tid == 0) { st->active = 0; st->halt = HALT_GRID_TIMEOUT; } return; }
-    if (wg == 0) {
-      if (fresh) { omp_store_new_slot(n, slot, k, xfs, f, nf, gff, cf); __syncthreads(); }
-      if (!hvalid0) rebuild_passive(n, k, scratch);
-      for (int j = tid; j < k1; j += blockDim.x) {
-        const bool in = (j == slot) || (a.act_w[j] > 0.0);
-        n.flag[j] = in ? FLAG_INS : 0;
-        if (n.ppos[j] < 0) n.x[j] = 0.0;
-      }
-      __syncthreads();
-      nnls_run(n, k1, tolscale, scratch);
-      // Publish the result for the other workgroups in buffers none of them has loaded in this launch, with
-      // write-through stores: their XCD's L2 may still hold the x / passive-list / np lines they read in the
-      // earlier phases, and an acquire fence does not drop stale L2 lines.
-      const int npub = st->np;
-      for (int q = tid; q < npub; q += blockDim.x) {
-        const int c = n.plist[q];
-        coh_store(&n.z[q], n.x[c]);
-        coh_store(&n.wbak[q], (double)c);
-      }
-      if (tid == 0) coh_store(&n.wbak[n.ldg - 1], (double)npub);
-    }
-    if (!grid_barrier(gs, 4, &s_flag)) { if (wg == 0 && tid == 0) { st->active = 0; st->halt = HALT_GRID_TIMEOUT; } return; }
-  } else {
-    grid_arrive(gs, 2);
-  }
-  // ---- phase 5: xw' = sum_P x_j row_j on 64-column blocks; bordered update of H ---------------------------
-  const bool acc_fast = mode == OMP_FAST_ACCEPT;
-  const int pn = (mode == OMP_GENERAL) ? (int)coh_load(&n.wbak[n.ldg - 1]) : (acc_fast ? p + 1 : p);
-  if (mode == OMP_GENERAL) {
-    for (int q = tid; q < pn; q += blockDim.x) { cs[q] = (int)coh_load(&n.wbak[q]); t0s[q] = coh_load(&n.z[q]); }
-  } else if (acc_fast) {
-    if (tid == 0) { cs[p] = slot; t0s[p] = tstep; }
-  } else {
-    for (int q = tid; q < pn; q += blockDim.x) t0s[q] = n.x[cs[q]];
-  }
-  __syncthreads();
-  const bool new_in_lds = acc_fast && fresh;          // the new slot's row is not in act_rows yet
-  const int pg = new_in_lds ? p : pn;
-  for (int cb = wg; cb * 64 < d; cb += nwg) {
-    const int col = cb * 64 + lane;
-    double acc = 0.0;
-    if (col < d) {
-      int q = wave;
-      for (; q + 7 * nw < pg; q += 8 * nw) {
-        double m[8];
-#pragma unroll
-        for (int t = 0; t < 8; ++t) m[t] = a.act_rows[(size_t)cs[q + t * nw] * d + col];
-#pragma unroll
-        for (int t = 0; t < 8; ++t) acc += t0s[q + t * nw] * m[t];
-      }
-      for (; q < pg; q += nw) acc += t0s[q] * a.act_rows[(size_t)cs[q] * d + col];
-      if (new_in_lds && wave == (p % nw)) acc += tstep * xfs[col];
-    }
-    seg[wave][lane] = acc;
-    __syncthreads();
-    if (wave == 0 && col < d) {
-      double t = seg[0][lane];
-      for (int w = 1; w < nw; ++w) t += seg[w][lane];
-      a.tmp[col] = t;
-    }
-    __syncthreads();
-  }
-  OMPF_STAMP(7);
-  if (acc_fast) {
-    // H <- [[H + u u^T / s, -u/s], [-u^T/s, 1/s]]; the workgroups without a column block start first
-    const int ncb = (d + 63) / 64;
-    const int shift = ncb < nwg ? ncb : 0;
-    const int vwg = (wg + nwg - shift) % nwg;
-    for (int rr = vwg * nw + wave; rr < p; rr += nwg * nw) {
-      const double ur = t1s[rr] * inv;
-      double* hrow = n.hinv + (size_t)rr * n.ldg;
-      for (int cc = lane; cc < p; cc += 64) hrow[cc] += ur * t1s[cc];
-    }
-    for (int q = wg * blockDim.x + tid; q < p; q += nwg * blockDim.x) {
-      const double e = -t1s[q] * inv;
-      n.hinv[(size_t)p * n.ldg + q] = e;
-      n.hinv[(size_t)q * n.ldg + p] = e;
-    }
-    if (wg == 0 && tid == 0) n.hinv[(size_t)p * n.ldg + p] = inv;
-  }
-  OMPF_STAMP(8);
-  if (fresh && mode != OMP_GENERAL && wg == nwg - 1) omp_store_new_slot(n, slot, k, xfs, f, nf, gff, cf);
-  if (wg != 0) { grid_arrive(gs, 1); return; }
-  if (!grid_barrier(gs, 5, &s_flag)) { if (tid == 0) { st->active = 0; st->halt = HALT_GRID_TIMEOUT; } return; }
-  OMPF_STAMP(9);
-  // ---- phase 6 (workgroup 0): commit the step's x, error, monotone check, trace, next query ------------------
-  if (acc_fast) {
-    for (int q = tid; q <= p; q += blockDim.x) n.x[cs[q]] = t0s[q];
-    if (tid == 0) { n.plist[p] = slot; n.ppos[slot] = p; st->np = p + 1; }
-    __syncthreads();
-  }
-  double v[2] = {0.0, 0.0};
-  for (int j = tid; j < d; j += blockDim.x) {
-    const double x = a.tmp[j], rr = x - bs[j];
-    v[0] += rr * rr; v[1] += x * x;
-  }
-  block_allsum<2>(v, scratch);
-  const double new_err = sqrt(v[0]);
-  int status = BCX_IT_OK;
-  if (checked && !st->no_monotone && new_err > err0) status = BCX_IT_FAIL_MONOTONE;      // snnls.py:56-58
-  if (status == BCX_IT_OK) {
-    for (int j = tid; j < k1; j += blockDim.x) a.act_w[j] = (n.ppos[j] >= 0) ? n.x[j] : 0.0;
-    for (int j = tid; j < d; j += blockDim.x) a.xw[j] = a.tmp[j];
-    if (tid == 0) {
-      st->k = k1;
-      st->err = new_err;
-      const double nwn = sqrt(v[1]);
-      st->nw = nwn == 0.0 ? 1.0 : nwn;
-      st->since_refresh += 1;
-      if (checked && !st->no_monotone) st->retried = 0;
-    }
-  } else if (tid == 0) {
-    st->hvalid = 0;        // weights were not touched; passive data is rebuilt lazily
-  }
-  __syncthreads();
-  if (tid == 0) {
-    const int64_t it = st->it;
-    a.tr_sel[it] = f; a.tr_err[it] = st->err; a.tr_status[it] = status;
-    st->it = it + 1;
-    st->exact_mode = 0;
-    st->omp_mode = OMP_IDLE;
-    st->hlo_valid = 0;
-    if (status != BCX_IT_OK) {
-      if (st->retried) { st->limit = 1; st->active = 0; st->halt = HALT_LIMIT; }
-      else st->retried = 1;
-    }
-  }
-  __syncthreads();
-  OMPF_STAMP(10);
-  if (st->active) prepare_next(a, scratch);
-  OMPF_STAMP(11);
-}
-
 void fill_nnls_args(bcx_solver* s, NnlsArgs& n, const double* recs) {
   fill_apply_args(s, n.a, recs);
   n.a.refresh_every = 0;   // OMP recomputes xw from the passive set on every step
@@ -977,34 +614,13 @@ int bcx_launch_apply_omp(bcx_solver* s, const double* recv_dev) {
   fill_nnls_args(s, n, recv_dev);
   s->k_ub += 1;                               // this step may add one slot
   const int64_t kub = s->k_ub;
-  // dev: BCX_OMP_FORM=fused (round 2's kernel: closed form until the first small Schur complement, then one workgroup
-  // solving from scratch) or =multi (one kernel per phase); default: the incremental multi-workgroup step of omp_lh.hip,
-  // multi-kernel form beyond its LDS budget
+  // default: the incremental multi-workgroup step of omp_lh.hip; beyond its LDS budget (or with BCX_OMP_MULTI=1 /
+  // BCX_OMP_FORM=multi, dev) the multi-kernel form below (plain-double inverse)
   static const char* form = getenv("BCX_OMP_FORM");
   static const bool legacy = getenv("BCX_OMP_MULTI") != nullptr || (form && form[0] == 'm');
-  const bool old_fused = form && form[0] == 'f';
-  if (!legacy && !old_fused && s->grid_counter) {
+  if (!legacy && s->grid_counter) {
     const int rc = bcx_launch_omp_lh(s, n);
     if (rc <= 0) return rc;
-  }
-  if (old_fused && s->grid_counter && kub < OMPF_MAX_K &&
-      (2 * (size_t)((kub + 1 + 63) / 64 * 64) + 3 * (size_t)((s->cfg.d + 63) / 64 * 64)) * 8 + (size_t)((kub + 1 + 63) / 64 * 64) * 4 <= 150 * 1024) {
-    const int kcap = (int)((kub + 1 + 63) / 64 * 64);
-    const int dpad = (s->cfg.d + 63) / 64 * 64;
-    const size_t lds = (2 * (size_t)kcap + 3 * (size_t)dpad) * sizeof(double) + (size_t)kcap * sizeof(int);
-    if (lds > s->omp_lds_allowed) {
-      const size_t mx = 150 * 1024;
-      BCX_HIP(hipFuncSetAttribute((const void*)omp_fused_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)mx));
-      s->omp_lds_allowed = mx;
-    }
-    GridSync gs;
-    gs.counter = s->grid_counter;
-    gs.base = (unsigned long long)s->grid_epoch * OMPF_NBAR * OMPF_WGS;
-    gs.timeout_ticks = 1000000000LL;   // 10 s
-    s->grid_epoch += 1;
-    hipLaunchKernelGGL(omp_fused_kernel, dim3(OMPF_WGS), dim3(NN_THREADS), lds, s->stream, n, gs, kcap, dpad);
-    BCX_HIP(hipGetLastError());
-    return BCX_OK;
   }
   const int d = s->cfg.d;
   hipLaunchKernelGGL(omp_rows_kernel, dim3((unsigned)((kub + 1 + 3) / 4)), dim3(256), 0, s->stream, n);
