@@ -14,11 +14,13 @@
 #include <algorithm>
 #include <atomic>
 #include <cstdlib>
+#include <mutex>
 #include <string>
 #include <utility>
 #include <vector>
 #include "bcx_internal.h"
 #include "dev_util.h"
+#include "proj_math.h"
 
 enum { FAM_LOGISTIC = 0, FAM_POISSON = 1, FAM_LINREG = 2 };
 enum { PMODE_WRITE = 0, PMODE_COLSUM = 1, PMODE_SELECT = 2 };
@@ -42,117 +44,40 @@ struct ProjArgs {
   double* part;         // SELECT on teams: ngc x N records {shift, s1, s2, sd} of partial row moments (select_combine_kernel)
   double* best_val;     // SELECT: gridDim.x
   int64_t* best_idx;    // SELECT: gridDim.x
+  const double* tab;    // the likelihood's tables (proj_math.h), PJT_DOUBLES doubles in device memory
 };
 
-// gammaln(y + 1) of the Poisson likelihood as a real call: inlined, its polynomial tables and temporaries land in the
-// epilogue's register budget (WRITE spilled 166 VGPRs, none with the call; SELECT 175 -> 6).
+// gammaln(y + 1) of the Poisson likelihood (model_poiss.py:37).  Only WRITE forms it: along a row it is a constant, which
+// cancels in (value - shift) of the column sums and of the row moments.  Responses are counts: log(y!) comes from a table
+// for the integers 0 .. 255 (rounded from long double); anything else goes to the library lgamma as a real call --
+// inlined, its polynomial tables and temporaries land in the epilogue's register budget (WRITE spilled 166 VGPRs).  The
+// library routine is some hundreds of fp64 instructions on the unit the MFMAs run on, and WRITE needs it for 8 rows
+// per lane and tile of 32 values.
 __device__ __attribute__((noinline)) double pj_lgamma1p_call(double y) { return lgamma(y + 1.0); }
-template <int MODE> __device__ __forceinline__ double pj_lgamma1p(double y) { return pj_lgamma1p_call(y); }
 
-// log1p(u) for 0 <= u <= 1 (u = exp(-|t|) of a softplus): 2 atanh(s) with s = u / (2 + u) <= 1/3 as the odd series
-// s (1 + s^2/3 + s^4/5 + ...) up to s^32/33 (truncation < 2e-17 relative), Horner in fp64: 2-3 ulp, 32 VALU instructions.
-// The library log1p is a double-double routine of 135 instructions (75 dependent v_add_f64): with exp (42) it made the
-// logistic epilogue 177 instructions per element on the unit the fp64 MFMAs run on -- a third of the kernel at D = 300.
-// a * b + C with the constant C held in a scalar register pair.  hipcc materialises every fp64 literal of a Horner chain
-// with two v_mov_b32 into a VGPR pair (v_fmac_f64 takes no 64-bit literal): 46 of the 104 VALU instructions of the
-// logistic likelihood were such moves -- paid on the port the fp64 MFMAs issue from.  As an SGPR operand of v_fma_f64 the
-// constant costs two s_mov_b32 on the scalar unit instead.
-__device__ __forceinline__ double pj_fma_c(double a, double b, double c) {
-  double r;
-  asm("v_fma_f64 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "s"(c));
-  return r;
-}
-__device__ __forceinline__ double pj_fma_k(double a, double k, double b) {   // a * K + b, K scalar
-  double r;
-  asm("v_fma_f64 %0, %1, %2, %3" : "=v"(r) : "v"(a), "s"(k), "v"(b));
-  return r;
-}
-// u / d for d in [1.7, 3]: hardware reciprocal + two Newton steps + one correction of the quotient (8 instructions, <= 1
-// ulp; the compiler's fp64 division is 14 with its scaling and fix-up steps, which a bounded divisor does not need)
-__device__ __forceinline__ double pj_div_bounded(double u, double d) {
-  double x = __builtin_amdgcn_rcp(d);
-  x = fma(fma(-d, x, 1.0), x, x);
-  x = fma(fma(-d, x, 1.0), x, x);
-  const double q = u * x;
-  return fma(fma(-d, q, u), x, q);
-}
-// exp(x) for x <= 0 (the softplus argument -|t|): x = k ln 2 + r with |r| <= 0.347 (Cody-Waite, ln 2 in two pieces), the
-// Taylor polynomial of degree 13 in Horner form (truncation 4e-18), ldexp: 20 instructions, 1 ulp against long double over
-// 2.3e6 arguments.  The library exp is ~45 VALU instructions here, most of them 32-bit moves and selects around its
-// double-double arithmetic; on this kernel they are paid on the unit the fp64 MFMAs issue from (profiles/r03_proj_*_mfma.txt:
-// MFMA busy + VALU busy = 97 % of the SIMD cycles for the logistic family).
-__device__ __forceinline__ double pj_exp_nonpos(double x) {
-  x = fmax(x, -800.0);
-  const double kf = __builtin_rint(x * 1.4426950408889634);
-  double r = pj_fma_k(kf, -6.93147180369123816490e-01, x);
-  r = pj_fma_k(kf, -1.90821492927058770002e-10, r);
-  double p = 1.0 / 6227020800.0;
-  p = pj_fma_c(p, r, 1.0 / 479001600.0); p = pj_fma_c(p, r, 1.0 / 39916800.0); p = pj_fma_c(p, r, 1.0 / 3628800.0);
-  p = pj_fma_c(p, r, 1.0 / 362880.0);    p = pj_fma_c(p, r, 1.0 / 40320.0);    p = pj_fma_c(p, r, 1.0 / 5040.0);
-  p = pj_fma_c(p, r, 1.0 / 720.0);       p = pj_fma_c(p, r, 1.0 / 120.0);      p = pj_fma_c(p, r, 1.0 / 24.0);
-  p = pj_fma_c(p, r, 1.0 / 6.0);         p = fma(p, r, 0.5);                   p = fma(p, r, 1.0);
-  p = fma(p, r, 1.0);
-  return ldexp(p, (int)kf);
-}
-__device__ __forceinline__ double pj_log1p01(double u) {
-  const double s = pj_div_bounded(u, 2.0 + u), q = s * s;
-  double p = 1.0 / 33.0;
-  p = pj_fma_c(p, q, 1.0 / 31.0); p = pj_fma_c(p, q, 1.0 / 29.0); p = pj_fma_c(p, q, 1.0 / 27.0); p = pj_fma_c(p, q, 1.0 / 25.0);
-  p = pj_fma_c(p, q, 1.0 / 23.0); p = pj_fma_c(p, q, 1.0 / 21.0); p = pj_fma_c(p, q, 1.0 / 19.0); p = pj_fma_c(p, q, 1.0 / 17.0);
-  p = pj_fma_c(p, q, 1.0 / 15.0); p = pj_fma_c(p, q, 1.0 / 13.0); p = pj_fma_c(p, q, 1.0 / 11.0); p = pj_fma_c(p, q, 1.0 / 9.0);
-  p = pj_fma_c(p, q, 1.0 / 7.0);  p = pj_fma_c(p, q, 1.0 / 5.0);  p = pj_fma_c(p, q, 1.0 / 3.0);  p = fma(p, q, 1.0);
-  return 2.0 * s * p;
-}
+// The transcendental pieces (exp on (-inf, 0], log1p on [0, 1], log of a positive number) are table driven: proj_math.h.
+// Their tables (PJT_DOUBLES doubles, built on the host from long double) sit behind the kernel's other LDS regions.
+typedef const double __attribute__((address_space(3)))* pj_tab_t;
+
 // log(1 + exp(t)) = max(t, 0) + log1p(exp(-|t|))
-__device__ __forceinline__ double pj_softplus(double t) { return fmax(t, 0.0) + pj_log1p01(pj_exp_nonpos(-fabs(t))); }
+__device__ __forceinline__ double pj_softplus(double t, pj_tab_t tab) { return fmax(t, 0.0) + pjm_log1p01(pjm_exp_nonpos(-fabs(t), tab), tab); }
 
-// log(x) for a positive normal x (the Poisson rate: >= log1p(e^-100) = 3.7e-44): x = 2^e m with m in [sqrt(1/2), sqrt(2)),
-// log m = 2 atanh(s), s = (m - 1) / (m + 1), |s| <= 0.172 -- the odd series up to s^22 / 23 (truncation < 1e-18 relative)
-// in Horner form, e ln 2 added in two pieces: <= 3 ulp (checked against long double over 4e6 arguments), ~35 VALU
-// instructions.  The library log is a double-double routine of 98, and it was the last library transcendental of the
-// Poisson epilogue beside exp.
-__device__ __forceinline__ double pj_log_pos(double x) {
-  const long long bits = __double_as_longlong(x);
-  int e = (int)((bits >> 52) & 0x7ff) - 1023;
-  double m = __longlong_as_double((bits & 0x000fffffffffffffLL) | 0x3ff0000000000000LL);   // [1, 2)
-  if (m > 1.4142135623730951) { m *= 0.5; e += 1; }
-  const double s = pj_div_bounded(m - 1.0, m + 1.0), q = s * s;
-  double p = 1.0 / 23.0;
-  p = pj_fma_c(p, q, 1.0 / 21.0); p = pj_fma_c(p, q, 1.0 / 19.0); p = pj_fma_c(p, q, 1.0 / 17.0); p = pj_fma_c(p, q, 1.0 / 15.0);
-  p = pj_fma_c(p, q, 1.0 / 13.0); p = pj_fma_c(p, q, 1.0 / 11.0); p = pj_fma_c(p, q, 1.0 / 9.0);  p = pj_fma_c(p, q, 1.0 / 7.0);
-  p = pj_fma_c(p, q, 1.0 / 5.0);  p = pj_fma_c(p, q, 1.0 / 3.0);  p = fma(p, q, 1.0);
-  const double ed = (double)e;
-  return ed * 6.93147180369123816490e-01 + (2.0 * s * p + ed * 1.90821492927058770002e-10);
-}
+// (Round 2/3 evaluated the logistic and Poisson likelihoods as real calls in SELECT and WRITE: inlined, the temporaries of
+// their long series spilled registers inside the k loop.  The table forms are short enough to inline everywhere.)
 
-// The Poisson likelihood as two real calls in sequence (rate, then its logarithm): inlined, the series' temporaries spill
-// registers inside the k loop (24.8 against 28.3 TFLOP/s at D = 300 although the epilogue got shorter); as ONE call the
-// two series interleave and cost the SELECT caller registers; nested, the outer call needs a stack frame.
-__device__ __attribute__((noinline)) double pj_rate_call(double m) { return fmax(m, 0.0) + pj_log1p01(pj_exp_nonpos(-fabs(m))); }
-__device__ __attribute__((noinline)) double pj_lograte_call(double lam) { return pj_log_pos(lam); }
-__device__ __forceinline__ double pj_poisson_call(double m, double y, double c0) {
-  const double lam = pj_rate_call(m);
-  const double sl = m > -100.0 ? pj_lograte_call(lam) : m;
-  return y * sl - c0 - lam;
-}
-
-// the logistic likelihood as a real call (SELECT: inlined beside the per-row moments its exp / log1p series spill registers)
-__device__ __attribute__((noinline)) double pj_logistic_call(double m) {
-  const double t = -m;
-  return t < 100.0 ? -pj_softplus(t) : -t;
-}
-
-template <int FAM, bool CALL = false> __device__ __forceinline__ double loglik(double m, double y, double param, double c0) {
+template <int FAM> __device__ __forceinline__ double loglik(double m, double y, double param, double c0, pj_tab_t tab) {
   if (FAM == FAM_LOGISTIC) {
-    if (CALL) return pj_logistic_call(m);
-    const double t = -m;                                   // model_lr.py:28
-    return t < 100.0 ? -pj_softplus(t) : -t;               // model_lr.py:29-31  (-log1p(exp(t)) below 100)
+    // model_lr.py:29-31 switches from -log1p(exp(t)) to -t at t = 100: there exp(-t) < 4e-44 and max(t, 0) + log1p(.) IS t to
+    // every bit, so the softplus form needs no branch.
+    return -pj_softplus(-m, tab);                          // model_lr.py:28-31  (t = -m; -log1p(exp(t)), -t from t = 100 on)
   } else if (FAM == FAM_POISSON) {
     // model_poiss.py:25-38: s' = log(lam) with the rate lam = log(1 + e^s) = max(s, 0) + log1p(exp(-|s|)) where s > -100,
     // s' = s below (there lam = e^s to every bit: log1p(e) = e for e < 4e-44); log-likelihood y s' - gammaln(y + 1) - exp(s').
     // exp(s') IS lam: the rate is used as computed instead of exponentiating its logarithm again (one 42-instruction exp
     // less per element, and a few ulp closer to the exact value than the reference's exp(log(.))).
-    return pj_poisson_call(m, y, c0);                      // (c0 = gammaln(y+1))
+    const double lam = pj_softplus(m, tab);
+    const double sl = m > -100.0 ? pjm_log_pos(lam, tab) : m;
+    return y * sl - c0 - lam;                              // (c0 = gammaln(y+1))
   } else {
     // model_linreg.py:10 (c0 = -0.5 log(2 pi sigsq)); param = 1 / (2 sigsq), formed once per kernel: the quotient by the
     // common divisor as a product (<= 1 ulp from the division; an fp64 division is ~25 instructions on the unit the
@@ -165,9 +90,9 @@ template <int FAM, bool CALL = false> __device__ __forceinline__ double loglik(d
 // predictor (see the epilogue), and the difference has a closed form without the cancellation:
 //   [c0 - (y^2 - 2 m y + m^2) / (2 sigsq)] - [c0 - y^2 / (2 sigsq)] = (2 y - m) m / (2 sigsq)
 // -- three operations instead of seven per element, and more accurate than forming both terms.
-template <int FAM, int MODE, bool CALL> __device__ __forceinline__ double loglik_shifted(double m, double y, double param, double c0, double shift) {
+template <int FAM, int MODE> __device__ __forceinline__ double loglik_shifted(double m, double y, double param, double c0, double shift, pj_tab_t tab) {
   if (FAM == FAM_LINREG && MODE == PMODE_COLSUM) return (2.0 * y - m) * m * param;
-  return loglik<FAM, CALL>(m, y, param, c0) - shift;
+  return loglik<FAM>(m, y, param, c0, tab) - shift;
 }
 
 // sum over the 16 lanes of a DPP row (lanes that share l >> 4)
@@ -305,6 +230,14 @@ __global__ __launch_bounds__(256, 2) void proj_kernel(ProjArgs p) {
   double* colacc = (double*)(pj_lds + PJ_STAGING_BYTES(NCT)) + (size_t)wave * cacc_n;
   if (MODE == PMODE_COLSUM) {
     for (int c = lane; c < cacc_n; c += 64) colacc[c] = 0.0;
+  }
+  // the likelihood's tables (proj_math.h), behind the accumulators; copied before the first LDS-DMA request is issued, so
+  // the compiler's wait for these ordinary loads is exact; the barrier that ends the first stage publishes them
+  constexpr int NTAB = FAM == FAM_POISSON ? PJT_DOUBLES : FAM == FAM_LOGISTIC ? PJT_DOUBLES_LOGISTIC : 0;
+  unsigned char* const tab_lds = pj_lds + PJ_STAGING_BYTES(NCT) + (MODE == PMODE_COLSUM ? (size_t)4 * cacc_n * sizeof(double) : 0);
+  const pj_tab_t tab = (pj_tab_t)tab_lds;
+  if (NTAB) {
+    for (int k = tid; k < NTAB; k += 256) ((double*)tab_lds)[k] = p.tab[k];
   }
   if (br0 >= nblk) {
     if (MODE == PMODE_COLSUM) {
@@ -535,8 +468,14 @@ __global__ __launch_bounds__(256, 2) void proj_kernel(ProjArgs p) {
             const int64_t row = r0 + 16 * (e >> 2) + lk + 4 * (e & 3);
             const double y = (p.ycol >= 0 && row < p.N) ? p.Z[row * p.ldz + p.ycol] : 0.0;
             yv[e] = y;
-            cp[e] = (FAM == FAM_POISSON) ? pj_lgamma1p<MODE>(y) : clin;
-            if (FAM == FAM_POISSON) __builtin_amdgcn_sched_barrier(0);   // one lgamma at a time
+            if (FAM == FAM_POISSON) {
+              const int yi = (int)y;
+              const bool small_count = (double)yi == y && (unsigned)yi < (unsigned)PJT_NFACT;
+              cp[e] = small_count ? tab[PJT_LFACT + (small_count ? yi : 0)] : pj_lgamma1p_call(y);
+              __builtin_amdgcn_sched_barrier(0);   // one at a time
+            } else {
+              cp[e] = clin;
+            }
           }
         }
         // (the row means are formed by the centring pass from the stored values: no state crosses the column groups)
@@ -546,7 +485,7 @@ __global__ __launch_bounds__(256, 2) void proj_kernel(ProjArgs p) {
 #pragma unroll
           for (int e = 0; e < 8; ++e) {
             const int64_t row = r0 + 16 * (e >> 2) + lk + 4 * (e & 3);
-            if (col < S && row < p.N) p.out[row * p.ldo + col] = loglik<FAM>(acc[e >> 2][tc][e & 3], yv[e], parg, cp[e]);
+            if (col < S && row < p.N) p.out[row * p.ldo + col] = loglik<FAM>(acc[e >> 2][tc][e & 3], yv[e], parg, cp[e], tab);
           }
         }
       } else {
@@ -559,17 +498,24 @@ __global__ __launch_bounds__(256, 2) void proj_kernel(ProjArgs p) {
         // COLSUM keeps its three loop-carried values (response, constant, shift).
         constexpr bool SEL = MODE == PMODE_SELECT;
         double syv[2], scp[2], spiv[2], rs[2], rq[2], rd[2];
-        double* const yq = SEL ? syv : yv;
-        double* const cq = SEL ? scp : cp;
-        double* const pq = SEL ? spiv : piv;
-        if (SEL || cg == 0 || teamed) {
+        // (the 128-column tile has no registers to carry the response across the k loop either: it re-reads it per tile)
+        constexpr bool LOCAL = SEL || NCT > 4;
+        double* const yq = LOCAL ? syv : yv;
+        double* const cq = LOCAL ? scp : cp;
+        double* const pq = LOCAL ? spiv : piv;
+        if (LOCAL || cg == 0 || teamed) {
 #pragma unroll
           for (int tr = 0; tr < 2; ++tr) {
             const int64_t row = r0 + 16 * tr + li;
             const double y = (p.ycol >= 0 && row < p.N) ? p.Z[row * p.ldz + p.ycol] : 0.0;
             yq[tr] = y;
-            cq[tr] = (FAM == FAM_POISSON) ? pj_lgamma1p<MODE>(y) : clin;
+            cq[tr] = (FAM == FAM_POISSON) ? 0.0 : clin;   // (Poisson: gammaln(y + 1) is constant along the row and cancels in value - shift)
             rs[tr] = 0.0; rq[tr] = 0.0; rd[tr] = 0.0;
+          }
+        }
+        {
+#pragma unroll
+          for (int tr = 0; tr < 2; ++tr) {
             // per-row shift: the row's value in the group's first column (lane group lk == 0, register 0 of column tile
             // 0), handed to the four lanes that share the row.  Sums, squares and dot products are accumulated on
             // (ll - shift): the one-pass moments then cancel on the scale of the row's SPREAD, not of |ll| (rows with
@@ -578,8 +524,14 @@ __global__ __launch_bounds__(256, 2) void proj_kernel(ProjArgs p) {
             // COLSUM only needs SOME shift that is constant along the row (the centring correction removes it); its
             // column groups may sit in different workgroups, so it takes one every workgroup can form from the row
             // alone: the likelihood at a zero linear predictor.
-            const double l0 = loglik<FAM, SEL>(MODE == PMODE_COLSUM ? 0.0 : acc[tr][0][0], yq[tr], parg, cq[tr]);
-            pq[tr] = MODE == PMODE_COLSUM ? l0 : __shfl(l0, li, BCX_WAVE);
+            // (logistic: -log 2 for every row; Poisson: y log(log 2) - log 2 -- formed per tile, nothing held across the k loop)
+            if (MODE == PMODE_COLSUM && FAM == FAM_LOGISTIC) pq[tr] = -0.693147180559945309;
+            else if (MODE == PMODE_COLSUM && FAM == FAM_POISSON) pq[tr] = fma(yq[tr], -0.366512920581664327, -0.693147180559945309);
+            else if (MODE == PMODE_COLSUM) pq[tr] = 0.0;            // (linear regression: closed form of value - shift, loglik_shifted)
+            else {
+              const double l0 = loglik<FAM>(MODE == PMODE_COLSUM ? 0.0 : acc[tr][0][0], yq[tr], parg, cq[tr], tab);
+              pq[tr] = MODE == PMODE_COLSUM ? l0 : __shfl(l0, li, BCX_WAVE);
+            }
           }
         }
         // 64 columns at a time, fenced: with all NCT column tiles in one scheduling region the compiler keeps every
@@ -599,14 +551,16 @@ __global__ __launch_bounds__(256, 2) void proj_kernel(ProjArgs p) {
 #pragma unroll
               for (int tr = 0; tr < 2; ++tr) {
                 const bool ok = cvalid && r0 + 16 * tr + li < p.N;
-                const double v = ok ? loglik_shifted<FAM, MODE, SEL>(acc[tr][tc][r], yq[tr], parg, cq[tr], pq[tr]) : 0.0;
+                const double v = ok ? loglik_shifted<FAM, MODE>(acc[tr][tc][r], yq[tr], parg, cq[tr], pq[tr], tab) : 0.0;
                 if (MODE == PMODE_COLSUM) csum += v;
                 else { rs[tr] += v; rq[tr] += v * v; rd[tr] += v * rsd; }
               }
               cs[4 * t4 + r] = csum;
-              // SELECT with a transcendental epilogue: two likelihood values (one column, the lane's two rows) per
-              // scheduling region -- given the whole tile the compiler interleaves the exp / log series of many values
-              if (MODE == PMODE_SELECT && FAM != FAM_LINREG) __builtin_amdgcn_sched_barrier(0);
+              // the 128-column tile with a transcendental epilogue: two likelihood values (one column, the lane's two rows)
+              // per scheduling region -- given more, the compiler interleaves many evaluations and runs out of registers.
+              // (SELECT on the 64-column tile used to be fenced the same way; with the table forms it is not, and went
+              // from 39.9 to 46.1 TFLOP/s for the logistic family.)
+              if (NCT > 4 && FAM != FAM_LINREG) __builtin_amdgcn_sched_barrier(0);
             }
           }
           if (MODE == PMODE_COLSUM) {
@@ -840,6 +794,24 @@ static int proj_grid(int64_t N) {
   return (int)std::max<int64_t>(1, std::min<int64_t>(blocks, resident));
 }
 
+// The likelihood tables of proj_math.h in device memory: built once per device (from long double, on the host), never freed.
+static const double* proj_tables() {
+  static std::mutex mu;
+  static double* tabs[64];
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+  std::lock_guard<std::mutex> lk(mu);
+  if (!tabs[dev]) {
+    double host[PJT_DOUBLES];
+    pjm_fill_tables(host);
+    double* d = nullptr;
+    if (hipMalloc((void**)&d, sizeof(host)) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    if (hipMemcpy(d, host, sizeof(host), hipMemcpyHostToDevice) != hipSuccess) { (void)hipGetLastError(); (void)hipFree(d); return nullptr; }
+    tabs[dev] = d;
+  }
+  return tabs[dev];
+}
+
 // ---- measurement: hipEvents around the projection kernel alone, on the stream it runs on (bcx_project_profile) ----
 namespace {
 struct ProjProfile {
@@ -927,9 +899,12 @@ static bool proj_aligned(const ProjArgs& p) {
   // 16-byte requests need 16-byte aligned rows: even leading dimensions and aligned bases (else 8-byte loads)
   return ((uintptr_t)p.Z % 16 == 0) && ((uintptr_t)p.theta % 16 == 0) && p.ldz % 2 == 0 && p.ldt % 2 == 0;
 }
-template <int MODE> static int launch_family(int family, dim3 grid, size_t extra_lds, hipStream_t st, const ProjArgs& p) {
+template <int MODE> static int launch_family(int family, dim3 grid, size_t extra_lds, hipStream_t st, const ProjArgs& p_in) {
+  ProjArgs p = p_in;
   const int nct = proj_nct(MODE, family, p.S, proj_aligned(p));
-  const size_t shmem = (nct == 8 ? PJ_STAGING_BYTES(8) : PJ_STAGING_BYTES(4)) + extra_lds;
+  const size_t tab_bytes = family == FAM_POISSON ? PJT_BYTES(PJT_DOUBLES) : family == FAM_LOGISTIC ? PJT_BYTES(PJT_DOUBLES_LOGISTIC) : 0;
+  const size_t shmem = (nct == 8 ? PJ_STAGING_BYTES(8) : PJ_STAGING_BYTES(4)) + extra_lds + tab_bytes;
+  if (tab_bytes && !(p.tab = proj_tables())) { g_proj_err = "bcx_project: no device memory for the likelihood tables"; return BCX_ERR_NOMEM; }
   if (shmem > 160 * 1024) { g_proj_err = "bcx_project: S too large for the column-sum accumulators (S <= 3072)"; return BCX_ERR_ARG; }
   const bool aligned = proj_aligned(p);
   if constexpr (MODE == PMODE_COLSUM) {
@@ -954,7 +929,7 @@ static int fill(ProjArgs& p, int family, const void* Z, int64_t N, int64_t ldz, 
   p.Z = (const double*)Z; p.theta = (const double*)theta; p.N = N; p.ldz = ldz; p.ldt = ldt; p.D = D; p.S = S;
   p.ycol = family == FAM_LOGISTIC ? -1 : ycol; p.param = param;
   p.out = nullptr; p.ldo = 0; p.rowsum = nullptr; p.colpart = nullptr; p.resid = nullptr; p.resid_sum = 0.0;
-  p.best_val = nullptr; p.best_idx = nullptr; p.team = 0; p.part = nullptr;
+  p.best_val = nullptr; p.best_idx = nullptr; p.team = 0; p.part = nullptr; p.tab = nullptr;
   return BCX_OK;
 }
 

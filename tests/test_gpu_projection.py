@@ -201,6 +201,31 @@ def test_project_extreme_arguments(bc, family):
     np.testing.assert_allclose(got, want, rtol=1e-10, atol=1e-12 * np.abs(want).max())
 
 
+def test_poisson_responses_outside_the_count_table(bc):
+    """gammaln(y + 1) of model_poiss.py:37: counts 0 .. 255 come from the kernel's log-factorial table, every other
+    response (large counts, non-integers) from the library routine.  Uncentred values, so the constant is visible; the
+    fused consumers (column sums, select) drop it analytically and have to agree with the centred reference."""
+    rs = np.random.RandomState(23)
+    D, S, N = 9, 130, 2600
+    X = 0.4 * rs.randn(N, D)
+    y = rs.poisson(3.0, size=N).astype(np.float64)
+    y[::7] = rs.choice([255.0, 256.0, 300.0, 1000.0, 1e5, 2.5, 0.25, 17.75, 254.0], size=y[::7].shape)
+    Z = np.hstack((X, y[:, None]))
+    theta = 0.5 * rs.randn(S, D)
+    prj = bc.DeviceProjector("poisson", lambda n, w, p: theta, S)
+    want = poisson_log_likelihood(Z, theta)
+    got = prj.project_uncentred(Z).cpu().numpy()
+    np.testing.assert_allclose(got, want, rtol=1e-11, atol=1e-12)
+    centred = want - want.mean(axis=1)[:, None]
+    np.testing.assert_allclose(prj.project(Z).cpu().numpy(), centred, rtol=1e-9, atol=1e-11 * np.abs(want).max())
+    resid = rs.randn(S)
+    corrs, best = _reference_select(centred, resid)
+    val, idx = prj.project_select(Z, resid)
+    assert int(idx) == best
+    np.testing.assert_allclose(float(val), corrs[best], rtol=1e-9)
+    np.testing.assert_allclose(prj.project_colsum(Z), centred.sum(axis=0), rtol=1e-9, atol=1e-10 * np.abs(centred).sum(axis=0).max())
+
+
 # ---- numerically hard rows for the fused SELECT / COLSUM consumers ---------------------------------------------------
 def _reference_select(vecs, resid):
     """sparsevi.py:49-55 on centred vectors: corrs, first arg-max (NaN counts as the maximum, as in NumPy)."""
