@@ -90,8 +90,10 @@ template <int FAM> __device__ __forceinline__ double loglik(double m, double y, 
 // predictor (see the epilogue), and the difference has a closed form without the cancellation:
 //   [c0 - (y^2 - 2 m y + m^2) / (2 sigsq)] - [c0 - y^2 / (2 sigsq)] = (2 y - m) m / (2 sigsq)
 // -- three operations instead of seven per element, and more accurate than forming both terms.
+// (The epilogue hands in 2 y for y and applies the common factor 1 / (2 sigsq) once per column sum: two fp64 instructions
+// per element -- subtract, multiply-add into the sum -- on the unit the MFMAs run on.)
 template <int FAM, int MODE> __device__ __forceinline__ double loglik_shifted(double m, double y, double param, double c0, double shift, pj_tab_t tab) {
-  if (FAM == FAM_LINREG && MODE == PMODE_COLSUM) return (2.0 * y - m) * m * param;
+  if (FAM == FAM_LINREG && MODE == PMODE_COLSUM) return (y - m) * m;
   return loglik<FAM>(m, y, param, c0, tab) - shift;
 }
 
@@ -508,7 +510,7 @@ __global__ __launch_bounds__(256, 2) void proj_kernel(ProjArgs p) {
           for (int tr = 0; tr < 2; ++tr) {
             const int64_t row = r0 + 16 * tr + li;
             const double y = (p.ycol >= 0 && row < p.N) ? p.Z[row * p.ldz + p.ycol] : 0.0;
-            yq[tr] = y;
+            yq[tr] = (FAM == FAM_LINREG && MODE == PMODE_COLSUM) ? 2.0 * y : y;      // (loglik_shifted)
             cq[tr] = (FAM == FAM_POISSON) ? 0.0 : clin;   // (Poisson: gammaln(y + 1) is constant along the row and cancels in value - shift)
             rs[tr] = 0.0; rq[tr] = 0.0; rd[tr] = 0.0;
           }
@@ -578,7 +580,7 @@ __global__ __launch_bounds__(256, 2) void proj_kernel(ProjArgs p) {
             for (int e = 0; e < 2; ++e) c2[e] = pj_fold<0x4E>(c4[e], c4[e + 2], (li & 2) != 0);
             const double tot = pj_fold<0xB1>(c2[0], c2[1], (li & 1) != 0);
             const int col = cg * COLS + 64 * h + 16 * (li >> 2) + lk + 4 * (li & 3);
-            if (col < S) colacc[col - cacc_0] += tot;
+            if (col < S) colacc[col - cacc_0] += (FAM == FAM_LINREG) ? tot * parg : tot;
           }
           if (NCT > 4) __builtin_amdgcn_sched_barrier(0);
         }
@@ -879,6 +881,7 @@ extern "C" int bcx_project_profile_read(double* ms_total, int64_t* launches, dou
 // SELECT's per-row moments and the transcendental epilogues (logistic, Poisson) spill with 128 accumulator VGPRs and
 // measured slower (logistic D=300: 29 against 35 TFLOP/s), WRITE holds eight rows per lane.
 static int proj_nct(int mode, int family, int S, bool aligned = true) {
+  // (SELECT on the 128-column tile spills ~200 registers in every family: not built)
   if (mode != PMODE_COLSUM) return 4;
   // the 128-column tile exists for the column sums of the linear-regression family and, on 16-byte aligned rows, of the
   // logistic one (round 3: with the series' constants in scalar registers and 32-bit Theta offsets it fits 255 VGPRs;
@@ -997,7 +1000,7 @@ extern "C" int bcx_project_colsum(void* stream, int32_t family, const void* Z_de
 // after 2048 doubles + 2048 int64 for the reduction of the arg-max.
 extern "C" int64_t bcx_project_select_scratch_bytes(int32_t family, int64_t N, int32_t S) {
   if (N < 0 || S < 1) return -1;
-  const int cols = 16 * proj_nct(PMODE_SELECT, family, S), ngc = (S + cols - 1) / cols;
+  const int cols = 64, ngc = (S + cols - 1) / cols;     // (the narrowest column group any instantiation uses)
   return (int64_t)(4096 * sizeof(double)) + (int64_t)ngc * N * 4 * (int64_t)sizeof(double);
 }
 
@@ -1015,7 +1018,7 @@ static int project_select(void* stream, int32_t family, const void* Z_dev, int64
   // The kernel leaves every column group's share of the row moments (32 bytes per row and group); the arg-max is taken
   // by select_combine_kernel.  On XCD teams the column groups of a row block run side by side (Z streamed once instead
   // of once per column group), otherwise one workgroup walks them; the records are the same.
-  const int cols = 16 * proj_nct(PMODE_SELECT, family, S), ngc = (S + cols - 1) / cols;
+  const int cols = 16 * proj_nct(PMODE_SELECT, family, S, proj_aligned(p)), ngc = (S + cols - 1) / cols;
   void* part = part_dev;
   bool own = false;
   if (!part && N > 0) {
@@ -1028,7 +1031,7 @@ static int project_select(void* stream, int32_t family, const void* Z_dev, int64
     }
     own = true;
   }
-  p.team = proj_team(PMODE_SELECT, family, S, grid);
+  p.team = proj_team(PMODE_SELECT, family, S, grid, proj_aligned(p));
   p.part = (double*)part;
   if (N > 0 && (rc = launch_family<PMODE_SELECT>(family, dim3(grid), 0, st, p))) { if (own) (void)hipFreeAsync(part, st); return rc; }
   const int nparts = (int)std::max<int64_t>(1, std::min<int64_t>((N + 255) / 256, 512));
