@@ -126,8 +126,13 @@ template <typename TD, int EPS> __device__ __forceinline__ void store_piece(TD* 
   }
 }
 
+// Workgroup size bound by the row length: a lane holds CHI * EPS values of the row AND as many column-sum accumulators,
+// both fp64.  Up to 16 values per lane (d <= 1024) that fits the 128 registers of a 1024-thread workgroup; with 32
+// (d <= 2048) or 64 (d <= 4096) it does not -- the kernel spilled up to 644 registers there -- so those instantiations are
+// built for 512 / 256 threads (the launcher's wave count for such rows is bounded by the LDS accumulators anyway).
+#define INGEST_VEC_THREADS(CHI, EPS) ((CHI) * (EPS) >= 64 ? 256 : (CHI) * (EPS) >= 32 ? 512 : 1024)
 template <typename TS, typename TD, int CHI>
-__global__ __launch_bounds__(1024) void ingest_vec_kernel(const TS* src, int64_t ld_src, int64_t row_begin,
+__global__ __launch_bounds__(INGEST_VEC_THREADS(CHI, SrcVec<TS>::EPS)) void ingest_vec_kernel(const TS* src, int64_t ld_src, int64_t row_begin,
                                                           int64_t rows, int d, TD* __restrict__ An, int ld, int ld64,
                                                           double* A64, double* __restrict__ norms,
                                                           double* __restrict__ chunk_sums, DevState* st, int center) {
@@ -242,6 +247,10 @@ int bcx_launch_ingest(bcx_solver* s, const void* src, int src_dtype, int64_t ld_
   const int64_t nblk = (rows + BCX_CHUNK_ROWS - 1) / BCX_CHUNK_ROWS;
   int nw = (int)((144 * 1024) / ((size_t)d * 8));   // column accumulators must fit the 160 KiB LDS
   if (nw > 16) nw = 16;
+  // long rows: the vector kernel's register budget (INGEST_VEC_THREADS).  The rule depends on d alone, and the scalar
+  // kernel follows it too, so both forms add the chunk sums in the same order (bit-identical b) for every row length.
+  if (d > 2048 && nw > 4) nw = 4;
+  else if (d > 1024 && nw > 8) nw = 8;
   if (nw < 1) nw = 1;
   const size_t shmem = ((size_t)nw * d + nw) * sizeof(double);
   dim3 grid((unsigned)nblk), block(64 * nw);
