@@ -79,10 +79,11 @@ template <int FAM> __device__ __forceinline__ double loglik(double m, double y, 
     const double sl = m > -100.0 ? pjm_log_pos(lam, tab) : m;
     return y * sl - c0 - lam;                              // (c0 = gammaln(y+1))
   } else {
-    // model_linreg.py:10 (c0 = -0.5 log(2 pi sigsq)); param = 1 / (2 sigsq), formed once per kernel: the quotient by the
-    // common divisor as a product (<= 1 ulp from the division; an fp64 division is ~25 instructions on the unit the
-    // fp64 MFMAs run on, and the epilogue has 32 of them per lane and tile)
-    return c0 - (y * y - 2.0 * m * y + m * m) * param;
+    // model_linreg.py:10: -0.5 log(2 pi sigsq) - (y^2 - 2 m y + m^2) / (2 sigsq).  The row's own part is formed once per
+    // row by the caller -- it hands in 2 y for y and c0 = -0.5 log(2 pi sigsq) - y^2 / (2 sigsq) -- and param = 1 / (2 sigsq)
+    // once per kernel, so an element costs three fp64 instructions (subtract, multiply, multiply-add) on the unit the
+    // MFMAs run on instead of seven.
+    return fma(-((m - y) * m), param, c0);
   }
 }
 
@@ -92,8 +93,12 @@ template <int FAM> __device__ __forceinline__ double loglik(double m, double y, 
 // -- three operations instead of seven per element, and more accurate than forming both terms.
 // (The epilogue hands in 2 y for y and applies the common factor 1 / (2 sigsq) once per column sum: two fp64 instructions
 // per element -- subtract, multiply-add into the sum -- on the unit the MFMAs run on.)
+// SELECT uses the same form about the value in the group's first column, (2 y - m) m - (2 y - m0) m0, and leaves the
+// factor out altogether: a correlation does not change when its vector is scaled by 2 sigsq > 0 (the records of p.part
+// are then moments of vecs * 2 sigsq, consistently; select_combine_kernel's quotient is the same).
 template <int FAM, int MODE> __device__ __forceinline__ double loglik_shifted(double m, double y, double param, double c0, double shift, pj_tab_t tab) {
   if (FAM == FAM_LINREG && MODE == PMODE_COLSUM) return (y - m) * m;
+  if (FAM == FAM_LINREG && MODE == PMODE_SELECT) return fma(y - m, m, -shift);
   return loglik<FAM>(m, y, param, c0, tab) - shift;
 }
 
@@ -475,6 +480,9 @@ __global__ __launch_bounds__(256, 2) void proj_kernel(ProjArgs p) {
               const bool small_count = (double)yi == y && (unsigned)yi < (unsigned)PJT_NFACT;
               cp[e] = small_count ? tab[PJT_LFACT + (small_count ? yi : 0)] : pj_lgamma1p_call(y);
               __builtin_amdgcn_sched_barrier(0);   // one at a time
+            } else if (FAM == FAM_LINREG) {
+              cp[e] = fma(-(y * y), parg, clin);       // the row's own part of the likelihood (loglik)
+              yv[e] = 2.0 * y;
             } else {
               cp[e] = clin;
             }
@@ -510,7 +518,7 @@ __global__ __launch_bounds__(256, 2) void proj_kernel(ProjArgs p) {
           for (int tr = 0; tr < 2; ++tr) {
             const int64_t row = r0 + 16 * tr + li;
             const double y = (p.ycol >= 0 && row < p.N) ? p.Z[row * p.ldz + p.ycol] : 0.0;
-            yq[tr] = (FAM == FAM_LINREG && MODE == PMODE_COLSUM) ? 2.0 * y : y;      // (loglik_shifted)
+            yq[tr] = (FAM == FAM_LINREG) ? 2.0 * y : y;      // (loglik_shifted)
             cq[tr] = (FAM == FAM_POISSON) ? 0.0 : clin;   // (Poisson: gammaln(y + 1) is constant along the row and cancels in value - shift)
             rs[tr] = 0.0; rq[tr] = 0.0; rd[tr] = 0.0;
           }
@@ -531,8 +539,9 @@ __global__ __launch_bounds__(256, 2) void proj_kernel(ProjArgs p) {
             else if (MODE == PMODE_COLSUM && FAM == FAM_POISSON) pq[tr] = fma(yq[tr], -0.366512920581664327, -0.693147180559945309);
             else if (MODE == PMODE_COLSUM) pq[tr] = 0.0;            // (linear regression: closed form of value - shift, loglik_shifted)
             else {
-              const double l0 = loglik<FAM>(MODE == PMODE_COLSUM ? 0.0 : acc[tr][0][0], yq[tr], parg, cq[tr], tab);
-              pq[tr] = MODE == PMODE_COLSUM ? l0 : __shfl(l0, li, BCX_WAVE);
+              const double m0 = acc[tr][0][0];
+              const double l0 = (FAM == FAM_LINREG) ? (yq[tr] - m0) * m0 : loglik<FAM>(m0, yq[tr], parg, cq[tr], tab);
+              pq[tr] = __shfl(l0, li, BCX_WAVE);
             }
           }
         }
