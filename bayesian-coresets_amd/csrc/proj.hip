@@ -60,7 +60,7 @@ __device__ __attribute__((noinline)) double pj_lgamma1p_call(double y) { return 
 typedef const double __attribute__((address_space(3)))* pj_tab_t;
 
 // log(1 + exp(t)) = max(t, 0) + log1p(exp(-|t|))
-__device__ __forceinline__ double pj_softplus(double t, pj_tab_t tab) { return fmax(t, 0.0) + pjm_log1p01(pjm_exp_nonpos(-fabs(t), tab), tab); }
+__device__ __forceinline__ double pj_softplus(double t, pj_tab_t tab) { return pjm_relu(t) + pjm_log1p01(pjm_exp_nonpos(-fabs(t), tab), tab); }
 
 // (Round 2/3 evaluated the logistic and Poisson likelihoods as real calls in SELECT and WRITE: inlined, the temporaries of
 // their long series spilled registers inside the k loop.  The table forms are short enough to inline everywhere.)
@@ -69,7 +69,8 @@ template <int FAM> __device__ __forceinline__ double loglik(double m, double y, 
   if (FAM == FAM_LOGISTIC) {
     // model_lr.py:29-31 switches from -log1p(exp(t)) to -t at t = 100: there exp(-t) < 4e-44 and max(t, 0) + log1p(.) IS t to
     // every bit, so the softplus form needs no branch.
-    return -pj_softplus(-m, tab);                          // model_lr.py:28-31  (t = -m; -log1p(exp(t)), -t from t = 100 on)
+    // -log1p(exp(-m)) = min(m, 0) - log1p(exp(-|m|)); min(m, 0) by the sign bit (pjm_relu)        model_lr.py:28-31
+    return (pjm_hi(m) < 0 ? m : 0.0) - pjm_log1p01(pjm_exp_nonpos(-fabs(m), tab), tab);
   } else if (FAM == FAM_POISSON) {
     // model_poiss.py:25-38: s' = log(lam) with the rate lam = log(1 + e^s) = max(s, 0) + log1p(exp(-|s|)) where s > -100,
     // s' = s below (there lam = e^s to every bit: log1p(e) = e for e < 4e-44); log-likelihood y s' - gammaln(y + 1) - exp(s').

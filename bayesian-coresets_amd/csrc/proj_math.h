@@ -6,7 +6,7 @@
 // therefore not hide under the MFMAs of the other resident workgroup; what it costs is its number of fp64 instructions.
 // The series forms of round 2/3 (exp: Cody-Waite + degree 13, log1p / log: 2 atanh with a division and 11-16 terms) spend
 // ~52 fp64 instructions per logistic value and ~95 per Poisson value.  With three small tables in LDS the same functions
-// take 12 + 10 and 12:
+// take 11 + 10 and 12:
 //   exp(x), x <= 0 : x = n ln2/64 + r, n = 64 k + j  ->  2^k * T[j] * (1 + r + ... + r^5/120),   |r| <= ln2/128
 //   log1p(u), 0<=u<=1 : c = i/64 nearest to u  ->  L1[i] + log1p(w), w = (u - c) / (1 + c), series to w^7/7, |w| <= 1/128
 //   log(x), x > 0 : x = 2^e m, c = 1 + i/128 nearest to m  ->  e ln2 + L2[i] + log1p(w), w = m R[i] - 1 (one fma; L2[i] is
@@ -82,10 +82,17 @@ PJM_HD double pjm_fma_k(double a, double k, double b) {
 #endif
 }
 
-// exp(x) for x <= 0.  12 fp64 instructions.
+// max(t, 0) by the sign bit (NaNs with a clear sign bit pass, the others meet a NaN term anyway)
+PJM_HD double pjm_relu(double t) { return pjm_hi(t) < 0 ? 0.0 : t; }
+
+// exp(x) for x <= 0.  11 fp64 instructions.
 template <class TP> PJM_HD double pjm_exp_nonpos(double x, TP tab) {
   const double magic = 6755399441055744.0;                  // 1.5 * 2^52: the sum's low mantissa bits hold rint(x * 64/ln2)
-  x = fmax(x, -800.0);
+  // clamp at -800 by the bit pattern (for x <= 0 the high word grows with |x|) so that a NaN passes and comes out as a
+  // NaN, as it does in the reference: fmax(x, -800) returns -800 for it and the likelihood of a point with a NaN feature
+  // would be a finite number.  (Measured against the fmax forms: 1-2 % of the transcendental kernels.)
+  const unsigned hx = (unsigned)pjm_hi(x);
+  x = (hx > 0xC0890000u && hx <= 0xFFF00000u) ? -800.0 : x;
   const double t = pjm_fma_k(x, 92.332482616893656877, magic);    // 64 / ln 2
   const int n = pjm_lo(t);                                  // <= 0, two's complement
   const double kf = t - magic;
@@ -102,7 +109,8 @@ template <class TP> PJM_HD double pjm_exp_nonpos(double x, TP tab) {
 // log1p(u) for 0 <= u <= 1.  10 fp64 instructions.
 template <class TP> PJM_HD double pjm_log1p01(double u, TP tab) {
   const double v = 1.0 + u;                                 // only its leading bits are used: the index
-  const int i = (pjm_hi(v) - 0x3FF00000 + (1 << 13)) >> 14; // rint((v - 1) * 64): 0 .. 64
+  int i = (pjm_hi(v) - 0x3FF00000 + (1 << 13)) >> 14;       // rint((v - 1) * 64): 0 .. 64
+  i = i < 0 ? 0 : (i > 64 ? 64 : i);                        // (a NaN stays a NaN below; it must not pick the address)
   const double c = tab[PJT_L1P + 4 * i], R = tab[PJT_L1P + 4 * i + 1], L = tab[PJT_L1P + 4 * i + 2];
   const double w = (u - c) * R;                             // u - c is exact
   double p = pjm_fma_k(w, 1.0 / 7.0, -1.0 / 6.0);

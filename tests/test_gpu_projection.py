@@ -226,6 +226,33 @@ def test_poisson_responses_outside_the_count_table(bc):
     np.testing.assert_allclose(prj.project_colsum(Z), centred.sum(axis=0), rtol=1e-9, atol=1e-10 * np.abs(centred).sum(axis=0).max())
 
 
+@pytest.mark.parametrize("family", ("logistic", "poisson", "linreg"))
+def test_nan_feature_gives_a_nan_row_as_in_the_reference(bc, family):
+    """A NaN among a point's features makes its whole log-likelihood row NaN in the reference (np.log1p / np.exp
+    propagate it); the table-driven epilogues pick table entries from bit patterns, so this pins that a NaN neither
+    disappears (max(NaN, 0) = 0 would) nor disturbs the other rows."""
+    rs = np.random.RandomState(5)
+    D, S, N = 7, 70, 700
+    X = rs.randn(N, D)
+    if family == "logistic":
+        Z, ll = X.copy(), logistic_log_likelihood
+    elif family == "poisson":
+        Z, ll = np.hstack((X, rs.poisson(2.0, size=(N, 1)).astype(np.float64))), poisson_log_likelihood
+    else:
+        Z, ll = np.hstack((X, rs.randn(N, 1))), (lambda z, th: linreg_log_likelihood(z, th, 1.3))
+    Z[41, 2] = np.nan
+    Z[300, 0] = -np.nan
+    theta = rs.randn(S, D)
+    prj = bc.DeviceProjector(family, lambda n, w, p: theta, S, **({"sigsq": 1.3} if family == "linreg" else {}))
+    with np.errstate(invalid="ignore"):
+        want = ll(Z, theta)
+    got = prj.project_uncentred(Z).cpu().numpy()
+    assert np.isnan(want[41]).all() and np.isnan(want[300]).all()
+    np.testing.assert_array_equal(np.isnan(got), np.isnan(want))
+    ok = ~np.isnan(want)
+    np.testing.assert_allclose(got[ok], want[ok], rtol=1e-11, atol=1e-12)
+
+
 # ---- numerically hard rows for the fused SELECT / COLSUM consumers ---------------------------------------------------
 def _reference_select(vecs, resid):
     """sparsevi.py:49-55 on centred vectors: corrs, first arg-max (NaN counts as the maximum, as in NumPy)."""
