@@ -84,9 +84,11 @@ template <typename ST> __device__ __forceinline__ typename Stor<ST>::Q load_q(co
     r.hi = ok ? ((const float4*)q)[2 * piece + 1] : make_float4(0.f, 0.f, 0.f, 0.f);
     return r;
   } else {
-    Q z;
-    memset(&z, 0, sizeof z);
-    return ok ? ((const Q*)q)[piece] : z;
+    // (load from a clamped index, then clear: written as `ok ? q[piece] : zero` hipcc selects between the ADDRESSES -- the
+    // zero lands in scratch memory and the query is fetched with four flat dword loads)
+    Q r = ((const Q*)q)[ok ? piece : 0];
+    if (!ok) memset(&r, 0, sizeof r);
+    return r;
   }
 }
 
