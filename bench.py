@@ -67,6 +67,7 @@ def parse():
                     help="rows of the CPU-baseline sample (SURVEY 8d: N = 1e6 when host memory allows; halved until "
                          "three copies of the fp64 sample fit the free memory)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    ap.add_argument("--no-f16-leg", action="store_true", help="c4: skip the extra leg with fp16-stored rows")
     ap.add_argument("--opt-itrs", type=int, default=100, help="c5: ADAM steps per greedy step (sparsevi.py:7)")
     ap.add_argument("--features", type=int, default=10, help="c3: regression features D (simple_lr/main.py:24)")
     a = ap.parse_args()
@@ -386,6 +387,34 @@ def run_snnls(args, torch, dist, nat, world, rank, local_rank):
             out["exact_mode_frac"] = out["config"]["exact_mode_frac"] = a2 / HBM_PEAK_GBS
             out["config"]["exact_mode_ms_per_step"] = el / max(len(tr2[0]), 1) * 1e3
         del ex
+        torch.cuda.empty_cache()
+        # ---- and with the rows stored in fp16 (opt-in storage: half the bytes per iteration; the interval filter widens by
+        # the storage term and the fp64 re-score on the resident raw rows decides, so the selections have to be THE SAME as
+        # the fp32 run's -- checked here, iteration by iteration, on the same warm-up + steps) -----------------------------
+        if not args.no_f16_leg:
+            hs = ShardedSolver(alg, args.rows, args.dim, device=local_rank, store_dtype=nat.F16, keep_exact_rows=True)
+            load_synthetic(args, torch, hs)
+            if hs.finalize(None) != nat.OK:
+                raise SystemExit("finalize (fp16 rows) failed")
+            el3, tr3, ms3, l3, ev3 = timed(hs, args.warmup, args.steps)
+            if rank == 0:
+                b16 = float(hs.n_local) * args.dim * 2
+                a3 = b16 / (ms3 / max(l3, 1) * 1e-3) / 1e9 if ms3 > 0 else 0.0
+                same = len(tr3[0]) == len(sel) and all(int(x) == int(y) for x, y in zip(tr3[0], sel))
+                st3 = hs.engine.stats()
+                out["f16_rows_its"] = out["config"]["f16_rows_its"] = len(tr3[0]) / el3
+                out["f16_rows_same_selections"] = out["config"]["f16_rows_same_selections"] = bool(same)
+                out["config"]["f16_rows"] = {
+                    "what": "rows stored in fp16 (dtype='float16'), fp32 accumulation, fp64 re-score of the candidates on the resident raw rows: "
+                            "not the headline (north_star: fp32 rows), reported beside it",
+                    "iterations_per_s": len(tr3[0]) / el3, "ms_per_step": el3 / max(len(tr3[0]), 1) * 1e3, "steps": len(tr3[0]),
+                    "scan_GBps": a3, "scan_frac_of_hbm_peak": a3 / HBM_PEAK_GBS, "algorithmic_bytes_per_launch": b16,
+                    "same_selections_as_fp32_rows": bool(same), "max_rel_error_difference": float(
+                        max((abs(float(x) - float(y)) / max(abs(float(y)), 1e-300) for x, y in zip(tr3[1], err)), default=0.0)),
+                    "rescue": {"exact_fallbacks": int(st3.get("exact_fallbacks", 0)), "candidates": int(st3.get("candidates", 0)),
+                               "resolves": int(st3.get("resolves", 0))},
+                }
+            del hs
     if rank == 0 and not args.no_cpu_baseline and world == 1:
         if args.kind == "logistic":
             X = cpu_sample
