@@ -7,7 +7,10 @@
 A "step" is one greedy iteration: one pass of the hot path over the resident rows.
 
   c4 (default)  BASELINE.json configs[3] and the metric's own config: synthetic randn N = 10,000,000, d = 512,
-                Frank-Wolfe, row-sharded over --gpus ranks (total N fixed => "scaling": "strong").
+                Frank-Wolfe, row-sharded over --gpus ranks (total N fixed => "scaling": "strong").  On one GPU the line
+                also carries two side legs of the same workload, neither of them the headline: rows stored in fp64
+                (`exact_mode_its`: the reference's arithmetic end to end) and rows stored in fp16 (`f16_rows_its`, with
+                `f16_rows_same_selections`: whether every selection equals the fp32 run's).
   c2            configs[1]: synthetic randn N = 1,000,000, d = 256, GIGA.
   c3            configs[2]: Laplace-projected logistic-regression vectors (examples/simple_lr pipeline: data, Laplace fit
                 at the MAP, S = 512 posterior samples, log-likelihood projection ON THE DEVICE), N = 1,000,000, OMP.
