@@ -908,6 +908,23 @@ static int proj_team(int mode, int family, int S, int grid, bool aligned = true)
   const int cols = 16 * proj_nct(mode, family, S, aligned), ngc = (S + cols - 1) / cols;
   return (!no_team && ngc > 1 && grid % 8 == 0 && grid / 8 >= 4 * ngc) ? ngc : 0;
 }
+// Grid and team size of one launch.  Large problems: the persistent grid of proj_grid, teams where they fit.  Small ones
+// (all tiles resident at once: row blocks x column groups <= resident workgroups -- the few coreset points SparseVI
+// projects beside the full data set at every ADAM step, sparsevi.py:35-41): one workgroup per TILE, as teams of one row
+// block each, so the column groups of a row block run side by side instead of one workgroup walking them (k = 4 points,
+// S = 256: 132 -> 35 us per call; that call sits on the critical path of every ADAM step).
+static void proj_plan(int mode, int family, int64_t N, int S, bool aligned, int* grid, int* team) {
+  *grid = proj_grid(N);
+  *team = proj_team(mode, family, S, *grid, aligned);
+  static const bool no_team = getenv("BCX_PROJ_NO_TEAM") != nullptr;   // dev knob
+  const int cols = 16 * proj_nct(mode, family, S, aligned), ngc = (S + cols - 1) / cols;
+  const int64_t nblk = (N + PJ_ROWS - 1) / PJ_ROWS;
+  if (!no_team && *team == 0 && ngc > 1 && N > 0 && nblk * ngc <= 2 * 256) {
+    const int per = (int)((nblk + 7) / 8);                     // teams (= row blocks) per XCD
+    *grid = 8 * per * ngc;
+    *team = ngc;
+  }
+}
 static bool proj_aligned(const ProjArgs& p) {
   // 16-byte requests need 16-byte aligned rows: even leading dimensions and aligned bases (else 8-byte loads)
   return ((uintptr_t)p.Z % 16 == 0) && ((uintptr_t)p.theta % 16 == 0) && p.ldz % 2 == 0 && p.ldt % 2 == 0;
@@ -957,8 +974,8 @@ static int project_write(void* stream, int32_t family, const void* Z_dev, int64_
   if (N == 0) return BCX_OK;
   p.out = (double*)out_dev; p.ldo = ldo; p.rowsum = (double*)rowsum_dev;
   hipStream_t st = (hipStream_t)stream;
-  const int wgrid = proj_grid(N);
-  p.team = proj_team(PMODE_WRITE, family, S, wgrid);
+  int wgrid = 0;
+  proj_plan(PMODE_WRITE, family, N, S, proj_aligned(p), &wgrid, &p.team);
   if ((rc = launch_family<PMODE_WRITE>(family, dim3(wgrid), 0, st, p))) return rc;
   if (!center) return BCX_OK;
   const int g = (int)std::min<int64_t>((N + 3) / 4, 8192);
@@ -993,9 +1010,9 @@ extern "C" int bcx_project_colsum(void* stream, int32_t family, const void* Z_de
   if (rc) return rc;
   if (!colsum_dev || !work_dev) { g_proj_err = "bcx_project_colsum: bad output"; return BCX_ERR_ARG; }
   hipStream_t st = (hipStream_t)stream;
-  const int grid = proj_grid(N);
+  int grid = 0;
   p.colpart = (double*)work_dev;
-  p.team = proj_team(PMODE_COLSUM, family, S, grid, proj_aligned(p));
+  proj_plan(PMODE_COLSUM, family, N, S, proj_aligned(p), &grid, &p.team);
   const size_t cacc = p.team ? (size_t)16 * proj_nct(PMODE_COLSUM, family, S, proj_aligned(p)) : (size_t)S;   // accumulators per wave
   if ((rc = launch_family<PMODE_COLSUM>(family, dim3(grid), 4 * cacc * sizeof(double), st, p))) return rc;
   hipLaunchKernelGGL(colsum_reduce_kernel, dim3((S + 63) / 64), dim3(256), 0, st, p.colpart, grid, S, (double*)colsum_dev);
@@ -1022,7 +1039,8 @@ static int project_select(void* stream, int32_t family, const void* Z_dev, int64
   if (rc) return rc;
   if (!resid_dev || !result_dev || !work_dev) { g_proj_err = "bcx_project_select: bad output"; return BCX_ERR_ARG; }
   hipStream_t st = (hipStream_t)stream;
-  const int grid = proj_grid(N);
+  int grid = 0;
+  proj_plan(PMODE_SELECT, family, N, S, proj_aligned(p), &grid, &p.team);
   p.resid = (const double*)resid_dev; p.resid_sum = resid_sum;
   p.best_val = (double*)work_dev; p.best_idx = (int64_t*)((double*)work_dev + 2048);
   // The kernel leaves every column group's share of the row moments (32 bytes per row and group); the arg-max is taken
@@ -1041,7 +1059,6 @@ static int project_select(void* stream, int32_t family, const void* Z_dev, int64
     }
     own = true;
   }
-  p.team = proj_team(PMODE_SELECT, family, S, grid, proj_aligned(p));
   p.part = (double*)part;
   if (N > 0 && (rc = launch_family<PMODE_SELECT>(family, dim3(grid), 0, st, p))) { if (own) (void)hipFreeAsync(part, st); return rc; }
   const int nparts = (int)std::max<int64_t>(1, std::min<int64_t>((N + 255) / 256, 512));

@@ -4,6 +4,7 @@ import numpy as np
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "bayesian-coresets_amd"))
 import torch
 from bayesiancoresets_amd import _native as nat
+nat.LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "bayesian-coresets_amd", "lib_timing", "libbcx.so")   # tools/build_timing.sh
 
 NAMES = ["entry", "partials+L*", "candidates", "rescored", "winner row", "slot/size", "step sums", "new state", "commit", "next query"]
 
@@ -26,3 +27,5 @@ if __name__ == "__main__":
     run(nat.ALG_FW, 1000000, 256)
     run(nat.ALG_GIGA, 1000000, 256)
     run(nat.ALG_GIGA, 1000000, 512)
+    run(nat.ALG_FW, 1250304, 512)
+    run(nat.ALG_FW, 10000000, 512, its=60)
