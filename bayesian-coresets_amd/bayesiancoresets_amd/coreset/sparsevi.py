@@ -94,6 +94,16 @@ class SparseVICoreset(Coreset):
         eng.has_zero_row = rc == nat.ERR_ZERO_ROW
         return eng
 
+    def _core_points_device(self):
+        """The coreset points as a device tensor, re-uploaded only when ``self.pts`` changed (it is replaced, never edited
+        in place, by _select / reset): every ADAM step projects the same points (sparsevi.py:38-39)."""
+        if self.pts.shape[0] == 0:
+            return None
+        c = getattr(self, "_core_dev", None)
+        if c is None or c[0] is not self.pts:
+            c = self._core_dev = (self.pts, self.ll_projector._dev(self.pts))
+        return c[1]
+
     def _corevecs(self):
         if self.pts.shape[0] == 0:
             return None
@@ -106,12 +116,13 @@ class SparseVICoreset(Coreset):
         pos, sub, pts, scaling = self._subsample(n_subsample)
         eng = None
         if isinstance(self.ll_projector, DeviceProjector):
-            colsum = self.ll_projector.project_colsum(pts)
+            # both projections of sparsevi.py:35-41 (data: column sums only; coreset points: the vectors), one read-back
+            colsum, corevecs = self.ll_projector.colsum_and_core(pts, self._core_points_device())
         else:
             vecs = self.ll_projector.project(pts)
             eng = self._engine_for(np.ascontiguousarray(vecs))
             colsum = eng.vector(0)                                                # vecs.sum(axis=0)
-        corevecs = self._corevecs()
+            corevecs = self._corevecs()
         S = colsum.shape[0]
         if corevecs is None:
             corevecs = np.zeros((0, S))

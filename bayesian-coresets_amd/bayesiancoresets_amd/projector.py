@@ -56,11 +56,23 @@ class DeviceProjector(Projector):
     """
     FAMILIES = {"logistic": 0, "poisson": 1, "linreg": 2}
 
-    def __init__(self, family, sampler, projection_dimension, sigsq=1.0, device=0, group=None, row_offset=0):
+    def __init__(self, family, sampler, projection_dimension, sigsq=1.0, device=0, group=None, row_offset=0, colsum="auto"):
         """``group`` / ``row_offset``: row-sharded use (one process per GPU, every rank constructs the
         projector with the same sampler and seeds): ``pts`` passed to the fused consumers are this
         rank's rows starting at global row ``row_offset``; column sums are all-reduced and the arg-max
-        is taken over all ranks (lowest global row wins ties)."""
+        is taken over all ranks (lowest global row wins ties).
+
+        ``colsum`` (family "linreg" only; the others always project): how ``project_colsum`` of a large data set is formed --
+        "mfma": one fused fp64-MFMA projection per call (2 N D S flops);
+        "moments": in closed form from the (D+1) x (D+1) second moments of the data, formed once per data set
+        (csrc/moments.hip; O(S D^2) per call -- SparseVI asks for 1 + opt_itrs column sums of the SAME data per step);
+        "auto" (default): moments, after checking them ONCE per data set against the projection kernel (relative
+        disagreement <= 1e-9 of the largest column sum; otherwise that data set stays on the projection kernel)."""
+        if colsum not in ("auto", "mfma", "moments"):
+            raise ValueError("colsum must be 'auto', 'mfma' or 'moments'")
+        self.colsum_mode = colsum
+        self._mom, self._mom_ref, self._mom_key, self._mom_work, self._mom_ok = None, None, None, None, False
+        self.moments_info = {}
         if family not in self.FAMILIES:
             raise ValueError("family must be one of %s" % sorted(self.FAMILIES))
         from . import _native
@@ -134,6 +146,57 @@ class DeviceProjector(Projector):
 
     def invalidate_cache(self):
         self._cache_val, self._cache_ref = None, None
+        self._mom, self._mom_ref, self._mom_key, self._mom_ok = None, None, None, False
+
+    # -- second moments of a data set (linear-regression family): csrc/moments.hip -----------------------------------
+    def _moments_for(self, pts, Z):
+        """The (D+1) x (D+1) matrix Z^T Z of the data set ``pts`` (device copy ``Z``), formed on first sight of that
+        object and kept while the SAME object keeps coming back (``invalidate_cache()`` after an in-place edit).
+        Row-sharded: the shards' moments are all-reduced once.  None when this data set does not take the closed form."""
+        torch = self._torch
+        if self.colsum_mode == "mfma" or self._fam != self.FAMILIES["linreg"] or Z.shape[0] < 4096 or Z.shape[1] > 1024:
+            return None
+        key = (Z.data_ptr(), tuple(Z.shape), Z.stride(0))
+        if self._mom_ref is pts and self._mom_key == key:
+            return self._mom if self._mom_ok else None
+        import time
+        t0 = time.perf_counter()
+        C = Z.shape[1]
+        need = int(self._lib.bcx_project_moments_scratch_bytes(int(Z.shape[0]), int(C)))
+        work = torch.empty((need + 7) // 8, dtype=torch.float64, device=self.device)
+        M = torch.empty((C, C), dtype=torch.float64, device=self.device)
+        self._check(self._lib.bcx_project_moments(self._stream(), Z.data_ptr(), Z.shape[0], Z.stride(0), C, M.data_ptr(), C,
+                                                  work.data_ptr(), work.numel() * 8))
+        if self._world > 1:
+            torch.distributed.all_reduce(M, op=torch.distributed.ReduceOp.SUM, group=self.group)
+        torch.cuda.synchronize(self.device)
+        del work
+        t1 = time.perf_counter()
+        self._mom, self._mom_ref, self._mom_key, self._mom_ok = M, pts, key, True
+        self.moments_info = {"rows": int(Z.shape[0]), "columns": int(C), "setup_ms": (t1 - t0) * 1e3, "checked": False}
+        if self.colsum_mode == "auto":
+            # one projection of this data set at the current samples, once: the closed form has to reproduce it
+            a = self._colsum_projected(Z)
+            b = self._colsum_from_moments(Z)
+            scale = float(np.max(np.abs(a))) if a.size else 0.0
+            dis = float(np.max(np.abs(a - b))) / scale if scale > 0 else 0.0
+            self._mom_ok = bool(np.isfinite(dis) and dis <= 1e-9)
+            self.moments_info.update({"checked": True, "disagreement": dis, "accepted": self._mom_ok,
+                                      "check_ms": (time.perf_counter() - t1) * 1e3})
+        return self._mom if self._mom_ok else None
+
+    def _colsum_from_moments(self, Z, out=None):
+        torch = self._torch
+        S, D = self.theta.shape[0], Z.shape[1] - 1
+        if self.theta.shape[1] != D:
+            raise ValueError("sampler returned %d-dimensional parameters for %d features" % (self.theta.shape[1], D))
+        if self._mom_work is None or self._mom_work.numel() < S + 1:
+            self._mom_work = torch.zeros(S + 1, dtype=torch.float64, device=self.device)
+        col = torch.empty(S, dtype=torch.float64, device=self.device) if out is None else out
+        self._check(self._lib.bcx_project_colsum_moments(self._stream(), self._mom.data_ptr(), self._mom.stride(0), D, D,
+                                                         self.theta.data_ptr(), S, self.theta.stride(0), self.sigsq,
+                                                         col.data_ptr(), self._mom_work.data_ptr()))
+        return col.cpu().numpy() if out is None else None
 
     def _dims(self, Z):
         cols = Z.shape[1]
@@ -163,8 +226,9 @@ class DeviceProjector(Projector):
         else:
             self.samples = np.atleast_2d(np.asarray(drawn, dtype=np.float64))
             t = torch.from_numpy(np.ascontiguousarray(self.samples)).to(self.device)
-        # the kernel reads 16-byte pieces of a parameter row: keep the rows 16-byte aligned (even leading dimension)
-        if t.shape[1] % 2 or not t.is_contiguous():
+        # the kernel reads 16-byte pieces of a parameter row: keep the rows 16-byte aligned (even leading dimension); a
+        # sampler that already hands over such rows (a view of a padded buffer) is used in place
+        if not (t.stride(1) == 1 and t.stride(0) % 2 == 0 and t.stride(0) >= t.shape[1] and t.data_ptr() % 16 == 0):
             buf = torch.zeros((t.shape[0], t.shape[1] + (t.shape[1] % 2)), dtype=torch.float64, device=self.device)
             buf[:, :t.shape[1]] = t
             t = buf[:, :t.shape[1]]
@@ -213,10 +277,15 @@ class DeviceProjector(Projector):
 
     def project_colsum(self, pts):
         """sum_n vecs[n, :] as a length-S ndarray, without forming vecs."""
-        torch = self._torch
         Z = self._dev(pts)
+        if self._moments_for(pts, Z) is not None:
+            return self._colsum_from_moments(Z)        # (row-sharded: the moments are already the global ones)
+        return self._colsum_projected(Z)
+
+    def _colsum_projected(self, Z, out=None):
+        torch = self._torch
         S = self.theta.shape[0]
-        col = torch.empty(S, dtype=torch.float64, device=self.device)
+        col = torch.empty(S, dtype=torch.float64, device=self.device) if out is None else out
         if Z.shape[0]:
             self._launch(self._lib.bcx_project_colsum, self._common(Z) + [col.data_ptr(), self._workspace(S).data_ptr()], Z)
         else:
@@ -225,7 +294,31 @@ class DeviceProjector(Projector):
             # every rank applied the centring correction with ITS raw sums; the correction is linear, so
             # the all-reduced vector is the centred global column sum
             torch.distributed.all_reduce(col, op=torch.distributed.ReduceOp.SUM, group=self.group)
-        return col.cpu().numpy()
+        return col.cpu().numpy() if out is None else None
+
+    def colsum_and_core(self, pts, core):
+        """(project_colsum(pts), project(core) as an ndarray) with ONE device->host copy: what every ADAM step of SparseVI
+        reads back (sparsevi.py:35-41, 70-74).  ``core`` is the k x (D+1) array of coreset points (ndarray or device tensor),
+        k may be 0."""
+        torch = self._torch
+        Z = self._dev(pts)
+        S = self.theta.shape[0]
+        C = None if core is None or core.shape[0] == 0 else self._dev(core)
+        k = 0 if C is None else C.shape[0]
+        if getattr(self, "_cc_buf", None) is None or self._cc_buf.numel() < S * (k + 1):
+            self._cc_buf = torch.empty(S * (max(k, 7) + 1), dtype=torch.float64, device=self.device)
+        buf = self._cc_buf[:S * (k + 1)]
+        col = buf[:S]
+        if not Z.shape[0]:
+            col.zero_()
+        elif self._moments_for(pts, Z) is not None:
+            self._colsum_from_moments(Z, out=col)
+        else:
+            self._colsum_projected(Z, out=col)
+        if k:
+            self._launch(self._lib.bcx_project_write, self._common(C) + [buf[S:].data_ptr(), S, None], C)
+        h = buf.cpu().numpy()
+        return h[:S], h[S:].reshape(k, S)
 
     def project_select(self, pts, resid, row_ids=None):
         """(max_n corr_n, arg-max row) with corr_n = vecs[n].resid / ||vecs[n]|| / S (first maximum).

@@ -380,7 +380,7 @@ int bcx_ensure_gram(bcx_solver* s, int64_t need) {
   if ((rc = grow(s, &s->nn_x, oc, nc))) return rc;
   if ((rc = grow(s, &s->nn_z, 0, nc))) return rc;
   if ((rc = grow(s, &s->nn_wv, 0, nc))) return rc;
-  if ((rc = grow(s, &s->nn_tmp, 0, 8 * nc))) return rc;   // t0..t3 + the exchange ring of grid_lh.h (8 buffers)
+  if ((rc = grow(s, &s->nn_tmp, 0, 16 * nc))) return rc;   // t0..t3 + the exchange ring of grid_lh.h (GRID_RING = 16 buffers)
   if ((rc = grow(s, &s->nn_flag, 0, nc))) return rc;
   if ((rc = grow(s, &s->nn_wbak, 0, nc))) return rc;
   if ((rc = grow(s, &s->nn_xr, 0, 2 * nc))) return rc;
@@ -416,6 +416,7 @@ extern "C" int bcx_build_begin(bcx_solver* s, int64_t itrs, double tol, int32_t*
     if (!s->grid_counter && dev_alloc(&s->grid_counter, 2) != hipSuccess) { s->err = "grid counter allocation failed"; return BCX_ERR_NOMEM; }
     BCX_HIP(hipMemsetAsync(s->grid_counter, 0, 2 * sizeof(unsigned long long), s->stream));
     s->grid_epoch = 0;
+    s->grid_dirty = false;
   }
   if ((rc = ensure_trace(s, itrs))) return rc;
   return bcx_launch_begin(s, itrs, tol);

@@ -147,7 +147,7 @@ struct bcx_solver {
   double* nn_x = nullptr;        // cap
   double* nn_z = nullptr;        // cap
   double* nn_wv = nullptr;       // cap
-  double* nn_tmp = nullptr;      // 8*cap: position scratch t0..t3 = the first half of the exchange ring (grid_lh.h)
+  double* nn_tmp = nullptr;      // 16*cap: position scratch t0..t3 = the first quarter of the exchange ring (grid_lh.h)
   int32_t* nn_flag = nullptr;    // cap: bit0 in problem set S, bit1 rejected, bit2 remove
   double* nn_wbak = nullptr;     // cap: weights before the step (revert on monotone failure)
   double* nn_xr = nullptr;       // 2*cap: row-phase exchange of the OMP step (omp_lh.hip)
@@ -155,6 +155,7 @@ struct bcx_solver {
   int64_t k_ub = 0;              // host upper bound of the slot count (grid sizing of the multi-kernel OMP step)
   unsigned long long* grid_counter = nullptr;   // [0] arrival counter of the grid barriers, [1] barrier base of the next OMP step
   uint64_t grid_epoch = 0;       // fused OMP launches since the counter was reset (bcx_build_begin)
+  bool grid_dirty = false;       // optimize() advanced grid_counter[0] past the OMP step's base [1]: re-zero both before the next OMP step
   size_t omp_lds_allowed = 0;
   // trace of the current build() call
   int64_t trace_cap = 0;

@@ -12,7 +12,7 @@
 //     column entry is written by the row's owner.  No line of H is ever shared between workgroups.
 //   * everything that does cross workgroups is a small EXCHANGE vector, written with write-through (sc1) stores
 //     and read with sc1 loads after a grid barrier; consecutive exchanges rotate through GRID_RING buffers, so a
-//     buffer is rewritten only three barriers after it was read and no trailing barrier is needed.
+//     buffer is rewritten only several barriers after it was read (see GRID_RING) and no trailing barrier is needed.
 // (A first version shared H between workgroups with plain accesses and fences only: 0.3 % of the runs of one
 //  test problem re-read a stale line and took a different path; tests/race_hunt.py.)
 static __device__ __forceinline__ double xld(const double* p) { return coh_load(p); }
@@ -30,8 +30,10 @@ static __device__ __forceinline__ void gsync(Grid& g) {
   g.bi += 1;
   if (!grid_barrier(g.gs, g.bi, g.s_flag)) g.ok = false;
 }
-#define GRID_RING 8   // exchange buffers (gram_cap doubles each, contiguous from n.t0): a buffer is rewritten only after >= 3
-                      // barriers even when two vectors are exchanged per barrier
+#define GRID_RING 16  // exchange buffers (gram_cap doubles each, contiguous from n.t0).  The busiest user, ompl_remove of
+                      // omp_lh.hip, takes FOUR buffers per barrier (hi and lo words of two rows): back-to-back removals come
+                      // back to a buffer after 4 barriers.  (A reuse distance of 2 barriers is already ordered -- the reads of
+                      // an exchange precede the reader's arrival at the next barrier -- the rest is margin.)
 static __device__ __forceinline__ double* xbuf(const NnlsArgs& n, Grid& g) {   // next exchange buffer (gram_cap doubles)
   return n.t0 + (size_t)((g.xi++) & (GRID_RING - 1)) * (size_t)n.ldg;
 }

@@ -1,0 +1,263 @@
+// moments.hip -- closed-form column sums of the Gaussian linear-regression projection.
+//
+// SparseVI needs  colsum_s = sum_n vecs[n][s]  of a FRESH projection of the whole data set at every ADAM step
+// (sparsevi.py:23-42, 69-76: 1 + opt_itrs projections per greedy step).  For the linear-regression likelihood
+// (examples/common/model_linreg.py:4-10)
+//     ll[n][s] = c - (y_n - x_n.theta_s)^2 / (2 sigsq),     vecs = ll - rowmean(ll)             (projector.py:19-21)
+// the sum over n is a quadratic form in the one-time second moments of the data  M = Z^T Z,  Z = [X, y]  ((D+1) x (D+1)):
+//     sum_n (y_n - x_n.theta)^2 = yy - 2 theta^T g + theta^T G theta =: Q(theta),     G = X^T X, g = X^T y
+//     colsum_s = -(Q(theta_s) - mean_t Q(theta_t)) / (2 sigsq)
+// Evaluated on the differences delta_s = theta_s - thetabar so that the common part cancels exactly:
+//     Q(thetabar + delta) = Q(thetabar) + 2 delta^T (G thetabar - g) + delta^T G delta
+//     T_s = 2 delta_s^T v + delta_s^T G delta_s,   v = G thetabar - g,       colsum_s = -(T_s - mean_t T_t) / (2 sigsq)
+// That is O(S D^2) per call instead of the 2 N D S flops of a projection (configs[4]: 2.3e7 against 7.7e11).
+//
+//   moments_kernel         M partials: fp64 MFMA (v_mfma_f64_16x16x4_f64), one workgroup per (64 x 64 block pair of the
+//                          upper triangle, slice of rows); operands staged through LDS, next chunk prefetched in registers
+//   moments_reduce_kernel  partials summed in slice order (fixed association: reproducible), both triangles written
+//   moments_colsum_kernel  T_s per workgroup, the last workgroup to finish centres and scales
+#include <algorithm>
+#include <string>
+#include "bcx_internal.h"
+#include "dev_util.h"
+
+typedef double mv4d __attribute__((ext_vector_type(4)));
+
+// write-through (sc1) store / sc1 load: coherent across the XCDs' L2s whatever the reader's L2 holds (csrc/nnls_common.h)
+static __device__ __forceinline__ double mom_ld(const double* p) {
+  return __longlong_as_double((long long)__hip_atomic_load((const unsigned long long*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+}
+static __device__ __forceinline__ void mom_st(double* p, double v) {
+  __hip_atomic_store((unsigned long long*)p, (unsigned long long)__double_as_longlong(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+#define MOM_BLK 64          // columns per block
+#define MOM_ROWS 32         // rows staged per chunk (4 waves x 2 k-steps x 4 rows)
+#define MOM_LDS_LD 80       // doubles per staged row: rows 0/1 and 2/3 of a k-step land on disjoint bank halves
+#define MOM_MAX_COLS 1024   // (D + 1) <= 1024: 16 blocks, 136 block pairs
+
+// part[(slice * npairs + pair) * 4096 + i * 64 + j]
+__global__ __launch_bounds__(256, 2) void moments_kernel(const double* __restrict__ Z, int64_t N, int64_t ldz, int C,
+                                                         int nblk, int nslices, int64_t rows_per_slice,
+                                                         double* __restrict__ part) {
+  __shared__ double sA[MOM_ROWS * MOM_LDS_LD];
+  __shared__ double sB[MOM_ROWS * MOM_LDS_LD];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 15, lk = lane >> 4;
+  const int npairs = nblk * (nblk + 1) / 2;
+  const int pair = blockIdx.x % npairs, slice = blockIdx.x / npairs;
+  int t = pair, I = 0;
+  while (t >= nblk - I) { t -= nblk - I; ++I; }
+  const int J = I + t;
+  const bool diag = I == J;
+  const int64_t r_begin = (int64_t)slice * rows_per_slice;
+  const int64_t r_end = r_begin + rows_per_slice < N ? r_begin + rows_per_slice : N;
+
+  // staging: 32 rows x 64 columns per block = 2048 doubles, 8 per thread: thread -> (row = q*4 + tid/64, col = tid%64)
+  const int scol = tid & 63, srow0 = tid >> 6;
+  const bool ca = I * MOM_BLK + scol < C, cb = J * MOM_BLK + scol < C;
+  const double* za = Z + (I * MOM_BLK + (ca ? scol : 0));
+  const double* zb = Z + (J * MOM_BLK + (cb ? scol : 0));
+  double ra[8], rb[8];
+  auto fetch = [&](int64_t r0) {
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const int64_t r = r0 + q * 4 + srow0;
+      const bool ok = r < r_end;
+      const int64_t rr = ok ? r : r_begin;
+      ra[q] = (ok && ca) ? za[rr * ldz] : 0.0;
+      if (!diag) rb[q] = (ok && cb) ? zb[rr * ldz] : 0.0;
+    }
+  };
+  mv4d acc[4][4];
+#pragma unroll
+  for (int u = 0; u < 4; ++u)
+#pragma unroll
+    for (int v = 0; v < 4; ++v) acc[u][v] = (mv4d){0.0, 0.0, 0.0, 0.0};
+
+  if (r_begin < r_end) fetch(r_begin);
+  for (int64_t r0 = r_begin; r0 < r_end; r0 += MOM_ROWS) {
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      sA[(q * 4 + srow0) * MOM_LDS_LD + scol] = ra[q];
+      if (!diag) sB[(q * 4 + srow0) * MOM_LDS_LD + scol] = rb[q];
+    }
+    __syncthreads();
+    if (r0 + MOM_ROWS < r_end) fetch(r0 + MOM_ROWS);      // next chunk in flight while this one is multiplied
+    const double* pB = diag ? sA : sB;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      const int row = wave * 8 + ks * 4 + lk;
+      double av[4], bv[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        av[u] = sA[row * MOM_LDS_LD + 16 * u + li];
+        bv[u] = pB[row * MOM_LDS_LD + 16 * u + li];
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int v = 0; v < 4; ++v) acc[u][v] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[u], bv[v], acc[u][v], 0, 0, 0);
+    }
+    __syncthreads();
+  }
+  // the four waves hold partial sums over disjoint rows: add them in wave order through LDS
+  __shared__ double sR[MOM_BLK * MOM_BLK];
+  double* red = sR;
+  for (int w = 0; w < 4; ++w) {
+    if (wave == w) {
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int v = 0; v < 4; ++v)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            // f64 C/D layout: col = lane & 15, row = (lane >> 4) + 4 * reg
+            const int i = 16 * u + lk + 4 * r, j = 16 * v + li;
+            if (w == 0) red[i * MOM_BLK + j] = acc[u][v][r];
+            else red[i * MOM_BLK + j] += acc[u][v][r];
+          }
+    }
+    __syncthreads();
+  }
+  double* dst = part + ((size_t)slice * npairs + pair) * (MOM_BLK * MOM_BLK);
+  for (int e = tid; e < MOM_BLK * MOM_BLK; e += 256) dst[e] = red[e];
+}
+
+// M[i][j] = sum over slices (in slice order) of the block partials; both triangles.
+__global__ __launch_bounds__(256) void moments_reduce_kernel(const double* __restrict__ part, int nblk, int nslices, int C,
+                                                             double* __restrict__ M, int64_t ldm) {
+  const int npairs = nblk * (nblk + 1) / 2;
+  const int pair = blockIdx.x;
+  int t = pair, I = 0;
+  while (t >= nblk - I) { t -= nblk - I; ++I; }
+  const int J = I + t;
+  for (int e = threadIdx.x; e < MOM_BLK * MOM_BLK; e += 256) {
+    double s = 0.0;
+    for (int sl = 0; sl < nslices; ++sl) s += part[((size_t)sl * npairs + pair) * (MOM_BLK * MOM_BLK) + e];
+    const int i = I * MOM_BLK + e / MOM_BLK, j = J * MOM_BLK + e % MOM_BLK;
+    if (i < C && j < C) {
+      if (I != J) { M[(size_t)i * ldm + j] = s; M[(size_t)j * ldm + i] = s; }
+      else if (i <= j) { M[(size_t)i * ldm + j] = s; M[(size_t)j * ldm + i] = s; }   // diagonal block: upper triangle decides
+    }
+  }
+}
+
+// One workgroup per sample s.  work: [0, S) the T_s, then one 32-bit arrival counter (self-resetting).
+__global__ __launch_bounds__(256) void moments_colsum_kernel(const double* __restrict__ M, int64_t ldm, int D, int ycol,
+                                                             const double* __restrict__ theta, int S, int ldt, double sigsq,
+                                                             double* __restrict__ colsum, double* __restrict__ work) {
+  extern __shared__ double sm[];        // delta[D], tbar[D]
+  __shared__ double scratch[BCX_SCRATCH];
+  __shared__ int last;
+  double* delta = sm;
+  double* tbar = sm + D;
+  const int tid = threadIdx.x, s = blockIdx.x;
+  for (int i = tid; i < D; i += 256) {
+    double m = 0.0;
+    for (int u = 0; u < S; ++u) m += theta[(size_t)u * ldt + i];     // the same order in every workgroup
+    m /= (double)S;
+    tbar[i] = m;
+    delta[i] = theta[(size_t)s * ldt + i] - m;
+  }
+  __syncthreads();
+  // t = sum_i delta_i (2 v_i + (G delta)_i),  v_i = (G tbar)_i - g_i;  G symmetric: column reads are coalesced over i
+  double t[1] = {0.0};
+  for (int i = tid; i < D; i += 256) {
+    double gd = 0.0, gt = 0.0;
+    for (int j = 0; j < D; ++j) {
+      const double g = M[(size_t)j * ldm + i];
+      gd = fma(g, delta[j], gd);
+      gt = fma(g, tbar[j], gt);
+    }
+    const double v = gt - M[(size_t)ycol * ldm + i];
+    t[0] += delta[i] * (2.0 * v + gd);
+  }
+  block_allsum<1>(t, scratch);
+  unsigned* counter = (unsigned*)(work + S);
+  if (tid == 0) {
+    mom_st(&work[s], t[0]);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    last = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)(S - 1);
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+  }
+  __syncthreads();
+  if (!last) return;
+  // the last workgroup to arrive: every T_s is in memory; summed in index order (the same bits whichever workgroup is last)
+  double m[1] = {0.0};
+  for (int u = tid; u < S; u += 256) m[0] += mom_ld(work + u);
+  block_allsum<1>(m, scratch);
+  const double mean = m[0] / (double)S, f = -1.0 / (2.0 * sigsq);
+  for (int u = tid; u < S; u += 256) colsum[u] = f * (mom_ld(work + u) - mean);
+  if (tid == 0) __hip_atomic_store(counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+void bcx_project_set_error(const std::string& msg);   // proj.hip: the message bcx_project_last_error() returns
+#define MOM_HIP(call)                                                             \
+  do {                                                                            \
+    hipError_t _e = (call);                                                       \
+    if (_e != hipSuccess) {                                                       \
+      bcx_project_set_error(std::string(#call) + ": " + hipGetErrorString(_e));   \
+      return BCX_ERR_HIP;                                                         \
+    }                                                                             \
+  } while (0)
+
+static void moments_plan(int64_t N, int C, int* nblk, int* nslices, int64_t* rows_per_slice) {
+  *nblk = (C + MOM_BLK - 1) / MOM_BLK;
+  const int npairs = *nblk * (*nblk + 1) / 2;
+  int cus = 256, dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
+  const int64_t chunks = (N + MOM_ROWS - 1) / MOM_ROWS;
+  // two workgroups per CU are resident; two rounds of them, and never fewer than 8 chunks per slice
+  int64_t sl = std::max<int64_t>(1, (int64_t)(4 * cus) / npairs);
+  sl = std::min<int64_t>(sl, std::max<int64_t>(1, chunks / 8));
+  *rows_per_slice = (chunks + sl - 1) / sl * MOM_ROWS;
+  *nslices = (int)std::max<int64_t>(1, (N + *rows_per_slice - 1) / *rows_per_slice);
+}
+
+// Bytes of scratch bcx_project_moments needs for an N x C matrix (the block partials of every row slice).
+extern "C" int64_t bcx_project_moments_scratch_bytes(int64_t N, int32_t C) {
+  if (N < 0 || C < 1 || C > MOM_MAX_COLS) return -1;
+  int nblk, nslices; int64_t rps;
+  moments_plan(N, C, &nblk, &nslices, &rps);
+  return (int64_t)nslices * (nblk * (nblk + 1) / 2) * MOM_BLK * MOM_BLK * (int64_t)sizeof(double);
+}
+
+// M_dev (C x ldm doubles, both triangles) = Z^T Z over the N rows of Z_dev (N x ldz doubles, C = D + 1 columns used).
+extern "C" int bcx_project_moments(void* stream, const void* Z_dev, int64_t N, int64_t ldz, int32_t C, void* M_dev, int64_t ldm,
+                                   void* work_dev, int64_t work_bytes) {
+  if (!Z_dev || !M_dev || !work_dev || N < 0 || C < 1 || C > MOM_MAX_COLS || ldz < C || ldm < C) {
+    bcx_project_set_error("bcx_project_moments: bad arguments (1 <= columns <= 1024)");
+    return BCX_ERR_ARG;
+  }
+  if (work_bytes < bcx_project_moments_scratch_bytes(N, C)) { bcx_project_set_error("bcx_project_moments: scratch too small"); return BCX_ERR_ARG; }
+  int nblk, nslices; int64_t rps;
+  moments_plan(N, C, &nblk, &nslices, &rps);
+  const int npairs = nblk * (nblk + 1) / 2;
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(moments_kernel, dim3(npairs * nslices), dim3(256), 0, st, (const double*)Z_dev, N, ldz, (int)C, nblk, nslices,
+                     rps, (double*)work_dev);
+  hipLaunchKernelGGL(moments_reduce_kernel, dim3(npairs), dim3(256), 0, st, (const double*)work_dev, nblk, nslices, (int)C,
+                     (double*)M_dev, ldm);
+  MOM_HIP(hipGetLastError());
+  return BCX_OK;
+}
+
+// colsum_dev[s] = sum_n vecs[n][s] of the linear-regression projection of the data whose moments are M_dev (features in
+// rows/columns [0, D), response in row/column ycol), for the S parameter rows of theta_dev.  work_dev: S + 1 doubles, the
+// last one zero before the first call (the kernel leaves it zero).
+extern "C" int bcx_project_colsum_moments(void* stream, const void* M_dev, int64_t ldm, int32_t D, int32_t ycol,
+                                          const void* theta_dev, int32_t S, int32_t ldt, double sigsq, void* colsum_dev,
+                                          void* work_dev) {
+  if (!M_dev || !theta_dev || !colsum_dev || !work_dev || D < 1 || D >= MOM_MAX_COLS || ycol < 0 || ycol >= ldm || ldm < D ||
+      S < 1 || ldt < D || !(sigsq > 0.0)) {
+    bcx_project_set_error("bcx_project_colsum_moments: bad arguments");
+    return BCX_ERR_ARG;
+  }
+  hipLaunchKernelGGL(moments_colsum_kernel, dim3(S), dim3(256), 2 * (size_t)D * sizeof(double), (hipStream_t)stream,
+                     (const double*)M_dev, ldm, (int)D, (int)ycol, (const double*)theta_dev, (int)S, (int)ldt, sigsq,
+                     (double*)colsum_dev, (double*)work_dev);
+  MOM_HIP(hipGetLastError());
+  return BCX_OK;
+}

@@ -225,7 +225,7 @@ int bcx_launch_optimize_grid(bcx_solver* s, double tol, int k) {
   if (!s->grid_counter) {
     BCX_HIP(hipMalloc((void**)&s->grid_counter, 2 * sizeof(unsigned long long)));
   }
-  BCX_HIP(hipMemsetAsync(s->grid_counter, 0, sizeof(unsigned long long), s->stream));
+  BCX_HIP(hipMemsetAsync(s->grid_counter, 0, 2 * sizeof(unsigned long long), s->stream));   // [0] arrivals, [1] the OMP step's barrier base
   s->grid_epoch = 0;
   NnlsArgs n;
   fill_nnls_args(s, n, nullptr);
@@ -241,5 +241,6 @@ int bcx_launch_optimize_grid(bcx_solver* s, double tol, int k) {
   gs.timeout_ticks = 1000000000LL;   // 10 s
   hipLaunchKernelGGL(optimize_grid_kernel, dim3(OPT_WGS), dim3(NN_THREADS), lds, s->stream, n, gs, tol, kcap, dpad);
   BCX_HIP(hipGetLastError());
+  s->grid_dirty = true;   // counter[0] now holds this launch's arrivals; an OMP step that follows without a build_begin re-zeroes
   return BCX_OK;
 }

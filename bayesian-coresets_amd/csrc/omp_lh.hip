@@ -193,6 +193,7 @@ static __device__ void ompl_remove(const NnlsArgs& n, const OmpLds& L, int& p, i
       L.u[a] = v.h; L.ul[a] = v.l;
     }
   }
+  __syncthreads();                                                   // every thread has read z[q] (f) before z[q] is rewritten
   for (int a = tid; a < p; a += blockDim.x) L.z[a] -= f * L.g[a];    // least-squares solution on P \ {q}
   __syncthreads();
   for (int rr = blockIdx.x * nw + wave; rr < last; rr += gridDim.x * nw) {
@@ -675,6 +676,10 @@ int bcx_launch_omp_lh(bcx_solver* s, NnlsArgs& n) {
   if (lds > s->omp_lds_allowed) {
     BCX_HIP(hipFuncSetAttribute((const void*)omp_lh_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)OMPL_LDS_MAX));
     s->omp_lds_allowed = OMPL_LDS_MAX;
+  }
+  if (s->grid_dirty) {                 // optimize() ran since the last bcx_build_begin: arrivals and base restart together
+    BCX_HIP(hipMemsetAsync(s->grid_counter, 0, 2 * sizeof(unsigned long long), s->stream));
+    s->grid_dirty = false;
   }
   GridSync gs;
   gs.counter = s->grid_counter;

@@ -778,6 +778,7 @@ __global__ __launch_bounds__(256) void select_final_kernel(const double* bv, con
 // ---- C ABI --------------------------------------------------------------------------------------
 static thread_local std::string g_proj_err;
 extern "C" const char* bcx_project_last_error(void) { return g_proj_err.c_str(); }
+void bcx_project_set_error(const std::string& msg) { g_proj_err = msg; }   // (moments.hip reports through the same string)
 
 #define PROJ_HIP(call)                                                            \
   do {                                                                            \
@@ -951,7 +952,8 @@ template <int MODE> static int launch_family(int family, dim3 grid, size_t extra
 
 static int fill(ProjArgs& p, int family, const void* Z, int64_t N, int64_t ldz, int D, int ycol, const void* theta,
                 int S, int ldt, double param) {
-  if (!Z || !theta || N < 0 || D < 1 || S < 1 || ldz < D || ldt < D || S > 4096) {
+  if (!Z || !theta || N < 0 || D < 1 || S < 1 || ldz < D || ldt < D || S > 4096 || (int64_t)(S + 128) * ldt >= (int64_t)1 << 31) {
+    // (the kernel forms Theta offsets (column) * ldt in 32 bits, columns up to S rounded to the tile width)
     g_proj_err = "bcx_project: bad arguments";
     return BCX_ERR_ARG;
   }

@@ -40,41 +40,95 @@ def posterior_sampler(mu0, Sig0, sigsq, device=None, seed=None):
         return sampler
 
     import torch
+    import scipy.linalg as sl
     dev = torch.device(device)
     gen = torch.Generator(device=dev)
     gen.manual_seed(0 if seed is None else int(seed))
+    D = mu0.shape[0]
+    Dp = D + (D % 2)      # rows of the returned draws start on 16-byte boundaries (bc.DeviceProjector then uses them in place)
     mu0_d = torch.from_numpy(mu0).to(dev)
     S0inv_d = torch.from_numpy(Sig0inv).to(dev)
-    eye = torch.eye(mu0.shape[0], dtype=torch.float64, device=dev)
+    eye = torch.eye(D, dtype=torch.float64, device=dev)
 
     # The prior's factor, once: Sig0^-1 = L0 L0^T, U0 = L0^-T (so Sig0 = U0 U0^T).  A weighted coreset of k points is a
-    # rank-k update  A = Sig0^-1 + B^T B,  B = diag(sqrt(w / sigsq)) X,  and with  C = B U0  (k x D)
-    #     A^-1 = U0 (I + C^T C)^-1 U0^T,      (I + C^T C)^(-1/2) = I + W diag(d) W^T,
-    # W = C^T Q, d_i = ((1 + l_i)^(-1/2) - 1) / l_i from the k x k eigenproblem C C^T = Q diag(l) Q^T (host, microseconds).
-    # SparseVI calls the sampler once per ADAM step with a handful of points: this replaces a 301 x 301 Cholesky and a
-    # triangular solve (rocSOLVER small-matrix kernels, ~0.7 ms of device time per call) by two D x D x k products.
-    import scipy.linalg as sl
+    # rank-k update  A = Sig0^-1 + B^T B,  B = diag(s) X,  s = sqrt(w / sigsq),  and with  C = B U0  (k x D)
+    #     A^-1 = U0 (I + C^T C)^-1 U0^T,      (I + C^T C)^(-1/2) = I + W diag(d) W^T,      (I + C^T C)^-1 = I + W diag(e) W^T,
+    # W = C^T Q, d_i = ((1 + l_i)^(-1/2) - 1) / l_i, e_i = -1 / (1 + l_i) from the k x k eigenproblem C C^T = Q diag(l) Q^T.
+    # SparseVI calls the sampler once per ADAM step with the SAME points and new weights: everything that depends on the
+    # points alone (X U0 on the device, its k x k Gram on the host) is kept while the points stay the same; a call then costs a
+    # k x k eigenproblem on the host, ONE small upload (diag(s) Q, d, e, the right-hand side) and eleven small device
+    # kernels -- against a 301 x 301 Cholesky + triangular solve (rocSOLVER small-matrix kernels, ~0.7 ms) per call.
     L0 = np.linalg.cholesky(Sig0inv)
-    U0 = sl.solve_triangular(L0, np.eye(mu0.shape[0]), lower=True, check_finite=False).T
-    U0_d = torch.from_numpy(np.ascontiguousarray(U0)).to(dev)
+    U0 = sl.solve_triangular(L0, np.eye(D), lower=True, check_finite=False).T
+    U0p = np.zeros((Dp, Dp))
+    U0p[:D, :D] = U0
+    U0_d = torch.from_numpy(U0p).to(dev)
+    U0T_d = U0_d.T.contiguous()
     rhs0 = Sig0inv.dot(mu0)
     LOWRANK_MAX = 32
+    cache = {"pts": None}
+    pinned = {}
 
-    def posterior_lowrank(wts, pts):
+    def staged(vec):
+        """one host->device copy of a packed vector through a pinned buffer (event-guarded reuse)"""
+        n = vec.shape[0]
+        if dev.type != "cuda":
+            return torch.from_numpy(np.ascontiguousarray(vec)).to(dev)
+        slot = pinned.get(n)
+        if slot is None:
+            slot = pinned[n] = (torch.empty(n, dtype=torch.float64).pin_memory(), torch.empty(n, dtype=torch.float64, device=dev),
+                                torch.cuda.Event())
+        host, devbuf, ev = slot
+        ev.synchronize()                       # the previous copy out of this buffer has completed
+        host.numpy()[:] = vec
+        devbuf.copy_(host, non_blocking=True)
+        ev.record(torch.cuda.current_stream(dev))
+        return devbuf
+
+    def points_state(pts):
+        c = cache
+        if c["pts"] is None or c["pts"].shape != pts.shape or not np.array_equal(c["pts"], pts):
+            X, y = pts[:, :-1], pts[:, -1]
+            XU0 = X.dot(U0)                                         # k x D
+            XU0Tp = np.zeros((Dp, pts.shape[0]))
+            XU0Tp[:D] = XU0.T
+            c.update(pts=pts.copy(), X=X.copy(), y=y.copy(), K0=XU0.dot(XU0.T), XU0T_d=torch.from_numpy(XU0Tp).to(dev))
+        return c
+
+    def lowrank_factors(wts, pts):
+        """(W (Dp x k), d, e, t = U0^T rhs) on the device"""
         pts = np.atleast_2d(np.asarray(pts, dtype=np.float64))
         wts = np.asarray(wts, dtype=np.float64)
-        X, y = pts[:, :-1], pts[:, -1]
-        C = (np.sqrt(wts / sigsq)[:, None] * X).dot(U0)
-        lam, Q = np.linalg.eigh(C.dot(C.T))
+        c = points_state(pts)
+        k = wts.shape[0]
+        sv = np.sqrt(wts / sigsq)
+        lam, Q = np.linalg.eigh(c["K0"] * np.outer(sv, sv))
         lam = np.maximum(lam, 0.0)
-        d = np.where(lam > 1e-290, (1.0 / np.sqrt(1.0 + lam) - 1.0) / np.where(lam > 1e-290, lam, 1.0), -0.5)
-        W = torch.from_numpy(np.ascontiguousarray(C.T.dot(Q))).to(dev)                 # D x k
-        rhs = torch.from_numpy(rhs0 + (wts * y).dot(X) / sigsq).to(dev)
-        U = U0_d + ((U0_d @ W) * torch.from_numpy(d).to(dev)) @ W.T                    # U0 (I + W diag(d) W^T)
-        return U @ (U.T @ rhs), U
+        safe = np.where(lam > 1e-290, lam, 1.0)
+        d = np.where(lam > 1e-290, (1.0 / np.sqrt(1.0 + lam) - 1.0) / safe, -0.5)
+        e = -1.0 / (1.0 + lam)
+        rhs = np.zeros(Dp)
+        rhs[:D] = rhs0 + (wts * c["y"]).dot(c["X"]) / sigsq
+        buf = staged(np.concatenate(((sv[:, None] * Q).ravel(), d, e, rhs)))
+        sQ, d_d, e_d, rhs_d = buf[:k * k].view(k, k), buf[k * k:k * k + k], buf[k * k + k:k * k + 2 * k], buf[k * k + 2 * k:]
+        W = c["XU0T_d"] @ sQ                                        # Dp x k
+        return W, d_d, e_d, torch.mv(U0T_d, rhs_d)
+
+    def lowrank_mean(W, e_d, t):
+        a = torch.mv(W.T, t)
+        a *= e_d
+        return torch.mv(U0_d, torch.addmv(t, W, a))                 # mu = U0 (I + W diag(e) W^T) U0^T rhs
+
+    def posterior_lowrank(wts, pts):
+        W, d_d, e_d, t = lowrank_factors(wts, pts)
+        U = U0_d + ((U0_d @ W) * d_d) @ W.T                         # U0 (I + W diag(d) W^T)
+        return lowrank_mean(W, e_d, t)[:D], U[:D, :D]
+
+    def use_lowrank(wts):
+        return wts is not None and 0 < len(wts) <= LOWRANK_MAX and np.all(np.asarray(wts) >= 0)
 
     def posterior(wts, pts):
-        if wts is not None and 0 < len(wts) <= LOWRANK_MAX and np.all(np.asarray(wts) >= 0):
+        if use_lowrank(wts):
             return posterior_lowrank(wts, pts)
         A, rhs = S0inv_d.clone(), S0inv_d @ mu0_d
         if wts is not None and len(wts):
@@ -88,7 +142,17 @@ def posterior_sampler(mu0, Sig0, sigsq, device=None, seed=None):
         return U @ (U.T @ rhs), U
 
     def sampler(n, wts, pts):
+        if use_lowrank(wts):
+            # draws = mu + R U^T with U = U0 (I + W diag(d) W^T), never forming U:  (R + ((R W) d) W^T) U0^T + mu
+            W, d_d, e_d, t = lowrank_factors(wts, pts)
+            mu = lowrank_mean(W, e_d, t)
+            R = torch.randn(n, Dp, dtype=torch.float64, device=dev, generator=gen)
+            B = R @ W
+            B *= d_d
+            return torch.addmm(mu, torch.addmm(R, B, W.T), U0T_d)[:, :D]
         mu, U = posterior(wts, pts)
-        return mu + torch.randn(n, mu.shape[0], dtype=torch.float64, device=dev, generator=gen) @ U.T
+        out = torch.zeros(n, Dp, dtype=torch.float64, device=dev)
+        out[:, :D] = mu + torch.randn(n, D, dtype=torch.float64, device=dev, generator=gen) @ U.T
+        return out[:, :D]
     sampler.posterior = posterior
     return sampler

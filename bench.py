@@ -72,6 +72,10 @@ def parse():
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--no-f16-leg", action="store_true", help="c4: skip the extra leg with fp16-stored rows")
     ap.add_argument("--opt-itrs", type=int, default=100, help="c5: ADAM steps per greedy step (sparsevi.py:7)")
+    ap.add_argument("--no-side-legs", action="store_true", help="default line only: skip the compact c2 / c3 / c5 legs")
+    ap.add_argument("--colsum", default="mfma", choices=["mfma", "moments", "auto"],
+                    help="c5: column sums of the full-data projection by the fp64-MFMA projection kernel (101 per greedy step), "
+                         "or in closed form from the one-time (D+1)x(D+1) moments of the data (linear-regression family)")
     ap.add_argument("--features", type=int, default=10, help="c3: regression features D (simple_lr/main.py:24)")
     a = ap.parse_args()
     explicit = a.config is not None
@@ -509,7 +513,7 @@ def run_sparsevi(args, torch, dist, nat, world, rank, local_rank):
     group = dist.group.WORLD if world > 1 else None
     sampler = model_linreg.posterior_sampler(mu0, Sig0, sigsq, device="cuda", seed=args.seed + 7)
     np.random.seed(args.seed)
-    prj = bc.DeviceProjector("linreg", sampler, S, sigsq=sigsq, device=local_rank, group=group, row_offset=lo)
+    prj = bc.DeviceProjector("linreg", sampler, S, sigsq=sigsq, device=local_rank, group=group, row_offset=lo, colsum=args.colsum)
     alg = bc.SparseVICoreset(Z, prj, opt_itrs=args.opt_itrs, row_offset=lo, group=group) if world > 1 else \
         bc.SparseVICoreset(Z, prj, opt_itrs=args.opt_itrs)
 
@@ -547,7 +551,12 @@ def run_sparsevi(args, torch, dist, nat, world, rank, local_rank):
                         "N=%d, S=%d Monte-Carlo samples, opt_itrs=%d, %d row shard(s), %d greedy steps"
                         % (D, N, S, args.opt_itrs, world, args.steps),
             "name": "c5", "baseline_config": args.what, "rows": N, "features": D, "dim": S, "rows_per_gpu": hi - lo,
-            "opt_itrs": args.opt_itrs, "projections_per_step": 1 + args.opt_itrs,
+            "opt_itrs": args.opt_itrs, "projections_per_step": 1 + args.opt_itrs if args.colsum == "mfma" else 1,
+            # mfma: every column sum is a fused fp64-MFMA projection of all rows (1 + opt_itrs per step, as the reference
+            # does); moments: the column sums come in closed form from the one-time (D+1) x (D+1) moments of the data
+            # (csrc/moments.hip), the select step's projection stays
+            "colsum": args.colsum, "moments": prj.moments_info or None,
+            "moments_setup_ms": (prj.moments_info or {}).get("setup_ms"),
             "sampler": "weighted conjugate posterior on the device (examples/common/model_linreg.py: rank-k update of the "
                        "prior's %d x %d factor per ADAM step, k = coreset size: the user-callback side of the Projector "
                        "interface)" % (D, D),
@@ -593,8 +602,97 @@ def cpu_baseline_sparsevi(args, Z, mu0, Sig0, sigsq, S):
     }
 
 
+def side_legs(args, out, torch, dist, nat):
+    """The default (c4) line also carries compact legs of BASELINE.json's other GPU configs, each at its full size on
+    this one GPU, as flat top-level keys (c2_* / c3_* / c5_*): the driver times only the default command, and these put
+    configs[1], [2] and [4] on its clock.  No CPU baseline in the legs; a leg that fails leaves `<cfg>_error`."""
+    import copy
+    import gc
+
+    def leg(name, **over):
+        a = copy.copy(args)
+        c = CONFIGS[name]
+        a.config, a.kind, a.alg, a.rows, a.dim, a.what, a.adhoc = name, c["kind"], c["alg"], c["rows"], c["dim"], c["what"], False
+        a.steps = {"sparsevi": 3, "logistic": 100}.get(a.kind, 300)
+        a.warmup = {"sparsevi": 1, "logistic": 20}.get(a.kind, 30)
+        a.no_cpu_baseline, a.no_exact_mode, a.dtype = True, True, "float32"
+        for k, v in over.items():
+            setattr(a, k, v)
+        gc.collect()
+        torch.cuda.empty_cache()
+        t0 = time.perf_counter()
+        try:
+            r = (run_sparsevi if a.kind == "sparsevi" else run_snnls)(a, torch, dist, nat, 1, 0, torch.cuda.current_device())
+        except Exception as e:      # the headline line must survive a broken side leg
+            out["%s_error" % name] = "%s: %s" % (type(e).__name__, e)
+            return None
+        r["leg_wall_s"] = time.perf_counter() - t0
+        return r
+
+    for name in ("c2", "c3"):
+        r = leg(name)
+        if r is None:
+            continue
+        bytes_it = r["roofline"]["algorithmic_bytes_per_launch"]
+        out["%s_its" % name] = r["value"]
+        out["%s_ms_per_step" % name] = r["ms_per_step"]
+        out["%s_scan_frac" % name] = r["roofline"]["frac"]
+        # whole-iteration fraction of the HBM peak: the scan's algorithmic bytes over the full step time
+        out["%s_iter_frac" % name] = bytes_it / (r["ms_per_step"] * 1e-3) / 1e9 / HBM_PEAK_GBS
+        out["%s_steps" % name] = r["config"]["iterations_run"]
+        out["%s_workload" % name] = r["config"]["workload"]
+        out["%s_leg_wall_s" % name] = r["leg_wall_s"]
+        if name == "c3":
+            # everything of an OMP iteration that is not the scan: the fused resolve + Lawson-Hanson step kernel
+            out["c3_omp_step_us"] = (r["ms_per_step"] - r["roofline"]["avg_launch_ms"]) * 1e3
+            out["c3_final_error"] = r["config"]["final_error"]
+    for key, over in (("c5_steps_s", dict(colsum="mfma")), ("c5_steps_s_moments", dict(colsum="moments"))):
+        r = leg("c5", **over)
+        if r is None:
+            continue
+        out[key] = r["value"]
+        out[key.replace("steps_s", "ms_per_step")] = r["ms_per_step"]
+        out[key.replace("steps_s", "leg_wall_s")] = r["leg_wall_s"]
+        if over["colsum"] == "mfma":
+            out["c5_mfma_frac"] = r["roofline"]["frac"]
+            out["c5_mfma_tflops"] = r["roofline"]["achieved"]
+            out["c5_workload"] = r["config"]["workload"]
+            out["c5_coreset_idcs"] = r["config"]["coreset_idcs"]
+        else:
+            out["c5_moments_mfma_frac"] = r["roofline"]["frac"]
+            out["c5_moments_same_idcs"] = r["config"]["coreset_idcs"] == out.get("c5_coreset_idcs")
+            out["c5_moments_setup_ms"] = r["config"].get("moments_setup_ms")
+
+
+def self_launch(args):
+    """`python bench.py --gpus N` with N > 1 and no launcher around it: start the N ranks here, one per GPU, under
+    torch.distributed.run (RCCL) on 127.0.0.1 and pass rank 0's JSON line through.  Never prints a line for fewer ranks
+    than --gpus asked for: too few devices is an error (exit 2) unless BENCH_SHARE_GPU=1 (testing: all ranks on cuda:0)."""
+    import socket
+    import subprocess
+    import torch
+    have = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    if have < args.gpus and os.environ.get("BENCH_SHARE_GPU") != "1":
+        sys.stderr.write("bench.py: --gpus %d but this box shows %d GPU(s); refusing to print a line for fewer ranks "
+                         "(BENCH_SHARE_GPU=1 lets the ranks share cuda:0 for testing)\n" % (args.gpus, have))
+        return 2
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    sys.stderr.write("bench.py: no launcher in the environment, starting %d ranks: %s\n" % (args.gpus, " ".join(cmd)))
+    env = dict(os.environ)
+    env["BENCH_SELF_LAUNCHED"] = "1"
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     args = parse()
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(self_launch(args))
     import torch
     import torch.distributed as dist
     from bayesiancoresets_amd import _native as nat
@@ -602,7 +700,7 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world > 1:
+    if world != args.gpus:      # never a line whose n_gpus differs from --gpus
         raise SystemExit("--gpus %d does not match WORLD_SIZE %d" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (no CPU fallback)")
@@ -611,15 +709,42 @@ def main():
     share = os.environ.get("BENCH_SHARE_GPU") == "1"
     if share:
         local_rank = 0
+    elif torch.cuda.device_count() <= local_rank:
+        raise SystemExit("rank %d: LOCAL_RANK %d but %d visible GPU(s)" % (rank, local_rank, torch.cuda.device_count()))
     torch.cuda.set_device(local_rank)
+    backend = None
     if world > 1:
+        backend = "gloo" if share else "nccl"
         if share:
             dist.init_process_group("gloo")
         else:
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     run = run_sparsevi if args.kind == "sparsevi" else run_snnls
     out = run(args, torch, dist, nat, world, rank, local_rank)
+    if world == 1 and args.config == "c4" and not args.adhoc and not args.no_side_legs:
+        side_legs(args, out, torch, dist, nat)
+    if args.kind == "sparsevi" and args.colsum == "mfma" and not args.no_side_legs:
+        # the same steps again with the column sums in closed form (every rank takes part), reported beside the headline
+        import copy
+        import gc
+        a2 = copy.copy(args)
+        a2.colsum, a2.no_cpu_baseline = "moments", True
+        gc.collect()
+        torch.cuda.empty_cache()
+        r2 = run_sparsevi(a2, torch, dist, nat, world, rank, local_rank)
+        if rank == 0:
+            out["steps_s_moments"] = r2["value"]
+            out["ms_per_step_moments"] = r2["ms_per_step"]
+            out["moments_same_idcs"] = r2["config"]["coreset_idcs"] == out["config"]["coreset_idcs"]
+            out["moments"] = r2["config"]["moments"]
+            out["moments_select_tflops"] = r2["roofline"]["achieved"]
     if rank == 0:
+        # the world the process group itself reports (RCCL ranks when backend == "nccl"), one rank per device
+        out["rccl_ranks"] = dist.get_world_size() if (world > 1 and backend == "nccl") else (1 if world == 1 else 0)
+        out["process_group"] = {"backend": backend, "world_size": dist.get_world_size() if world > 1 else 1,
+                                "self_launched": os.environ.get("BENCH_SELF_LAUNCHED") == "1",
+                                "devices_visible": torch.cuda.device_count(), "share_gpu": share}
+        assert out["n_gpus"] == args.gpus
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

@@ -225,6 +225,21 @@ int64_t bcx_project_select_scratch_bytes(int32_t family, int64_t N, int32_t S);
 int bcx_project_select_ws(void* stream, int32_t family, const void* Z_dev, int64_t N, int64_t ldz, int32_t D,
                           int32_t ycol, const void* theta_dev, int32_t S, int32_t ldt, double param,
                           const void* resid_dev, double resid_sum, void* result_dev, void* work_dev, int64_t work_bytes);
+/* Closed-form column sums of the linear-regression family (family 2) from the one-time second moments of the data:
+ *   sum_n (y_n - x_n.theta)^2 = yy - 2 theta^T X^T y + theta^T X^T X theta
+ * so the 1 + opt_itrs full-data column sums of a SparseVI step (sparsevi.py:23-42, 69-76; model_linreg.py:4-10) cost
+ * O(S D^2) each instead of a 2 N D S projection.
+ *   bcx_project_moments        M_dev (C x ldm doubles, both triangles) = Z^T Z over the N rows of Z_dev (N x ldz, C <= 1024
+ *                              columns used: the D features and the response); fp64 MFMA, fixed summation order;
+ *                              work_dev: bcx_project_moments_scratch_bytes(N, C) bytes.  Row shards: sum the M of the shards.
+ *   bcx_project_colsum_moments colsum_dev[s] = sum_n vecs[n][s] (centred over s, as bcx_project_colsum returns it) for the
+ *                              data whose moments are M_dev (features in [0, D), response at ycol);
+ *                              work_dev: S + 1 doubles, the last one zero before the first call. */
+int64_t bcx_project_moments_scratch_bytes(int64_t N, int32_t C);
+int bcx_project_moments(void* stream, const void* Z_dev, int64_t N, int64_t ldz, int32_t C, void* M_dev, int64_t ldm,
+                        void* work_dev, int64_t work_bytes);
+int bcx_project_colsum_moments(void* stream, const void* M_dev, int64_t ldm, int32_t D, int32_t ycol,
+                               const void* theta_dev, int32_t S, int32_t ldt, double sigsq, void* colsum_dev, void* work_dev);
 const char* bcx_project_last_error(void);
 /* Measurement: hipEvents around the projection kernel alone, recorded on the stream the kernel is launched on.
  * bcx_project_profile(1) starts timing every later projection launch of the calling host thread, (0) stops;

@@ -254,6 +254,12 @@ def test_config5_sparsevi_5m_rbf(bc):
         colsum, arg, best, second = restated(theta, wts0, pts0)
         assert best - second > 1e-9 * abs(best), "near-tie in the test input"
         np.testing.assert_allclose(prj.project_colsum(Z), colsum, rtol=1e-7, atol=1e-9 * np.abs(colsum).max())
+        # the two forms of the column sums (default: closed form on the moments, checked once against the projection kernel)
+        assert prj.moments_info["accepted"] and prj.moments_info["disagreement"] <= 1e-10
+        prj.colsum_mode = "mfma"
+        via_mfma = prj.project_colsum(Z)
+        prj.colsum_mode = "auto"
+        np.testing.assert_allclose(prj.project_colsum(Z), via_mfma, rtol=1e-10, atol=1e-10 * np.abs(via_mfma).max())
         assert len(alg.idcs) == n0 + 1 and int(alg.idcs[-1]) == arg, "step %d: engine added %s, restated reference %d" % (step, alg.idcs, arg)
         np.testing.assert_array_equal(alg.pts[-1], Z[arg].cpu().numpy())
         alg._optimize()

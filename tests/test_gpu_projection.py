@@ -118,16 +118,18 @@ def test_center_rows_flag_on_host_and_fp32_sources(bc):
     np.testing.assert_allclose(np.asarray(bc.snnls.FrankWolfe(V.T, None, center_rows=True).A), C.T, rtol=1e-13, atol=1e-13)
 
 
-@pytest.mark.parametrize("kind", ("device", "blackbox"))
+@pytest.mark.parametrize("kind", ("device", "device-mfma", "device-moments", "blackbox"))
 def test_sparsevi_matches_reference(bc, kind):
-    """F6: 5 greedy steps x 20 ADAM steps; same points in the same order, weights to 1e-5."""
+    """F6: 5 greedy steps x 20 ADAM steps; same points in the same order, weights to 1e-5 -- with the column sums from the
+    fused projection kernel ("device-mfma"), in closed form from the data's moments ("device-moments"), and in the default
+    mode (moments after a one-time check against the projection)."""
     g = np.load(os.path.join(ROOT, "tests", "golden", "svi_golden.npz"))
     N, D, S, sigsq = int(g["N"]), int(g["D"]), int(g["S"]), float(g["sigsq"])
     Z = make_linreg_data(1, N, D)
     sampler = linreg_sampler(np.zeros(D), np.eye(D), sigsq)
     np.random.seed(2)
-    if kind == "device":
-        prj = bc.DeviceProjector("linreg", sampler, S, sigsq=sigsq)
+    if kind.startswith("device"):
+        prj = bc.DeviceProjector("linreg", sampler, S, sigsq=sigsq, colsum={"device": "auto"}.get(kind, kind[7:]))
     else:
         prj = bc.BlackBoxProjector(sampler, S, lambda z, th: linreg_log_likelihood(z, th, sigsq))
     alg = bc.SparseVICoreset(Z, prj, opt_itrs=int(g["opt_itrs"]))
@@ -135,6 +137,10 @@ def test_sparsevi_matches_reference(bc, kind):
         alg.build(1)
         assert np.array_equal(alg.idcs, g["step%d_idcs" % i]), "step %d picked a different point" % i
         np.testing.assert_allclose(alg.wts, g["step%d_wts" % i], rtol=1e-5, atol=1e-8)
+    if kind == "device":
+        assert prj.moments_info["checked"] and prj.moments_info["accepted"] and prj.moments_info["disagreement"] < 1e-10
+    if kind == "device-mfma":
+        assert not prj.moments_info
     wts, pts, idcs = alg.get()
     assert np.array_equal(idcs, g["get_idcs"])
     np.testing.assert_allclose(wts, g["get_wts"], rtol=1e-5)
@@ -377,7 +383,7 @@ def test_rbf_workload_one_state_against_reference(bc):
     np.testing.assert_allclose(corr_head, g["corr_head0"], rtol=1e-9)
 
 
-@pytest.mark.parametrize("kind", ("device", "blackbox"))
+@pytest.mark.parametrize("kind", ("device", "device-mfma", "device-moments", "blackbox"))
 def test_sparsevi_rbf_matches_reference(bc, kind):
     """F6b: the reference's SparseVI run on the RBF regression (N = 50k, D = 301, S = 64, 20 ADAM steps per greedy step):
     same points in the same order, weights to 1e-5."""
@@ -386,8 +392,8 @@ def test_sparsevi_rbf_matches_reference(bc, kind):
     Z, sigsq, S = wl["Z"], wl["sigsq"], int(g["S"])
     sampler = linreg_sampler(wl["mu0"], wl["Sig0"], sigsq)
     np.random.seed(2)
-    if kind == "device":
-        prj = bc.DeviceProjector("linreg", sampler, S, sigsq=sigsq)
+    if kind.startswith("device"):
+        prj = bc.DeviceProjector("linreg", sampler, S, sigsq=sigsq, colsum={"device": "auto"}.get(kind, kind[7:]))
     else:
         prj = bc.BlackBoxProjector(sampler, S, lambda z, th: linreg_log_likelihood(z, th, sigsq))
     alg = bc.SparseVICoreset(Z, prj, opt_itrs=int(g["opt_itrs"]))
@@ -395,6 +401,72 @@ def test_sparsevi_rbf_matches_reference(bc, kind):
         alg.build(1)
         assert np.array_equal(alg.idcs, g["step%d_idcs" % i]), "step %d picked a different point" % i
         np.testing.assert_allclose(alg.wts, g["step%d_wts" % i], rtol=1e-5, atol=1e-8)
+
+
+@pytest.mark.parametrize("N,C,pad", ((4096, 2, 0), (5000, 22, 1), (33333, 65, 3), (20011, 302, 0), (4100, 130, 2)))
+def test_moments_kernel_matches_numpy(bc, N, C, pad):
+    """csrc/moments.hip: M = Z^T Z (fp64 MFMA, block pairs of the upper triangle x row slices) against NumPy, for column
+    counts around the 64-wide block edges, padded leading dimensions and row counts that leave ragged slices."""
+    import torch
+    from bayesiancoresets_amd import _native as nat
+    lib = nat.load()
+    rs = np.random.RandomState(N + C)
+    Z = rs.randn(N, C) * np.exp(rs.randn(C))[None, :]
+    buf = torch.zeros(N, C + pad, dtype=torch.float64, device="cuda")
+    buf[:, :C] = torch.from_numpy(Z).cuda()
+    need = lib.bcx_project_moments_scratch_bytes(N, C)
+    assert need > 0
+    work = torch.empty(need // 8, dtype=torch.float64, device="cuda")
+    M = torch.full((C, C + 1), float("nan"), dtype=torch.float64, device="cuda")
+    rc = lib.bcx_project_moments(int(torch.cuda.current_stream().cuda_stream), buf.data_ptr(), N, C + pad, C, M.data_ptr(), C + 1,
+                                 work.data_ptr(), need)
+    assert rc == 0, lib.bcx_project_last_error()
+    got = M[:, :C].cpu().numpy()
+    want = Z.T.dot(Z)
+    assert np.array_equal(got, got.T)
+    bound = 1e-12 * np.sqrt(np.outer(np.diag(want), np.diag(want)))       # |M_ij| <= sqrt(M_ii M_jj)
+    assert (np.abs(got - want) <= bound).all(), float((np.abs(got - want) / bound).max())
+    assert torch.isnan(M[:, C]).all()                         # nothing written outside the C x C block
+    # same bits on a second run (fixed summation order)
+    M2 = torch.empty_like(M)
+    assert lib.bcx_project_moments(int(torch.cuda.current_stream().cuda_stream), buf.data_ptr(), N, C + pad, C, M2.data_ptr(), C + 1,
+                                   work.data_ptr(), need) == 0
+    assert torch.equal(M[:, :C], M2[:, :C])
+    # argument errors come back as codes, not crashes
+    assert lib.bcx_project_moments(0, buf.data_ptr(), N, C + pad, C, M.data_ptr(), C + 1, work.data_ptr(), need - 8) != 0
+    assert lib.bcx_project_moments_scratch_bytes(N, 2000) == -1
+
+
+@pytest.mark.parametrize("D,S", ((30, 130), (301, 256), (7, 1), (64, 37)))
+def test_colsum_from_moments_equals_projected_colsum(bc, D, S):
+    """project_colsum of the linear-regression family: the closed form on the data's moments against the fused projection
+    kernel (rtol 1e-10 of the largest column sum) and against NumPy."""
+    rs = np.random.RandomState(D * 1000 + S)
+    N = 50_000
+    Z = make_linreg_data(5, N, D)
+    theta = 0.7 + 1.3 * rs.randn(S, D)
+    a = bc.DeviceProjector("linreg", lambda n, w, p: theta, S, sigsq=0.7, colsum="mfma")
+    b = bc.DeviceProjector("linreg", lambda n, w, p: theta, S, sigsq=0.7, colsum="moments")
+    ca, cb = a.project_colsum(Z), b.project_colsum(Z)
+    assert b.moments_info["rows"] == N and not a.moments_info
+    scale = np.abs(ca).max() if S > 1 else 1.0
+    np.testing.assert_allclose(cb, ca, rtol=1e-10, atol=1e-10 * scale)
+    want = linreg_log_likelihood(Z, theta, 0.7)
+    want -= want.mean(axis=1)[:, None]
+    np.testing.assert_allclose(cb, want.sum(axis=0), rtol=1e-9, atol=1e-10 * scale)
+    # new samples, same data object: the moments are reused
+    theta2 = theta + 0.1 * rs.randn(S, D)
+    b.sampler = a.sampler = lambda n, w, p: theta2
+    a.update(np.array([]), np.array([])); b.update(np.array([]), np.array([]))
+    info = dict(b.moments_info)
+    np.testing.assert_allclose(b.project_colsum(Z), a.project_colsum(Z), rtol=1e-10, atol=1e-10 * scale)
+    assert b.moments_info == info
+    # another data object: new moments; a small one: the projection kernel
+    Z2 = Z[:9000].copy()
+    np.testing.assert_allclose(b.project_colsum(Z2), a.project_colsum(Z2), rtol=1e-10, atol=1e-10 * scale)
+    assert b.moments_info["rows"] == 9000
+    np.testing.assert_allclose(b.project_colsum(Z[:100].copy()), a.project_colsum(Z[:100].copy()), rtol=1e-12, atol=1e-12 * scale)
+    assert b.moments_info["rows"] == 9000
 
 
 def test_rbf_shard_size_select_and_colsum(bc):
@@ -440,9 +512,14 @@ def test_rbf_shard_size_select_and_colsum(bc):
                     second, bestv, besti = bestv, val, r + idx
                 elif val > second:
                     second = val
-        prj = bc.DeviceProjector("linreg", lambda n, w, p: theta, S, sigsq=sigsq)
+        prj = bc.DeviceProjector("linreg", lambda n, w, p: theta, S, sigsq=sigsq, colsum="mfma")
         got = prj.project_colsum(Zd)
         np.testing.assert_allclose(got, colsum.cpu().numpy(), rtol=1e-7, atol=1e-9 * float(colsum.abs().max()), err_msg=name)
+        # the closed form on the moments: at the prior state to 1e-10 of the projection kernel's sums; at the concentrated one
+        # (v = G thetabar - g cancels to ~1e-9 of its terms next to the least-squares fit) to the reference's own accuracy
+        mom = bc.DeviceProjector("linreg", lambda n, w, p: theta, S, sigsq=sigsq, colsum="moments").project_colsum(Zd)
+        tol = 1e-10 if name == "prior" else 1e-6
+        np.testing.assert_allclose(mom, got, rtol=tol, atol=tol * float(np.abs(got).max()), err_msg=name)
         best, row = prj.project_select(Zd, resid_h)
         assert bestv - second > 1e-7 * abs(bestv), "near-tie in the test input (%s)" % name
         assert row == besti, name

@@ -240,6 +240,38 @@ def test_bench_contract_one_and_two_ranks():
     assert four["config"]["final_error"] is not None
 
 
+def test_bench_launches_its_own_ranks():
+    """`python bench.py --gpus N` with NO launcher around it starts N ranks itself (torch.distributed.run on 127.0.0.1) and
+    prints one line with n_gpus == N; without enough devices (and without the share-one-GPU test switch) it exits non-zero
+    instead of printing a line for fewer ranks; a WORLD_SIZE that contradicts --gpus is an error too."""
+    import json
+    import subprocess
+    bench = os.path.join(ROOT, "bench.py")
+    args = ["--rows", "300000", "--dim", "64", "--steps", "10", "--warmup", "5", "--no-cpu-baseline"]
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    one, _ = _run_bench({}, 1, args)
+    assert one["rccl_ranks"] == 1 and one["process_group"]["world_size"] == 1
+    out = subprocess.run([sys.executable, bench, "--gpus", "2"] + args, capture_output=True, text=True, timeout=900,
+                         env=dict(env, BENCH_SHARE_GPU="1"), cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    two = json.loads(lines[0])
+    assert two["n_gpus"] == 2 and two["config"]["exchange"] in ("mailbox", "collective")
+    assert two["process_group"]["world_size"] == 2 and two["process_group"]["self_launched"]
+    assert two["config"]["final_error"] == one["config"]["final_error"]
+    assert "starting 2 ranks" in out.stderr
+    if _device_count() < 8:
+        out = subprocess.run([sys.executable, bench, "--gpus", "8"] + args, capture_output=True, text=True, timeout=300,
+                             env={k: v for k, v in env.items() if k != "BENCH_SHARE_GPU"}, cwd=ROOT)
+        assert out.returncode != 0 and "refusing" in out.stderr
+        assert not [l for l in out.stdout.splitlines() if l.startswith("{")]
+    out = subprocess.run([sys.executable, bench, "--gpus", "4"] + args, capture_output=True, text=True, timeout=300,
+                         env=dict(env, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0"), cwd=ROOT)
+    assert out.returncode != 0 and "does not match" in out.stderr
+    assert not [l for l in out.stdout.splitlines() if l.startswith("{")]
+
+
 @pytest.mark.parametrize("exchange", ("collective", "mailbox"))
 def test_empty_shard(tmp_path, exchange):
     """N = 1500 rows are two 1024-row chunks: with three ranks the last shard owns no rows at all and still
