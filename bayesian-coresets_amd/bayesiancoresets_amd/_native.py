@@ -29,6 +29,7 @@ SYMBOLS = (
     "bcx_build_enqueue_exact", "bcx_exchange_export", "bcx_exchange_attach", "bcx_exchange_probe", "bcx_exchange_disable", "bcx_exchange_set_timeout",
     "bcx_set_check_monotone", "bcx_project_profile", "bcx_project_profile_read", "bcx_exchange_stats", "bcx_load_rows_flags", "bcx_project_write_raw", "bcx_omp_stats", "bcx_project_select_ws", "bcx_project_select_scratch_bytes",
     "bcx_project_moments", "bcx_project_colsum_moments", "bcx_project_moments_scratch_bytes",
+    "bcx_project_colsum_moments_scratch_bytes",
 )
 
 
@@ -146,12 +147,14 @@ def load():
     sigs["bcx_project_colsum_moments"] = [vp, vp, i64, i32, i32, vp, i32, i32, dbl, vp, vp]
     lib.bcx_project_moments_scratch_bytes.restype = ctypes.c_int64
     lib.bcx_project_moments_scratch_bytes.argtypes = [i64, i32]
+    lib.bcx_project_colsum_moments_scratch_bytes.restype = ctypes.c_int64
+    lib.bcx_project_colsum_moments_scratch_bytes.argtypes = [i32, i32]
     lib.bcx_project_select_scratch_bytes.restype = ctypes.c_int64
     lib.bcx_project_select_scratch_bytes.argtypes = [i32, i64, i32]
     lib.bcx_project_last_error.restype = ctypes.c_char_p
     lib.bcx_project_last_error.argtypes = []
     for name, args in sigs.items():
-        if name in ("bcx_project_select_scratch_bytes", "bcx_project_moments_scratch_bytes"):
+        if name.endswith("_scratch_bytes"):
             continue
         fn = getattr(lib, name)
         fn.argtypes = args

@@ -190,8 +190,9 @@ class DeviceProjector(Projector):
         S, D = self.theta.shape[0], Z.shape[1] - 1
         if self.theta.shape[1] != D:
             raise ValueError("sampler returned %d-dimensional parameters for %d features" % (self.theta.shape[1], D))
-        if self._mom_work is None or self._mom_work.numel() < S + 1:
-            self._mom_work = torch.zeros(S + 1, dtype=torch.float64, device=self.device)
+        need = int(self._lib.bcx_project_colsum_moments_scratch_bytes(int(D), int(S))) // 8
+        if self._mom_work is None or self._mom_work.numel() != need:
+            self._mom_work = torch.zeros(need, dtype=torch.float64, device=self.device)     # (zero: the arrival counter)
         col = torch.empty(S, dtype=torch.float64, device=self.device) if out is None else out
         self._check(self._lib.bcx_project_colsum_moments(self._stream(), self._mom.data_ptr(), self._mom.stride(0), D, D,
                                                          self.theta.data_ptr(), S, self.theta.stride(0), self.sigsq,

@@ -478,10 +478,19 @@ static int enqueue_one(bcx_solver* s, int exact) {
     if ((rc = prof_end(s))) return rc;
     return bcx_launch_tail_exchange(s, exact);
   }
-  const bool fuse = s->cfg.alg != BCX_ALG_OMP;
-  int rc = step_scan(s, nullptr, exact, fuse);
-  if (rc != BCX_OK) return rc;
-  return fuse ? BCX_OK : bcx_launch_apply(s, s->rec_local);
+  if (s->cfg.alg == BCX_ALG_OMP) {
+    // scan, then the fused resolve + OMP step (omp_lh.hip); where that does not apply: resolve_kernel + the multi-kernel step
+    int rc;
+    if (exact && (rc = bcx_launch_resume_exact(s))) return rc;
+    if ((rc = prof_begin(s))) return rc;
+    if ((rc = bcx_launch_scan(s, exact))) return rc;
+    if ((rc = prof_end(s))) return rc;
+    rc = bcx_launch_omp_fused(s, exact);
+    if (rc != 1) return rc;
+    if ((rc = bcx_launch_resolve(s, s->rec_local, exact))) return rc;
+    return bcx_launch_apply(s, s->rec_local);
+  }
+  return step_scan(s, nullptr, exact, true);
 }
 
 extern "C" int bcx_build_enqueue(bcx_solver* s, int64_t itrs) {

@@ -184,6 +184,7 @@ int bcx_launch_resolve(bcx_solver* s, double* send_dev, int exact);
 int bcx_launch_begin(bcx_solver* s, int64_t itrs, double tol);
 int bcx_launch_apply(bcx_solver* s, const double* recv_dev);
 int bcx_launch_tail(bcx_solver* s, int exact);
+int bcx_launch_omp_fused(bcx_solver* s, int exact);   // nnls.hip: scan partials -> OMP step in one launch; 1 = not applicable
 int bcx_launch_tail_exchange(bcx_solver* s, int exact);   // resolve + mailbox exchange + apply (world_size > 1)
 int bcx_launch_exchange_probe(bcx_solver* s);
 Mailbox bcx_mailbox(const bcx_solver* s);

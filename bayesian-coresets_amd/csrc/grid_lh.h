@@ -50,7 +50,7 @@ static __device__ __forceinline__ bool owns_row(int rr) {
 }
 
 // out[rr] = sum_cc H[rr][cc] v[cc] for the rows this wave owns (v in LDS); out is an exchange buffer
-static __device__ void g_mv_rows(const NnlsArgs& n, int p, const double* v, double* out) {
+static __device__ __forceinline__ void g_mv_rows(const NnlsArgs& n, int p, const double* v, double* out) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
   for (int rr = blockIdx.x * nw + wave; rr < p; rr += gridDim.x * nw) {
     const double* hrow = n.hinv + (size_t)rr * n.ldg;
@@ -68,7 +68,7 @@ static __device__ void g_mv_rows(const NnlsArgs& n, int p, const double* v, doub
 }
 
 // Add `slot` to the passive set (bordered inverse).  False: numerically dependent on P.  1 barrier.
-static __device__ bool g_border_add(const NnlsArgs& n, const Rep& r, int& p, int& ill, int slot, Grid& g,
+static __device__ __forceinline__ bool g_border_add(const NnlsArgs& n, const Rep& r, int& p, int& ill, int slot, Grid& g,
                                     double* scratch) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = blockDim.x >> 6;
   const int64_t ld = n.ldg;
@@ -105,7 +105,7 @@ static __device__ bool g_border_add(const NnlsArgs& n, const Rep& r, int& p, int
 }
 
 // Remove position q (rank-1 downdate, then the last position moves into q).  1-2 barriers.
-static __device__ void g_border_del(const NnlsArgs& n, const Rep& r, int& p, int q, Grid& g) {
+static __device__ __forceinline__ void g_border_del(const NnlsArgs& n, const Rep& r, int& p, int q, Grid& g) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = blockDim.x >> 6;
   const int64_t ld = n.ldg;
   const int last = p - 1;
@@ -151,7 +151,7 @@ static __device__ void g_border_del(const NnlsArgs& n, const Rep& r, int& p, int
 }
 
 // z = argmin on the passive set: z = H c_P, then refinement (as passive_solve in nnls.hip).  3+ barriers.
-static __device__ void g_passive_solve(const NnlsArgs& n, const Rep& r, int p, int ill, Grid& g, double (*seg)[64],
+static __device__ __forceinline__ void g_passive_solve(const NnlsArgs& n, const Rep& r, int p, int ill, Grid& g, double (*seg)[64],
                                        double* scratch) {
   const int tid = threadIdx.x;
   double cmax = 0.0;

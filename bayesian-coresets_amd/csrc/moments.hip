@@ -15,7 +15,9 @@
 //   moments_kernel         M partials: fp64 MFMA (v_mfma_f64_16x16x4_f64), one workgroup per (64 x 64 block pair of the
 //                          upper triangle, slice of rows); operands staged through LDS, next chunk prefetched in registers
 //   moments_reduce_kernel  partials summed in slice order (fixed association: reproducible), both triangles written
-//   moments_colsum_kernel  T_s per workgroup, the last workgroup to finish centres and scales
+//   moments_mean_kernel    thetabar
+//   moments_quad_kernel    T_s: Delta G on the fp64 matrix cores (one wave per 16 x 16 tile), the last workgroup to finish
+//                          sums the tile partials, centres and scales
 #include <algorithm>
 #include <string>
 #include "bcx_internal.h"
@@ -143,50 +145,105 @@ __global__ __launch_bounds__(256) void moments_reduce_kernel(const double* __res
   }
 }
 
-// One workgroup per sample s.  work: [0, S) the T_s, then one 32-bit arrival counter (self-resetting).
-__global__ __launch_bounds__(256) void moments_colsum_kernel(const double* __restrict__ M, int64_t ldm, int D, int ycol,
-                                                             const double* __restrict__ theta, int S, int ldt, double sigsq,
-                                                             double* __restrict__ colsum, double* __restrict__ work) {
-  extern __shared__ double sm[];        // delta[D], tbar[D]
+// thetabar[c] = mean_s theta[s][c]: four partial sums over interleaved samples per column, combined in a fixed order.
+__global__ __launch_bounds__(256) void moments_mean_kernel(const double* __restrict__ theta, int S, int ldt, int D,
+                                                           double* __restrict__ tbar) {
+  __shared__ double part[4][64];
+  const int c = blockIdx.x * 64 + (threadIdx.x & 63), q = threadIdx.x >> 6;
+  double m = 0.0;
+  if (c < D) {
+#pragma unroll 8
+    for (int u = q; u < S; u += 4) m += theta[(size_t)u * ldt + c];
+  }
+  part[q][threadIdx.x & 63] = m;
+  __syncthreads();
+  if (q == 0 && c < D) tbar[c] = (((part[0][threadIdx.x] + part[1][threadIdx.x]) + part[2][threadIdx.x]) + part[3][threadIdx.x]) / (double)S;
+}
+
+// T_s = sum_i (Delta G)[s][i] (delta_si + 2 tbar_i) - 2 delta_si g_i   (= delta_s^T G delta_s + 2 delta_s^T (G tbar - g)),
+// Delta G on the fp64 matrix cores: one wave per 16 samples x 16 columns tile of Delta G, k over all D rows of G
+// (v_mfma_f64_16x16x4_f64; lane group lk feeds k = 8t + 2 lk (+1) to steps 2t (2t+1): one 16-byte load of theta per two steps).
+// Partials [column tile][sample] go to `work`; the last workgroup to arrive sums them in tile order, centres and scales.
+// work: nct * Spad partials, then one arrival counter (self-resetting).
+template <bool AL>
+__global__ __launch_bounds__(256) void moments_quad_kernel(const double* __restrict__ M, int64_t ldm, int D, int ycol,
+                                                           const double* __restrict__ theta, int S, int ldt,
+                                                           const double* __restrict__ tbar, double sigsq,
+                                                           double* __restrict__ colsum, double* __restrict__ work, int nct, int Spad) {
   __shared__ double scratch[BCX_SCRATCH];
   __shared__ int last;
-  double* delta = sm;
-  double* tbar = sm + D;
-  const int tid = threadIdx.x, s = blockIdx.x;
-  for (int i = tid; i < D; i += 256) {
-    double m = 0.0;
-    for (int u = 0; u < S; ++u) m += theta[(size_t)u * ldt + i];     // the same order in every workgroup
-    m /= (double)S;
-    tbar[i] = m;
-    delta[i] = theta[(size_t)s * ldt + i] - m;
-  }
-  __syncthreads();
-  // t = sum_i delta_i (2 v_i + (G delta)_i),  v_i = (G tbar)_i - g_i;  G symmetric: column reads are coalesced over i
-  double t[1] = {0.0};
-  for (int i = tid; i < D; i += 256) {
-    double gd = 0.0, gt = 0.0;
-    for (int j = 0; j < D; ++j) {
-      const double g = M[(size_t)j * ldm + i];
-      gd = fma(g, delta[j], gd);
-      gt = fma(g, tbar[j], gt);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 15, lk = lane >> 4;
+  const int w = blockIdx.x * 4 + wave, nst = Spad / 16;
+  const int st = w / nct, ct = w - st * nct;
+  if (st < nst) {
+    const int sa = st * 16 + li, cb = ct * 16 + li;
+    const bool va = sa < S, vb = cb < D;
+    const double* th = theta + (size_t)(va ? sa : 0) * ldt;
+    const double* gc = M + (vb ? cb : 0);
+    mv4d acc = (mv4d){0.0, 0.0, 0.0, 0.0};
+    const int ksteps = (D + 7) / 8;
+    for (int t0 = 0; t0 < ksteps; t0 += 4) {
+      // four double-steps per trip: all their loads are issued before the first MFMA (addresses clamped, values masked)
+      double a0[4], a1[4], b0[4], b1[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int k = 8 * (t0 + u) + 2 * lk;
+        const bool k0 = k < D, k1 = k + 1 < D;
+        const int kc = k0 ? k : 0, kd = k1 ? k + 1 : 0;
+        double x0, x1;
+        if (AL) { const double2 v = *(const double2*)(th + kc); x0 = v.x; x1 = v.y; }   // (kc + 1 <= ldt - 1: ldt is even)
+        else { x0 = th[kc]; x1 = th[kd]; }
+        const double t0v = tbar[kc], t1v = tbar[kd];
+        const double g0 = gc[(size_t)kc * ldm], g1 = gc[(size_t)kd * ldm];
+        a0[u] = (va && k0) ? x0 - t0v : 0.0;
+        a1[u] = (va && k1) ? x1 - t1v : 0.0;
+        b0[u] = (vb && k0) ? g0 : 0.0;
+        b1[u] = (vb && k1) ? g1 : 0.0;
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[u], b0[u], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[u], b1[u], acc, 0, 0, 0);
+      }
     }
-    const double v = gt - M[(size_t)ycol * ldm + i];
-    t[0] += delta[i] * (2.0 * v + gd);
+    // f64 C/D layout: col = lane & 15, row = (lane >> 4) + 4 * reg
+    const double tb = vb ? tbar[cb] : 0.0, gy = vb ? M[(size_t)ycol * ldm + cb] : 0.0;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int sr = st * 16 + lk + 4 * r;
+      double v = 0.0;
+      if (vb && sr < S) {
+        const double dl = theta[(size_t)sr * ldt + cb] - tb;
+        v = acc[r] * (dl + 2.0 * tb) - 2.0 * dl * gy;
+      }
+      v += bcx_dpp_f64<0xB1>(v);     // sum over the 16 lanes (columns) of the row group
+      v += bcx_dpp_f64<0x4E>(v);
+      v += bcx_dpp_f64<0x141>(v);
+      v += bcx_dpp_f64<0x140>(v);
+      if (li == 0) mom_st(&work[(size_t)ct * Spad + sr], v);
+    }
   }
-  block_allsum<1>(t, scratch);
-  unsigned* counter = (unsigned*)(work + S);
+  unsigned* counter = (unsigned*)(work + (size_t)nct * Spad);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
   if (tid == 0) {
-    mom_st(&work[s], t[0]);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    last = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)(S - 1);
+    last = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1;
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
   }
   __syncthreads();
   if (!last) return;
-  // the last workgroup to arrive: every T_s is in memory; summed in index order (the same bits whichever workgroup is last)
+  // the last workgroup to arrive: every partial is in memory; tile order, then sample order -- the same bits whichever it is
   double m[1] = {0.0};
-  for (int u = tid; u < S; u += 256) m[0] += mom_ld(work + u);
+  for (int u = tid; u < S; u += 256) {
+    double t = 0.0;
+    for (int c = 0; c < nct; ++c) t += mom_ld(work + (size_t)c * Spad + u);
+    mom_st(&work[u], t);
+    m[0] += t;
+  }
+  __syncthreads();
   block_allsum<1>(m, scratch);
   const double mean = m[0] / (double)S, f = -1.0 / (2.0 * sigsq);
   for (int u = tid; u < S; u += 256) colsum[u] = f * (mom_ld(work + u) - mean);
@@ -244,9 +301,18 @@ extern "C" int bcx_project_moments(void* stream, const void* Z_dev, int64_t N, i
   return BCX_OK;
 }
 
+// Doubles of scratch bcx_project_colsum_moments needs: the (column tile, sample) partials, thetabar, the arrival counter.
+static void colsum_plan(int D, int S, int* nct, int* Spad) { *nct = (D + 15) / 16; *Spad = (S + 15) / 16 * 16; }
+extern "C" int64_t bcx_project_colsum_moments_scratch_bytes(int32_t D, int32_t S) {
+  if (D < 1 || D >= MOM_MAX_COLS || S < 1) return -1;
+  int nct, Spad;
+  colsum_plan(D, S, &nct, &Spad);
+  return ((int64_t)nct * Spad + 1 + (D + 1) / 2 * 2) * (int64_t)sizeof(double);
+}
+
 // colsum_dev[s] = sum_n vecs[n][s] of the linear-regression projection of the data whose moments are M_dev (features in
-// rows/columns [0, D), response in row/column ycol), for the S parameter rows of theta_dev.  work_dev: S + 1 doubles, the
-// last one zero before the first call (the kernel leaves it zero).
+// rows/columns [0, D), response in row/column ycol), for the S parameter rows of theta_dev.  work_dev:
+// bcx_project_colsum_moments_scratch_bytes(D, S) bytes, ZERO before the first call (the kernel leaves its counter zero).
 extern "C" int bcx_project_colsum_moments(void* stream, const void* M_dev, int64_t ldm, int32_t D, int32_t ycol,
                                           const void* theta_dev, int32_t S, int32_t ldt, double sigsq, void* colsum_dev,
                                           void* work_dev) {
@@ -255,9 +321,20 @@ extern "C" int bcx_project_colsum_moments(void* stream, const void* M_dev, int64
     bcx_project_set_error("bcx_project_colsum_moments: bad arguments");
     return BCX_ERR_ARG;
   }
-  hipLaunchKernelGGL(moments_colsum_kernel, dim3(S), dim3(256), 2 * (size_t)D * sizeof(double), (hipStream_t)stream,
-                     (const double*)M_dev, ldm, (int)D, (int)ycol, (const double*)theta_dev, (int)S, (int)ldt, sigsq,
-                     (double*)colsum_dev, (double*)work_dev);
+  int nct, Spad;
+  colsum_plan(D, S, &nct, &Spad);
+  double* work = (double*)work_dev;
+  double* tbar = work + (size_t)nct * Spad + 1;
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(moments_mean_kernel, dim3((D + 63) / 64), dim3(256), 0, st, (const double*)theta_dev, (int)S, (int)ldt, (int)D, tbar);
+  const int waves = nct * (Spad / 16);
+  const bool al = ((uintptr_t)theta_dev % 16 == 0) && ldt % 2 == 0;
+  if (al)
+    hipLaunchKernelGGL(moments_quad_kernel<true>, dim3((waves + 3) / 4), dim3(256), 0, st, (const double*)M_dev, ldm, (int)D, (int)ycol,
+                       (const double*)theta_dev, (int)S, (int)ldt, (const double*)tbar, sigsq, (double*)colsum_dev, work, nct, Spad);
+  else
+    hipLaunchKernelGGL(moments_quad_kernel<false>, dim3((waves + 3) / 4), dim3(256), 0, st, (const double*)M_dev, ldm, (int)D, (int)ycol,
+                       (const double*)theta_dev, (int)S, (int)ldt, (const double*)tbar, sigsq, (double*)colsum_dev, work, nct, Spad);
   MOM_HIP(hipGetLastError());
   return BCX_OK;
 }

@@ -16,6 +16,7 @@
 #include "dev_util.h"
 #include "apply_common.h"
 #include "nnls_common.h"
+#include "resolve_core.h"
 
 #ifdef BCX_TIMING
 #define NN_COUNT(st, i) do { if (threadIdx.x == 0) (st)->dbg_t[12 + (i)] += 1; } while (0)
@@ -619,7 +620,7 @@ int bcx_launch_apply_omp(bcx_solver* s, const double* recv_dev) {
   static const char* form = getenv("BCX_OMP_FORM");
   static const bool legacy = getenv("BCX_OMP_MULTI") != nullptr || (form && form[0] == 'm');
   if (!legacy && s->grid_counter) {
-    const int rc = bcx_launch_omp_lh(s, n);
+    const int rc = bcx_launch_omp_lh(s, n, nullptr);
     if (rc <= 0) return rc;
   }
   const int d = s->cfg.d;
@@ -634,6 +635,24 @@ int bcx_launch_apply_omp(bcx_solver* s, const double* recv_dev) {
   hipLaunchKernelGGL(omp_finish_kernel, dim3(1), dim3(BCX_APPLY_THREADS), 0, s->stream, n);
   BCX_HIP(hipGetLastError());
   return BCX_OK;
+}
+
+// Single shard: the whole tail of an OMP iteration (resolve of the scan's partials + negative direction + incremental
+// Lawson-Hanson step) as ONE launch of omp_lh_kernel.  1 = not applicable (its LDS budget, or the dev knobs that select the
+// multi-kernel form): the caller launches resolve_kernel and bcx_launch_apply instead.
+int bcx_launch_omp_fused(bcx_solver* s, int exact) {
+  static const char* form = getenv("BCX_OMP_FORM");
+  static const bool off = getenv("BCX_OMP_MULTI") != nullptr || (form && form[0] == 'm') || getenv("BCX_OMP_UNFUSED") != nullptr;
+  if (off || !s->grid_counter) return 1;
+  NnlsArgs n;
+  fill_nnls_args(s, n, nullptr);
+  ResolveArgs r;
+  bcx_fill_resolve_args(s, r, nullptr, exact);
+  r.need_score = 1;                          // the score is compared with the negative direction (orthopursuit.py:32)
+  s->k_ub += 1;                              // this step may add one slot
+  const int rc = bcx_launch_omp_lh(s, n, &r);
+  if (rc == 1) s->k_ub -= 1;
+  return rc;
 }
 
 // ---- optimize(): Gram matrix on the fp64 matrix cores + cold-start NNLS ---------------------------

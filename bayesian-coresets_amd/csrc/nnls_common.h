@@ -32,7 +32,7 @@ struct NnlsArgs {
 // ---- small workgroup-wide helpers ---------------------------------------------------------------
 // arg-max of (val, idx): larger val wins, ties -> smaller idx.  Entries with idx < 0 are ignored.
 struct ArgBest { double v; int i; };
-static __device__ ArgBest block_argbest(double v, int i, double* scratch) {
+static __device__ __forceinline__ ArgBest block_argbest(double v, int i, double* scratch) {
   __shared__ double sv[16];
   __shared__ int si[16];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
@@ -113,7 +113,7 @@ static __device__ bool grid_barrier(const GridSync& g, int index, int* s_flag) {
 
 // ---- shared by the OMP step kernels (nnls.hip legacy forms, omp_lh.hip) -------------------------------------------------
 // winner over the shards' records: (score desc, global index asc); -1 if none is valid.  One thread.
-static __device__ int omp_pick_record(const ApplyArgs& a, int* overflow) {
+static __device__ __forceinline__ int omp_pick_record(const ApplyArgs& a, int* overflow) {
   const int recw = a.d + BCX_REC_HDR;
   int win = -1, ovf = 0;
   for (int r = 0; r < a.world; ++r) {
@@ -136,5 +136,6 @@ static __device__ __forceinline__ bool negbest_better(double v, long long i, dou
 
 
 void fill_nnls_args(bcx_solver* s, NnlsArgs& n, const double* recs);   // nnls.hip
-int bcx_launch_omp_lh(bcx_solver* s, NnlsArgs& n);                      // omp_lh.hip; 1 = not applicable (LDS budget)
+struct ResolveArgs;
+int bcx_launch_omp_lh(bcx_solver* s, NnlsArgs& n, const ResolveArgs* fused);   // omp_lh.hip; 1 = not applicable (LDS budget)
 int bcx_launch_optimize_grid(bcx_solver* s, double tol, int k);         // nnls_grid.hip

@@ -37,7 +37,9 @@
 // The number of barriers of a launch depends on the data, so the barrier base lives in device memory: workgroup 0 advances
 // it at the end of the launch by what the launch used.
 #include <stdlib.h>
+#include <string.h>
 #include "grid_lh.h"
+#include "resolve_core.h"
 
 #define OMPL_WGS 16
 #define OMPL_STAMP(st, i) do { if (blockIdx.x == 0) BCX_STAMP(st, i); } while (0)
@@ -106,7 +108,7 @@ struct OmpLds {
 };
 
 // (u, mon)[rr] = (H[rr] . v in double-double, H_hi[rr] . m in double) for the rows this wave owns; m may be null
-static __device__ void ompl_mv_rows(const NnlsArgs& n, int p, const double* v, const double* m, double* Uh, double* Ul, double* M) {
+static __device__ __forceinline__ void ompl_mv_rows(const NnlsArgs& n, int p, const double* v, const double* m, double* Uh, double* Ul, double* M) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
   for (int rr = blockIdx.x * nw + wave; rr < p; rr += gridDim.x * nw) {
     const double* hh = n.hinv + (size_t)rr * n.ldg;
@@ -134,7 +136,7 @@ static __device__ void ompl_mv_rows(const NnlsArgs& n, int p, const double* v, c
 
 // H <- [[H + u u^T / s, -u/s], [-u^T/s, 1/s]] for the column entering at position p (inv = 1/s): every wave updates the rows
 // it owns, in double-double
-static __device__ void ompl_border_apply(const NnlsArgs& n, const OmpLds& L, int p, dd inv) {
+static __device__ __forceinline__ void ompl_border_apply(const NnlsArgs& n, const OmpLds& L, int p, dd inv) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
   const int64_t ld = n.ldg;
   for (int rr = blockIdx.x * nw + wave; rr < p; rr += gridDim.x * nw) {
@@ -161,7 +163,7 @@ static __device__ void ompl_border_apply(const NnlsArgs& n, const OmpLds& L, int
 // Position q leaves the passive set: closed-form update of the carried solution z, rank-1 downdate of H (double-double),
 // the last position moves into the hole (z, the feasible point xs and the lists move with it).  ONE barrier: the owners
 // publish row q and the not yet downdated row `last` together, every workgroup downdates its copy of the latter itself.
-static __device__ void ompl_remove(const NnlsArgs& n, const OmpLds& L, int& p, int q, Grid& G) {
+static __device__ __forceinline__ void ompl_remove(const NnlsArgs& n, const OmpLds& L, int& p, int q, Grid& G) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = blockDim.x >> 6;
   const int64_t ld = n.ldg;
   const int last = p - 1;
@@ -231,7 +233,7 @@ static __device__ void ompl_remove(const NnlsArgs& n, const OmpLds& L, int& p, i
 // Lawson-Hanson inner loop on the carried data: z = least-squares solution on the passive set, xs = a feasible point.
 // Columns leave until z > 0; then x <- z.  `entered`: the slot that just entered (left again at once => never re-picked).
 // n_out: members of the call's active set that are outside P and may still be picked (kept by every workgroup alike).
-static __device__ int ompl_inner(const NnlsArgs& n, const OmpLds& L, int& p, int entered, int max_it, int& n_out, Grid& G,
+static __device__ __forceinline__ int ompl_inner(const NnlsArgs& n, const OmpLds& L, int& p, int entered, int max_it, int& n_out, Grid& G,
                                  double* scratch) {
   const int tid = threadIdx.x;
   int removed = 0;
@@ -281,8 +283,13 @@ static __device__ int ompl_inner(const NnlsArgs& n, const OmpLds& L, int& p, int
   return removed;
 }
 
-__global__ __launch_bounds__(NN_THREADS) void omp_lh_kernel(NnlsArgs n, GridSync gs, unsigned long long* base_ptr, int kcap, int dpad,
-                                                            int force_resolve) {
+// fused != 0 (single shard): the step starts from the scan's partials -- every workgroup runs the resolve phase itself
+// (resolve_core.h: the same winner everywhere, nothing is exchanged) instead of reading the record a resolve_kernel
+// launch left behind: one launch and one dependent launch boundary less per iteration.
+// THREADS = the launch's workgroup width (256 / 512 / 1024): the register budget follows it (512 / 256 / 128 VGPRs).
+template <int THREADS>
+__global__ __launch_bounds__(THREADS) void omp_lh_kernel(NnlsArgs n, GridSync gs, unsigned long long* base_ptr, int kcap, int dpad,
+                                                            int force_resolve, int fused, ResolveArgs rsv) {
   const ApplyArgs& a = n.a;
   DevState* st = a.st;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = blockDim.x >> 6, d = a.d;
@@ -295,13 +302,17 @@ __global__ __launch_bounds__(NN_THREADS) void omp_lh_kernel(NnlsArgs n, GridSync
   L.xfs = dyn + 7 * (size_t)kcap; L.qs = L.xfs + dpad; L.bs = L.qs + dpad;
   L.cs = (int*)(L.bs + dpad); L.pos = L.cs + kcap; L.fl = L.pos + kcap;
   __shared__ double scratch[BCX_SCRATCH];
-  __shared__ double seg[NN_THREADS / 64][64];
-  __shared__ double w_v[NN_THREADS / 64];
-  __shared__ long long w_i[NN_THREADS / 64];
-  __shared__ int w_s[NN_THREADS / 64], w_np[NN_THREADS / 64], w_m[NN_THREADS / 64];
+  __shared__ double seg[THREADS / 64 < 2 ? 2 : THREADS / 64][64];
+  __shared__ double w_v[THREADS / 64];
+  __shared__ long long w_i[THREADS / 64];
+  __shared__ int w_s[THREADS / 64], w_np[THREADS / 64], w_m[THREADS / 64];
   __shared__ int s_win, s_ovf, s_flag;
+  __shared__ Winner s_winner;
   OMPL_STAMP(st, 0);
-  if (tid == 0) { int o; s_win = omp_pick_record(a, &o); s_ovf = o; }
+  if (fused) {
+    resolve_core<BCX_MAX_PARTIALS / THREADS>(rsv, &s_winner, L.xfs, scratch);          // winner's raw row lands in L.xfs
+    if (tid == 0) { s_ovf = s_winner.flags == BCX_REC_OVERFLOW; s_win = s_winner.flags == BCX_REC_VALID ? 0 : -1; }
+  } else if (tid == 0) { int o; s_win = omp_pick_record(a, &o); s_ovf = o; }
   __syncthreads();
   if (s_ovf || s_win < 0) {
     if (wg == 0 && tid == 0) { st->active = 0; st->halt = s_ovf ? HALT_NEED_EXACT : HALT_DONE; }
@@ -309,13 +320,16 @@ __global__ __launch_bounds__(NN_THREADS) void omp_lh_kernel(NnlsArgs n, GridSync
   }
   Grid G;
   G.gs = gs; G.gs.base = *base_ptr; G.bi = 0; G.xi = 0; G.s_flag = &s_flag; G.ok = true;
-  const double* rec = a.recs + (size_t)s_win * (d + BCX_REC_HDR);
+  const double* rec = a.recs + (size_t)(fused ? 0 : s_win) * (d + BCX_REC_HDR);
+  const double rec_score = fused ? s_winner.score : rec[0];
+  const int64_t rec_row = fused ? s_winner.gidx : (int64_t)rec[1];
+  const double rec_norm = fused ? s_winner.norm : rec[2];
   const double* xf = rec + BCX_REC_HDR;
   const int k = st->k;
   int p = st->np;
   const double err0 = st->err, bnorm0 = st->bnorm;
   const int hvalid0 = st->hvalid, hlo0 = st->hlo_valid;
-  for (int i = tid; i < d; i += blockDim.x) { L.xfs[i] = xf[i]; L.qs[i] = a.q64[i]; L.bs[i] = a.b[i]; }
+  for (int i = tid; i < d; i += blockDim.x) { if (!fused) L.xfs[i] = xf[i]; L.qs[i] = a.q64[i]; L.bs[i] = a.b[i]; }
   for (int q = tid; q < p; q += blockDim.x) L.cs[q] = n.plist[q];
   for (int j = tid; j <= k; j += blockDim.x) {
     const int pj = (j < k && hvalid0) ? n.ppos[j] : -1;
@@ -366,8 +380,8 @@ __global__ __launch_bounds__(NN_THREADS) void omp_lh_kernel(NnlsArgs n, GridSync
   gsync(G);                                                                                   // ---- B1
   OMPL_STAMP(st, 2);
   // ---- decide (every workgroup, one pass over the slots) -----------------------------------------------------------------
-  const int64_t fpos = (int64_t)rec[1];
-  const double nf = rec[2];
+  const int64_t fpos = rec_row;
+  const double nf = rec_norm;
   int npos = 0, match = 0x7fffffff;
   double bv = -INFINITY; long long bidx = -1; int bslot = -1;
   for (int j = tid; j < k; j += blockDim.x) {
@@ -406,7 +420,7 @@ __global__ __launch_bounds__(NN_THREADS) void omp_lh_kernel(NnlsArgs n, GridSync
   const bool checked = npos > 0;
   int64_t f = fpos;
   int slot = match == 0x7fffffff ? -1 : match;
-  if (checked && !(rec[0] >= bv)) { f = bidx; slot = bslot; }   // orthopursuit.py:32-35
+  if (checked && !(rec_score >= bv)) { f = bidx; slot = bslot; }   // orthopursuit.py:32-35
   const bool fresh = slot < 0;
   if (fresh) slot = k;
   const int k1 = fresh ? k + 1 : k;
@@ -653,7 +667,7 @@ __global__ __launch_bounds__(NN_THREADS) void omp_lh_kernel(NnlsArgs n, GridSync
 #ifdef BCX_TIMING
   const int64_t log_it = st->it - 1;
 #endif
-  if (st->active) prepare_next(a, scratch);
+  if (st->active) { [[clang::always_inline]] prepare_next(a, scratch); }
   OMPL_STAMP(st, 10);
 #ifdef BCX_TIMING
   __syncthreads();
@@ -666,7 +680,7 @@ __global__ __launch_bounds__(NN_THREADS) void omp_lh_kernel(NnlsArgs n, GridSync
 #endif
 }
 
-int bcx_launch_omp_lh(bcx_solver* s, NnlsArgs& n) {
+int bcx_launch_omp_lh(bcx_solver* s, NnlsArgs& n, const ResolveArgs* fused) {
   static const int force = getenv("BCX_OMP_FORCE_RESOLVE") ? atoi(getenv("BCX_OMP_FORCE_RESOLVE")) : 0;   // tests: re-solve every N-th step
   const int64_t kub = s->k_ub;
   const int kcap = (int)((kub + 1 + 63) / 64 * 64);
@@ -674,7 +688,9 @@ int bcx_launch_omp_lh(bcx_solver* s, NnlsArgs& n) {
   const size_t lds = (size_t)kcap * (7 * sizeof(double) + 3 * sizeof(int)) + 3 * (size_t)dpad * sizeof(double);
   if (lds > OMPL_LDS_MAX) return 1;
   if (lds > s->omp_lds_allowed) {
-    BCX_HIP(hipFuncSetAttribute((const void*)omp_lh_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)OMPL_LDS_MAX));
+    BCX_HIP(hipFuncSetAttribute((const void*)omp_lh_kernel<256>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)OMPL_LDS_MAX));
+    BCX_HIP(hipFuncSetAttribute((const void*)omp_lh_kernel<512>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)OMPL_LDS_MAX));
+    BCX_HIP(hipFuncSetAttribute((const void*)omp_lh_kernel<1024>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)OMPL_LDS_MAX));
     s->omp_lds_allowed = OMPL_LDS_MAX;
   }
   if (s->grid_dirty) {                 // optimize() ran since the last bcx_build_begin: arrivals and base restart together
@@ -693,7 +709,15 @@ int bcx_launch_omp_lh(bcx_solver* s, NnlsArgs& n) {
   // with 1024 threads, 30.2 with 512, 28.8 with 256.  Wider workgroups once a wave would own more than ~3 rows.
   static const int forced_threads = getenv("BCX_OMP_THREADS") ? atoi(getenv("BCX_OMP_THREADS")) : 0;   // dev: 256 / 512 / 1024
   const int threads = forced_threads ? forced_threads : (kub <= 192 ? 256 : (kub <= 448 ? 512 : NN_THREADS));
-  hipLaunchKernelGGL(omp_lh_kernel, dim3(OMPL_WGS), dim3(threads), lds, s->stream, n, gs, s->grid_counter + 1, kcap, dpad, fr);
+  ResolveArgs rsv;
+  if (fused) rsv = *fused; else memset(&rsv, 0, sizeof(rsv));
+  if (threads != 256 && threads != 512 && threads != 1024) { s->err = "BCX_OMP_THREADS must be 256, 512 or 1024"; return BCX_ERR_ARG; }
+  if (threads == 256)
+    hipLaunchKernelGGL(omp_lh_kernel<256>, dim3(OMPL_WGS), dim3(256), lds, s->stream, n, gs, s->grid_counter + 1, kcap, dpad, fr, fused ? 1 : 0, rsv);
+  else if (threads == 512)
+    hipLaunchKernelGGL(omp_lh_kernel<512>, dim3(OMPL_WGS), dim3(512), lds, s->stream, n, gs, s->grid_counter + 1, kcap, dpad, fr, fused ? 1 : 0, rsv);
+  else
+    hipLaunchKernelGGL(omp_lh_kernel<1024>, dim3(OMPL_WGS), dim3(1024), lds, s->stream, n, gs, s->grid_counter + 1, kcap, dpad, fr, fused ? 1 : 0, rsv);
   BCX_HIP(hipGetLastError());
   return BCX_OK;
 }
