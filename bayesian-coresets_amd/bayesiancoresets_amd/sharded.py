@@ -180,13 +180,44 @@ class ShardedSolver(object):
         return rc
 
     # ---- the hot loop --------------------------------------------------------
-    def _one_iteration(self, exact=False):
-        self.engine.step_scan_tensor(self.send, exact)
-        if self.world > 1:
-            self._all_gather(self.recv, self.send)
-            self.engine.step_apply_tensor(self.recv)
-        else:
-            self.engine.step_apply_tensor(self.send)
+    def _iterations(self, n, exact=False):
+        """n host-driven iterations (scan -> all-gather of the records -> replicated apply).  A rank whose engine fails
+        keeps taking part in the all-gathers of the batch -- with an empty record -- so that its peers are never left
+        inside a collective; the error is returned (not raised) and settled by every rank together in build()."""
+        err = None
+        for _ in range(n):
+            if err is None:
+                try:
+                    self.engine.step_scan_tensor(self.send, exact)
+                except nat.EngineError as e:
+                    err = e
+                    self.send.zero_()          # flags 0: "no candidate from this shard"
+            if self.world > 1:
+                self._all_gather(self.recv, self.send)
+            if err is None:
+                try:
+                    self.engine.step_apply_tensor(self.recv if self.world > 1 else self.send)
+                except nat.EngineError as e:
+                    err = e
+                    self.send.zero_()
+        return err
+
+    def _settle(self, err):
+        """Collective: None if no rank failed; otherwise EVERY rank raises -- the failing ones their own error, the others
+        one that names the failing ranks -- so a failure on one rank can neither hang the others in a collective nor let
+        them carry on with a state their peer no longer shares."""
+        if self.world == 1:
+            if err is not None:
+                raise err
+            return
+        if self._agree(err is None):
+            return
+        msgs = [None] * self.world
+        self.dist.all_gather_object(msgs, None if err is None else "%s" % err, group=self.group)
+        if err is not None:
+            raise err
+        bad = ["rank %d: %s" % (r, m) for r, m in enumerate(msgs) if m is not None]
+        raise nat.EngineError(nat.ERR_STATE, "sharded build stopped: " + "; ".join(bad))
 
     def build(self, itrs, tol=1e-12):
         itrs = int(itrs)
@@ -196,20 +227,30 @@ class ShardedSolver(object):
         while True:
             on_device = self.exchange == "mailbox" or (
                 self.world == 1 and hasattr(self.engine, "enqueue") and not os.environ.get("BCX_SHARDED_GENERIC"))
-            if on_device:
-                self.engine.enqueue(remaining)       # scan + merged resolve / (exchange) / apply launches
-            else:
-                for _ in range(remaining):
-                    self._one_iteration()
-            done, need_exact, limit = self.engine.poll()   # replicated state: same answer on every rank
-            if need_exact:
-                if self.exchange == "mailbox":
-                    self.engine.enqueue_exact()
+            err, done, need_exact, limit = None, 0, 0, 0
+            try:
+                if on_device:
+                    self.engine.enqueue(remaining)       # scan + merged resolve / (exchange) / apply launches
                 else:
-                    self._one_iteration(exact=True)
-                done, need_exact, limit = self.engine.poll()
-                if need_exact:
-                    raise nat.EngineError(nat.ERR_STATE, "exact scan did not resolve the iteration")
+                    err = self._iterations(remaining)
+                if err is None:
+                    done, need_exact, limit = self.engine.poll()   # replicated state: same answer on every rank
+            except nat.EngineError as e:
+                err = e
+            self._settle(err)                          # (one tiny all-reduce per batch; raises on every rank or on none)
+            if need_exact:
+                try:
+                    if self.exchange == "mailbox":
+                        self.engine.enqueue_exact()
+                    else:
+                        err = self._iterations(1, exact=True)
+                    if err is None:
+                        done, need_exact, limit = self.engine.poll()
+                        if need_exact:
+                            err = nat.EngineError(nat.ERR_STATE, "exact scan did not resolve the iteration")
+                except nat.EngineError as e:
+                    err = e
+                self._settle(err)
             if limit or done >= itrs:
                 break
             remaining = itrs - done

@@ -629,7 +629,16 @@ extern "C" int bcx_build_poll(bcx_solver* s, int64_t* n_done, int32_t* need_exac
   if (rc != BCX_OK) return rc;
   if (h.halt == HALT_GRID_TIMEOUT) { s->err = "OMP step: grid barrier timed out"; return BCX_ERR_STATE; }
   if (h.halt == HALT_EXCHANGE_TIMEOUT) {
-    s->err = "peer mailbox: a shard did not deliver its record within " + std::to_string(s->exchange_timeout_s) + " s";
+    // which peers' flags never arrived (recorded by the waiting lanes, csrc/resolve.hip mailbox_exchange)
+    unsigned long long late[2] = {0, 0};
+    std::string who;
+    if (s->xseq && hipMemcpy(late, s->xseq + 6, sizeof late, hipMemcpyDeviceToHost) == hipSuccess) {
+      for (int r = 0; r < s->cfg.world_size && r < 64; ++r)
+        if (late[0] >> r & 1ull) who += (who.empty() ? "" : ", ") + std::to_string(r);
+      (void)hipMemset(s->xseq + 6, 0, sizeof late);
+    } else (void)hipGetLastError();
+    s->err = "peer mailbox: rank " + std::to_string(s->cfg.rank) + " got no record from rank(s) " + (who.empty() ? "?" : who) +
+             " within " + std::to_string(s->exchange_timeout_s) + " s (exchange #" + std::to_string(late[1]) + ")";
     return BCX_ERR_EXCHANGE;
   }
   if (n_done) *n_done = h.it;

@@ -48,7 +48,8 @@ struct Mailbox {
   void* const* peers;          // world mailbox base addresses (device array; [rank] is this shard's own)
   unsigned long long* seq;     // exchanges completed so far (device word; identical on every shard)
   int32_t* probe;              // result of bcx_exchange_probe: 1 ok, -1 timeout, -2 payload mismatch
-  unsigned long long* stat;    // [0] exchanges timed, [1] sum / [2] max of the wait for the peers' records, [3] sum / [4] max
+  unsigned long long* stat;    // [5] ranks whose record did not arrive before the timeout (bit per rank & 63), [6] that exchange's number;
+                               // [0] exchanges timed, [1] sum / [2] max of the wait for the peers' records, [3] sum / [4] max
                                // of the whole exchange (own stores + wait), wall_clock64 ticks (100 MHz); bcx_exchange_stats
   int world, rank, recw;
   unsigned off_slots;
@@ -126,7 +127,8 @@ struct bcx_solver {
   size_t mbox_bytes = 0;
   std::vector<void*> peer_mbox;  // mapped mailboxes by rank ([rank] == mbox)
   void** peer_tab = nullptr;     // device copy of peer_mbox
-  unsigned long long* xseq = nullptr;   // [0] exchanges completed; [1..5] timing statistics (Mailbox::stat)
+  unsigned long long* xseq = nullptr;   // [0] exchanges completed; [1..5] timing statistics, [6] late ranks (bit mask) and [7] the exchange
+                                        // number of the last timeout (Mailbox::stat[0..6])
   int32_t* xprobe = nullptr;
   double* rec_gather = nullptr;  // world x (d+4): records of the last exchange (input of the OMP apply kernels)
   bool exchange_ready = false;

@@ -343,10 +343,24 @@ static __device__ const double* mailbox_exchange(const Mailbox& m, const double*
     unsigned long long* out = (unsigned long long*)m.peers[tid] + (par * m.world + m.rank);
     __hip_atomic_store(out, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     const unsigned long long* in = (const unsigned long long*)m.peers[m.rank] + (par * m.world + tid);
+    // Spin, then back off: a record that is a few microseconds away (the normal case: the peers' scans end within a few
+    // percent of each other) is caught by the short sleeps; a peer that is late by milliseconds -- its kernel not
+    // co-resident (ranks sharing a GPU, a profiler or a second job on its queue) -- is polled every ~50 us, which leaves
+    // the memory system and this CU's other waves alone.  A flag that never arrives: the rank is recorded for the host's
+    // error message (stat[5]: bit per rank, stat[6]: the exchange number).
     const long long t0 = wall_clock64();
+    unsigned polls = 0;
     while (__hip_atomic_load(in, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) < seq) {
-      __builtin_amdgcn_s_sleep(2);
-      if (wall_clock64() - t0 > m.timeout_ticks) { atomicOr(s_flag, 1); break; }
+      ++polls;
+      if (polls < 64) __builtin_amdgcn_s_sleep(2);                                  // ~0.1 us each
+      else if (polls < 256) __builtin_amdgcn_s_sleep(32);                           // ~1 us each
+      else { for (int z = 0; z < 40; ++z) __builtin_amdgcn_s_sleep(127); }          // ~50 us each
+      if (wall_clock64() - t0 > m.timeout_ticks) {
+        atomicOr(s_flag, 1);
+        atomicOr(&m.stat[5], 1ull << (tid & 63));
+        m.stat[6] = seq;
+        break;
+      }
     }
   }
   __syncthreads();

@@ -371,6 +371,21 @@ def run_snnls(args, torch, dist, nat, world, rank, local_rank):
                 "algorithmic_bytes_per_launch": bytes_per_launch,
             },
         }
+    # ---- row shards: the same iterations over the OTHER exchange mode (RCCL all-gather of the records per iteration, host
+    # driven) right after the headline's timed region, so a multi-GPU line can be read whichever mode the probe chose ----
+    if world > 1 and solver.exchange == "mailbox" and not args.no_side_legs:
+        n_c = min(args.steps, 100)
+        solver.fallback_to_collective()
+        solver.engine.reset()
+        el_c, tr_c, _, _, _ = timed(solver, min(args.warmup, 5), n_c)
+        if rank == 0:
+            out["mailbox_ms_per_step"] = out["ms_per_step"]
+            out["collective_ms_per_step"] = el_c / max(len(tr_c[0]), 1) * 1e3
+            out["config"]["collective_leg"] = {
+                "what": "same shards, records exchanged by one RCCL all-gather per iteration (host-driven scan / apply launches) "
+                        "instead of the device-side peer mailbox; %d iterations after a reset" % len(tr_c[0]),
+                "ms_per_step": out["collective_ms_per_step"], "iterations_per_s": len(tr_c[0]) / el_c,
+                "final_error": float(tr_c[1][-1]) if len(tr_c[1]) else None}
     # ---- the same workload with fp64-stored rows (the reference's own arithmetic end to end), c4 line only ----------
     if args.config == "c4" and not args.adhoc and store == nat.F32 and not args.no_exact_mode and world == 1:
         del solver

@@ -261,6 +261,9 @@ def test_bench_launches_its_own_ranks():
     assert two["process_group"]["world_size"] == 2 and two["process_group"]["self_launched"]
     assert two["config"]["final_error"] == one["config"]["final_error"]
     assert "starting 2 ranks" in out.stderr
+    if two["config"]["exchange"] == "mailbox":      # the other exchange mode is timed beside it
+        assert two["collective_ms_per_step"] > 0 and two["mailbox_ms_per_step"] == two["ms_per_step"]
+        assert two["config"]["collective_leg"]["final_error"] is not None
     if _device_count() < 8:
         out = subprocess.run([sys.executable, bench, "--gpus", "8"] + args, capture_output=True, text=True, timeout=300,
                              env={k: v for k, v in env.items() if k != "BENCH_SHARE_GPU"}, cwd=ROOT)

@@ -254,3 +254,77 @@ def test_mailbox_setup_and_fallback_host_logic(tmp_path, fail_probe):
     o = SnnlsOracle(X.T, X.sum(axis=0), alg="fw", mode="onepass")
     o.build(12)
     assert np.array_equal(r0["sel"], np.array([t[0] for t in o.trace]))
+
+
+def _flaky_worker(rank, world, port, where, out_dir):
+    for p in (ROOT, os.path.join(ROOT, "bayesian-coresets_amd"), os.path.join(ROOT, "tests")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ["BCX_EXCHANGE"] = "collective"
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from fake_engine import FakeEngine
+    from bayesiancoresets_amd import _native as nat
+    from bayesiancoresets_amd.sharded import ShardedSolver
+
+    class FlakyEngine(FakeEngine):
+        """fails ONCE, on rank 1 only, in the 6th iteration of the first build"""
+        armed = True
+
+        def _maybe_fail(self, phase):
+            if self.rank == 1 and self.armed and self.done == 5 and phase == where:
+                FlakyEngine.armed = False
+                raise nat.EngineError(nat.ERR_HIP, "injected failure in %s" % phase)
+
+        def step_scan_tensor(self, send, exact=False):
+            self._maybe_fail("scan")
+            return FakeEngine.step_scan_tensor(self, send, exact)
+
+        def step_apply_tensor(self, recv):
+            self._maybe_fail("apply")
+            return FakeEngine.step_apply_tensor(self, recv)
+
+        def poll(self):
+            self._maybe_fail("poll")
+            return FakeEngine.poll(self)
+
+    N, d = 4000, 16
+    X = np.random.RandomState(23).randn(N, d)
+    FakeEngine.FULL = X
+    s = ShardedSolver(1, N, d, engine_factory=FlakyEngine)
+    s.load_local(X[s.row_begin:s.row_end])
+    assert s.finalize(None) == 0
+    import time
+    t0 = time.time()
+    msg = None
+    try:
+        s.build(5 if where == "poll" else 12)
+    except nat.EngineError as e:
+        msg = str(e)
+    took = time.time() - t0
+    # every rank raised -- the failing one its own error, its peer one that names it -- and nobody hung in a collective
+    assert msg is not None and took < 60.0, (msg, took)
+    assert ("injected failure" in msg) if rank == 1 else ("rank 1" in msg and "injected failure" in msg), msg
+    # the solver survives: after a reset on every rank the next build is the oracle's again
+    s.engine.reset()
+    tr = s.build(12)
+    np.savez(os.path.join(out_dir, "fl_%s_r%d.npz" % (where, rank)), sel=tr[0], err=tr[1])
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("where", ("scan", "apply", "poll"))
+def test_engine_error_on_one_rank_stops_every_rank_and_the_solver_survives(tmp_path, where):
+    """An EngineError in the middle of a build on ONE rank (in the scan, in the apply, at the poll): the rank keeps its peers'
+    all-gathers matched, every rank settles the failure together (ShardedSolver._settle) and raises; a reset + rebuild
+    then reproduces the oracle on both ranks."""
+    from oracle.snnls_oracle import SnnlsOracle
+    world = 2
+    mp.spawn(_flaky_worker, args=(world, _free_port(), where, str(tmp_path)), nprocs=world, join=True)
+    r0, r1 = np.load(tmp_path / ("fl_%s_r0.npz" % where)), np.load(tmp_path / ("fl_%s_r1.npz" % where))
+    assert np.array_equal(r0["sel"], r1["sel"]) and np.array_equal(r0["err"], r1["err"])
+    X = np.random.RandomState(23).randn(4000, 16)
+    o = SnnlsOracle(X.T, X.sum(axis=0), alg="fw", mode="onepass")
+    o.build(12)
+    assert np.array_equal(r0["sel"], np.array([t[0] for t in o.trace]))
