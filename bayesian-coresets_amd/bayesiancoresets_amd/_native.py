@@ -15,7 +15,7 @@ OK, ERR_ARG, ERR_HIP, ERR_ZERO_ROW, ERR_ZERO_B, ERR_NOMEM, ERR_STATE = 0, -1, -2
 IT_OK, IT_FAIL_SELECT, IT_FAIL_REWEIGHT, IT_FAIL_MONOTONE = 0, 1, 2, 3
 REC_HDR = 4
 LOAD_CENTER_ROWS = 1
-MAX_ROW_LENGTH = 8192      # BCX_MAX_ROW_LENGTH of include/bcx.h (tests/test_abi.py keeps the two equal)
+MAX_ROW_LENGTH = 1048576      # BCX_MAX_ROW_LENGTH of include/bcx.h (tests/test_abi.py keeps the two equal)
 CHUNK_ROWS = 1024
 
 # every symbol include/bcx.h declares (checked by tests/test_abi.py)

@@ -531,6 +531,11 @@ static int mailbox_alloc(bcx_solver* s) {
 extern "C" int bcx_exchange_export(bcx_solver* s, void* handle_out, int32_t handle_bytes) {
   if (!s || !handle_out) return BCX_ERR_ARG;
   if (handle_bytes < (int32_t)sizeof(hipIpcMemHandle_t)) { s->err = "bcx_exchange_export: handle buffer too small"; return BCX_ERR_ARG; }
+  if ((size_t)s->cfg.d * sizeof(double) > 144 * 1024) {
+    // the exchange kernels stage one record (d doubles) in LDS; longer rows use the host-driven all-gather exchange
+    s->err = "peer mailbox: rows of more than 18432 values exchange their records through the all-gather";
+    return BCX_ERR_ARG;
+  }
   BCX_HIP(hipSetDevice(s->cfg.device));
   int rc = mailbox_alloc(s);
   if (rc != BCX_OK) return rc;

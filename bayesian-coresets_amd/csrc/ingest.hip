@@ -23,13 +23,14 @@ template <typename TS, typename TD>
 __global__ __launch_bounds__(1024) void ingest_kernel(const TS* src, int64_t ld_src, int64_t row_begin,
                                                       int64_t rows, int d, TD* __restrict__ An, int ld, int ld64,
                                                       double* A64, double* __restrict__ norms,
-                                                      double* __restrict__ chunk_sums, DevState* st, int center) {
+                                                      double* __restrict__ chunk_sums, DevState* st, int center, int acc_global) {
   extern __shared__ double lds[];  // nw * d column accumulators + nw norm accumulators
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
-  double* colacc = lds + (size_t)wave * d;
+  const int64_t chunk = blockIdx.x;
+  // acc_global (rows too long for d doubles of LDS; one wave per workgroup): the chunk's row of chunk_sums IS the accumulator
+  double* colacc = acc_global ? chunk_sums + (row_begin / BCX_CHUNK_ROWS + chunk) * (int64_t)(d + 1) : lds + (size_t)wave * d;
   for (int c = lane; c < d; c += 64) colacc[c] = 0.0;
   double normacc = 0.0;
-  const int64_t chunk = blockIdx.x;
   const int64_t r0 = chunk * BCX_CHUNK_ROWS;
   const int64_t r1 = (r0 + BCX_CHUNK_ROWS < rows) ? r0 + BCX_CHUNK_ROWS : rows;
   for (int64_t r = r0 + wave; r < r1; r += nw) {
@@ -87,6 +88,10 @@ __global__ __launch_bounds__(1024) void ingest_kernel(const TS* src, int64_t ld_
   __syncthreads();
   const int64_t gchunk = row_begin / BCX_CHUNK_ROWS + chunk;
   double* out = chunk_sums + gchunk * (int64_t)(d + 1);
+  if (acc_global) {                       // (one wave: the sums are in place)
+    if (threadIdx.x == 0) out[d] = normacc;
+    return;
+  }
   for (int c = threadIdx.x; c < d; c += blockDim.x) {
     double acc = lds[c];
     for (int w = 1; w < nw; ++w) acc += lds[(size_t)w * d + c];
@@ -135,7 +140,7 @@ template <typename TS, typename TD, int CHI>
 __global__ __launch_bounds__(INGEST_VEC_THREADS(CHI, SrcVec<TS>::EPS)) void ingest_vec_kernel(const TS* src, int64_t ld_src, int64_t row_begin,
                                                           int64_t rows, int d, TD* __restrict__ An, int ld, int ld64,
                                                           double* A64, double* __restrict__ norms,
-                                                          double* __restrict__ chunk_sums, DevState* st, int center) {
+                                                          double* __restrict__ chunk_sums, DevState* st, int center, int /*acc_global: scalar kernel only*/) {
   typedef typename SrcVec<TS>::V V;
   constexpr int EPS = SrcVec<TS>::EPS;
   extern __shared__ double lds[];  // nw * d column sums + nw norm sums
@@ -251,8 +256,11 @@ int bcx_launch_ingest(bcx_solver* s, const void* src, int src_dtype, int64_t ld_
   // kernel follows it too, so both forms add the chunk sums in the same order (bit-identical b) for every row length.
   if (d > 2048 && nw > 4) nw = 4;
   else if (d > 1024 && nw > 8) nw = 8;
+  // rows of more than 18432 values: not even one wave's d column accumulators fit the LDS -- one wave per chunk adds into
+  // the chunk's row of chunk_sums directly (its lanes own their columns: no conflicts, the same fixed order)
+  const int acc_global = nw < 1 ? 1 : 0;
   if (nw < 1) nw = 1;
-  const size_t shmem = ((size_t)nw * d + nw) * sizeof(double);
+  const size_t shmem = acc_global ? 64 : ((size_t)nw * d + nw) * sizeof(double);
   dim3 grid((unsigned)nblk), block(64 * nw);
   const int esz = src_dtype == BCX_F64 ? 8 : 4, eps = 16 / esz;
   const bool vec_ok = d % eps == 0 && ld_src % eps == 0 && ((uintptr_t)src % 16 == 0) && d / eps <= 64 * 16 &&
@@ -265,7 +273,7 @@ int bcx_launch_ingest(bcx_solver* s, const void* src, int src_dtype, int64_t ld_
     if (shmem > 48 * 1024)                                                                                    \
       BCX_HIP(hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));  \
     hipLaunchKernelGGL(kfn, grid, block, shmem, s->stream, (const TS_*)src, ld_src, row_begin, rows, d,       \
-                       (TD_*)s->An, s->ld, s->ld64, s->A64, s->norms, s->chunk_sums, s->st, center);          \
+                       (TD_*)s->An, s->ld, s->ld64, s->A64, s->norms, s->chunk_sums, s->st, center, acc_global); \
   } while (0)
 #define LAUNCH(TS, TD)                                                                                        \
   do {                                                                                                        \

@@ -229,6 +229,7 @@ struct ScanArgs {
   int ldv;            // row stride in 16-byte vectors
   int qstride;        // distance between query 0 and query 1 in 16-byte vectors
   int nvec;           // 16-byte vectors that hold data in a row (<= ldv)
+  int nv_lds;         // scan_long_kernel: query pieces [0, nv_lds) rest in LDS, the others are read from global memory (L2)
   float err_coef;     // |fp32 score - exact score| <= err_coef * qscale   (0 for fp64 storage)
 };
 
@@ -464,8 +465,9 @@ __global__ __launch_bounds__(BCX_SCAN_THREADS) void scan_long_kernel(ScanArgs a)
   constexpr int WAVES = BCX_SCAN_THREADS / 64;
   extern __shared__ __attribute__((aligned(16))) unsigned char scan_qlds[];
   Q* ql0 = (Q*)scan_qlds;
-  Q* ql1 = ql0 + a.nvec;
-  for (int v = threadIdx.x; v < a.nvec; v += blockDim.x) {
+  Q* ql1 = ql0 + a.nv_lds;
+  const int nvl = a.nv_lds;
+  for (int v = threadIdx.x; v < nvl; v += blockDim.x) {
     ql0[v] = load_q<ST>(a.q, v, true);
     if (DUAL) ql1[v] = load_q<ST>(a.q, a.qstride + v, true);
   }
@@ -498,8 +500,9 @@ __global__ __launch_bounds__(BCX_SCAN_THREADS) void scan_long_kernel(ScanArgs a)
           if constexpr (sizeof(T) == 8) {
             if (a.norms) { x[c].x /= nr; x[c].y /= nr; }     // raw fp64 rows: An = A / Anorms element by element (giga.py:13)
           }
-          s0 = vdot(x[c], ql0[v], s0);
-          if (DUAL) s1 = vdot(x[c], ql1[v], s1);
+          // (rows beyond the LDS budget of the query: its tail comes from global memory -- the query is L2 resident)
+          s0 = vdot(x[c], v < nvl ? ql0[v] : load_q<ST>(a.q, v, true), s0);
+          if (DUAL) s1 = vdot(x[c], v < nvl ? ql1[v] : load_q<ST>(a.q, a.qstride + v, true), s1);
         }
       }
     }
@@ -533,9 +536,11 @@ __global__ __launch_bounds__(BCX_SCAN_THREADS) void scan_long_kernel(ScanArgs a)
   }
 }
 
-template <typename ST, bool DUAL> static int launch_long(bcx_solver* s, const ScanArgs& a, int grid) {
-  const size_t lds = (size_t)a.nvec * sizeof(typename Stor<ST>::Q) * (DUAL ? 2 : 1);
-  if (lds > 150 * 1024) { s->err = "scan: row too long for the query staging"; return BCX_ERR_ARG; }
+template <typename ST, bool DUAL> static int launch_long(bcx_solver* s, const ScanArgs& a_in, int grid) {
+  ScanArgs a = a_in;
+  const size_t per = sizeof(typename Stor<ST>::Q) * (DUAL ? 2 : 1);
+  a.nv_lds = (int)std::min<size_t>((size_t)a.nvec, (144 * 1024) / per);
+  const size_t lds = (size_t)a.nv_lds * per;
   if (lds > 48 * 1024)
     BCX_HIP(hipFuncSetAttribute((const void*)scan_long_kernel<ST, DUAL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   hipLaunchKernelGGL((scan_long_kernel<ST, DUAL>), dim3(grid), dim3(BCX_SCAN_THREADS), lds, s->stream, a);

@@ -68,10 +68,13 @@ typedef struct bcx_config {
 /* ---- lifetime -------------------------------------------------------- */
 /* Replaces SparseNNLS.__init__ storage (snnls/snnls.py:9-16): allocates An (N x d, store_dtype),
  * norms (fp64), optional raw rows (fp64) and the replicated O(d) solver state. */
-/* Longest supported row (the projection dimension d of the vectors; the reference takes any).  Up to 4096 floats / 2048
- * doubles of stored row the scan keeps the query in registers; longer rows take a one-wave-per-row form with the query in
- * LDS, the O(d) state kernels keep their five d-vectors in LDS up to d = 3584 and in global scratch beyond. */
-#define BCX_MAX_ROW_LENGTH 8192
+/* Longest supported row (the projection dimension d of the vectors; the reference takes any): a bound on the argument, not
+ * a capacity of any kernel.  Up to 4096 floats / 2048 doubles of stored row the scan keeps the query in registers; longer rows
+ * take a one-wave-per-row form with the query in LDS (its tail beyond 144 KiB is read from global memory), the O(d) state
+ * kernels keep their five d-vectors in LDS up to d = 3584 and in global scratch beyond, the constructor pass adds column sums
+ * in LDS up to d = 18432 and in place beyond, the OMP step takes its multi-kernel form once three d-vectors exceed its LDS
+ * budget, and row shards of more than 18432 values exchange their records by all-gather instead of the peer mailbox. */
+#define BCX_MAX_ROW_LENGTH 1048576
 int bcx_create(const bcx_config* cfg, bcx_solver** out);
 int bcx_destroy(bcx_solver* s);
 /* Last error text for this handle (or for a failed bcx_create when s == NULL). */

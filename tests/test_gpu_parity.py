@@ -135,12 +135,13 @@ def test_wide_rows_against_oracle(bc, alg, d, dtype):
 
 @pytest.mark.parametrize("dtype", ("float32", "float64"))
 @pytest.mark.parametrize("alg", ("giga", "fw", "omp"))
-@pytest.mark.parametrize("d", (4096, 5000, 8192))
+@pytest.mark.parametrize("d", (4096, 5000, 8192, 16384, 20000, 41001))
 def test_long_rows_against_oracle(bc, alg, d, dtype):
     """Rows beyond the register form of the scan (more than 1024 16-byte pieces: d > 4096 floats / 2048 doubles take the
     one-wave-per-row kernel with the query in LDS) and beyond the LDS budget of the O(d) state kernels (d > 3584: their
-    five d-vectors live in global scratch; OMP at d = 8192: the multi-kernel step).  The reference accepts any projection
-    dimension (snnls.py:9-16, projector.py:12); the engine's limit is BCX_MAX_ROW_LENGTH = 8192."""
+    five d-vectors live in global scratch; OMP at d >= 8192: the multi-kernel step; d = 20000: the query's tail beyond the LDS
+    budget of the long scan comes from global memory and the constructor pass adds its column sums in place; d = 41001: odd,
+    beyond every LDS budget).  The reference accepts any projection dimension (snnls.py:9-16, projector.py:12)."""
     from oracle.snnls_oracle import SnnlsOracle
     N, itrs = 2500, 20
     X = np.random.RandomState(2000 + d).randn(N, d)
@@ -177,9 +178,12 @@ def test_omp_large_active_set_crosses_workgroup_widths(bc):
 
 
 def test_row_length_limit_is_a_value_error(bc):
-    X = np.zeros((4, 8193))
-    with pytest.raises(ValueError, match="8192"):
-        bc.snnls.FrankWolfe(X.T, np.ones(8193))
+    """(the bound is on the argument -- 2^20 -- not a capacity of a kernel; see test_long_rows_against_oracle)"""
+    from bayesiancoresets_amd import _native as nat
+    d = nat.MAX_ROW_LENGTH + 1
+    X = np.zeros((2, d))
+    with pytest.raises(ValueError, match=str(nat.MAX_ROW_LENGTH)):
+        bc.snnls.FrankWolfe(X.T, np.ones(d))
 
 
 def test_monotone_error_property(bc, normal_inputs):

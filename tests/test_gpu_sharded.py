@@ -25,7 +25,7 @@ def _data(N, d):
     return np.random.RandomState(21).randn(N, d)
 
 
-def _worker(rank, world, port, alg, itrs, N, d, out_dir, exchange="collective", tag="", explicit_b=False):
+def _worker(rank, world, port, alg, itrs, N, d, out_dir, exchange="collective", tag="", explicit_b=False, expect=None):
     os.environ["BCX_EXCHANGE"] = exchange
     for p in (ROOT, os.path.join(ROOT, "bayesian-coresets_amd")):
         if p not in sys.path:
@@ -45,7 +45,7 @@ def _worker(rank, world, port, alg, itrs, N, d, out_dir, exchange="collective", 
     tr = s.build(itrs)
     idx, w = s.sparse_weights()
     b = s.engine.vector(0)
-    assert s.exchange == (exchange if world > 1 else "collective"), s.exchange
+    assert s.exchange == (expect or (exchange if world > 1 else "collective")), s.exchange
     np.savez(os.path.join(out_dir, "%sw%d_r%d.npz" % (tag, world, rank)), sel=tr[0], err=tr[1], status=tr[2], idx=idx, w=w, b=b)
     dist.barrier()
     dist.destroy_process_group()
@@ -92,6 +92,22 @@ def test_peer_mailbox_exchange_matches_one_shard(tmp_path, alg, name):
             r = np.load(tmp_path / ("mb_w%d_r%d.npz" % (world, rank)))
             for k in ("sel", "err", "status", "idx", "w", "b"):
                 assert np.array_equal(ref[k], r[k]), (world, rank, k)
+
+
+@pytest.mark.parametrize("alg", (0, 1, 2))
+def test_rows_beyond_the_mailbox_record_use_the_all_gather(tmp_path, alg):
+    """Rows of 20000 values: a record no longer fits the LDS staging of the exchange kernels, the mailbox set-up says so and
+    every rank takes the all-gather exchange; two shards equal one shard bit for bit (long scan with the query's tail in
+    global memory, in-place column sums of the constructor pass, multi-kernel OMP step)."""
+    import torch.multiprocessing as mp
+    N, d, itrs = 2500, 20000, 10
+    mp.spawn(_worker, args=(1, _free_port(), alg, itrs, N, d, str(tmp_path), "collective", "lr_"), nprocs=1, join=True)
+    ref = np.load(tmp_path / "lr_w1_r0.npz")
+    mp.spawn(_worker, args=(2, _free_port(), alg, itrs, N, d, str(tmp_path), "mailbox", "lr_", False, "collective"), nprocs=2, join=True)
+    for rank in range(2):
+        r = np.load(tmp_path / ("lr_w2_r%d.npz" % rank))
+        for k in ("sel", "err", "status", "idx", "w", "b"):
+            assert np.array_equal(ref[k], r[k]), (rank, k)
 
 
 @pytest.mark.parametrize("exchange", ("collective", "mailbox"))
