@@ -886,6 +886,7 @@ extern "C" int bcx_omp_stats(bcx_solver* s, int64_t* out4) {
   int rc = read_state(s, &h);
   if (rc != BCX_OK) return rc;
   for (int i = 0; i < 4; ++i) out4[i] = h.n_omp[i];
+  out4[2] += s->opt_fallbacks;          // optimize() calls that needed the refined solve count as re-solves too
   return BCX_OK;
 }
 

@@ -18,7 +18,8 @@
 #define BCX_APPLY_THREADS 256
 
 enum { HALT_NONE = 0, HALT_DONE = 1, HALT_LIMIT = 2, HALT_NEED_EXACT = 3, HALT_EXCHANGE_TIMEOUT = 4, HALT_GRID_TIMEOUT = 5 };
-enum { OMP_IDLE = 0, OMP_DONE = 1, OMP_FAST_TRY = 2, OMP_FAST_ACCEPT = 3, OMP_GENERAL = 4 };
+enum { OMP_IDLE = 0, OMP_DONE = 1, OMP_FAST_TRY = 2, OMP_FAST_ACCEPT = 3, OMP_GENERAL = 4,
+       OMP_OPT_FALLBACK = 5 };   // optimize_lh_kernel asks for the refined solve of nnls_grid.hip (its Newton check failed)
 
 // Per-workgroup result of the correlation scan, stored as separate arrays (coalesced reads in the
 // resolve step): the two best upper bounds with their local row indices, a bound on everything else
@@ -157,6 +158,7 @@ struct bcx_solver {
   int64_t k_ub = 0;              // host upper bound of the slot count (grid sizing of the multi-kernel OMP step)
   unsigned long long* grid_counter = nullptr;   // [0] arrival counter of the grid barriers, [1] barrier base of the next OMP step
   uint64_t grid_epoch = 0;       // fused OMP launches since the counter was reset (bcx_build_begin)
+  int64_t opt_fallbacks = 0;     // optimize() calls that took the refined solve after the incremental one's check failed (bcx_omp_stats)
   bool grid_dirty = false;       // optimize() advanced grid_counter[0] past the OMP step's base [1]: re-zero both before the next OMP step
   size_t omp_lds_allowed = 0;
   // trace of the current build() call

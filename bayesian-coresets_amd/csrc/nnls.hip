@@ -10,6 +10,7 @@
 // previous passive set gives the reference's result.  The Gram matrix of optimize() is a small
 // GEMM and runs on the fp64 matrix cores (v_mfma_f64_16x16x4_f64); everything else is
 // latency-bound single-workgroup work.
+#include <stddef.h>
 #include <stdlib.h>
 #include <algorithm>
 #include "bcx_internal.h"
@@ -783,7 +784,18 @@ int bcx_launch_optimize(bcx_solver* s, double tol) {
     BCX_HIP(hipGetLastError());
   }
   if (k > 0) {
-    const int rc = bcx_launch_optimize_grid(s, tol, k);   // multi-workgroup solve (nnls_grid.hip); 1 = not applicable
+    // incremental Lawson-Hanson on the double-double inverse (omp_lh.hip); where its closing Newton check fails -- or its
+    // LDS budget does not hold k slots -- the refined multi-workgroup solve of nnls_grid.hip, then the single-workgroup form
+    int rc = bcx_launch_optimize_lh(s, tol, k);
+    if (rc < 0) return rc;
+    if (rc == 0) {
+      BCX_HIP(hipStreamSynchronize(s->stream));
+      BCX_HIP(hipMemcpy(&h, s->st, sizeof h, hipMemcpyDeviceToHost));
+      if (h.omp_mode != OMP_OPT_FALLBACK) return BCX_OK;
+      s->opt_fallbacks += 1;
+      BCX_HIP(hipMemsetAsync((char*)s->st + offsetof(DevState, omp_mode), 0, sizeof(int32_t), s->stream));
+    }
+    rc = bcx_launch_optimize_grid(s, tol, k);             // 1 = not applicable
     if (rc <= 0) return rc;
   }
   NnlsArgs n;

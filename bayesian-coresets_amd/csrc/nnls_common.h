@@ -139,3 +139,4 @@ void fill_nnls_args(bcx_solver* s, NnlsArgs& n, const double* recs);   // nnls.h
 struct ResolveArgs;
 int bcx_launch_omp_lh(bcx_solver* s, NnlsArgs& n, const ResolveArgs* fused);   // omp_lh.hip; 1 = not applicable (LDS budget)
 int bcx_launch_optimize_grid(bcx_solver* s, double tol, int k);         // nnls_grid.hip
+int bcx_launch_optimize_lh(bcx_solver* s, double tol, int k);           // omp_lh.hip; 1 = not applicable

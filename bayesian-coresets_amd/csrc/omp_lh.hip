@@ -680,6 +680,273 @@ __global__ __launch_bounds__(THREADS) void omp_lh_kernel(NnlsArgs n, GridSync gs
 #endif
 }
 
+// ---- optimize(): w[active] = nnls(A[:, active], b) (snnls.py:82-97) on the same incremental machinery ------------------
+// Lawson-Hanson from the empty passive set in its own order -- the dual of every candidate, the largest enters, columns
+// leave while the solution is not positive -- with the carried solution z and the double-double inverse of this file:
+// entering costs two grid barriers (duals; u = H g), leaving one.  No solve from scratch and no refinement inside the
+// iteration (nnls_grid.hip re-solves z = H c with two data-space refinement passes after every change: 185 us per
+// entering column at k = 1497, d = 1024).  At the end ONE data-space Newton step on the passive set, x += H (V_P (b - V_P^T x)),
+// measures what the Gram-space recurrences lost -- it is applied when it is a correction (<= 1e-3 of the weights and every
+// weight stays positive); otherwise the launch restores the weights and reports OMP_OPT_FALLBACK, and the host runs the
+// refined solve of nnls_grid.hip instead.
+#define OPTL_MAX_WGS 64
+#define OPTL_BATCH 8
+template <int THREADS>
+__global__ __launch_bounds__(THREADS) void optimize_lh_kernel(NnlsArgs n, GridSync gs, double tol, int kcap) {
+  const ApplyArgs& a = n.a;
+  DevState* st = a.st;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = blockDim.x >> 6, d = a.d;
+  const int wg = blockIdx.x, nwg = gridDim.x;
+  extern __shared__ double dyn[];
+  OmpLds L;
+  L.g = dyn; L.gl = dyn + kcap; L.u = dyn + 2 * (size_t)kcap; L.ul = dyn + 3 * (size_t)kcap;
+  L.x = dyn + 4 * (size_t)kcap; L.z = dyn + 5 * (size_t)kcap; L.xs = dyn + 6 * (size_t)kcap;
+  L.xfs = nullptr; L.qs = nullptr; L.bs = nullptr;
+  double* Ld = dyn + 7 * (size_t)kcap;                      // duals of the current pass, by slot
+  L.cs = (int*)(dyn + 8 * (size_t)kcap); L.pos = L.cs + kcap; L.fl = L.pos + kcap;
+  __shared__ double scratch[BCX_SCRATCH];
+  __shared__ double seg[THREADS / 64 < 2 ? 2 : THREADS / 64][64];
+  __shared__ int s_flag;
+  Grid G;
+  G.gs = gs; G.bi = 0; G.xi = 0; G.s_flag = &s_flag; G.ok = true;
+  const int k = st->k;
+  double prev_cost = 0.0;
+  if (wg == 0) {
+    refresh_state(a, scratch, k > 0);                 // prev_cost = error()   snnls.py:84
+    prev_cost = st->err;
+    for (int j = tid; j < k; j += blockDim.x) n.wbak[j] = a.act_w[j];
+    for (int j = tid; j < d; j += blockDim.x) a.tmp[2 * (size_t)d + j] = a.xw[j];
+  }
+  for (int j = wg * nw + wave; j < k; j += nwg * nw) {      // c = V b
+    double acc = 0.0;
+    for (int i = lane; i < d; i += 64) acc += a.act_rows[(size_t)j * d + i] * a.b[i];
+    acc = wave_allsum(acc);
+    if (lane == 0) xst(&n.cvec[j], acc);
+  }
+  double cnt[1] = {0.0};
+  for (int j = tid; j < k; j += blockDim.x) {
+    const int ins = a.act_w[j] > 0.0;                       // nz_idcs = w > 0   snnls.py:86
+    L.pos[j] = -1; L.x[j] = 0.0; L.fl[j] = ins ? FLAG_INS : 0;
+    cnt[0] += ins;
+  }
+  block_allsum<1>(cnt, scratch);
+  int n_out = (int)cnt[0];
+  gsync(G);
+  const double eps = 2.220446049250313e-16;
+  const double bnorm = st->bnorm;
+  const double tolscale = 10.0 * eps * (double)(d > k ? d : k) * bnorm;
+  int p = 0;
+  const int max_outer = 3 * k + 16;
+  bool more = true;
+  for (int outer = 0; outer < max_outer && G.ok && n_out > 0 && more; ++outer) {
+    // duals w_j = c_j - G[j, P] x of the members without weight: one wave per candidate, dealt over all workgroups
+    double* D = xbuf(n, G);
+    for (int j = wg * nw + wave; j < k; j += nwg * nw) {
+      const int fl = L.fl[j];
+      if (!(fl & FLAG_INS) || (fl & FLAG_REJ) || L.pos[j] >= 0) continue;
+      const double* grow = n.gram + (size_t)j * n.ldg;
+      double acc = 0.0;
+      for (int q0 = 0; q0 < p; q0 += 256) {
+        double gv[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) { const int q = q0 + t * 64 + lane; gv[t] = q < p ? grow[L.cs[q]] : 0.0; }
+#pragma unroll
+        for (int t = 0; t < 4; ++t) { const int q = q0 + t * 64 + lane; if (q < p) acc += gv[t] * L.z[q]; }
+      }
+      acc = wave_allsum(acc);
+      if (lane == 0) xst(&D[j], xld(&n.cvec[j]) - acc);
+    }
+    gsync(G);
+    for (int j = tid; j < k; j += blockDim.x) {
+      const int fl = L.fl[j];
+      const bool cnd = (fl & FLAG_INS) && !(fl & FLAG_REJ) && L.pos[j] < 0;
+      Ld[j] = cnd ? xld(&D[j]) : -INFINITY;
+    }
+    __syncthreads();
+    // Up to OPTL_BATCH columns enter per dual pass, in the order of these duals.  Lawson-Hanson asks for A column with a
+    // positive dual (the largest is its heuristic): from the second of a batch on the list is stale, so the candidate's
+    // exact dual at the current solution is formed first -- replicated, O(p), no barrier -- and a candidate whose dual
+    // is no longer positive waits for the next pass.  One grid barrier less per entering column.
+    for (int bth = 0; bth < OPTL_BATCH && G.ok; ++bth) {
+      double dbv = -INFINITY; int dbi = -1;
+      for (int j = tid; j < k; j += blockDim.x) {
+        const double wvj = Ld[j];
+        if (wvj > tolscale * a.act_norm[j] && (dbi < 0 || wvj > dbv)) { dbv = wvj; dbi = j; }
+      }
+      const ArgBest pick = block_argbest(dbv, dbi, scratch);
+      const int cand = pick.i;
+      if (cand < 0) { if (bth == 0) more = false; break; }
+      if (tid == 0) Ld[cand] = -INFINITY;
+      // g = G[cand, P], exact dual c_cand - g . z
+      double r1[1] = {0.0};
+      for (int q = tid; q < p; q += blockDim.x) { const double gq = n.gram[(size_t)cand * n.ldg + L.cs[q]]; L.g[q] = gq; r1[0] += gq * L.z[q]; }
+      block_allsum<1>(r1, scratch);
+      const double wv = xld(&n.cvec[cand]) - r1[0];
+      if (!(wv > tolscale * a.act_norm[cand])) continue;
+      if (p > 0) {
+        double* Uh = xbuf(n, G);
+        double* Ul = xbuf(n, G);
+        ompl_mv_rows(n, p, L.g, nullptr, Uh, Ul, nullptr);
+        gsync(G);
+        for (int q = tid; q < p; q += blockDim.x) { L.u[q] = xld(&Uh[q]); L.ul[q] = xld(&Ul[q]); }
+        __syncthreads();
+      }
+      dd gu = dd_make(0.0, 0.0);
+      for (int q = tid; q < p; q += blockDim.x) gu = dd_add(gu, dd_mul_d(dd_make(L.u[q], L.ul[q]), L.g[q]));
+      gu = dd_wave_allsum(gu);
+      if (lane == 0) { seg[0][wave] = gu.h; seg[1][wave] = gu.l; }
+      __syncthreads();
+      gu = dd_make(seg[0][0], seg[1][0]);
+      for (int w = 1; w < nw; ++w) gu = dd_add(gu, dd_make(seg[0][w], seg[1][w]));
+      __syncthreads();
+      const double gcc = n.gram[(size_t)cand * n.ldg + cand];
+      const dd sc = dd_add(dd_make(gcc, 0.0), dd_neg(gu));
+      if (!(sc.h > 1e-12 * gcc)) {                            // numerically dependent on P: never enters
+        if (tid == 0) L.fl[cand] |= FLAG_REJ;
+        --n_out;
+        __syncthreads();
+        continue;
+      }
+      const double t = wv / sc.h;
+      const dd inv = dd_recip(sc);
+      for (int q = tid; q < p; q += blockDim.x) L.z[q] -= t * L.u[q];      // (z == xs == x on P at this point)
+      ompl_border_apply(n, L, p, inv);
+      if (tid == 0) { L.z[p] = t; L.xs[p] = 0.0; L.cs[p] = cand; L.pos[cand] = p; }
+      p += 1;
+      --n_out;
+      __syncthreads();
+      ompl_inner(n, L, p, cand, max_outer, n_out, G, scratch);
+      for (int q = tid; q < p; q += blockDim.x) { L.xs[q] = L.x[L.cs[q]]; L.z[q] = L.xs[q]; }
+      __syncthreads();
+    }
+  }
+  // ---- one data-space Newton step on the passive set: xw0 = V_P^T x | gv = V_P (b - xw0) | dz = H gv ---------------------
+  auto combine = [&](double* out) {                          // out[col] = sum_q z[q] row_{cs[q]}[col], fixed position order
+    for (int cb = wg; cb * 64 < d; cb += nwg) {
+      const int col = cb * 64 + lane;
+      double acc = 0.0;
+      if (col < d) {
+        int q = wave;
+        for (; q + 7 * nw < p; q += 8 * nw) {
+          double m[8];
+#pragma unroll
+          for (int t8 = 0; t8 < 8; ++t8) m[t8] = a.act_rows[(size_t)L.cs[q + t8 * nw] * d + col];
+#pragma unroll
+          for (int t8 = 0; t8 < 8; ++t8) acc += L.z[q + t8 * nw] * m[t8];
+        }
+        for (; q < p; q += nw) acc += L.z[q] * a.act_rows[(size_t)L.cs[q] * d + col];
+      }
+      seg[wave][lane] = acc;
+      __syncthreads();
+      if (wave == 0 && col < d) {
+        double tsum = seg[0][lane];
+        for (int w = 1; w < nw; ++w) tsum += seg[w][lane];
+        xst(&out[col], tsum);
+      }
+      __syncthreads();
+    }
+  };
+  combine(a.tmp);
+  gsync(G);
+  double* GV = xbuf(n, G);
+  for (int q = wg * nw + wave; q < p; q += nwg * nw) {
+    const double* row = a.act_rows + (size_t)L.cs[q] * d;
+    double acc = 0.0;
+    for (int i = lane; i < d; i += 64) acc += row[i] * (a.b[i] - xld(&a.tmp[i]));
+    acc = wave_allsum(acc);
+    if (lane == 0) xst(&GV[q], acc);
+  }
+  gsync(G);
+  for (int q = tid; q < p; q += blockDim.x) L.g[q] = xld(&GV[q]);
+  __syncthreads();
+  double* Zh = xbuf(n, G);
+  double* Zl = xbuf(n, G);
+  ompl_mv_rows(n, p, L.g, nullptr, Zh, Zl, nullptr);
+  gsync(G);
+  double dm = 0.0, xm = 0.0;
+  int neg = 0;
+  for (int q = tid; q < p; q += blockDim.x) {
+    const double dz = xld(&Zh[q]), xq = L.z[q];
+    dm = fmax(dm, fabs(dz)); xm = fmax(xm, fabs(xq));
+    L.u[q] = xq + dz;
+    if (!(xq + dz > 0.0)) neg = 1;
+  }
+  dm = block_allmax(dm, scratch);
+  xm = block_allmax(xm, scratch);
+  const double negs = block_allmax((double)neg, scratch);
+  const bool fallback = !G.ok || (p > 0 && (!(dm <= 1e-3 * xm) || negs > 0.0));
+  if (!fallback) {
+    for (int q = tid; q < p; q += blockDim.x) { L.z[q] = L.u[q]; L.x[L.cs[q]] = L.u[q]; }
+    __syncthreads();
+  }
+  combine(a.tmp);                                            // V_P^T x of the weights that are committed
+  if (wg != 0) { if (G.ok) grid_arrive(G.gs, 1); return; }
+  gsync(G);
+  // ---- workgroup 0: publish the passive data, new weights, accept / revert (snnls.py:88-97) ------------------------------
+  if (!G.ok) { if (tid == 0) { st->hvalid = 0; st->halt = HALT_GRID_TIMEOUT; } return; }
+  if (fallback) {
+    if (tid == 0) { st->omp_mode = OMP_OPT_FALLBACK; st->hvalid = 0; }
+    return;                                                  // weights and xw untouched: the host launches nnls_grid.hip's solve
+  }
+  for (int q = tid; q < p; q += blockDim.x) n.plist[q] = L.cs[q];
+  for (int j = tid; j < k; j += blockDim.x) {
+    n.ppos[j] = L.pos[j];
+    n.x[j] = L.pos[j] >= 0 ? L.x[j] : 0.0;
+    if (L.fl[j] & FLAG_INS) a.act_w[j] = (L.pos[j] >= 0) ? L.x[j] : 0.0;
+  }
+  for (int j = tid; j < d; j += blockDim.x) a.xw[j] = xld(&a.tmp[j]);
+  if (tid == 0) st->np = p;
+  __syncthreads();
+  refresh_state(a, scratch, false);
+  const double new_cost = st->err;
+  if (new_cost > prev_cost * (1.0 + tol)) {                  // snnls.py:91-97
+    for (int j = tid; j < k; j += blockDim.x) a.act_w[j] = n.wbak[j];
+    for (int j = tid; j < d; j += blockDim.x) a.xw[j] = a.tmp[2 * (size_t)d + j];
+    __syncthreads();
+    refresh_state(a, scratch, false);
+    if (tid == 0) { st->limit = 1; st->hvalid = 0; }
+  } else if (tid == 0) {
+    st->hvalid = 1;
+    st->hlo_valid = 1;                                       // H is the double-double inverse of gram[P, P]
+    st->since_refresh = 0;
+  }
+}
+
+// 1 = not applicable (LDS budget, dev knob BCX_OPT_GRID=1): the caller takes nnls_grid.hip's kernel
+int bcx_launch_optimize_lh(bcx_solver* s, double tol, int k) {
+  if (getenv("BCX_OPT_GRID") || getenv("BCX_OPT_SINGLE")) return 1;
+  // Small independent supports (k <= d, k <= 512) stay with nnls_grid.hip: all their columns join the passive set by
+  // bordering, one barrier each and no dual passes (k = 400, d = 512: 3.9 ms against 7.8 here); from there on -- and for
+  // every k > d, where that kernel has to take Lawson-Hanson's order with a refined solve per column -- this one is
+  // faster (k = 999, d = 512: 12.7 against 28.3 ms; k = 1497, d = 1024: 45 against 191 ms).  BCX_OPT_LH=1 forces it (tests).
+  if (k <= s->cfg.d && k <= 512 && !getenv("BCX_OPT_LH")) return 1;
+  const int kcap = (k + 1 + 63) / 64 * 64;
+  const size_t lds = (size_t)kcap * (8 * sizeof(double) + 3 * sizeof(int));
+  if (lds > OMPL_LDS_MAX) return 1;
+  if (!s->grid_counter) BCX_HIP(hipMalloc((void**)&s->grid_counter, 2 * sizeof(unsigned long long)));
+  BCX_HIP(hipMemsetAsync(s->grid_counter, 0, 2 * sizeof(unsigned long long), s->stream));
+  s->grid_epoch = 0;
+  NnlsArgs n;
+  fill_nnls_args(s, n, nullptr);
+  GridSync gs;
+  gs.counter = s->grid_counter;
+  gs.base = 0;
+  gs.timeout_ticks = 1000000000LL;     // 10 s
+  static const int forced_wgs = getenv("BCX_OPT_WGS") ? atoi(getenv("BCX_OPT_WGS")) : 0;     // dev
+  const int wgs = forced_wgs > 0 ? forced_wgs : (k <= 256 ? 16 : (k <= 1024 ? 32 : OPTL_MAX_WGS));
+  const int threads = k <= 192 ? 256 : (k <= 768 ? 512 : 1024);
+#define OPTL_LAUNCH(T)                                                                                                          \
+  do {                                                                                                                          \
+    if (lds > 48 * 1024) BCX_HIP(hipFuncSetAttribute((const void*)optimize_lh_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+    hipLaunchKernelGGL(optimize_lh_kernel<T>, dim3(wgs), dim3(T), lds, s->stream, n, gs, tol, kcap);                          \
+  } while (0)
+  if (threads == 256) OPTL_LAUNCH(256); else if (threads == 512) OPTL_LAUNCH(512); else OPTL_LAUNCH(1024);
+#undef OPTL_LAUNCH
+  BCX_HIP(hipGetLastError());
+  s->grid_dirty = true;
+  return BCX_OK;
+}
+
 int bcx_launch_omp_lh(bcx_solver* s, NnlsArgs& n, const ResolveArgs* fused) {
   static const int force = getenv("BCX_OMP_FORCE_RESOLVE") ? atoi(getenv("BCX_OMP_FORCE_RESOLVE")) : 0;   // tests: re-solve every N-th step
   const int64_t kub = s->k_ub;

@@ -194,7 +194,8 @@ int bcx_stats(bcx_solver* s, int64_t* exact_fallbacks, int64_t* candidates, int6
 /* Sum of scan-kernel time recorded by hipEvents during bcx_build_enqueue: on = 1 times every scan launch,
  * on = N > 1 every N-th one (an event pair costs several microseconds of stream time), on = 0 stops. */
 /* OMP step diagnostics since construction: out4 = {steps taken, columns that left the passive set, from-scratch re-solves
- * (the incremental inverse had drifted, or a reverted step), columns that entered beyond the selected one}. */
+ * (the incremental inverse had drifted, or a reverted step; also optimize() calls whose incremental solve failed its closing
+ * Newton check and were redone by the refined solve), columns that entered beyond the selected one}. */
 int bcx_omp_stats(bcx_solver* s, int64_t* out4);
 int bcx_profile_scan(bcx_solver* s, int32_t on);
 int bcx_profile_read(bcx_solver* s, double* scan_ms_total, int64_t* scan_launches);

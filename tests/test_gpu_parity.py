@@ -216,12 +216,18 @@ def test_reset(bc, normal_inputs):
     np.testing.assert_array_equal(w1, s.weights())
 
 
+@pytest.mark.parametrize("kernel", ("default", "incremental"))
 @pytest.mark.parametrize("alg", ("giga", "fw", "omp"))
-def test_F7_optimize(bc, golden, normal_inputs, alg):
-    """optimize(): NNLS re-solve on the support (snnls.py:82-97); Gram on the fp64 matrix cores."""
+def test_F7_optimize(bc, golden, normal_inputs, alg, kernel, monkeypatch):
+    """optimize(): NNLS re-solve on the support (snnls.py:82-97); Gram on the fp64 matrix cores.  Both solve kernels: the
+    bordering + refined solve of nnls_grid.hip (what a support of this size takes) and the incremental Lawson-Hanson on the
+    double-double inverse (omp_lh.hip optimize_lh_kernel; larger supports and every k > d), forced here by BCX_OPT_LH."""
+    if kernel == "incremental":
+        monkeypatch.setenv("BCX_OPT_LH", "1")
     X = normal_inputs(1, 10000, 100, "F2_input_sha256")
     s = _run(bc, X, alg, 100)
     s.optimize()
+    assert s._eng.omp_stats()["resolves"] == 0             # (the incremental solve passed its closing Newton check)
     w = s.weights()
     idx = np.flatnonzero(w > 0)
     assert np.array_equal(idx, golden["F7_%s_idx" % alg])
@@ -230,6 +236,30 @@ def test_F7_optimize(bc, golden, normal_inputs, alg):
     np.testing.assert_allclose(s.error(), float(golden["F7_%s_final_err" % alg]), rtol=ERR_RTOL, atol=1e-9)
     if alg != "omp":   # OMP sits at k = d = 100 with error ~1e-12 * ||b||: accept/reject of optimize() is rounding noise
         assert s.reached_numeric_limit == bool(golden["F7_%s_limit" % alg])
+
+
+@pytest.mark.parametrize("alg,N,d,itrs", (("fw", 8000, 640, 700), ("fw", 8000, 256, 700), ("giga", 6000, 200, 500)))
+def test_optimize_large_supports_against_the_oracle(bc, alg, N, d, itrs):
+    """optimize() on supports beyond 512 columns and beyond d columns (the incremental double-double Lawson-Hanson kernel by
+    default): error against the oracle's scipy.optimize.nnls re-solve; weights too where the minimiser is unique (k <= d)."""
+    from oracle.snnls_oracle import SnnlsOracle
+    X = np.random.RandomState(1000 + d).randn(N, d)
+    o = SnnlsOracle(X.T, X.sum(axis=0), alg=alg, mode="onepass")
+    o.build(itrs)
+    s = _run(bc, X, alg, itrs)
+    k = int((s.weights() > 0).sum())
+    assert k > 512 or k > d
+    e0 = s.error()
+    s.optimize()
+    o.optimize()
+    assert s._eng.omp_stats()["resolves"] == 0
+    assert s.error() <= e0 * (1 + 1e-12)
+    np.testing.assert_allclose(s.error(), o.error(), rtol=1e-6, atol=1e-9 * np.sqrt((X.sum(axis=0) ** 2).sum()))
+    if k <= d:
+        w, ow = s.weights(), o.weights()
+        assert np.array_equal(np.flatnonzero(w > 0), np.flatnonzero(ow > 0))
+        np.testing.assert_allclose(w[w > 0], ow[ow > 0], rtol=WEIGHT_RTOL, atol=WEIGHT_ATOL_REL * ow.max())
+    assert s.reached_numeric_limit == o.reached_numeric_limit
 
 
 def test_hilbert_coreset_api(bc, golden, normal_inputs):

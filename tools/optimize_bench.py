@@ -19,7 +19,8 @@ def run(alg, N, d, its):
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     k = len(idx)
-    print("alg %d N=%d d=%d k=%d: optimize %.2f ms accepted=%s err %.6g -> %.6g  (Gram flops %.2e)" % (alg, N, d, k, dt * 1e3, ok, e0, eng.error(), 2.0 * k * k * d))
+    print("alg %d N=%d d=%d k=%d: optimize %.2f ms accepted=%s err %.6g -> %.10g  (Gram flops %.2e; refined-solve fallbacks %d)"
+          % (alg, N, d, k, dt * 1e3, ok, e0, eng.error(), 2.0 * k * k * d, eng.omp_stats()["resolves"]))
 
 if __name__ == "__main__":
     run(nat.ALG_FW, 1000000, 512, 400)
