@@ -892,7 +892,13 @@ extern "C" int bcx_project_profile_read(double* ms_total, int64_t* launches, dou
 // SELECT's per-row moments and the transcendental epilogues (logistic, Poisson) spill with 128 accumulator VGPRs and
 // measured slower (logistic D=300: 29 against 35 TFLOP/s), WRITE holds eight rows per lane.
 static int proj_nct(int mode, int family, int S, bool aligned = true) {
-  // (SELECT on the 128-column tile spills ~200 registers in every family: not built)
+  // SELECT on the 128-column tile spilled ~200 registers in every family in round 2.  Since the row moments moved to
+  // per-column-group records the linear-regression instantiation parks 24 VGPRs of request-pointer state (12 stores, 13
+  // loads per launch-long loop body, none between the MFMAs of a group) and is the faster one: N = 5M, D = 301, S = 256
+  // 13.80 against 15.08 ms per call (55.8 against 51.1 TFLOP/s).  The transcendental families stay at 64 columns
+  // (logistic SELECT at 128: 231 spilled VGPRs).  BCX_PROJ_SEL_NCT=4 selects the 64-column tile (dev).
+  static const bool sel8 = [] { const char* e = getenv("BCX_PROJ_SEL_NCT"); return !(e && atoi(e) == 4); }();
+  if (mode == PMODE_SELECT && family == FAM_LINREG && aligned && sel8) return (S + 127) / 128 * 128 == (S + 63) / 64 * 64 ? 8 : 4;
   if (mode != PMODE_COLSUM) return 4;
   // the 128-column tile exists for the column sums of the linear-regression family and, on 16-byte aligned rows, of the
   // logistic one (round 3: with the series' constants in scalar registers and 32-bit Theta offsets it fits 255 VGPRs;
@@ -938,6 +944,9 @@ template <int MODE> static int launch_family(int family, dim3 grid, size_t extra
   if (tab_bytes && !(p.tab = proj_tables())) { g_proj_err = "bcx_project: no device memory for the likelihood tables"; return BCX_ERR_NOMEM; }
   if (shmem > 160 * 1024) { g_proj_err = "bcx_project: S too large for the column-sum accumulators (S <= 3072)"; return BCX_ERR_ARG; }
   const bool aligned = proj_aligned(p);
+  if constexpr (MODE == PMODE_SELECT) {
+    if (nct == 8 && family == FAM_LINREG) return launch_one<FAM_LINREG, MODE, 8, true>(true, grid, shmem, st, p);
+  }
   if constexpr (MODE == PMODE_COLSUM) {
     if (nct == 8 && family == FAM_LINREG) return launch_one<FAM_LINREG, MODE, 8>(aligned, grid, shmem, st, p);
     if (nct == 8 && family == FAM_LOGISTIC) return launch_one<FAM_LOGISTIC, MODE, 8, true>(true, grid, shmem, st, p);

@@ -12,7 +12,7 @@ def run(family, N, D, S, reps=5):
     if family == "poisson":
         Z[:, -1] = torch.poisson(torch.ones(N, dtype=torch.float64, device="cuda"))
     theta = 0.1 * rs.randn(S, D)
-    prj = bc.DeviceProjector(family, lambda n, w, p: theta, S, sigsq=1.0)
+    prj = bc.DeviceProjector(family, lambda n, w, p: theta, S, sigsq=1.0, colsum="mfma")      # (time the projection kernel, not the moments form)
     resid = rs.randn(S)
     for name, fn in (("colsum", lambda: prj.project_colsum(Z)), ("select", lambda: prj.project_select(Z, resid)),
                      ("write", lambda: prj.project(Z))):
@@ -25,6 +25,11 @@ def run(family, N, D, S, reps=5):
         print("%-8s %-6s N=%d D=%d S=%d: %.2f ms  %.1f TFLOP/s(gemm)  %.2f Gelem/s" % (family, name, N, D, S, dt * 1e3, fl / dt / 1e12, N * S / dt / 1e9), flush=True)
 
 if __name__ == "__main__":
+    if len(sys.argv) > 1:
+        for spec in sys.argv[1:]:
+            fam, n, dd, ss = spec.split(",")
+            run(fam, int(n), int(dd), int(ss))
+        sys.exit(0)
     run("linreg", 1000000, 300, 256)
     run("logistic", 1000000, 10, 512)
     run("poisson", 1000000, 16, 256)
