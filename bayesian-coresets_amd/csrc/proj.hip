@@ -902,8 +902,11 @@ static int proj_nct(int mode, int family, int S, bool aligned = true) {
   if (mode != PMODE_COLSUM) return 4;
   // the 128-column tile exists for the column sums of the linear-regression family and, on 16-byte aligned rows, of the
   // logistic one (round 3: with the series' constants in scalar registers and 32-bit Theta offsets it fits 255 VGPRs;
-  // +8 % at D = 300); the unaligned logistic and the Poisson instantiations would spill and are not built
-  if (family == FAM_POISSON || (family == FAM_LOGISTIC && !aligned)) return 4;
+  // +8 % at D = 300) and the Poisson one (round 4, below); the unaligned transcendental instantiations are not built
+  // Poisson COLSUM on the 128-column tile parks 16 VGPRs (request pointers, outside the MFMA groups) and is the faster one
+  // on 16-byte aligned rows: N = 2M, D = 301, S = 256 6.15 against 6.72 ms (50.1 against 45.9 TFLOP/s).  BCX_PROJ_POIS_NCT=4: dev.
+  static const bool pois8 = [] { const char* e = getenv("BCX_PROJ_POIS_NCT"); return !(e && atoi(e) == 4); }();
+  if ((family == FAM_POISSON && !(pois8 && aligned)) || (family == FAM_LOGISTIC && !aligned)) return 4;
   static const int forced = [] { const char* e = getenv("BCX_PROJ_NCT"); return e ? atoi(e) : 0; }();   // dev knob
   if (forced == 4 || forced == 8) return forced;
   return (S + 127) / 128 * 128 == (S + 63) / 64 * 64 ? 8 : 4;
@@ -950,6 +953,7 @@ template <int MODE> static int launch_family(int family, dim3 grid, size_t extra
   if constexpr (MODE == PMODE_COLSUM) {
     if (nct == 8 && family == FAM_LINREG) return launch_one<FAM_LINREG, MODE, 8>(aligned, grid, shmem, st, p);
     if (nct == 8 && family == FAM_LOGISTIC) return launch_one<FAM_LOGISTIC, MODE, 8, true>(true, grid, shmem, st, p);
+    if (nct == 8 && family == FAM_POISSON) return launch_one<FAM_POISSON, MODE, 8, true>(true, grid, shmem, st, p);
   }
   switch (family) {
     case FAM_LOGISTIC: return launch_one<FAM_LOGISTIC, MODE, 4>(aligned, grid, shmem, st, p);

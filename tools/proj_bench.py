@@ -5,7 +5,7 @@ sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."
 import torch
 import bayesiancoresets_amd as bc
 
-def run(family, N, D, S, reps=5):
+def run(family, N, D, S, reps=20):
     rs = np.random.RandomState(0)
     cols = D if family == "logistic" else D + 1
     Z = torch.randn(N, cols, dtype=torch.float64, device="cuda")
@@ -16,13 +16,17 @@ def run(family, N, D, S, reps=5):
     resid = rs.randn(S)
     for name, fn in (("colsum", lambda: prj.project_colsum(Z)), ("select", lambda: prj.project_select(Z, resid)),
                      ("write", lambda: prj.project(Z))):
-        fn(); torch.cuda.synchronize()
+        fn(); fn(); torch.cuda.synchronize()
+        prj.profile(True)
         t0 = time.perf_counter()
         for _ in range(reps): fn()
         torch.cuda.synchronize()
         dt = (time.perf_counter() - t0) / reps
+        kms, launches, flops = prj.profile_read()          # hipEvents around the projection kernel alone
+        prj.profile(False)
         fl = 2.0 * N * D * S
-        print("%-8s %-6s N=%d D=%d S=%d: %.2f ms  %.1f TFLOP/s(gemm)  %.2f Gelem/s" % (family, name, N, D, S, dt * 1e3, fl / dt / 1e12, N * S / dt / 1e9), flush=True)
+        print("%-8s %-6s N=%d D=%d S=%d: wall %.2f ms  %.1f TFLOP/s | kernel %.3f ms  %.1f TFLOP/s  (%d launches)"
+              % (family, name, N, D, S, dt * 1e3, fl / dt / 1e12, kms / max(launches, 1), flops / max(kms, 1e-9) / 1e9, launches), flush=True)
 
 if __name__ == "__main__":
     if len(sys.argv) > 1:
