@@ -161,8 +161,10 @@ __global__ __launch_bounds__(256) void moments_mean_kernel(const double* __restr
 }
 
 // T_s = sum_i (Delta G)[s][i] (delta_si + 2 tbar_i) - 2 delta_si g_i   (= delta_s^T G delta_s + 2 delta_s^T (G tbar - g)),
-// Delta G on the fp64 matrix cores: one wave per 16 samples x 16 columns tile of Delta G, k over all D rows of G
-// (v_mfma_f64_16x16x4_f64; lane group lk feeds k = 8t + 2 lk (+1) to steps 2t (2t+1): one 16-byte load of theta per two steps).
+// Delta G on the fp64 matrix cores: one WORKGROUP per 16 samples x 16 columns tile of Delta G, its four waves take the
+// k steps 4 t + wave of the D rows of G (v_mfma_f64_16x16x4_f64; lane group lk feeds k = 8 t + 2 lk (+1) to steps 2 t (2 t + 1):
+// one 16-byte load of theta per two steps) and meet in LDS in wave order -- the chain of dependent load batches is a
+// quarter as long as with one wave per tile (this kernel is all latency: 46 MFLOP).
 // Partials [column tile][sample] go to `work`; the last workgroup to arrive sums them in tile order, centres and scales.
 // work: nct * Spad partials, then one arrival counter (self-resetting).
 template <bool AL>
@@ -171,24 +173,25 @@ __global__ __launch_bounds__(256) void moments_quad_kernel(const double* __restr
                                                            const double* __restrict__ tbar, double sigsq,
                                                            double* __restrict__ colsum, double* __restrict__ work, int nct, int Spad) {
   __shared__ double scratch[BCX_SCRATCH];
+  __shared__ double red[4][4][64];
   __shared__ int last;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int li = lane & 15, lk = lane >> 4;
-  const int w = blockIdx.x * 4 + wave, nst = Spad / 16;
-  const int st = w / nct, ct = w - st * nct;
-  if (st < nst) {
+  const int st = blockIdx.x / nct, ct = blockIdx.x - st * nct;
+  {
     const int sa = st * 16 + li, cb = ct * 16 + li;
     const bool va = sa < S, vb = cb < D;
     const double* th = theta + (size_t)(va ? sa : 0) * ldt;
     const double* gc = M + (vb ? cb : 0);
     mv4d acc = (mv4d){0.0, 0.0, 0.0, 0.0};
     const int ksteps = (D + 7) / 8;
-    for (int t0 = 0; t0 < ksteps; t0 += 4) {
-      // four double-steps per trip: all their loads are issued before the first MFMA (addresses clamped, values masked)
+    for (int t0 = wave; t0 < ksteps; t0 += 16) {
+      // four double-steps per trip (t0, t0 + 4, t0 + 8, t0 + 12): all their loads are issued before the first MFMA
+      // (addresses clamped, values masked)
       double a0[4], a1[4], b0[4], b1[4];
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
-        const int k = 8 * (t0 + u) + 2 * lk;
+        const int k = 8 * (t0 + 4 * u) + 2 * lk;
         const bool k0 = k < D, k1 = k + 1 < D;
         const int kc = k0 ? k : 0, kd = k1 ? k + 1 : 0;
         double x0, x1;
@@ -207,21 +210,27 @@ __global__ __launch_bounds__(256) void moments_quad_kernel(const double* __restr
         acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[u], b1[u], acc, 0, 0, 0);
       }
     }
-    // f64 C/D layout: col = lane & 15, row = (lane >> 4) + 4 * reg
-    const double tb = vb ? tbar[cb] : 0.0, gy = vb ? M[(size_t)ycol * ldm + cb] : 0.0;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int sr = st * 16 + lk + 4 * r;
-      double v = 0.0;
-      if (vb && sr < S) {
-        const double dl = theta[(size_t)sr * ldt + cb] - tb;
-        v = acc[r] * (dl + 2.0 * tb) - 2.0 * dl * gy;
+    for (int r = 0; r < 4; ++r) red[wave][r][lane] = acc[r];
+    __syncthreads();
+    if (wave == 0) {
+      // f64 C/D layout: col = lane & 15, row = (lane >> 4) + 4 * reg
+      const double tb = vb ? tbar[cb] : 0.0, gy = vb ? M[(size_t)ycol * ldm + cb] : 0.0;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const double y4 = ((red[0][r][lane] + red[1][r][lane]) + red[2][r][lane]) + red[3][r][lane];
+        const int sr = st * 16 + lk + 4 * r;
+        double v = 0.0;
+        if (vb && sr < S) {
+          const double dl = theta[(size_t)sr * ldt + cb] - tb;
+          v = y4 * (dl + 2.0 * tb) - 2.0 * dl * gy;
+        }
+        v += bcx_dpp_f64<0xB1>(v);     // sum over the 16 lanes (columns) of the row group
+        v += bcx_dpp_f64<0x4E>(v);
+        v += bcx_dpp_f64<0x141>(v);
+        v += bcx_dpp_f64<0x140>(v);
+        if (li == 0) mom_st(&work[(size_t)ct * Spad + sr], v);
       }
-      v += bcx_dpp_f64<0xB1>(v);     // sum over the 16 lanes (columns) of the row group
-      v += bcx_dpp_f64<0x4E>(v);
-      v += bcx_dpp_f64<0x141>(v);
-      v += bcx_dpp_f64<0x140>(v);
-      if (li == 0) mom_st(&work[(size_t)ct * Spad + sr], v);
     }
   }
   unsigned* counter = (unsigned*)(work + (size_t)nct * Spad);
@@ -327,13 +336,13 @@ extern "C" int bcx_project_colsum_moments(void* stream, const void* M_dev, int64
   double* tbar = work + (size_t)nct * Spad + 1;
   hipStream_t st = (hipStream_t)stream;
   hipLaunchKernelGGL(moments_mean_kernel, dim3((D + 63) / 64), dim3(256), 0, st, (const double*)theta_dev, (int)S, (int)ldt, (int)D, tbar);
-  const int waves = nct * (Spad / 16);
+  const int tiles = nct * (Spad / 16);
   const bool al = ((uintptr_t)theta_dev % 16 == 0) && ldt % 2 == 0;
   if (al)
-    hipLaunchKernelGGL(moments_quad_kernel<true>, dim3((waves + 3) / 4), dim3(256), 0, st, (const double*)M_dev, ldm, (int)D, (int)ycol,
+    hipLaunchKernelGGL(moments_quad_kernel<true>, dim3(tiles), dim3(256), 0, st, (const double*)M_dev, ldm, (int)D, (int)ycol,
                        (const double*)theta_dev, (int)S, (int)ldt, (const double*)tbar, sigsq, (double*)colsum_dev, work, nct, Spad);
   else
-    hipLaunchKernelGGL(moments_quad_kernel<false>, dim3((waves + 3) / 4), dim3(256), 0, st, (const double*)M_dev, ldm, (int)D, (int)ycol,
+    hipLaunchKernelGGL(moments_quad_kernel<false>, dim3(tiles), dim3(256), 0, st, (const double*)M_dev, ldm, (int)D, (int)ycol,
                        (const double*)theta_dev, (int)S, (int)ldt, (const double*)tbar, sigsq, (double*)colsum_dev, work, nct, Spad);
   MOM_HIP(hipGetLastError());
   return BCX_OK;

@@ -675,6 +675,77 @@ __global__ __launch_bounds__(256) void center_kernel(double* out, int64_t ldo, i
   }
 }
 
+// A handful of rows (the coreset points SparseVI projects at every ADAM step, sparsevi.py:38-39): one workgroup per row, a
+// thread per sample -- x_row in LDS, the sample's parameter row streamed with 16-byte loads (D = 301: 151 per thread, L2
+// resident), likelihood, row mean over the workgroup, centred values stored.  One ~6 us launch where the tiled MFMA kernel
+// (one 128-row block, D / 16 barrier-separated stages) takes 35 us plus 5 us for the centring pass; that call sits on the
+// critical path of every ADAM step.  Same arithmetic per value (loglik<FAM>); the dot product is summed in k order.
+#define PJ_SMALL_ROWS 32
+template <int FAM, bool AL>
+__global__ __launch_bounds__(256) void proj_small_kernel(ProjArgs p, int center) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char pj_lds[];
+  __shared__ double scratch[BCX_SCRATCH];
+  double* xs = (double*)pj_lds;                                        // D (+1) doubles
+  const int tid = threadIdx.x, D = p.D, S = p.S;
+  const int Dp = (D + 1) & ~1;
+  constexpr int NTAB = FAM == FAM_POISSON ? PJT_DOUBLES : FAM == FAM_LOGISTIC ? PJT_DOUBLES_LOGISTIC : 0;
+  double* tabw = xs + Dp;
+  const pj_tab_t tab = (pj_tab_t)tabw;
+  const int64_t row = blockIdx.x;
+  const double* z = p.Z + row * p.ldz;
+  for (int k = tid; k < Dp; k += 256) xs[k] = k < D ? z[k] : 0.0;
+  if (NTAB) for (int k = tid; k < NTAB; k += 256) tabw[k] = p.tab[k];
+  const double y = p.ycol >= 0 ? z[p.ycol] : 0.0;
+  const double clin = (FAM == FAM_LINREG) ? -0.5 * log(2.0 * 3.14159265358979323846 * p.param) : 0.0;
+  const double parg = (FAM == FAM_LINREG) ? 1.0 / (2.0 * p.param) : p.param;
+  double yv = y, c0 = clin;
+  if (FAM == FAM_POISSON) {
+    const int yi = (int)y;
+    const bool small_count = (double)yi == y && (unsigned)yi < (unsigned)PJT_NFACT;
+    c0 = small_count ? p.tab[PJT_LFACT + (small_count ? yi : 0)] : pj_lgamma1p_call(y);
+  } else if (FAM == FAM_LINREG) {
+    c0 = fma(-(y * y), parg, clin);
+    yv = 2.0 * y;
+  }
+  __syncthreads();
+  double part[1] = {0.0};
+  double vals[4];                                                      // up to 1024 samples per row stay in registers
+  for (int q = 0; q < 4; ++q) {
+    const int sidx = tid + 256 * q;
+    double m = 0.0;
+    if (sidx < S) {
+      const double* th = p.theta + (size_t)sidx * p.ldt;
+      if (AL) {
+        double m1 = 0.0;
+        int k = 0;
+        for (; k + 8 <= Dp; k += 8) {
+          pv2d t0 = *(const pv2d*)(th + k), t1 = *(const pv2d*)(th + k + 2), t2 = *(const pv2d*)(th + k + 4), t3 = *(const pv2d*)(th + k + 6);
+          m = fma(xs[k], t0.x, m); m1 = fma(xs[k + 1], t0.y, m1);
+          m = fma(xs[k + 2], t1.x, m); m1 = fma(xs[k + 3], t1.y, m1);
+          m = fma(xs[k + 4], t2.x, m); m1 = fma(xs[k + 5], t2.y, m1);
+          m = fma(xs[k + 6], t3.x, m); m1 = fma(xs[k + 7], t3.y, m1);
+        }
+        for (; k < D; ++k) m = fma(xs[k], th[k], m);                  // (the pad column is never read: its x is 0, its theta may be anything)
+        m += m1;
+      } else {
+        for (int k = 0; k < D; ++k) m = fma(xs[k], th[k], m);
+      }
+    }
+    vals[q] = sidx < S ? loglik<FAM>(m, yv, parg, c0, tab) : 0.0;
+    part[0] += vals[q];
+  }
+  double mean = 0.0;
+  if (center) {
+    block_allsum<1>(part, scratch);
+    mean = part[0] / (double)S;
+  }
+  double* out = p.out + row * p.ldo;
+  for (int q = 0; q < 4; ++q) {
+    const int sidx = tid + 256 * q;
+    if (sidx < S) out[sidx] = vals[q] - mean;
+  }
+}
+
 // colsum[s] = sum over the workgroup partials in a fixed order: one workgroup per 64 columns, four
 // partial-index segments per column combined 0..3 (8 independent loads in flight per thread).
 __global__ __launch_bounds__(256) void colsum_reduce_kernel(const double* part, int nparts, int S, double* colsum) {
@@ -989,6 +1060,24 @@ static int project_write(void* stream, int32_t family, const void* Z_dev, int64_
   if (N == 0) return BCX_OK;
   p.out = (double*)out_dev; p.ldo = ldo; p.rowsum = (double*)rowsum_dev;
   hipStream_t st = (hipStream_t)stream;
+  static const bool no_small = getenv("BCX_PROJ_NO_SMALL") != nullptr;    // dev: the tiled kernel for every N
+  if (N <= PJ_SMALL_ROWS && S <= 1024 && D <= 4096 && !no_small) {
+    // a handful of rows: one workgroup per row, likelihood and centring in the same launch (proj_small_kernel)
+    const size_t tabd = family == FAM_POISSON ? PJT_DOUBLES : family == FAM_LOGISTIC ? PJT_DOUBLES_LOGISTIC : 0;
+    if (tabd && !(p.tab = proj_tables())) { g_proj_err = "bcx_project: no device memory for the likelihood tables"; return BCX_ERR_NOMEM; }
+    const size_t lds = ((size_t)((D + 1) & ~1) + tabd) * sizeof(double);
+    const bool al = ((uintptr_t)p.theta % 16 == 0) && p.ldt % 2 == 0;
+    const int cen = center ? 1 : 0;
+#define PJ_SMALL(F)                                                                                                   \
+    do {                                                                                                                \
+      if (al) hipLaunchKernelGGL((proj_small_kernel<F, true>), dim3((unsigned)N), dim3(256), lds, st, p, cen);          \
+      else hipLaunchKernelGGL((proj_small_kernel<F, false>), dim3((unsigned)N), dim3(256), lds, st, p, cen);           \
+    } while (0)
+    if (family == FAM_LOGISTIC) PJ_SMALL(FAM_LOGISTIC); else if (family == FAM_POISSON) PJ_SMALL(FAM_POISSON); else PJ_SMALL(FAM_LINREG);
+#undef PJ_SMALL
+    PROJ_HIP(hipGetLastError());
+    return BCX_OK;
+  }
   int wgrid = 0;
   proj_plan(PMODE_WRITE, family, N, S, proj_aligned(p), &wgrid, &p.team);
   if ((rc = launch_family<PMODE_WRITE>(family, dim3(wgrid), 0, st, p))) return rc;

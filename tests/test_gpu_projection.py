@@ -699,6 +699,29 @@ print(json.dumps({"colsum": [float(v) for v in prj.project_colsum(Z)], "select":
     assert sels[2][1] == sels[0][1] and abs(sels[2][0] - sels[0][0]) <= 1e-12 * abs(sels[0][0])
 
 
+@pytest.mark.parametrize("family", ("logistic", "poisson", "linreg"))
+@pytest.mark.parametrize("N,D,S", ((1, 301, 256), (7, 30, 37), (32, 16, 1000), (33, 16, 1000), (5, 301, 1500)))
+def test_few_rows_take_the_row_per_workgroup_kernel(bc, family, N, D, S):
+    """project() / project_uncentred() of a handful of rows (csrc/proj.hip proj_small_kernel: N <= 32, S <= 1024; one row and
+    one sample beyond, and S beyond, take the tiled kernel) against NumPy, with even and odd parameter row lengths."""
+    rs = np.random.RandomState(N * 1000 + D + S)
+    theta = 0.3 * rs.randn(S, D)
+    if family == "logistic":
+        Z, ll = 1.5 * rs.randn(N, D), logistic_log_likelihood
+    elif family == "poisson":
+        Z = np.hstack((rs.randn(N, D - 1), np.ones((N, 1)), rs.poisson(2.0, size=(N, 1)).astype(np.float64)))
+        ll = poisson_log_likelihood
+    else:
+        Z = np.hstack((rs.randn(N, D), rs.randn(N, 1)))
+        ll = lambda z, th: linreg_log_likelihood(z, th, 0.9)
+    want = ll(Z, theta)
+    prj = bc.DeviceProjector(family, lambda n, w, p: theta, S, sigsq=0.9)
+    scale = np.abs(want).max()
+    np.testing.assert_allclose(prj.project_uncentred(Z).cpu().numpy(), want, rtol=1e-11, atol=1e-12 * scale)
+    want -= want.mean(axis=1)[:, None]
+    np.testing.assert_allclose(prj.project(Z).cpu().numpy(), want, rtol=1e-11, atol=1e-12 * scale)
+
+
 @pytest.mark.parametrize("family,S", (("linreg", 256), ("logistic", 640)))
 def test_write_on_teams_matches_numpy(bc, family, S):
     """project() on a full 512-workgroup grid: the column groups of a row block are written by different workgroups (XCD
