@@ -23,7 +23,7 @@ class HilbertCoreset(Coreset):
         # a device projector feeding a device solver on the full data: take the raw log-likelihoods and let the solver's
         # constructor pass subtract the row means (projector.py:21) -- one pass over N x S less (csrc/ingest.hip)
         fold = (rows is None and hasattr(ll_projector, "project_uncentred")
-                and isinstance(snnls, type) and issubclass(snnls, _DeviceSolver))
+                and isinstance(snnls, type) and issubclass(snnls, _DeviceSolver) and self._accepts(snnls, "center_rows"))
         if fold:
             vecs = ll_projector.project_uncentred(data)
         else:
@@ -43,6 +43,17 @@ class HilbertCoreset(Coreset):
         super().__init__(**kw)
 
     # ---- construction helpers ------------------------------------------------------------
+    @staticmethod
+    def _accepts(fn, keyword):
+        """Does ``fn`` (a class: its __init__) take ``keyword``?  A user subclass of a device solver written against the
+        reference's (A, b) signature does not know ``center_rows``: it then gets the centred vectors of project() instead."""
+        import inspect
+        try:
+            params = inspect.signature(fn).parameters
+        except (TypeError, ValueError):
+            return False
+        return keyword in params or any(q.kind == q.VAR_KEYWORD for q in params.values())
+
     @staticmethod
     def _draw_subsample(n, n_subsample):
         # randint then unique: cheap for huge n, duplicates removed (hilbert.py:16)

@@ -53,7 +53,11 @@ class ShardedHilbertCoreset(Coreset):
                              % (lo, hi, int(local_data.shape[0])))
         self.data, self.group = local_data, group
         self.row_begin, self.row_end = lo, hi
-        fold = n_subsample is None and hasattr(ll_projector, "project_uncentred")
+        # (an engine_factory written for the two-argument load_rows_any gets the centred vectors of project())
+        from .hilbert import HilbertCoreset as _H
+        load = getattr(engine_factory, "load_rows_any", None) if engine_factory is not None else None
+        fold = (n_subsample is None and hasattr(ll_projector, "project_uncentred")
+                and (load is None or _H._accepts(load, "center")))
         if n_subsample is None:
             # a device projector: raw log-likelihoods, centred by the solver's constructor pass (one pass over N x S less)
             vecs = ll_projector.project_uncentred(local_data) if fold else ll_projector.project(local_data)

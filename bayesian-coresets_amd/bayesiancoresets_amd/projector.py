@@ -148,6 +148,12 @@ class DeviceProjector(Projector):
         self._cache_val, self._cache_ref = None, None
         self._mom, self._mom_ref, self._mom_key, self._mom_ok = None, None, None, False
 
+    def release_scratch(self):
+        """Give back the device scratch the fused consumers keep between calls (select: 32 bytes per row and 64-column
+        group; column sums: 2048 x S doubles; the read-back buffer) -- e.g. between experiments on data sets of different
+        sizes.  The next call allocates what it needs again."""
+        self._work, self._sel_work, self._cc_buf, self._mom_work = None, None, None, None
+
     # -- second moments of a data set (linear-regression family): csrc/moments.hip -----------------------------------
     def _moments_for(self, pts, Z):
         """The (D+1) x (D+1) matrix Z^T Z of the data set ``pts`` (device copy ``Z``), formed on first sight of that

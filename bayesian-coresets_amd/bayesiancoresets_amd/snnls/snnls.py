@@ -198,7 +198,10 @@ class DeviceSparseNNLS(SparseNNLS):
 
     @property
     def A(self):
-        """The d x N matrix the solver works on (with ``center_rows`` the centred one, formed on first use)."""
+        """The d x N matrix the solver works on.  With ``center_rows`` (HilbertCoreset behind a device projector: the engine
+        centred the rows while it ingested them and keeps no d x N copy for the caller) the centred matrix is FORMED ON FIRST
+        USE -- a second N x d fp64 array next to the engine's, on the argument's device; ``An`` goes through it too.  Nothing
+        in the build path touches it: read ``Anorms`` / ``weights()`` / ``error()`` instead where that is enough."""
         if not self._center_rows:
             return self._A_arg
         if self._A_centred is None:

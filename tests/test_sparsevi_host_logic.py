@@ -32,6 +32,13 @@ class NumpyFusedProjector(DeviceProjector):
     def project_colsum(self, pts):
         return self._vecs(pts).sum(axis=0)
 
+    def _dev(self, pts):
+        return pts
+
+    def colsum_and_core(self, pts, core):
+        S = self.samples.shape[0]
+        return self.project_colsum(pts), (self._vecs(core) if core is not None and len(core) else np.zeros((0, S)))
+
     def project_select(self, pts, resid, row_ids=None):
         v = self._vecs(pts)
         corrs = v.dot(resid) / np.sqrt((v ** 2).sum(axis=1)) / v.shape[1]
