@@ -34,7 +34,7 @@
 #define PJT_LFACT (PJT_LOG + 129 * 2)  // 256: log(y!) = gammaln(y + 1) for the integer responses y = 0 .. 255 of a Poisson model
 #define PJT_NFACT 256
 #define PJT_DOUBLES (PJT_LFACT + PJT_NFACT)
-#define PJT_DOUBLES_LOGISTIC PJT_LOG   // (the logistic family has neither log nor gammaln)
+#define PJT_DOUBLES_LOGISTIC PJT_LFACT   // (the logistic family has no gammaln; its column sums take ONE log per column and tile: proj.hip)
 #define PJT_BYTES(n) (((n) * 8 + 15) / 16 * 16)
 
 PJM_HD int pjm_hi(double x) {
