@@ -58,8 +58,8 @@ fam) # the other two likelihood families at the shard shape (N=625k, D=300, S=25
      done; done ;;
 xch) # the two exchange modes, two ranks sharing this GPU (what a 1-GPU box can run): per-iteration cost next to one shard
      bash $R/tools/share_gpu_bench.sh 2 200000 512 fw 2000 > $O/exchange_modes_2ranks.txt 2>&1
-     BENCH_SHARE_GPU=1 python $R/bench.py --gpus 2 --steps 300 --warmup 30 --no-cpu-baseline > $O/bench_c4_2ranks_shared_gpu.json 2> $O/bench_c4_2ranks_shared_gpu.err
-     BENCH_SHARE_GPU=1 python $R/bench.py --gpus 8 --steps 100 --warmup 10 --no-cpu-baseline > $O/bench_c4_8ranks_shared_gpu.json 2> $O/bench_c4_8ranks_shared_gpu.err ;;
+     [ -n "$XCH_ONLY_SMALL" ] || BENCH_SHARE_GPU=1 python $R/bench.py --gpus 2 --steps 300 --warmup 30 --no-cpu-baseline > $O/bench_c4_2ranks_shared_gpu.json 2> $O/bench_c4_2ranks_shared_gpu.err
+     [ -n "$XCH_ONLY_SMALL" ] || BENCH_SHARE_GPU=1 python $R/bench.py --gpus 8 --steps 100 --warmup 10 --no-cpu-baseline > $O/bench_c4_8ranks_shared_gpu.json 2> $O/bench_c4_8ranks_shared_gpu.err ;;
 opt) kt optimize python $R/tools/optimize_bench.py
      pmc optimize_mfma "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE" python $R/tools/optimize_bench.py ;;
 probe) [ -x $R/tools/probe/mfma_f64_peak ] || /opt/rocm/bin/hipcc -O3 --offload-arch=gfx950 -o $R/tools/probe/mfma_f64_peak $R/tools/probe/mfma_f64_peak.hip

@@ -2,6 +2,7 @@
 # dev: N ranks sharing cuda:0 (gloo for the host-side collectives): per-iteration cost of the two exchange modes
 # usage: tools/share_gpu_bench.sh <ranks> <rows> <dim> <alg> <steps>
 R=${1:-2}; N=${2:-200000}; D=${3:-512}; ALG=${4:-fw}; K=${5:-2000}
+cd "$(dirname "$0")/.." || exit 1
 for mode in mailbox collective; do
   echo "== $mode"
   BCX_EXCHANGE=$mode BENCH_SHARE_GPU=1 python -m torch.distributed.run --nnodes=1 --nproc-per-node $R --master-addr 127.0.0.1 \
