@@ -679,6 +679,60 @@ def side_legs(args, out, torch, dist, nat):
             out["c5_moments_setup_ms"] = r["config"].get("moments_setup_ms")
 
 
+def mailbox_preflight_child():
+    """`bench.py --mailbox-preflight` (one short-lived helper process per rank, started by mailbox_preflight below): map the
+    peer mailboxes of a tiny row-sharded solver across the ranks' GPUs, run the probe and twenty greedy iterations through
+    the device-side exchange, exit 0.  Anything else -- an exception, a GPU fault that kills the process, a hang past the
+    parent's timeout -- tells the parent that this box cannot run the mailbox exchange."""
+    import torch
+    import torch.distributed as dist
+    from bayesiancoresets_amd import _native as nat
+    from bayesiancoresets_amd.sharded import ShardedSolver
+    world, rank = int(os.environ["WORLD_SIZE"]), int(os.environ["RANK"])
+    dev = 0 if os.environ.get("BENCH_SHARE_GPU") == "1" else int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(dev)
+    dist.init_process_group("gloo")                  # host-side rendezvous only (handles, agreement); the exchange itself is device-side
+    if os.environ.get("BENCH_PREFLIGHT_CRASH") == str(rank):
+        os.abort()                                   # tests: a helper that dies the way a GPU fault kills a process
+    n, d = world * 4096, 64
+    s = ShardedSolver(nat.ALG_FW, n, d, device=dev)
+    g = torch.Generator(device="cuda")
+    g.manual_seed(1234 + s.row_begin)
+    s.load_local(torch.randn(s.n_local, d, dtype=torch.float64, device="cuda", generator=g))
+    torch.cuda.synchronize()
+    if s.finalize(None) != nat.OK:
+        raise SystemExit("preflight: finalize failed")
+    if s.exchange != "mailbox":
+        raise SystemExit("preflight: mailbox unavailable (%s)" % s.probe_info.get("reason"))
+    s.build(20)                                      # (ends with the cross-rank trace check)
+    torch.cuda.synchronize()
+    dist.barrier()
+    dist.destroy_process_group()
+    print("preflight ok: rank %d of %d, exchange %s" % (rank, world, s.exchange), flush=True)
+
+
+def mailbox_preflight(world, rank, local_rank):
+    """Before a multi-GPU run commits its own process to the device-side record exchange (hipIpc-mapped peer mailboxes,
+    system-scope stores over xGMI -- never exercised across physical GPUs on the boxes this was developed on), every rank
+    tries it in a throw-away helper process.  Returns (ok, why).  A helper that crashes or hangs costs the helper, not
+    the benchmark: the run then uses the RCCL all-gather exchange and says so (config.exchange_probe)."""
+    import subprocess
+    env = dict(os.environ)
+    env["MASTER_PORT"] = str((int(os.environ.get("MASTER_PORT", "29500")) + 23) % 65000 + 500)
+    env["BCX_EXCHANGE_TIMEOUT"] = "5"
+    env.pop("BCX_EXCHANGE", None)
+    for k in ("TORCHELASTIC_RUN_ID", "TORCHELASTIC_RESTART_COUNT", "TORCHELASTIC_MAX_RESTARTS", "TORCHELASTIC_USE_AGENT_STORE"):
+        env.pop(k, None)                             # (the helpers rendezvous by themselves, not through the launcher's agent store)
+    try:
+        out = subprocess.run([sys.executable, os.path.abspath(__file__), "--mailbox-preflight"], env=env, capture_output=True, text=True,
+                             timeout=float(os.environ.get("BENCH_PREFLIGHT_TIMEOUT", "180")))
+        ok = out.returncode == 0 and "preflight ok" in out.stdout
+        why = "" if ok else "helper exit code %d: %s" % (out.returncode, (out.stderr or out.stdout).strip().splitlines()[-1:] or "")
+    except subprocess.TimeoutExpired:
+        ok, why = False, "helper did not finish in time"
+    return ok, why
+
+
 def self_launch(args):
     """`python bench.py --gpus N` with N > 1 and no launcher around it: start the N ranks here, one per GPU, under
     torch.distributed.run (RCCL) on 127.0.0.1 and pass rank 0's JSON line through.  Never prints a line for fewer ranks
@@ -703,6 +757,8 @@ def self_launch(args):
 
 
 def main():
+    if "--mailbox-preflight" in sys.argv[1:]:
+        return mailbox_preflight_child()
     args = parse()
     if args.gpus < 1:
         raise SystemExit("--gpus must be >= 1")
@@ -728,12 +784,27 @@ def main():
         raise SystemExit("rank %d: LOCAL_RANK %d but %d visible GPU(s)" % (rank, local_rank, torch.cuda.device_count()))
     torch.cuda.set_device(local_rank)
     backend = None
+    preflight = None
     if world > 1:
+        # one rank per GPU and the exchange mode not forced: try the device-side exchange in helper processes first
+        want = os.environ.get("BENCH_PREFLIGHT", "0" if share else "1") == "1" and args.kind != "sparsevi" \
+            and os.environ.get("BCX_EXCHANGE", "mailbox") == "mailbox"
+        mine = mailbox_preflight(world, rank, local_rank) if want else None
         backend = "gloo" if share else "nccl"
         if share:
             dist.init_process_group("gloo")
         else:
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if want:
+            flag = torch.tensor([0.0 if mine[0] else 1.0], dtype=torch.float64, device="cuda")
+            dist.all_reduce(flag, op=dist.ReduceOp.SUM)
+            failed = int(flag.item())
+            preflight = {"ran": True, "ranks_failed": failed, "this_rank": "ok" if mine[0] else mine[1]}
+            if failed:
+                os.environ["BCX_EXCHANGE"] = "collective"       # every rank alike
+                if rank == 0:
+                    sys.stderr.write("bench.py: mailbox preflight failed on %d rank(s) (rank 0: %s); using the all-gather exchange\n"
+                                     % (failed, "ok" if mine[0] else mine[1]))
     run = run_sparsevi if args.kind == "sparsevi" else run_snnls
     out = run(args, torch, dist, nat, world, rank, local_rank)
     if world == 1 and args.config == "c4" and not args.adhoc and not args.no_side_legs:
@@ -756,6 +827,7 @@ def main():
     if rank == 0:
         # the world the process group itself reports (RCCL ranks when backend == "nccl"), one rank per device
         out["rccl_ranks"] = dist.get_world_size() if (world > 1 and backend == "nccl") else (1 if world == 1 else 0)
+        out["mailbox_preflight"] = preflight
         out["process_group"] = {"backend": backend, "world_size": dist.get_world_size() if world > 1 else 1,
                                 "self_launched": os.environ.get("BENCH_SELF_LAUNCHED") == "1",
                                 "devices_visible": torch.cuda.device_count(), "share_gpu": share}

@@ -94,6 +94,22 @@ def test_peer_mailbox_exchange_matches_one_shard(tmp_path, alg, name):
                 assert np.array_equal(ref[k], r[k]), (world, rank, k)
 
 
+def test_bench_mailbox_preflight_in_helper_processes():
+    """Multi-GPU runs try the device-side exchange in throw-away helper processes first (bench.py mailbox_preflight): a
+    helper that dies -- as a GPU fault would kill it -- costs the helper, and every rank of the benchmark proper then takes
+    the all-gather exchange and says why; a clean preflight leaves the mailbox mode on.  (Ranks share the GPU here.)"""
+    args = ["--rows", "300000", "--dim", "64", "--steps", "10", "--warmup", "5", "--no-cpu-baseline", "--no-side-legs"]
+    one, _ = _run_bench({}, 1, args)
+    ok, _ = _run_bench({"BENCH_SHARE_GPU": "1", "BENCH_PREFLIGHT": "1"}, 2, args)
+    assert ok["mailbox_preflight"] == {"ran": True, "ranks_failed": 0, "this_rank": "ok"}
+    assert ok["config"]["exchange"] == "mailbox" and ok["config"]["final_error"] == one["config"]["final_error"]
+    bad, err = _run_bench({"BENCH_SHARE_GPU": "1", "BENCH_PREFLIGHT": "1", "BENCH_PREFLIGHT_CRASH": "1", "BENCH_PREFLIGHT_TIMEOUT": "60"}, 2, args)
+    assert bad["mailbox_preflight"]["ran"] and bad["mailbox_preflight"]["ranks_failed"] >= 1
+    assert bad["config"]["exchange"] == "collective" and "preflight failed" in err
+    assert bad["config"]["exchange_probe"]["reason"] == "BCX_EXCHANGE=collective"
+    assert bad["config"]["final_error"] == one["config"]["final_error"]
+
+
 @pytest.mark.parametrize("alg", (0, 1, 2))
 def test_rows_beyond_the_mailbox_record_use_the_all_gather(tmp_path, alg):
     """Rows of 20000 values: a record no longer fits the LDS staging of the exchange kernels, the mailbox set-up says so and
