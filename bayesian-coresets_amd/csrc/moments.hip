@@ -278,7 +278,7 @@ static void moments_plan(int64_t N, int C, int* nblk, int* nslices, int64_t* row
   // two workgroups per CU are resident; two rounds of them, and never fewer than 8 chunks per slice
   int64_t sl = std::max<int64_t>(1, (int64_t)(4 * cus) / npairs);
   sl = std::min<int64_t>(sl, std::max<int64_t>(1, chunks / 8));
-  *rows_per_slice = (chunks + sl - 1) / sl * MOM_ROWS;
+  *rows_per_slice = std::max<int64_t>(MOM_ROWS, (chunks + sl - 1) / sl * MOM_ROWS);      // (N = 0: one empty slice, M = 0)
   *nslices = (int)std::max<int64_t>(1, (N + *rows_per_slice - 1) / *rows_per_slice);
 }
 

@@ -470,12 +470,13 @@ def omp_fields(args, solver):
 
 def measured_traffic(args, n_local):
     """HBM bytes per scan launch from the committed PMC pass (profiles/scan_traffic.json) -- only if that pass was taken
-    with THIS tree's kernel sources (stamp = tools/stamp.py); otherwise null rather than a stale constant."""
+    with THIS tree's scan kernel (csrc/scan.hip, its headers and the compiler flags: tools/stamp.py kernel_digest);
+    otherwise null rather than a stale constant."""
     tpath = os.path.join(ROOT, "profiles", "scan_traffic.json")
     try:
-        from tools.stamp import source_digest
+        from tools.stamp import source_digest, kernel_digest
         tj = json.load(open(tpath))
-        if tj.get("_stamp") != source_digest():
+        if tj.get("_stamp_scan", None) != kernel_digest("scan") and tj.get("_stamp") != source_digest():
             return None
         return tj.get("%s_n%d_d%d_%s" % (args.alg, n_local, args.dim, args.dtype))
     except Exception:
@@ -486,9 +487,9 @@ def projection_traffic(n_local, D, S):
     """HBM bytes per full-data projection launch (COLSUM, linear-regression family) from the committed FETCH_SIZE pass,
     under the same stamp rule as the scan's."""
     try:
-        from tools.stamp import source_digest
+        from tools.stamp import source_digest, kernel_digest
         tj = json.load(open(os.path.join(ROOT, "profiles", "scan_traffic.json")))
-        if tj.get("_stamp") != source_digest():
+        if tj.get("_stamp_proj", None) != kernel_digest("proj") and tj.get("_stamp") != source_digest():
             return None
         return tj.get("proj_colsum_linreg_n%d_d%d_s%d" % (n_local, D, S))
     except Exception:

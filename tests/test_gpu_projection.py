@@ -403,7 +403,7 @@ def test_sparsevi_rbf_matches_reference(bc, kind):
         np.testing.assert_allclose(alg.wts, g["step%d_wts" % i], rtol=1e-5, atol=1e-8)
 
 
-@pytest.mark.parametrize("N,C,pad", ((4096, 2, 0), (5000, 22, 1), (33333, 65, 3), (20011, 302, 0), (4100, 130, 2)))
+@pytest.mark.parametrize("N,C,pad", ((4096, 2, 0), (5000, 22, 1), (33333, 65, 3), (20011, 302, 0), (4100, 130, 2), (1, 5, 0), (31, 64, 0), (0, 3, 1)))
 def test_moments_kernel_matches_numpy(bc, N, C, pad):
     """csrc/moments.hip: M = Z^T Z (fp64 MFMA, block pairs of the upper triangle x row slices) against NumPy, for column
     counts around the 64-wide block edges, padded leading dimensions and row counts that leave ragged slices."""
@@ -412,10 +412,10 @@ def test_moments_kernel_matches_numpy(bc, N, C, pad):
     lib = nat.load()
     rs = np.random.RandomState(N + C)
     Z = rs.randn(N, C) * np.exp(rs.randn(C))[None, :]
-    buf = torch.zeros(N, C + pad, dtype=torch.float64, device="cuda")
-    buf[:, :C] = torch.from_numpy(Z).cuda()
+    buf = torch.zeros(max(N, 1), C + pad, dtype=torch.float64, device="cuda")
+    buf[:N, :C] = torch.from_numpy(Z).cuda()
     need = lib.bcx_project_moments_scratch_bytes(N, C)
-    assert need > 0
+    assert need > 0 and need % 8 == 0
     work = torch.empty(need // 8, dtype=torch.float64, device="cuda")
     M = torch.full((C, C + 1), float("nan"), dtype=torch.float64, device="cuda")
     rc = lib.bcx_project_moments(int(torch.cuda.current_stream().cuda_stream), buf.data_ptr(), N, C + pad, C, M.data_ptr(), C + 1,

@@ -1,4 +1,6 @@
-"""Builds profiles/scan_traffic.json entries from rocprofv3 --pmc FETCH_SIZE result databases (scan kernel; also the
+"""(The file carries three stamps: `_stamp` = all kernel sources at the time of the pass, `_stamp_scan` / `_stamp_proj` = the sources
+the scan / projection kernel is built from; bench.py checks the kernel's own.)
+Builds profiles/scan_traffic.json entries from rocprofv3 --pmc FETCH_SIZE result databases (scan kernel; also the
 projection kernel of the c5 line: key proj_colsum_linreg_n<N>_d<D>_s<S>).
 usage: python tools/scan_traffic.py out.json key=path/to/results.db [key=db ...]
 HBM bytes per scan launch = mean FETCH_SIZE (KB) over the scan_kernel dispatches x 1024 x 2 (gfx950 counts a 128-byte
@@ -10,7 +12,7 @@ import sqlite3
 import sys
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from tools.stamp import source_digest
+from tools.stamp import source_digest, kernel_digest
 
 
 def fetch_bytes(db, key):
@@ -36,7 +38,7 @@ def fetch_bytes(db, key):
 def main():
     out = sys.argv[1]
     data = {"_comment": "HBM bytes per scan_kernel launch from rocprofv3 --pmc FETCH_SIZE (separate pass): mean KB x 1024 x 2 (gfx950 "
-                        "half-count correction). Key = alg_nlocal_d_dtype as built by bench.py (proj_colsum_linreg_n_d_s: the projection kernel of the c5 line).", "_stamp": source_digest(), "_sources": {}}
+                        "half-count correction). Key = alg_nlocal_d_dtype as built by bench.py (proj_colsum_linreg_n_d_s: the projection kernel of the c5 line).", "_stamp": source_digest(), "_stamp_scan": kernel_digest("scan"), "_stamp_proj": kernel_digest("proj"), "_sources": {}}
     if os.path.exists(out):
         old = json.load(open(out))
         if old.get("_stamp") == data["_stamp"]:

@@ -9,10 +9,7 @@ import os
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def source_digest():
-    pkg = os.path.join(ROOT, "bayesian-coresets_amd")
-    files = sorted(glob.glob(os.path.join(pkg, "csrc", "*.hip")) + glob.glob(os.path.join(pkg, "csrc", "*.h")))
-    files += [os.path.join(ROOT, "include", "bcx.h"), os.path.join(pkg, "Makefile")]
+def _digest(files):
     h = hashlib.sha256()
     for f in files:
         h.update(os.path.basename(f).encode())
@@ -20,5 +17,23 @@ def source_digest():
     return h.hexdigest()[:16]
 
 
+def source_digest():
+    pkg = os.path.join(ROOT, "bayesian-coresets_amd")
+    files = sorted(glob.glob(os.path.join(pkg, "csrc", "*.hip")) + glob.glob(os.path.join(pkg, "csrc", "*.h")))
+    files += [os.path.join(ROOT, "include", "bcx.h"), os.path.join(pkg, "Makefile")]
+    return _digest(files)
+
+
+def kernel_digest(kind):
+    """Identity of ONE kernel's sources: what a per-launch HBM traffic figure of that kernel depends on -- the kernel's own
+    file, the headers it includes and the compiler flags -- so that an edit elsewhere in csrc/ does not void it.
+    kind: "scan" (csrc/scan.hip) or "proj" (csrc/proj.hip)."""
+    pkg = os.path.join(ROOT, "bayesian-coresets_amd")
+    names = {"scan": ["scan.hip", "dev_util.h", "bcx_internal.h"],
+             "proj": ["proj.hip", "proj_math.h", "dev_util.h", "bcx_internal.h"]}[kind]
+    return _digest([os.path.join(pkg, "csrc", n) for n in names] + [os.path.join(ROOT, "include", "bcx.h"), os.path.join(pkg, "Makefile")])
+
+
 if __name__ == "__main__":
-    print(source_digest())
+    import sys
+    print(kernel_digest(sys.argv[1]) if len(sys.argv) > 1 else source_digest())
