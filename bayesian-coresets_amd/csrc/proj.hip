@@ -200,6 +200,17 @@ template <int CTRL> __device__ __forceinline__ double pj_foldm(double a, double 
   return keep * __longlong_as_double((long long)(((unsigned long long)hi32 << 32) | lo));
 }
 
+// lane rows (16 lanes each) r0 r1 r2 r3 of a and b  ->  a = (a.r0, b.r0, a.r2, b.r2), b = (a.r1, b.r1, a.r3, b.r3)
+__device__ __forceinline__ void pj_swap16(double& a, double& b) {
+  typedef unsigned pj_v2u __attribute__((ext_vector_type(2)));
+  const unsigned long long ua = (unsigned long long)__double_as_longlong(a), ub = (unsigned long long)__double_as_longlong(b);
+  const pj_v2u lo = __builtin_amdgcn_permlane16_swap((unsigned)ua, (unsigned)ub, false, false);
+  const pj_v2u hi = __builtin_amdgcn_permlane16_swap((unsigned)(ua >> 32), (unsigned)(ub >> 32), false, false);
+  const unsigned al = lo.x, bl = lo.y, ah = hi.x, bh = hi.y;   // (element reads through named scalars: see scan.hip)
+  a = __longlong_as_double((long long)(((unsigned long long)ah << 32) | al));
+  b = __longlong_as_double((long long)(((unsigned long long)bh << 32) | bl));
+}
+
 struct PjPos {       // one stage of the workgroup's sequence: k stage s of column group cg of row block br
   int s, cg;
   int64_t br;
@@ -222,7 +233,8 @@ __global__ __launch_bounds__(256, 2) void proj_kernel(ProjArgs p) {
   const double parg = (FAM == FAM_LINREG) ? 1.0 / (2.0 * p.param) : p.param;
 
   // Orientation of the wave's 32 rows x 64 columns (see the compute loop): COLSUM / SELECT compute the transposed product.
-  constexpr bool TRP = MODE != PMODE_WRITE;
+  // (WRITE on the 128-column tile runs transposed as well: two data rows per lane instead of eight -- see its epilogue)
+  constexpr bool TRP = MODE != PMODE_WRITE || NCT == 8;
 
   // Block -> tile sequence.  Default: workgroup b takes row blocks b, b + gridDim, ... and walks their column groups
   // itself -- Z is then streamed from HBM once per column group (the 64 workgroups of an XCD push ~20 MB through its 4 MB
@@ -476,7 +488,7 @@ __global__ __launch_bounds__(256, 2) void proj_kernel(ProjArgs p) {
     if (last) {
       // ---- epilogue of tile (br, cg).  f64 C/D layout: D[i = (lane >> 4) + 4 * reg][j = lane & 15] ---------------
       const int64_t r0 = br * PJ_ROWS + 32 * wave;
-      if (!TRP) {
+      if constexpr (!TRP) {
         // i = data row (lk + 4 reg), j = column (li)
         if (cg == 0 || teamed) {
 #pragma unroll
@@ -505,6 +517,82 @@ __global__ __launch_bounds__(256, 2) void proj_kernel(ProjArgs p) {
           for (int e = 0; e < 8; ++e) {
             const int64_t row = r0 + 16 * (e >> 2) + lk + 4 * (e & 3);
             if (col < S && row < p.N) p.out[row * p.ldo + col] = loglik<FAM>(acc[e >> 2][tc][e & 3], yv[e], parg, cp[e], tab);
+          }
+        }
+      } else if constexpr (MODE == PMODE_WRITE) {
+        // WRITE on the 128-column tile, transposed product: i = column (lk + 4 reg within column tile tc), j = data row (li
+        // within row tile tr).  A lane holds 2 data rows x 64 columns: the per-row state (response, row constant, output
+        // pointer) is 2 values per lane instead of 8 -- what lets the 128 accumulator registers of this tile fit.  A store
+        // instruction (fixed tr, tc, reg) covers 16 rows x 4 consecutive columns (32-byte pieces); the four registers of a
+        // column tile complete the rows' 128-byte lines back to back, and the write-back L2 hands HBM whole lines.
+        double* orow[2];
+        bool rok[2];
+        double y2[2], c2[2];                     // (formed per tile: nothing of the epilogue is held across the k loop)
+#pragma unroll
+        for (int tr = 0; tr < 2; ++tr) {
+          const int64_t row = r0 + 16 * tr + li;
+          rok[tr] = row < p.N;
+          const double y = (p.ycol >= 0 && rok[tr]) ? p.Z[row * p.ldz + p.ycol] : 0.0;
+          y2[tr] = y;
+          if (FAM == FAM_POISSON) {
+            const int yi = (int)y;
+            const bool small_count = (double)yi == y && (unsigned)yi < (unsigned)PJT_NFACT;
+            c2[tr] = small_count ? tab[PJT_LFACT + (small_count ? yi : 0)] : pj_lgamma1p_call(y);
+            __builtin_amdgcn_sched_barrier(0);   // one at a time
+          } else if (FAM == FAM_LINREG) {
+            c2[tr] = fma(-(y * y), parg, clin);       // the row's own part of the likelihood (loglik)
+            y2[tr] = 2.0 * y;
+          } else {
+            c2[tr] = clin;
+          }
+          orow[tr] = p.out + (rok[tr] ? row : 0) * p.ldo + cg * COLS + lk;
+        }
+        if constexpr (FAM != FAM_LINREG) {
+#pragma unroll
+          for (int tc = 0; tc < NCT; ++tc) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const bool cvalid = cg * COLS + 16 * tc + lk + 4 * r < S;
+#pragma unroll
+              for (int tr = 0; tr < 2; ++tr) {
+                const double v = loglik<FAM>(acc[tr][tc][r], y2[tr], parg, c2[tr], tab);
+                if (cvalid && rok[tr]) orow[tr][16 * tc + 4 * r] = v;
+              }
+              // (transcendental epilogues: two values per scheduling region, as in the column sums of this tile)
+              __builtin_amdgcn_sched_barrier(0);
+            }
+          }
+        } else {
+          // 16-byte stores: lane rows lk and lk ^ 1 exchange one register each (v_permlane16_swap), after which a lane holds
+          // two ADJACENT columns -- even lk: (lk + 4 r, lk + 4 r + 1), odd lk: (lk - 1 + 4 r2, lk + 4 r2) -- and a store
+          // instruction covers 16 rows x 8 consecutive columns (64-byte pieces), half as many instructions.  On one box, N = 2M,
+          // D = 301, S = 256: 56.2 TFLOP/s against 54.0 with 8-byte stores (59.3 with the stores left out; the 64-column tile
+          // of round 3: 52).  The transcendental families measured no gain from it (four values per scheduling region) and keep
+          // the 8-byte form.
+          const bool pair_ok = (p.ldo & 1) == 0 && ((uintptr_t)p.out & 15) == 0;
+          const bool odd = (lk & 1) != 0;
+#pragma unroll
+          for (int tc = 0; tc < NCT; ++tc) {
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+              const int cbase = 16 * tc + 4 * (2 * h + (odd ? 1 : 0)) - (odd ? 1 : 0);     // relative to orow (which carries + lk)
+              const bool c0ok = cg * COLS + lk + cbase < S, c1ok = cg * COLS + lk + cbase + 1 < S;
+#pragma unroll
+              for (int tr = 0; tr < 2; ++tr) {
+                double a = loglik<FAM>(acc[tr][tc][2 * h], y2[tr], parg, c2[tr], tab);
+                double b = loglik<FAM>(acc[tr][tc][2 * h + 1], y2[tr], parg, c2[tr], tab);
+                if (pair_ok) {
+                  pj_swap16(a, b);
+                  if (rok[tr]) {
+                    if (c1ok) *(pv2d*)(orow[tr] + cbase) = (pv2d){a, b};
+                    else if (c0ok) orow[tr][cbase] = a;
+                  }
+                } else if (rok[tr]) {
+                  if (cg * COLS + 16 * tc + lk + 8 * h < S) orow[tr][16 * tc + 8 * h] = a;
+                  if (cg * COLS + 16 * tc + lk + 8 * h + 4 < S) orow[tr][16 * tc + 8 * h + 4] = b;
+                }
+              }
+            }
           }
         }
       } else {
@@ -999,7 +1087,7 @@ extern "C" int bcx_project_profile_read(double* ms_total, int64_t* launches, dou
 // padded columns over 64-wide groups (54 against 50 TFLOP/s at the configs[4] shard shape).  Everything else keeps 64:
 // SELECT's per-row moments and the transcendental epilogues (logistic, Poisson) spill with 128 accumulator VGPRs and
 // measured slower (logistic D=300: 29 against 35 TFLOP/s), WRITE holds eight rows per lane.
-static int proj_nct(int mode, int family, int S, bool aligned = true) {
+static int proj_nct(int mode, int family, int S, bool aligned, int D) {
   // SELECT on the 128-column tile spilled ~200 registers in every family in round 2.  Since the row moments moved to
   // per-column-group records the linear-regression instantiation parks 24 VGPRs of request-pointer state (12 stores, 13
   // loads per launch-long loop body, none between the MFMAs of a group) and is the faster one: N = 5M, D = 301, S = 256
@@ -1007,6 +1095,12 @@ static int proj_nct(int mode, int family, int S, bool aligned = true) {
   // (logistic SELECT at 128: 231 spilled VGPRs).  BCX_PROJ_SEL_NCT=4 selects the 64-column tile (dev).
   static const bool sel8 = [] { const char* e = getenv("BCX_PROJ_SEL_NCT"); return !(e && atoi(e) == 4); }();
   if (mode == PMODE_SELECT && family == FAM_LINREG && aligned && sel8) return (S + 127) / 128 * 128 == (S + 63) / 64 * 64 ? 8 : 4;
+  // WRITE on the 128-column tile (round 4, transposed product: two data rows per lane; 16-byte aligned rows only): on one
+  // box, N = 2M, S = 256, D = 300 / 301: linreg 56.3 against 51.5 TFLOP/s, logistic 51.6 / 48.6, Poisson 48.3 / 43.9.  Short
+  // rows (D < 64) are bound by the stores of the N x S output, and there the 64-column tile's 128-byte pieces are the
+  // better ones (logistic D = 10, S = 512: 1.22 against 1.25 ms).  BCX_PROJ_WRITE_NCT=4 selects the 64-column tile (dev).
+  static const bool wr8 = [] { const char* e = getenv("BCX_PROJ_WRITE_NCT"); return !(e && atoi(e) == 4); }();
+  if (mode == PMODE_WRITE && aligned && wr8 && D >= 64) return (S + 127) / 128 * 128 == (S + 63) / 64 * 64 ? 8 : 4;
   if (mode != PMODE_COLSUM) return 4;
   // the 128-column tile exists for the column sums of the linear-regression family and, on 16-byte aligned rows, of the
   // logistic one (round 3: with the series' constants in scalar registers and 32-bit Theta offsets it fits 255 VGPRs;
@@ -1021,9 +1115,9 @@ static int proj_nct(int mode, int family, int S, bool aligned = true) {
 }
 // XCD teams (COLSUM, WRITE) need a grid that covers the 8 XCDs evenly; workgroups of an XCD that do not fill a team stay
 // idle (at most a fifth of them).  Returns the team size = number of column groups, 0 for the one-workgroup walk.
-static int proj_team(int mode, int family, int S, int grid, bool aligned = true) {
+static int proj_team(int mode, int family, int S, int grid, bool aligned, int D) {
   static const bool no_team = getenv("BCX_PROJ_NO_TEAM") != nullptr;   // dev knob
-  const int cols = 16 * proj_nct(mode, family, S, aligned), ngc = (S + cols - 1) / cols;
+  const int cols = 16 * proj_nct(mode, family, S, aligned, D), ngc = (S + cols - 1) / cols;
   return (!no_team && ngc > 1 && grid % 8 == 0 && grid / 8 >= 4 * ngc) ? ngc : 0;
 }
 // Grid and team size of one launch.  Large problems: the persistent grid of proj_grid, teams where they fit.  Small ones
@@ -1031,11 +1125,11 @@ static int proj_team(int mode, int family, int S, int grid, bool aligned = true)
 // projects beside the full data set at every ADAM step, sparsevi.py:35-41): one workgroup per TILE, as teams of one row
 // block each, so the column groups of a row block run side by side instead of one workgroup walking them (k = 4 points,
 // S = 256: 132 -> 35 us per call; that call sits on the critical path of every ADAM step).
-static void proj_plan(int mode, int family, int64_t N, int S, bool aligned, int* grid, int* team) {
+static void proj_plan(int mode, int family, int64_t N, int S, bool aligned, int D, int* grid, int* team) {
   *grid = proj_grid(N);
-  *team = proj_team(mode, family, S, *grid, aligned);
+  *team = proj_team(mode, family, S, *grid, aligned, D);
   static const bool no_team = getenv("BCX_PROJ_NO_TEAM") != nullptr;   // dev knob
-  const int cols = 16 * proj_nct(mode, family, S, aligned), ngc = (S + cols - 1) / cols;
+  const int cols = 16 * proj_nct(mode, family, S, aligned, D), ngc = (S + cols - 1) / cols;
   const int64_t nblk = (N + PJ_ROWS - 1) / PJ_ROWS;
   if (!no_team && *team == 0 && ngc > 1 && N > 0 && nblk * ngc <= 2 * 256) {
     const int per = (int)((nblk + 7) / 8);                     // teams (= row blocks) per XCD
@@ -1049,7 +1143,7 @@ static bool proj_aligned(const ProjArgs& p) {
 }
 template <int MODE> static int launch_family(int family, dim3 grid, size_t extra_lds, hipStream_t st, const ProjArgs& p_in) {
   ProjArgs p = p_in;
-  const int nct = proj_nct(MODE, family, p.S, proj_aligned(p));
+  const int nct = proj_nct(MODE, family, p.S, proj_aligned(p), p.D);
   const size_t tab_bytes = family == FAM_POISSON ? PJT_BYTES(PJT_DOUBLES) : family == FAM_LOGISTIC ? PJT_BYTES(PJT_DOUBLES_LOGISTIC) : 0;
   const size_t shmem = (nct == 8 ? PJ_STAGING_BYTES(8) : PJ_STAGING_BYTES(4)) + extra_lds + tab_bytes;
   if (tab_bytes && !(p.tab = proj_tables())) { g_proj_err = "bcx_project: no device memory for the likelihood tables"; return BCX_ERR_NOMEM; }
@@ -1057,6 +1151,11 @@ template <int MODE> static int launch_family(int family, dim3 grid, size_t extra
   const bool aligned = proj_aligned(p);
   if constexpr (MODE == PMODE_SELECT) {
     if (nct == 8 && family == FAM_LINREG) return launch_one<FAM_LINREG, MODE, 8, true>(true, grid, shmem, st, p);
+  }
+  if constexpr (MODE == PMODE_WRITE) {
+    if (nct == 8 && family == FAM_LINREG) return launch_one<FAM_LINREG, MODE, 8, true>(true, grid, shmem, st, p);
+    if (nct == 8 && family == FAM_LOGISTIC) return launch_one<FAM_LOGISTIC, MODE, 8, true>(true, grid, shmem, st, p);
+    if (nct == 8 && family == FAM_POISSON) return launch_one<FAM_POISSON, MODE, 8, true>(true, grid, shmem, st, p);
   }
   if constexpr (MODE == PMODE_COLSUM) {
     if (nct == 8 && family == FAM_LINREG) return launch_one<FAM_LINREG, MODE, 8>(aligned, grid, shmem, st, p);
@@ -1116,7 +1215,7 @@ static int project_write(void* stream, int32_t family, const void* Z_dev, int64_
     return BCX_OK;
   }
   int wgrid = 0;
-  proj_plan(PMODE_WRITE, family, N, S, proj_aligned(p), &wgrid, &p.team);
+  proj_plan(PMODE_WRITE, family, N, S, proj_aligned(p), D, &wgrid, &p.team);
   if ((rc = launch_family<PMODE_WRITE>(family, dim3(wgrid), 0, st, p))) return rc;
   if (!center) return BCX_OK;
   const int g = (int)std::min<int64_t>((N + 3) / 4, 8192);
@@ -1153,8 +1252,8 @@ extern "C" int bcx_project_colsum(void* stream, int32_t family, const void* Z_de
   hipStream_t st = (hipStream_t)stream;
   int grid = 0;
   p.colpart = (double*)work_dev;
-  proj_plan(PMODE_COLSUM, family, N, S, proj_aligned(p), &grid, &p.team);
-  const size_t cacc = p.team ? (size_t)16 * proj_nct(PMODE_COLSUM, family, S, proj_aligned(p)) : (size_t)S;   // accumulators per wave
+  proj_plan(PMODE_COLSUM, family, N, S, proj_aligned(p), D, &grid, &p.team);
+  const size_t cacc = p.team ? (size_t)16 * proj_nct(PMODE_COLSUM, family, S, proj_aligned(p), D) : (size_t)S;   // accumulators per wave
   if ((rc = launch_family<PMODE_COLSUM>(family, dim3(grid), 4 * cacc * sizeof(double), st, p))) return rc;
   hipLaunchKernelGGL(colsum_reduce_kernel, dim3((S + 63) / 64), dim3(256), 0, st, p.colpart, grid, S, (double*)colsum_dev);
   hipLaunchKernelGGL(colsum_center_kernel, dim3(1), dim3(256), 0, st, S, (double*)colsum_dev);
@@ -1181,13 +1280,13 @@ static int project_select(void* stream, int32_t family, const void* Z_dev, int64
   if (!resid_dev || !result_dev || !work_dev) { g_proj_err = "bcx_project_select: bad output"; return BCX_ERR_ARG; }
   hipStream_t st = (hipStream_t)stream;
   int grid = 0;
-  proj_plan(PMODE_SELECT, family, N, S, proj_aligned(p), &grid, &p.team);
+  proj_plan(PMODE_SELECT, family, N, S, proj_aligned(p), D, &grid, &p.team);
   p.resid = (const double*)resid_dev; p.resid_sum = resid_sum;
   p.best_val = (double*)work_dev; p.best_idx = (int64_t*)((double*)work_dev + 2048);
   // The kernel leaves every column group's share of the row moments (32 bytes per row and group); the arg-max is taken
   // by select_combine_kernel.  On XCD teams the column groups of a row block run side by side (Z streamed once instead
   // of once per column group), otherwise one workgroup walks them; the records are the same.
-  const int cols = 16 * proj_nct(PMODE_SELECT, family, S, proj_aligned(p)), ngc = (S + cols - 1) / cols;
+  const int cols = 16 * proj_nct(PMODE_SELECT, family, S, proj_aligned(p), D), ngc = (S + cols - 1) / cols;
   void* part = part_dev;
   bool own = false;
   if (!part && N > 0) {

@@ -556,11 +556,12 @@ def test_linear_regression_example_cli(tmp_path, alg):
 
 @pytest.mark.parametrize("family", ("logistic", "poisson", "linreg"))
 @pytest.mark.parametrize("N,D,S", ((1, 1, 1), (2, 3, 5), (127, 2, 16), (129, 16, 64), (257, 17, 65), (300, 33, 130), (1031, 48, 200),
-                                   (140, 20, 100), (515, 40, 256), (700, 24, 1100)))
+                                   (140, 20, 100), (515, 40, 256), (700, 24, 1100),
+                                   (257, 64, 65), (300, 81, 200), (515, 72, 256), (260, 64, 1100), (131, 67, 128)))
 def test_projection_tile_edges(bc, family, N, D, S):
     """Shapes around the kernel's tile sizes (128 rows x 64 or -- linreg column sums when S pads to a multiple of 128: S =
     65, 100, 200, 256, 1100 here -- 128 columns x 16 features per stage; S = 1100 also takes the column-sum accumulators past
-    the LDS budget of two workgroups per CU), odd and even leading
+    the LDS budget of two workgroups per CU; project() takes the 128-column tile for rows of 64 features and more), odd and even leading
     dimensions (16-byte and 8-byte operand loads), single row / column / feature: values, column sums and the
     correlation arg-max against NumPy for every consumer."""
     rs = np.random.RandomState(N * 1000 + D * 10 + S)
@@ -738,3 +739,87 @@ def test_write_on_teams_matches_numpy(bc, family, S):
     want -= want.mean(axis=1)[:, None]
     got = bc.DeviceProjector(family, lambda n, w, p: theta, S, sigsq=0.8).project(Z).cpu().numpy()
     np.testing.assert_allclose(got, want, rtol=1e-10, atol=1e-11 * np.abs(want).max())
+
+
+@pytest.mark.parametrize("family", ("logistic", "poisson", "linreg"))
+@pytest.mark.parametrize("pad,shift", ((1, 0), (0, 1), (3, 1), (2, 0)))
+def test_write_into_strided_and_unaligned_outputs(bc, family, pad, shift):
+    """bcx_project_write_raw through the C ABI into an output whose leading dimension is odd and / or whose base is only
+    8-byte aligned (S = 256: the 128-column tile, whose linear-regression epilogue stores 16-byte column pairs when the
+    output allows it and single values otherwise), with rows and columns beyond the matrix left untouched."""
+    import torch
+    rs = np.random.RandomState(77 + pad + 10 * shift)
+    N, D, S = 700, 70, 256
+    X = rs.randn(N, D) * 0.4
+    theta = rs.randn(S, D) * 0.3
+    if family == "logistic":
+        Z, ll = X, logistic_log_likelihood
+    elif family == "poisson":
+        Z, ll = np.hstack((X, rs.poisson(2.0, size=(N, 1)).astype(np.float64))), poisson_log_likelihood
+    else:
+        Z, ll = np.hstack((X, rs.randn(N, 1))), (lambda z, th: linreg_log_likelihood(z, th, 0.8))
+    want = ll(Z.copy(), theta)
+    prj = bc.DeviceProjector(family, lambda n, w, p: theta, S, sigsq=0.8)
+    Zd = prj._dev(Z)
+    ldo = S + pad
+    buf = torch.full((N * ldo + 8,), -7.0, dtype=torch.float64, device=Zd.device)
+    out = buf[shift:shift + N * ldo].view(N, ldo)
+    assert out.data_ptr() % 16 == 8 * (shift % 2)
+    prj._launch(prj._lib.bcx_project_write_raw, prj._common(Zd) + [out.data_ptr(), ldo], Zd)
+    torch.cuda.synchronize()
+    got = out.cpu().numpy()
+    np.testing.assert_allclose(got[:, :S], want, rtol=1e-11, atol=1e-12 * np.abs(want).max())
+    assert np.all(got[:, S:] == -7.0)
+    h = buf.cpu().numpy()
+    assert np.all(h[:shift] == -7.0) and np.all(h[shift + N * ldo:] == -7.0)
+
+
+def test_write_tile_variants_agree():
+    """project() from the 128-column tile (transposed product, the default where S pads to a multiple of 128) and from the
+    64-column tile (BCX_PROJ_WRITE_NCT=4): every value accumulates its D products in the same order in both, so the raw
+    log-likelihoods agree to the last bits; each against NumPy.  One subprocess per tile (the knob is read once)."""
+    import json
+    import subprocess
+    import sys
+    code = r'''
+import json, os, sys
+import numpy as np
+sys.path.insert(0, os.path.join(%r, "bayesian-coresets_amd"))
+sys.path.insert(0, %r)
+import bayesiancoresets_amd as bc
+rs = np.random.RandomState(15)
+N, D = 66000, 65
+X = rs.randn(N, D) * 0.4
+out = {}
+for family, S in (("linreg", 200), ("poisson", 256), ("logistic", 128)):
+    theta = rs.randn(S, D) * 0.3
+    y = rs.randn(N, 1) if family == "linreg" else rs.poisson(2.0, size=(N, 1)).astype(np.float64)
+    Z = X if family == "logistic" else np.hstack((X, y))
+    prj = bc.DeviceProjector(family, lambda n, w, p: theta, S, sigsq=0.8)
+    v = prj.project_uncentred(Z).cpu().numpy()
+    np.save(os.path.join(sys.argv[1], family + ".npy"), v)
+''' % (ROOT, ROOT)
+    import tempfile
+    dirs = []
+    for env in ({}, {"BCX_PROJ_WRITE_NCT": "4"}):
+        e = dict(os.environ)
+        e.update(env)
+        d = tempfile.mkdtemp()
+        r = subprocess.run([sys.executable, "-c", code, d], capture_output=True, text=True, timeout=600, env=e)
+        assert r.returncode == 0, r.stderr[-2000:]
+        dirs.append(d)
+    rs = np.random.RandomState(15)
+    N, D = 66000, 65
+    X = rs.randn(N, D) * 0.4
+    for family, S in (("linreg", 200), ("poisson", 256), ("logistic", 128)):
+        theta = rs.randn(S, D) * 0.3
+        y = rs.randn(N, 1) if family == "linreg" else rs.poisson(2.0, size=(N, 1)).astype(np.float64)
+        Z = X if family == "logistic" else np.hstack((X, y))
+        ll = {"linreg": (lambda z, th: linreg_log_likelihood(z, th, 0.8)), "poisson": poisson_log_likelihood,
+              "logistic": logistic_log_likelihood}[family]
+        want = ll(Z.copy(), theta)
+        a, b = (np.load(os.path.join(d, family + ".npy")) for d in dirs)
+        scale = np.abs(want).max()
+        np.testing.assert_allclose(a, want, rtol=1e-11, atol=1e-12 * scale)
+        np.testing.assert_allclose(b, want, rtol=1e-11, atol=1e-12 * scale)
+        np.testing.assert_allclose(a, b, rtol=1e-13, atol=1e-14 * scale)
