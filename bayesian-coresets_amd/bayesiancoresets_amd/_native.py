@@ -29,7 +29,7 @@ SYMBOLS = (
     "bcx_build_enqueue_exact", "bcx_exchange_export", "bcx_exchange_attach", "bcx_exchange_probe", "bcx_exchange_disable", "bcx_exchange_set_timeout",
     "bcx_set_check_monotone", "bcx_project_profile", "bcx_project_profile_read", "bcx_exchange_stats", "bcx_load_rows_flags", "bcx_project_write_raw", "bcx_omp_stats", "bcx_project_select_ws", "bcx_project_select_scratch_bytes",
     "bcx_project_moments", "bcx_project_colsum_moments", "bcx_project_moments_scratch_bytes",
-    "bcx_project_colsum_moments_scratch_bytes",
+    "bcx_project_colsum_moments_scratch_bytes", "bcx_gram", "bcx_gram_scratch_bytes",
 )
 
 
@@ -145,6 +145,9 @@ def load():
     sigs["bcx_project_profile_read"] = [P(dbl), P(i64), P(dbl)]
     sigs["bcx_project_moments"] = [vp, vp, i64, i64, i32, vp, i64, vp, i64]
     sigs["bcx_project_colsum_moments"] = [vp, vp, i64, i32, i32, vp, i32, i32, dbl, vp, vp]
+    sigs["bcx_gram"] = [vp, vp, i32, i32, i64, vp, i64, vp, i64]
+    lib.bcx_gram_scratch_bytes.restype = ctypes.c_int64
+    lib.bcx_gram_scratch_bytes.argtypes = [i32, i32]
     lib.bcx_project_moments_scratch_bytes.restype = ctypes.c_int64
     lib.bcx_project_moments_scratch_bytes.argtypes = [i64, i32]
     lib.bcx_project_colsum_moments_scratch_bytes.restype = ctypes.c_int64

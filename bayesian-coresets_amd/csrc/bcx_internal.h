@@ -155,6 +155,8 @@ struct bcx_solver {
   double* nn_wbak = nullptr;     // cap: weights before the step (revert on monotone failure)
   double* nn_xr = nullptr;       // 2*cap: row-phase exchange of the OMP step (omp_lh.hip)
   int64_t gram_cap = 0;
+  double* gram_work = nullptr;   // optimize(): slice partials of the Gram kernel (moments.hip), grown on demand
+  size_t gram_work_bytes = 0;
   int64_t k_ub = 0;              // host upper bound of the slot count (grid sizing of the multi-kernel OMP step)
   unsigned long long* grid_counter = nullptr;   // [0] arrival counter of the grid barriers, [1] barrier base of the next OMP step
   uint64_t grid_epoch = 0;       // fused OMP launches since the counter was reset (bcx_build_begin)
@@ -195,6 +197,9 @@ Mailbox bcx_mailbox(const bcx_solver* s);
 int bcx_launch_resume_exact(bcx_solver* s);
 int bcx_launch_error_refresh(bcx_solver* s);
 int bcx_launch_optimize(bcx_solver* s, double tol);
+// moments.hip: G = rows rows^T (k x k, both triangles) on the fp64 matrix cores; work: bcx_gram_rows_scratch_bytes(k, d) bytes
+int64_t bcx_gram_rows_scratch_bytes(int k, int d);
+int bcx_gram_rows(hipStream_t st, const double* rows, int k, int d, int64_t ld, double* G, int64_t ldg, double* work);
 int bcx_scan_grid(const bcx_solver* s);
 
 #ifdef BCX_TIMING

@@ -310,6 +310,184 @@ extern "C" int bcx_project_moments(void* stream, const void* Z_dev, int64_t N, i
   return BCX_OK;
 }
 
+// ---- optimize(): G = V V^T over the k active rows (nnls.hip; snnls.py:82-97) ------------------------------------------------
+// G[i][j] = rows[i] . rows[j] for i, j < k (rows: k rows of d doubles, row stride ld), both triangles, leading dimension ldg.
+// One workgroup per 64 x 64 block of the upper triangle (and slice of the row length, see gram_plan); its four waves own
+// the block's four 32 x 32 quadrants (2 x 2 tiles of v_mfma_f64_16x16x4_f64) -- nothing is combined across waves.  The
+// row length advances in chunks of 32: both operand blocks (64 rows x 32 values, one of them on the diagonal) are staged
+// through LDS transposed (k-major, so that an MFMA operand is a conflict-free 8-byte read per lane: rows 80 doubles apart
+// put lane groups lk and lk + 1 on disjoint bank halves), the next chunk's 16-byte global loads are in flight while this
+// one is multiplied.  With one slice the block goes straight to G (mirror image included); with more the slices leave
+// partial blocks that moments_reduce_kernel adds in slice order.
+template <bool DIRECT>
+__global__ __launch_bounds__(256, 2) void gram_tile_kernel(const double* __restrict__ V, int k, int d, int64_t ld, int nblk,
+                                                           int64_t len_per_slice, int pshift, double* __restrict__ part,
+                                                           double* __restrict__ G, int64_t ldg) {
+  __shared__ double sA[MOM_ROWS * MOM_LDS_LD];
+  __shared__ double sB[MOM_ROWS * MOM_LDS_LD];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 15, lk = lane >> 4;
+  const int npairs = nblk * (nblk + 1) / 2;
+  // Workgroup -> block.  A 64 x 64 block re-reads 1 KiB of rows per 8 Ki flops, and the blocks of one launch share rows only
+  // through the L2 of their XCD (4 MiB; the k x d matrix of a large support does not fit): in block-row order every
+  // workgroup streams its two row panels from beyond L2.  The blocks can therefore be dealt out in P x P patches, one patch per
+  // XCD at a time: workgroups b, b + 8, ... sit on the same XCD (round-robin dispatch: a speed assumption, not a correctness
+  // one) and take the P^2 blocks of a patch, which share P + P row panels.  Patch positions below the diagonal or beyond
+  // the matrix stay idle.  (It matters little -- gram_plan: the panels come out of the infinity cache fast enough, and what
+  // bounds the large supports is the 16x16x4 instruction form itself, 47.6 TFLOP/s on this chip: 41-42 measured.)
+  const int P = 1 << pshift, PP = P * P;                           // patch edge in blocks (gram_plan: 8 for large supports ... 1)
+  const int nsb = (nblk + P - 1) >> pshift, nsu = nsb * (nsb + 1) / 2, per_slice = (nsu + 7) / 8 * PP;
+  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+  const int slice = slot / per_slice, s2 = slot - slice * per_slice;
+  const int sb = (s2 / PP) * 8 + ((xcd + slice) & 7), tin = s2 % PP;   // (rotated by the slice: the last, partial group of patches lands on different XCDs)
+  if (sb >= nsu) return;
+  int t = sb, SI = 0;
+  while (t >= nsb - SI) { t -= nsb - SI; ++SI; }
+  const int I = SI * P + (tin >> pshift), J = (SI + t) * P + (tin & (P - 1));
+  if (I >= nblk || J >= nblk || I > J) return;
+  const int pair = I * nblk - I * (I - 1) / 2 + (J - I);           // block-row order: what moments_reduce_kernel indexes by
+  const bool diag = I == J;
+  const int64_t c_begin = (int64_t)slice * len_per_slice;
+  const int64_t c_end = c_begin + len_per_slice < d ? c_begin + len_per_slice : d;
+  // staging: thread -> (row of the block = tid / 4, values 2 (tid % 4) + 8 j (+1), j = 0..3 of the chunk): 16-byte pieces along
+  // the stored rows, the four threads of a row read 64 contiguous bytes per j (8-byte loads when rows are not 16-byte aligned)
+  const int srow = tid >> 2, sk0 = 2 * (tid & 3);
+  const bool ra_ok = I * MOM_BLK + srow < k, rb_ok = J * MOM_BLK + srow < k;
+  const double* za = V + (size_t)(I * MOM_BLK + (ra_ok ? srow : 0)) * ld;
+  const double* zb = V + (size_t)(J * MOM_BLK + (rb_ok ? srow : 0)) * ld;
+  const bool al16 = (ld & 1) == 0 && ((uintptr_t)V & 15) == 0;
+  // (two register sets -- the loads of chunks c + 1 and c + 2 in flight -- measured slower: 163 VGPRs, one workgroup fewer per CU)
+  double ra[8], rb[8];
+  auto fetch = [&](int64_t c0) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int64_t c = c0 + sk0 + 8 * j;                        // even: c0 is a multiple of 32
+      const bool ok0 = c < c_end, ok1 = c + 1 < c_end;
+      if (al16 && ok1) {
+        const double2 va = *(const double2*)(za + c);
+        ra[2 * j] = ra_ok ? va.x : 0.0; ra[2 * j + 1] = ra_ok ? va.y : 0.0;
+        if (!diag) { const double2 vb = *(const double2*)(zb + c); rb[2 * j] = rb_ok ? vb.x : 0.0; rb[2 * j + 1] = rb_ok ? vb.y : 0.0; }
+      } else {
+        const int64_t q0 = ok0 ? c : c_begin, q1 = ok1 ? c + 1 : c_begin;
+        ra[2 * j] = (ok0 && ra_ok) ? za[q0] : 0.0; ra[2 * j + 1] = (ok1 && ra_ok) ? za[q1] : 0.0;
+        if (!diag) { rb[2 * j] = (ok0 && rb_ok) ? zb[q0] : 0.0; rb[2 * j + 1] = (ok1 && rb_ok) ? zb[q1] : 0.0; }
+      }
+    }
+  };
+  mv4d acc[2][2];
+#pragma unroll
+  for (int u = 0; u < 2; ++u)
+#pragma unroll
+    for (int v = 0; v < 2; ++v) acc[u][v] = (mv4d){0.0, 0.0, 0.0, 0.0};
+  const int ar = 32 * (wave >> 1), bc = 32 * (wave & 1);     // this wave's quadrant of the block
+  if (c_begin < c_end) fetch(c_begin);
+  for (int64_t c0 = c_begin; c0 < c_end; c0 += MOM_ROWS) {
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const int kk = sk0 + 8 * (q >> 1) + (q & 1);
+      sA[kk * MOM_LDS_LD + srow] = ra[q];
+      if (!diag) sB[kk * MOM_LDS_LD + srow] = rb[q];
+    }
+    __syncthreads();
+    if (c0 + MOM_ROWS < c_end) fetch(c0 + MOM_ROWS);        // next chunk in flight while this one is multiplied
+    const double* pB = diag ? sA : sB;
+#pragma unroll
+    for (int ks = 0; ks < MOM_ROWS / 4; ++ks) {
+      const int kk = ks * 4 + lk;
+      double av[2], bv[2];
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        av[u] = sA[kk * MOM_LDS_LD + ar + 16 * u + li];
+        bv[u] = pB[kk * MOM_LDS_LD + bc + 16 * u + li];
+      }
+#pragma unroll
+      for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int v = 0; v < 2; ++v) acc[u][v] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[u], bv[v], acc[u][v], 0, 0, 0);
+    }
+    __syncthreads();
+  }
+  // f64 C/D layout: col = lane & 15, row = (lane >> 4) + 4 * reg
+#pragma unroll
+  for (int u = 0; u < 2; ++u)
+#pragma unroll
+    for (int v = 0; v < 2; ++v)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int bi = ar + 16 * u + lk + 4 * r, bj = bc + 16 * v + li;
+        if (DIRECT) {
+          const int row = I * MOM_BLK + bi, col = J * MOM_BLK + bj;
+          if (row < k && col < k && (!diag || row <= col)) {      // diagonal block: the upper triangle decides, as in the reduce kernel
+            G[(size_t)row * ldg + col] = acc[u][v][r];
+            if (row != col) G[(size_t)col * ldg + row] = acc[u][v][r];
+          }
+        } else {
+          part[((size_t)slice * npairs + pair) * (MOM_BLK * MOM_BLK) + bi * MOM_BLK + bj] = acc[u][v][r];
+        }
+      }
+}
+
+// Slices of the row length: one (the block goes straight to G) when the blocks alone give every CU two workgroups or the
+// rows are short; otherwise enough of them for ~3 workgroups per CU, never fewer than 4 chunks of 32 per slice.
+static void gram_plan(int k, int d, int* nblk, int* nslices, int64_t* len_per_slice, int* pshift) {
+  *nblk = (k + MOM_BLK - 1) / MOM_BLK;
+  const int npairs = *nblk * (*nblk + 1) / 2;
+  int cus = 256, dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
+  const int64_t chunks = ((int64_t)d + MOM_ROWS - 1) / MOM_ROWS;
+  static const int force = [] { const char* e = getenv("BCX_GRAM_SLICES"); return e ? atoi(e) : 0; }();    // dev knobs
+  static const int force_p = [] { const char* e = getenv("BCX_GRAM_PATCH"); return e ? atoi(e) : -1; }();
+  int64_t sl = 1;
+  if (npairs < 2 * cus) {
+    sl = ((int64_t)3 * cus + npairs - 1) / npairs;
+    sl = std::max<int64_t>(1, std::min<int64_t>(sl, chunks / 4));
+  }
+  if (force > 0) sl = std::max<int64_t>(1, std::min<int64_t>(force, chunks));
+  *len_per_slice = std::max<int64_t>(MOM_ROWS, (chunks + sl - 1) / sl * MOM_ROWS);
+  *nslices = (int)std::max<int64_t>(1, ((int64_t)d + *len_per_slice - 1) / *len_per_slice);
+  // patch edge (measured, k x d = 1497 x 1024 / 2048 x 2048 / 4096 x 1024, us per call: P = 1: 90 / 290 / 420, 2: 91 / 283 / 411,
+  // 4: 110 / 280 / 409, 8: 120 / 344 / 441 -- the row panels mostly come out of the infinity cache either way, large patches
+  // leave XCDs idle at the end)
+  *pshift = *nblk >= 32 ? 1 : 0;
+  if (force_p >= 0 && force_p <= 3) *pshift = force_p;
+}
+int64_t bcx_gram_rows_scratch_bytes(int k, int d) {
+  int nblk, nslices, ps; int64_t lps;
+  gram_plan(k, d, &nblk, &nslices, &lps, &ps);
+  if (nslices == 1) return 8;                                    // (unused)
+  return (int64_t)nslices * (nblk * (nblk + 1) / 2) * MOM_BLK * MOM_BLK * (int64_t)sizeof(double);
+}
+int bcx_gram_rows(hipStream_t st, const double* rows, int k, int d, int64_t ld, double* G, int64_t ldg, double* work) {
+  int nblk, nslices, ps; int64_t lps;
+  gram_plan(k, d, &nblk, &nslices, &lps, &ps);
+  const int npairs = nblk * (nblk + 1) / 2;
+  const int P = 1 << ps, nsb = (nblk + P - 1) / P, nsu = nsb * (nsb + 1) / 2;
+  const unsigned grid = (unsigned)((nsu + 7) / 8 * P * P * 8 * nslices);      // (gram_tile_kernel: patches of blocks, one per XCD at a time)
+  if (nslices == 1) {
+    hipLaunchKernelGGL(gram_tile_kernel<true>, dim3(grid), dim3(256), 0, st, rows, k, d, ld, nblk, lps, ps, (double*)nullptr, G, ldg);
+  } else {
+    hipLaunchKernelGGL(gram_tile_kernel<false>, dim3(grid), dim3(256), 0, st, rows, k, d, ld, nblk, lps, ps, work, G, ldg);
+    hipLaunchKernelGGL(moments_reduce_kernel, dim3(npairs), dim3(256), 0, st, (const double*)work, nblk, nslices, k, G, ldg);
+  }
+  return hipGetLastError() == hipSuccess ? BCX_OK : BCX_ERR_HIP;
+}
+// The same through the C ABI (include/bcx.h): the dense re-weight's Gram as an operator of its own.
+extern "C" int64_t bcx_gram_scratch_bytes(int32_t k, int32_t d) {
+  if (k < 1 || d < 1 || k > BCX_GRAM_MAX_ROWS) return -1;
+  return bcx_gram_rows_scratch_bytes(k, d);
+}
+extern "C" int bcx_gram(void* stream, const void* rows_dev, int32_t k, int32_t d, int64_t ld, void* G_dev, int64_t ldg,
+                        void* work_dev, int64_t work_bytes) {
+  if (!rows_dev || !G_dev || !work_dev || k < 1 || d < 1 || k > BCX_GRAM_MAX_ROWS || ld < d || ldg < k) {
+    bcx_project_set_error("bcx_gram: bad arguments");
+    return BCX_ERR_ARG;
+  }
+  if (work_bytes < bcx_gram_rows_scratch_bytes(k, d)) { bcx_project_set_error("bcx_gram: scratch too small"); return BCX_ERR_ARG; }
+  const int rc = bcx_gram_rows((hipStream_t)stream, (const double*)rows_dev, k, d, ld, (double*)G_dev, ldg, (double*)work_dev);
+  if (rc != BCX_OK) bcx_project_set_error("bcx_gram: kernel launch failed");
+  return rc;
+}
+
 // Doubles of scratch bcx_project_colsum_moments needs: the (column tile, sample) partials, thetabar, the arrival counter.
 static void colsum_plan(int D, int S, int* nct, int* Spad) { *nct = (D + 15) / 16; *Spad = (S + 15) / 16 * 16; }
 extern "C" int64_t bcx_project_colsum_moments_scratch_bytes(int32_t D, int32_t S) {

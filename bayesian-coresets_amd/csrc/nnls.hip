@@ -777,11 +777,24 @@ int bcx_launch_optimize(bcx_solver* s, double tol) {
   BCX_HIP(hipMemcpy(&h, s->st, sizeof h, hipMemcpyDeviceToHost));
   const int k = h.k;
   if (k > 0) {
-    const int nblk = (k + 31) / 32;
-    const int nwave = nblk * (nblk + 1) / 2;
-    hipLaunchKernelGGL(gram_mfma_kernel, dim3((nwave + 3) / 4), dim3(256), 0, s->stream, s->act_rows, k,
-                       s->cfg.d, s->gram, (int64_t)s->gram_cap, nblk);
-    BCX_HIP(hipGetLastError());
+    static const bool old_gram = getenv("BCX_GRAM_DIRECT") != nullptr;     // dev: round 2's kernel (operands straight from L2)
+    const size_t need = (size_t)bcx_gram_rows_scratch_bytes(k, s->cfg.d);
+    if (!old_gram && s->gram_work_bytes < need) {
+      if (s->gram_work) BCX_HIP(hipFree(s->gram_work));
+      s->gram_work = nullptr; s->gram_work_bytes = 0;
+      BCX_HIP(hipMalloc((void**)&s->gram_work, need));
+      s->gram_work_bytes = need;
+    }
+    if (old_gram) {
+      const int nblk = (k + 31) / 32;
+      const int nwave = nblk * (nblk + 1) / 2;
+      hipLaunchKernelGGL(gram_mfma_kernel, dim3((nwave + 3) / 4), dim3(256), 0, s->stream, s->act_rows, k,
+                         s->cfg.d, s->gram, (int64_t)s->gram_cap, nblk);
+      BCX_HIP(hipGetLastError());
+    } else {
+      const int rc = bcx_gram_rows(s->stream, s->act_rows, k, s->cfg.d, (int64_t)s->cfg.d, s->gram, (int64_t)s->gram_cap, s->gram_work);
+      if (rc != BCX_OK) { s->err = "optimize: Gram kernel launch failed"; return rc; }
+    }
   }
   if (k > 0) {
     // incremental Lawson-Hanson on the double-double inverse (omp_lh.hip); where its closing Newton check fails -- or its

@@ -246,6 +246,15 @@ int bcx_project_moments(void* stream, const void* Z_dev, int64_t N, int64_t ldz,
                         void* work_dev, int64_t work_bytes);
 int bcx_project_colsum_moments(void* stream, const void* M_dev, int64_t ldm, int32_t D, int32_t ycol,
                                const void* theta_dev, int32_t S, int32_t ldt, double sigsq, void* colsum_dev, void* work_dev);
+/* The dense re-weight's Gram matrix as an operator of its own (optimize() forms it over the active rows, snnls.py:82-97:
+ * `nnls(A[:, active], b)` solves the normal equations of that k-column block): G_dev (k x ldg doubles, both triangles) =
+ * V V^T for the k rows of d doubles at rows_dev (row stride ld >= d), on the fp64 matrix cores; the d products of an entry
+ * are summed in a fixed order (64 x 64 blocks of G, slices of the row length added in slice order).  k <= BCX_GRAM_MAX_ROWS;
+ * work_dev: bcx_gram_scratch_bytes(k, d) bytes.  Errors: bcx_project_last_error(). */
+#define BCX_GRAM_MAX_ROWS 16384
+int64_t bcx_gram_scratch_bytes(int32_t k, int32_t d);
+int bcx_gram(void* stream, const void* rows_dev, int32_t k, int32_t d, int64_t ld, void* G_dev, int64_t ldg,
+             void* work_dev, int64_t work_bytes);
 const char* bcx_project_last_error(void);
 /* Measurement: hipEvents around the projection kernel alone, recorded on the stream the kernel is launched on.
  * bcx_project_profile(1) starts timing every later projection launch of the calling host thread, (0) stops;

@@ -823,3 +823,38 @@ for family, S in (("linreg", 200), ("poisson", 256), ("logistic", 128)):
         np.testing.assert_allclose(a, want, rtol=1e-11, atol=1e-12 * scale)
         np.testing.assert_allclose(b, want, rtol=1e-11, atol=1e-12 * scale)
         np.testing.assert_allclose(a, b, rtol=1e-13, atol=1e-14 * scale)
+
+
+@pytest.mark.parametrize("k,d,pad", ((1, 1, 0), (5, 3, 1), (64, 32, 0), (65, 33, 0), (100, 100, 0), (130, 257, 1), (200, 129, 0), (333, 1000, 2),
+                                     (1497, 1024, 0), (700, 8192, 0), (2100, 64, 0)))
+def test_gram_operator_matches_numpy(bc, k, d, pad):
+    """bcx_gram (csrc/moments.hip, the transposed-layout instance of the second-moment kernel): G = V V^T of k rows of d
+    doubles against NumPy -- block edges (k around multiples of 64), slice edges (d around multiples of 32), odd row strides
+    (8-byte staging loads) and padded ones, both triangles written, nothing outside the k x k block touched."""
+    import torch
+    from bayesiancoresets_amd import _native as nat
+    lib = nat.load()
+    rs = np.random.RandomState(k * 7 + d)
+    V = rs.randn(k, d)
+    ld = d + pad
+    buf = torch.zeros((k, ld), dtype=torch.float64, device="cuda")
+    buf[:, :d] = torch.from_numpy(V).cuda()
+    if pad:
+        buf[:, d:] = float("nan")                      # (the pad is never read)
+    ldg = k + 3
+    G = torch.full((k, ldg), -5.0, dtype=torch.float64, device="cuda")
+    need = int(lib.bcx_gram_scratch_bytes(k, d))
+    assert need > 0
+    work = torch.empty((need + 7) // 8, dtype=torch.float64, device="cuda")
+    st = int(torch.cuda.current_stream().cuda_stream)
+    rc = lib.bcx_gram(st, buf.data_ptr(), k, d, ld, G.data_ptr(), ldg, work.data_ptr(), work.numel() * 8)
+    assert rc == 0, lib.bcx_project_last_error()
+    torch.cuda.synchronize()
+    got = G.cpu().numpy()
+    want = V @ V.T
+    np.testing.assert_allclose(got[:, :k], want, rtol=1e-12, atol=1e-12 * np.abs(want).max())
+    assert np.array_equal(got[:, :k], got[:, :k].T)          # the mirror image is a copy
+    assert np.all(got[:, k:] == -5.0)
+    # argument checks: scratch too small, too many rows
+    assert lib.bcx_gram(st, buf.data_ptr(), k, d, ld, G.data_ptr(), ldg, work.data_ptr(), need - 8) != 0
+    assert lib.bcx_gram_scratch_bytes(20000, 8) == -1
