@@ -333,8 +333,9 @@ __global__ __launch_bounds__(256, 2) void gram_tile_kernel(const double* __restr
   // workgroup streams its two row panels from beyond L2.  The blocks can therefore be dealt out in P x P patches, one patch per
   // XCD at a time: workgroups b, b + 8, ... sit on the same XCD (round-robin dispatch: a speed assumption, not a correctness
   // one) and take the P^2 blocks of a patch, which share P + P row panels.  Patch positions below the diagonal or beyond
-  // the matrix stay idle.  (It matters little -- gram_plan: the panels come out of the infinity cache fast enough, and what
-  // bounds the large supports is the 16x16x4 instruction form itself, 47.6 TFLOP/s on this chip: 41-42 measured.)
+  // the matrix stay idle.  (It matters little -- gram_plan: the panels come out of the infinity cache fast enough.  Large
+  // supports run at 41-43 TFLOP/s; the same loop on v_mfma_f64_4x4x4_4b_f64 with a replicated operand -- 10 LDS reads per
+  // k-step instead of 4 -- measured the same to 1 %, so it is the staging through LDS, not the instruction form, that bounds it.)
   const int P = 1 << pshift, PP = P * P;                           // patch edge in blocks (gram_plan: 8 for large supports ... 1)
   const int nsb = (nblk + P - 1) >> pshift, nsu = nsb * (nsb + 1) / 2, per_slice = (nsu + 7) / 8 * PP;
   const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
