@@ -309,6 +309,34 @@ __global__ __launch_bounds__(THREADS) void omp_lh_kernel(NnlsArgs n, GridSync gs
   __shared__ int s_win, s_ovf, s_flag;
   __shared__ Winner s_winner;
   OMPL_STAMP(st, 0);
+  // The replicated state of the step -- solver scalars, query, b, the passive lists -- does not depend on the resolve phase:
+  // its loads are issued first and ride out their round trip under the resolve phase's own (two dependent round trips
+  // less between the winner and the rows phase).  Registers hold the first PRE_D x THREADS elements of the vectors and
+  // PRE_K x THREADS list entries (every workgroup width covers its slot range); longer ones follow after the resolve.
+  constexpr int PRE_D = 4, PRE_K = 2;
+  double pre_q[PRE_D], pre_b[PRE_D], pre_x[PRE_K];
+  int pre_cs[PRE_K], pre_pos[PRE_K];
+#pragma unroll
+  for (int t = 0; t < PRE_D; ++t) {
+    const int i = tid + t * THREADS;
+    pre_q[t] = i < d ? a.q64[i] : 0.0;
+    pre_b[t] = i < d ? a.b[i] : 0.0;
+  }
+#pragma unroll
+  for (int t = 0; t < PRE_K; ++t) {
+    const int j = tid + t * THREADS;
+    const bool ok = j < kcap && (int64_t)j < n.ldg;          // (inside the allocations whatever k is)
+    pre_cs[t] = ok ? n.plist[j] : 0;
+    pre_pos[t] = ok ? n.ppos[j] : -1;
+    pre_x[t] = ok ? n.x[j] : 0.0;
+  }
+  const int k = st->k;
+  int p = st->np;
+  const double err0 = st->err, bnorm0 = st->bnorm;
+  const int hvalid0 = st->hvalid, hlo0 = st->hlo_valid;
+  // (what the end of the step needs of the solver state -- only workgroup 0's thread 0 changes it, at the very end)
+  const int64_t it0 = st->it, itrs0 = st->itrs;
+  const int since0 = st->since_refresh, no_mono0 = st->no_monotone;
   if (fused) {
     resolve_core<BCX_MAX_PARTIALS / THREADS>(rsv, &s_winner, L.xfs, scratch);          // winner's raw row lands in L.xfs
     if (tid == 0) { s_ovf = s_winner.flags == BCX_REC_OVERFLOW; s_win = s_winner.flags == BCX_REC_VALID ? 0 : -1; }
@@ -325,13 +353,26 @@ __global__ __launch_bounds__(THREADS) void omp_lh_kernel(NnlsArgs n, GridSync gs
   const int64_t rec_row = fused ? s_winner.gidx : (int64_t)rec[1];
   const double rec_norm = fused ? s_winner.norm : rec[2];
   const double* xf = rec + BCX_REC_HDR;
-  const int k = st->k;
-  int p = st->np;
-  const double err0 = st->err, bnorm0 = st->bnorm;
-  const int hvalid0 = st->hvalid, hlo0 = st->hlo_valid;
-  for (int i = tid; i < d; i += blockDim.x) { if (!fused) L.xfs[i] = xf[i]; L.qs[i] = a.q64[i]; L.bs[i] = a.b[i]; }
-  for (int q = tid; q < p; q += blockDim.x) L.cs[q] = n.plist[q];
-  for (int j = tid; j <= k; j += blockDim.x) {
+#pragma unroll
+  for (int t = 0; t < PRE_D; ++t) {
+    const int i = tid + t * THREADS;
+    if (i < d) { L.qs[i] = pre_q[t]; L.bs[i] = pre_b[t]; }
+  }
+  for (int i = tid + PRE_D * THREADS; i < d; i += THREADS) { L.qs[i] = a.q64[i]; L.bs[i] = a.b[i]; }
+  if (!fused) for (int i = tid; i < d; i += THREADS) L.xfs[i] = xf[i];
+#pragma unroll
+  for (int t = 0; t < PRE_K; ++t) {
+    const int j = tid + t * THREADS;
+    if (j < p) L.cs[j] = pre_cs[t];
+    if (j <= k) {
+      const int pj = (j < k && hvalid0) ? pre_pos[t] : -1;
+      L.pos[j] = pj;
+      L.x[j] = pj >= 0 ? pre_x[t] : 0.0;
+      L.fl[j] = 0;
+    }
+  }
+  for (int q = tid + PRE_K * THREADS; q < p; q += THREADS) L.cs[q] = n.plist[q];
+  for (int j = tid + PRE_K * THREADS; j <= k; j += THREADS) {
     const int pj = (j < k && hvalid0) ? n.ppos[j] : -1;
     L.pos[j] = pj;
     L.x[j] = pj >= 0 ? n.x[j] : 0.0;
@@ -621,7 +662,11 @@ __global__ __launch_bounds__(THREADS) void omp_lh_kernel(NnlsArgs n, GridSync gs
   block_allsum<2>(v, scratch);
   const double new_err = sqrt(v[0]);
   int status = BCX_IT_OK;
-  if (checked && !st->no_monotone && new_err > err0) status = BCX_IT_FAIL_MONOTONE;      // snnls.py:56-58
+  if (checked && !no_mono0 && new_err > err0) status = BCX_IT_FAIL_MONOTONE;      // snnls.py:56-58
+  // The usual end of a step -- accepted, more iterations to go, no periodic refresh of xw due -- writes the next select's
+  // query b - xw' (prepare_query, orthopursuit.py:18) in the pass that commits xw', from the copies in LDS: prepare_next
+  // would read the counters, b and xw' back from memory (three dependent round trips, ~2 us of every step).
+  const bool fast_next = status == BCX_IT_OK && it0 + 1 < itrs0 && !(a.refresh_every > 0 && since0 + 1 >= a.refresh_every);
   if (status == BCX_IT_OK) {
     for (int q = tid; q < p; q += blockDim.x) n.plist[q] = L.cs[q];
     for (int j = tid; j < k1; j += blockDim.x) {
@@ -630,7 +675,10 @@ __global__ __launch_bounds__(THREADS) void omp_lh_kernel(NnlsArgs n, GridSync gs
       n.x[j] = pj >= 0 ? L.x[j] : 0.0;
       a.act_w[j] = pj >= 0 ? L.x[j] : 0.0;
     }
-    for (int j = tid; j < d; j += blockDim.x) a.xw[j] = L.qs[j];
+    for (int j = tid; j < d; j += blockDim.x) {
+      a.xw[j] = L.qs[j];
+      if (fast_next) store_query(a, 0, j, L.bs[j] - L.qs[j]);
+    }
     if (tid == 0) {
       st->k = k1;
       st->np = p;
@@ -639,18 +687,17 @@ __global__ __launch_bounds__(THREADS) void omp_lh_kernel(NnlsArgs n, GridSync gs
       st->err = new_err;
       const double nwn = sqrt(v[1]);
       st->nw = nwn == 0.0 ? 1.0 : nwn;
-      st->since_refresh += 1;
-      if (checked && !st->no_monotone) st->retried = 0;
+      st->since_refresh = since0 + 1;
+      if (checked && !no_mono0) st->retried = 0;
+      if (fast_next) st->qscale = new_err;
     }
   } else if (tid == 0) {
     st->hvalid = 0;        // weights were not touched; H and the lists changed: rebuilt from the weights next time
   }
-  __syncthreads();
   if (tid == 0) {
     *base_ptr = G.gs.base + (unsigned long long)G.bi * (unsigned long long)nwg;
-    const int64_t it = st->it;
-    a.tr_sel[it] = f; a.tr_err[it] = st->err; a.tr_status[it] = status;
-    st->it = it + 1;
+    a.tr_sel[it0] = f; a.tr_err[it0] = status == BCX_IT_OK ? new_err : err0; a.tr_status[it0] = status;
+    st->it = it0 + 1;
     st->exact_mode = 0;
     st->omp_mode = OMP_IDLE;
     st->n_omp[0] += 1;
@@ -662,12 +709,14 @@ __global__ __launch_bounds__(THREADS) void omp_lh_kernel(NnlsArgs n, GridSync gs
       else st->retried = 1;
     }
   }
-  __syncthreads();
   OMPL_STAMP(st, 9);
 #ifdef BCX_TIMING
-  const int64_t log_it = st->it - 1;
+  const int64_t log_it = it0;
 #endif
-  if (st->active) { [[clang::always_inline]] prepare_next(a, scratch); }
+  if (!fast_next) {
+    __syncthreads();
+    if (st->active) { [[clang::always_inline]] prepare_next(a, scratch); }
+  }
   OMPL_STAMP(st, 10);
 #ifdef BCX_TIMING
   __syncthreads();

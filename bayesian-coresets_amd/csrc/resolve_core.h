@@ -134,21 +134,48 @@ static __device__ __forceinline__ void resolve_core(const ResolveArgs& a, Winner
   // single candidate on a single shard, whose score nobody reads (the usual case: 1.00-1.01 candidates per iteration).
   const bool unscored = exact || (!a.need_score && nc == 1);
   if (unscored && tid < nc) cscore[tid] = exact ? Lstar : 0.0;
+  // A single candidate that has to be scored (the OMP step compares its score with the negative direction, a row shard
+  // sends it to its peers): the wave that scores it leaves the raw row in LDS / in the record as it reads it, and the
+  // winner's row is not fetched a second time -- one dependent round trip less (the usual case: 1.00-1.01 candidates).
+  const bool stage1 = !unscored && nc == 1;
+  __shared__ double s_nrm;
   for (int c = wave; c < nc && !unscored; c += nwaves) {
     const int64_t i = cand[c];
     const double nrm = a.norms[i];
     double s0 = 0.0, s1 = 0.0;
-    for (int j = lane; j < a.d; j += 64) {
-      // An = A / Anorms element by element (giga.py:13): exactly +-1 for d = 1, so mathematically tied
-      // rows tie bit-for-bit as they do in the reference; stored rows are already normalised
-      double v = raw_elem(a, i, j, 1.0);
-      if (a.A64) v /= nrm;
-      s0 += v * q0[j];
-      if (dual) s1 += v * q1[j];
+    // a lane's elements j = lane, lane + 64, ... are summed in that order (what makes rows that tie mathematically tie bit
+    // for bit, for any number of candidates); the loads of eight of them are in flight together
+    for (int j0 = 0; j0 < a.d; j0 += 512) {
+      double rv[8], qa[8], qb[8];
+#pragma unroll
+      for (int t = 0; t < 8; ++t) {
+        const int j = j0 + 64 * t + lane;
+        const bool ok = j < a.d;
+        // An = A / Anorms element by element (giga.py:13): exactly +-1 for d = 1, so mathematically tied
+        // rows tie bit-for-bit as they do in the reference; stored rows are already normalised
+        rv[t] = ok ? raw_elem(a, i, j, 1.0) : 0.0;
+        qa[t] = ok ? q0[j] : 0.0;
+        qb[t] = (ok && dual) ? q1[j] : 0.0;
+      }
+#pragma unroll
+      for (int t = 0; t < 8; ++t) {
+        const int j = j0 + 64 * t + lane;
+        if (j < a.d) {
+          double v = rv[t];
+          if (stage1) {
+            const double raw = a.A64 ? v : v * nrm;
+            if (xf_lds) xf_lds[j] = raw;
+            if (a.rec) a.rec[BCX_REC_HDR + j] = raw;
+          }
+          if (a.A64) v /= nrm;
+          s0 += v * qa[t];
+          if (dual) s1 += v * qb[t];
+        }
+      }
     }
     s0 = wave_allsum(s0);
     if (dual) s1 = wave_allsum(s1);
-    if (lane == 0) cscore[c] = dual ? giga_score64(s0, s1) : s0;
+    if (lane == 0) { cscore[c] = dual ? giga_score64(s0, s1) : s0; if (stage1) s_nrm = nrm; }
   }
   __syncthreads();
   BCX_STAMP(a.st, 3);
@@ -165,15 +192,17 @@ static __device__ __forceinline__ void resolve_core(const ResolveArgs& a, Winner
   }
   __syncthreads();
   const int64_t wrow = win->lrow;
-  const double nrm = a.norms[wrow];
+  const double nrm = stage1 ? s_nrm : a.norms[wrow];
   if (tid == 0) {
     win->norm = nrm;
     if (a.rec) { a.rec[0] = win->score; a.rec[1] = (double)win->gidx; a.rec[2] = nrm; a.rec[3] = BCX_REC_VALID; }
   }
-  for (int j = tid; j < a.d; j += blockDim.x) {
-    const double raw = raw_elem(a, wrow, j, nrm);
-    if (xf_lds) xf_lds[j] = raw;
-    if (a.rec) a.rec[BCX_REC_HDR + j] = raw;
+  if (!stage1) {
+    for (int j = tid; j < a.d; j += blockDim.x) {
+      const double raw = raw_elem(a, wrow, j, nrm);
+      if (xf_lds) xf_lds[j] = raw;
+      if (a.rec) a.rec[BCX_REC_HDR + j] = raw;
+    }
   }
   __syncthreads();
   BCX_STAMP(a.st, 4);
