@@ -1094,6 +1094,11 @@ static int proj_nct(int mode, int family, int S, bool aligned, int D) {
   // 13.80 against 15.08 ms per call (55.8 against 51.1 TFLOP/s).  The transcendental families stay at 64 columns
   // (logistic SELECT at 128: 231 spilled VGPRs).  BCX_PROJ_SEL_NCT=4 selects the 64-column tile (dev).
   static const bool sel8 = [] { const char* e = getenv("BCX_PROJ_SEL_NCT"); return !(e && atoi(e) == 4); }();
+  // (round 4, with the table forms: logistic / Poisson SELECT on the 128-column tile still spill 225 / 208 VGPRs and run at 16 /
+  // 32 TFLOP/s against 48 / 45 on the 64-column tile.  Tried for the registers they would need: the residual in LDS instead
+  // of per-column global loads (no change in the spills; Poisson + 1 %, linreg - 0.5 %), and recomputing the request pointers
+  // at every stage instead of carrying them (frees 12 VGPRs and the parked ones of the other 128-column instantiations, but
+  // costs 2-4 % in every instantiation).  Neither is in.)
   if (mode == PMODE_SELECT && family == FAM_LINREG && aligned && sel8) return (S + 127) / 128 * 128 == (S + 63) / 64 * 64 ? 8 : 4;
   // WRITE on the 128-column tile (round 4, transposed product: two data rows per lane; 16-byte aligned rows only): on one
   // box, N = 2M, S = 256, D = 300 / 301: linreg 56.3 against 51.5 TFLOP/s, logistic 51.6 / 48.6, Poisson 48.3 / 43.9.  Short
