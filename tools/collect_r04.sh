@@ -8,7 +8,7 @@ S=$(python -c "import json;print(json.load(open('$O/scan_traffic.json')).get('_s
 for f in $(ls $O | grep -v "\.err$"); do
   case $f in
     scan_traffic.json) cp $O/$f profiles/scan_traffic.json;;
-    proj_bench_kernel_times.txt|optimize_times.txt|exchange_modes_2ranks.txt)
+    proj_bench_kernel_times.txt|optimize_times.txt|exchange_modes_2ranks.txt|gram_times.txt|upload_rate.txt|scan_row_lengths.txt|omp_hist_c3.txt|tail_phases.txt)
       { echo "# source digest $D, head $H"; cat $O/$f; } > profiles/r04_$f;;
     *) cp $O/$f profiles/r04_$f;;
   esac

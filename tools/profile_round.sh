@@ -61,7 +61,9 @@ xch) # the two exchange modes, two ranks sharing this GPU (what a 1-GPU box can 
      [ -n "$XCH_ONLY_SMALL" ] || BENCH_SHARE_GPU=1 python $R/bench.py --gpus 2 --steps 300 --warmup 30 --no-cpu-baseline > $O/bench_c4_2ranks_shared_gpu.json 2> $O/bench_c4_2ranks_shared_gpu.err
      [ -n "$XCH_ONLY_SMALL" ] || BENCH_SHARE_GPU=1 python $R/bench.py --gpus 8 --steps 100 --warmup 10 --no-cpu-baseline > $O/bench_c4_8ranks_shared_gpu.json 2> $O/bench_c4_8ranks_shared_gpu.err ;;
 opt) kt optimize python $R/tools/optimize_bench.py
-     pmc optimize_mfma "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE" python $R/tools/optimize_bench.py ;;
+     pmc optimize_mfma "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE" python $R/tools/optimize_bench.py
+     kt gram python $R/tools/gram_bench.py 400,512 999,512 1497,1024 2048,2048 4096,1024
+     pmc gram_mfma "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE" python $R/tools/gram_bench.py 1497,1024 4096,1024 ;;
 probe) [ -x $R/tools/probe/mfma_f64_peak ] || /opt/rocm/bin/hipcc -O3 --offload-arch=gfx950 -o $R/tools/probe/mfma_f64_peak $R/tools/probe/mfma_f64_peak.hip
        $R/tools/probe/mfma_f64_peak > $O/mfma_f64_probe.txt 2>&1
        pmc mfma_f64_probe_pmc "GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES" $R/tools/probe/mfma_f64_peak ;;
