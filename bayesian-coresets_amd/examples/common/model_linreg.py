@@ -156,3 +156,45 @@ def posterior_sampler(mu0, Sig0, sigsq, device=None, seed=None):
         return out[:, :D]
     sampler.posterior = posterior
     return sampler
+
+
+def tangent_space_projector(bc, bV, mu0, Sig0, sigsq):
+    """The EXACT tangent-space projection of this model (examples/linear_regression/main.py:158-185, `LinRegProjector`), as a
+    ``bc.Projector``.  With theta = mu_w + U_w eps the log-likelihood of a point is -(nu - beta.eps)^2 / (2 sigsq),
+    beta = U_w^T x, nu = y - x.mu_w, and its centred version lives in the span of eps and eps eps^T: the vector
+
+        [ nu beta ,  vec(beta beta^T) / sqrt(2) ] / sigsq            (D + D^2 numbers)
+
+    has exactly the inner products Cov_eps(ll_n, ll_m) -- no Monte-Carlo samples.  As in the reference the quadratic block is
+    formed from the projection of beta onto ``bV`` (D x p: leading eigenvectors of X^T X; main.py:110-111), p^2 numbers
+    instead of D^2.  ``update(wts, pts)`` moves the tangent point to the weighted posterior (the prior when the coreset is
+    empty, main.py:172-176).  Rows come out as a host array of D + p^2 columns -- e.g. 10301 at the defaults: a row length
+    the device engine takes as any other."""
+    mu0 = np.asarray(mu0, dtype=np.float64)
+    Sig0 = np.asarray(Sig0, dtype=np.float64)
+    Sig0inv = np.linalg.inv(Sig0)
+    bV = np.asarray(bV, dtype=np.float64)
+
+    class TangentSpaceProjector(bc.Projector):
+        def __init__(self):
+            self.bV = bV
+            self.update(None, None)
+
+        def update(self, wts, pts):
+            if wts is None or pts is None or np.asarray(pts).shape[0] == 0:
+                self.muw, self.USigw = mu0, np.linalg.cholesky(Sig0)           # any M with Sigma = M M^T serves
+            else:
+                self.muw, self.USigw = weighted_posterior(mu0, Sig0inv, sigsq, np.atleast_2d(pts), np.asarray(wts, dtype=np.float64))
+
+        def project(self, pts, grad=False):
+            if grad:
+                raise NotImplementedError("the exact projector has no gradient form (nor has the reference's)")
+            pts = np.atleast_2d(np.asarray(pts, dtype=np.float64))
+            X, Y = pts[:, :-1], pts[:, -1]
+            beta = X.dot(self.USigw)
+            nu = Y - X.dot(self.muw)
+            bp = beta.dot(self.bV)
+            quad = (bp[:, :, None] * bp[:, None, :]).reshape(pts.shape[0], -1)
+            return np.hstack((nu[:, None] * beta, quad / np.sqrt(2.0))) / sigsq
+
+    return TangentSpaceProjector()

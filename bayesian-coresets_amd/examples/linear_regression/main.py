@@ -12,7 +12,9 @@ from the posterior of a sqrt(N)-point subsample), incremental build over the siz
 reverse KL to the true posterior and the relative errors of mean and covariance, stored with the arguments in
 results/<arg-hash>.csv.  Projection runs on the GPU (bc.DeviceProjector "linreg"); --host-sampler keeps the per-step
 weighted-posterior sampler in NumPy exactly as main.py:141-147 writes it, the default draws it on the device too.
-`--alg US` is the uniform-sampling baseline.  The exact tangent-space projector variants (`*-EXACT`) are not offered.
+`--alg US` is the uniform-sampling baseline.  The `*-EXACT` variants (main.py:158-191) use the exact tangent-space projector
+of this model (common/model_linreg.py: `tangent_space_projector`) on the host -- rows of D + proj_dim^2 numbers, no samples --
+with the greedy construction on the device as for any other projector.
 """
 import argparse
 import os
@@ -66,10 +68,21 @@ def run(a):
     muh, Uh = model_linreg.weighted_posterior(mu0, Sig0inv, sigsq, Zhat, np.ones(Zhat.shape[0]))
     sampler_w = model_linreg.posterior_sampler(mu0, Sig0, sigsq, device=None if a.host_sampler else "cuda", seed=a.trial)
     dev = lambda sampler: bc.DeviceProjector("linreg", sampler, S, sigsq=sigsq)
+    def exact(at=None):
+        # main.py:110-111, 158-191: quadratic block in the span of the leading proj_dim eigenvectors of X^T X
+        X = Z[:, :-1]
+        bV = np.linalg.eigh(X.T.dot(X))[1][:, -min(a.proj_dim, X.shape[1]):]
+        prj = model_linreg.tangent_space_projector(bc, bV, mu0, Sig0, sigsq)
+        if at is not None:
+            prj.update(np.ones(at.shape[0]), at)
+        return prj
     build = {
         "SVI": lambda: bc.SparseVICoreset(Z, dev(sampler_w), opt_itrs=a.opt_itrs, step_sched=eval(a.step_sched)),
+        "SVI-EXACT": lambda: bc.SparseVICoreset(Z, exact(), opt_itrs=a.opt_itrs, step_sched=eval(a.step_sched)),
         "GIGA-OPT": lambda: bc.HilbertCoreset(Z, dev(fixed(mup, Up))),
+        "GIGA-OPT-EXACT": lambda: bc.HilbertCoreset(Z, exact(Z)),
         "GIGA-REAL": lambda: bc.HilbertCoreset(Z, dev(fixed(muh, Uh))),
+        "GIGA-REAL-EXACT": lambda: bc.HilbertCoreset(Z, exact(Zhat)),
         "US": lambda: bc.UniformSamplingCoreset(Z),
     }
     alg = build[a.alg]()
@@ -105,7 +118,7 @@ def parser():
     rp = sub.add_parser("run", help="Runs the main computational code")
     rp.set_defaults(func=run)
     ap.add_argument("--data_num", type=int, default=10000)
-    ap.add_argument("--alg", type=str, default="SVI", choices=["SVI", "GIGA-OPT", "GIGA-REAL", "US"])
+    ap.add_argument("--alg", type=str, default="SVI", choices=["SVI", "SVI-EXACT", "GIGA-OPT", "GIGA-OPT-EXACT", "GIGA-REAL", "GIGA-REAL-EXACT", "US"])
     ap.add_argument("--proj_dim", type=int, default=100)
     ap.add_argument("--coreset_size_max", type=int, default=300)
     ap.add_argument("--coreset_num_sizes", type=int, default=6)
