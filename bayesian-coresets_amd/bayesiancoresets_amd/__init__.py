@@ -4,9 +4,9 @@
     alg = bc.HilbertCoreset(X, projector, snnls=bc.snnls.GIGA)
     alg.build(1000); wts, pts, idcs = alg.get()
 
-Namespace mirrors bayesiancoresets/__init__.py:1-2 for the components on that path
-(SURVEY.md section 8); the batch pseudocoreset (BPSVI) is out of scope of this engine."""
-from .coreset import Coreset, HilbertCoreset, UniformSamplingCoreset, SparseVICoreset, ShardedHilbertCoreset
+Namespace mirrors bayesiancoresets/__init__.py:1-2 (the batch pseudocoreset keeps the reference's host loop; its
+N-sized column sums run on the device behind a DeviceProjector)."""
+from .coreset import Coreset, HilbertCoreset, UniformSamplingCoreset, SparseVICoreset, BatchPSVICoreset, ShardedHilbertCoreset
 from .projector import BlackBoxProjector, Projector, DeviceProjector
 from . import snnls
 from . import util

@@ -56,7 +56,8 @@ class DeviceProjector(Projector):
     """
     FAMILIES = {"logistic": 0, "poisson": 1, "linreg": 2}
 
-    def __init__(self, family, sampler, projection_dimension, sigsq=1.0, device=0, group=None, row_offset=0, colsum="auto"):
+    def __init__(self, family, sampler, projection_dimension, sigsq=1.0, device=0, group=None, row_offset=0, colsum="auto",
+                 loglikelihood=None, grad_loglikelihood=None):
         """``group`` / ``row_offset``: row-sharded use (one process per GPU, every rank constructs the
         projector with the same sampler and seeds): ``pts`` passed to the fused consumers are this
         rank's rows starting at global row ``row_offset``; column sums are all-reduced and the arg-max
@@ -67,7 +68,11 @@ class DeviceProjector(Projector):
         "moments": in closed form from the (D+1) x (D+1) second moments of the data, formed once per data set
         (csrc/moments.hip; O(S D^2) per call -- SparseVI asks for 1 + opt_itrs column sums of the SAME data per step);
         "auto" (default): moments, after checking them ONCE per data set against the projection kernel (relative
-        disagreement <= 1e-9 of the largest column sum; otherwise that data set stays on the projection kernel)."""
+        disagreement <= 1e-9 of the largest column sum; otherwise that data set stays on the projection kernel).
+
+        ``loglikelihood`` / ``grad_loglikelihood`` (optional host callbacks with ``BlackBoxProjector``'s signatures):
+        only for ``project(pts, grad=True)`` -- the handful of pseudo-points whose gradients ``BatchPSVICoreset`` asks
+        for (bpsvi.py:38) -- which is evaluated on the host at the current samples; everything N-sized stays on the device."""
         if colsum not in ("auto", "mfma", "moments"):
             raise ValueError("colsum must be 'auto', 'mfma' or 'moments'")
         self.colsum_mode = colsum
@@ -92,6 +97,7 @@ class DeviceProjector(Projector):
             self._world = torch.distributed.get_world_size(group)
         self._cache_val, self._cache_ref = None, None
         self._work = None
+        self.loglikelihood, self.grad_loglikelihood = loglikelihood, grad_loglikelihood
         self.update(np.array([]), np.array([]))
 
     # -- plumbing -----------------------------------------------------------
@@ -243,7 +249,17 @@ class DeviceProjector(Projector):
 
     def project(self, pts, grad=False):
         if grad:
-            raise NotImplementedError("gradient projections are not on the device path")
+            # (projector.py:19-29 on the host, at the samples the device holds)
+            if self.loglikelihood is None or self.grad_loglikelihood is None:
+                raise NotImplementedError("gradient projections are not on the device path: construct the projector with "
+                                          "loglikelihood= and grad_loglikelihood= host callbacks")
+            samples = self.theta.cpu().numpy()
+            pts = np.atleast_2d(np.asarray(pts, dtype=np.float64))
+            lls = self.loglikelihood(pts, samples)
+            lls -= lls.mean(axis=1)[:, np.newaxis]
+            glls = self.grad_loglikelihood(pts, samples)
+            glls -= glls.mean(axis=2)[:, :, np.newaxis]
+            return lls, glls
         torch = self._torch
         Z = self._dev(pts)
         N, S = Z.shape[0], self.theta.shape[0]

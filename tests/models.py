@@ -26,6 +26,15 @@ def linreg_log_likelihood(z, th, sigsq):
     return -0.5 * np.log(2.0 * np.pi * sigsq) - 1.0 / (2.0 * sigsq) * (y ** 2 - 2 * xst * y + xst ** 2)
 
 
+def linreg_grad_z_log_likelihood(z, th, sigsq):
+    """N x S x (D + 1): the gradient the reference's example hands to its projectors (model_linreg.py:12-17: residual / sigsq
+    times [theta, 1] -- as written there, including the sign of the response component)."""
+    z, th = np.atleast_2d(z), np.atleast_2d(th)
+    x, y = z[:, :-1], z[:, -1][:, None]
+    r = (y - x.dot(th.T)) / sigsq
+    return r[:, :, None] * np.hstack((th, np.ones((th.shape[0], 1))))[None, :, :]
+
+
 def linreg_weighted_post(th0, Sig0inv, sigsq, z, w):
     """Gaussian posterior of the weighted linear regression: mean and U with Sigma = U U^T."""
     if w.shape[0] > 0:
