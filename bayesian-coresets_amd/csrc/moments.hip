@@ -134,13 +134,22 @@ __global__ __launch_bounds__(256) void moments_reduce_kernel(const double* __res
   int t = pair, I = 0;
   while (t >= nblk - I) { t -= nblk - I; ++I; }
   const int J = I + t;
-  for (int e = threadIdx.x; e < MOM_BLK * MOM_BLK; e += 256) {
-    double s = 0.0;
-    for (int sl = 0; sl < nslices; ++sl) s += part[((size_t)sl * npairs + pair) * (MOM_BLK * MOM_BLK) + e];
-    const int i = I * MOM_BLK + e / MOM_BLK, j = J * MOM_BLK + e % MOM_BLK;
-    if (i < C && j < C) {
-      if (I != J) { M[(size_t)i * ldm + j] = s; M[(size_t)j * ldm + i] = s; }
-      else if (i <= j) { M[(size_t)i * ldm + j] = s; M[(size_t)j * ldm + i] = s; }   // diagonal block: upper triangle decides
+  // (four entries per thread at a time: their loads of a slice are independent; each entry's slices are added in slice order)
+  for (int e0 = threadIdx.x; e0 < MOM_BLK * MOM_BLK; e0 += 1024) {
+    double s[4] = {0.0, 0.0, 0.0, 0.0};
+    for (int sl = 0; sl < nslices; ++sl) {
+      const double* ps = part + ((size_t)sl * npairs + pair) * (MOM_BLK * MOM_BLK) + e0;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) s[q] += ps[256 * q];
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int e = e0 + 256 * q;
+      const int i = I * MOM_BLK + e / MOM_BLK, j = J * MOM_BLK + e % MOM_BLK;
+      if (i < C && j < C) {
+        if (I != J) { M[(size_t)i * ldm + j] = s[q]; M[(size_t)j * ldm + i] = s[q]; }
+        else if (i <= j) { M[(size_t)i * ldm + j] = s[q]; M[(size_t)j * ldm + i] = s[q]; }   // diagonal block: upper triangle decides
+      }
     }
   }
 }
@@ -383,11 +392,15 @@ __global__ __launch_bounds__(256, 2) void gram_tile_kernel(const double* __restr
   const int ar = 32 * (wave >> 1), bc = 32 * (wave & 1);     // this wave's quadrant of the block
   if (c_begin < c_end) fetch(c_begin);
   for (int64_t c0 = c_begin; c0 < c_end; c0 += MOM_ROWS) {
+    // (the staging stores of a wave go to k-slots 2 p + const, p = lane & 3: 80-double rows put all four on the same banks;
+    // the 16-column halves of every second k-slot pair are swapped -- column ^ 16 -- so the four fall on both bank halves
+    // twice, which is what a 64-lane 8-byte store costs anyway; the reads undo it by taking the other tile)
 #pragma unroll
     for (int q = 0; q < 8; ++q) {
       const int kk = sk0 + 8 * (q >> 1) + (q & 1);
-      sA[kk * MOM_LDS_LD + srow] = ra[q];
-      if (!diag) sB[kk * MOM_LDS_LD + srow] = rb[q];
+      const int sc = srow ^ (((kk >> 1) & 1) << 4);
+      sA[kk * MOM_LDS_LD + sc] = ra[q];
+      if (!diag) sB[kk * MOM_LDS_LD + sc] = rb[q];
     }
     __syncthreads();
     if (c0 + MOM_ROWS < c_end) fetch(c0 + MOM_ROWS);        // next chunk in flight while this one is multiplied
@@ -395,11 +408,12 @@ __global__ __launch_bounds__(256, 2) void gram_tile_kernel(const double* __restr
 #pragma unroll
     for (int ks = 0; ks < MOM_ROWS / 4; ++ks) {
       const int kk = ks * 4 + lk;
+      const int sw = ((kk >> 1) & 1) << 4;                   // (= (lk >> 1) << 4: lane groups lk = 2, 3 read the swapped halves)
       double av[2], bv[2];
 #pragma unroll
       for (int u = 0; u < 2; ++u) {
-        av[u] = sA[kk * MOM_LDS_LD + ar + 16 * u + li];
-        bv[u] = pB[kk * MOM_LDS_LD + bc + 16 * u + li];
+        av[u] = sA[kk * MOM_LDS_LD + ((ar + 16 * u + li) ^ sw)];
+        bv[u] = pB[kk * MOM_LDS_LD + ((bc + 16 * u + li) ^ sw)];
       }
 #pragma unroll
       for (int u = 0; u < 2; ++u)
