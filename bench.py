@@ -678,6 +678,45 @@ def side_legs(args, out, torch, dist, nat):
             out["c5_moments_mfma_frac"] = r["roofline"]["frac"]
             out["c5_moments_same_idcs"] = r["config"]["coreset_idcs"] == out.get("c5_coreset_idcs")
             out["c5_moments_setup_ms"] = r["config"].get("moments_setup_ms")
+    gram_leg(out, torch, nat)
+
+
+def gram_leg(out, torch, nat):
+    """MFMA utilisation of the dense re-weight on the driver's clock: the Gram operator optimize() forms over its active rows
+    (bcx_gram: csrc/moments.hip gram_tile_kernel + moments_reduce_kernel), timed by events on the stream it runs on; flops =
+    the upper triangle's k (k + 1) d, peak = the fp64 MFMA peak.  Flat keys reweight_gram_*."""
+    try:
+        lib = nat.load()
+        st = int(torch.cuda.current_stream().cuda_stream)
+        for k, d in ((1497, 1024), (4096, 1024)):
+            g = torch.Generator(device="cuda")
+            g.manual_seed(99)
+            V = torch.randn(k, d, dtype=torch.float64, device="cuda", generator=g)
+            G = torch.empty(k, k, dtype=torch.float64, device="cuda")
+            need = int(lib.bcx_gram_scratch_bytes(k, d))
+            work = torch.empty((need + 7) // 8, dtype=torch.float64, device="cuda")
+            call = lambda: lib.bcx_gram(st, V.data_ptr(), k, d, d, G.data_ptr(), k, work.data_ptr(), work.numel() * 8)
+            for _ in range(3):
+                if call() != 0:
+                    raise RuntimeError(lib.bcx_project_last_error().decode())
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            reps = 30
+            e0.record()
+            for _ in range(reps):
+                call()
+            e1.record()
+            torch.cuda.synchronize()
+            us = e0.elapsed_time(e1) * 1e3 / reps
+            tf = float(k) * (k + 1) * d / us / 1e6
+            ref = V[:64] @ V.T
+            ok = bool(((G[:64] - ref).abs().max() / ref.abs().max()).item() < 1e-12)
+            out["reweight_gram_k%d_us" % k] = us
+            out["reweight_gram_k%d_tflops" % k] = tf
+            out["reweight_gram_k%d_mfma_frac" % k] = tf / F64_MFMA_PEAK_TF
+            out["reweight_gram_k%d_checked" % k] = ok
+            del V, G, work
+    except Exception as e:      # the headline line must survive a broken side leg
+        out["reweight_gram_error"] = "%s: %s" % (type(e).__name__, e)
 
 
 def mailbox_preflight_child():
