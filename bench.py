@@ -760,6 +760,8 @@ def mailbox_preflight(world, rank, local_rank):
     env = dict(os.environ)
     env["MASTER_PORT"] = str((int(os.environ.get("MASTER_PORT", "29500")) + 23) % 65000 + 500)
     env["BCX_EXCHANGE_TIMEOUT"] = "5"
+    env.setdefault("GLOO_SOCKET_IFNAME", "lo")       # (the helpers' gloo rendezvous stays on the loopback: one node, and the
+                                                     # container's host name need not resolve)
     env.pop("BCX_EXCHANGE", None)
     for k in ("TORCHELASTIC_RUN_ID", "TORCHELASTIC_RESTART_COUNT", "TORCHELASTIC_MAX_RESTARTS", "TORCHELASTIC_USE_AGENT_STORE"):
         env.pop(k, None)                             # (the helpers rendezvous by themselves, not through the launcher's agent store)
