@@ -5,13 +5,11 @@ from . import hilbert as _hilbert
 from . import sampling as _sampling
 from . import sparsevi as _sparsevi
 from . import sharded_hilbert as _sharded
-from . import bpsvi as _bpsvi
 
 Coreset = _base.Coreset
 HilbertCoreset = _hilbert.HilbertCoreset
 UniformSamplingCoreset = _sampling.UniformSamplingCoreset
 SparseVICoreset = _sparsevi.SparseVICoreset
 ShardedHilbertCoreset = _sharded.ShardedHilbertCoreset
-BatchPSVICoreset = _bpsvi.BatchPSVICoreset
 
-__all__ = ["Coreset", "HilbertCoreset", "UniformSamplingCoreset", "SparseVICoreset", "BatchPSVICoreset", "ShardedHilbertCoreset"]
+__all__ = ["Coreset", "HilbertCoreset", "UniformSamplingCoreset", "SparseVICoreset", "ShardedHilbertCoreset"]

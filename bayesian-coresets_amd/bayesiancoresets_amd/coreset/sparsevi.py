@@ -117,7 +117,7 @@ class SparseVICoreset(Coreset):
         eng = None
         if isinstance(self.ll_projector, DeviceProjector):
             # both projections of sparsevi.py:35-41 (data: column sums only; coreset points: the vectors), one read-back
-            colsum, corevecs = self.ll_projector.colsum_and_core(pts, self._core_points_device())
+            colsum, corevecs = self.ll_projector.colsum_and_core(pts, self._core_points_device(), persistent=pts is self.data)
         else:
             vecs = self.ll_projector.project(pts)
             eng = self._engine_for(np.ascontiguousarray(vecs))

@@ -71,12 +71,13 @@ class DeviceProjector(Projector):
         disagreement <= 1e-9 of the largest column sum; otherwise that data set stays on the projection kernel).
 
         ``loglikelihood`` / ``grad_loglikelihood`` (optional host callbacks with ``BlackBoxProjector``'s signatures):
-        only for ``project(pts, grad=True)`` -- the handful of pseudo-points whose gradients ``BatchPSVICoreset`` asks
-        for (bpsvi.py:38) -- which is evaluated on the host at the current samples; everything N-sized stays on the device."""
+        only for ``project(pts, grad=True)`` (projector.py:25-29), which is evaluated on the host at the current samples;
+        everything N-sized stays on the device."""
         if colsum not in ("auto", "mfma", "moments"):
             raise ValueError("colsum must be 'auto', 'mfma' or 'moments'")
         self.colsum_mode = colsum
         self._mom, self._mom_ref, self._mom_key, self._mom_work, self._mom_ok = None, None, None, None, False
+        self._mom_seen, self._mom_calls = None, 0
         self.moments_info = {}
         if family not in self.FAMILIES:
             raise ValueError("family must be one of %s" % sorted(self.FAMILIES))
@@ -153,6 +154,7 @@ class DeviceProjector(Projector):
     def invalidate_cache(self):
         self._cache_val, self._cache_ref = None, None
         self._mom, self._mom_ref, self._mom_key, self._mom_ok = None, None, None, False
+        self._mom_seen, self._mom_calls = None, 0
 
     def release_scratch(self):
         """Give back the device scratch the fused consumers keep between calls (select: 32 bytes per row and 64-column
@@ -161,41 +163,78 @@ class DeviceProjector(Projector):
         self._work, self._sel_work, self._cc_buf, self._mom_work = None, None, None, None
 
     # -- second moments of a data set (linear-regression family): csrc/moments.hip -----------------------------------
-    def _moments_for(self, pts, Z):
-        """The (D+1) x (D+1) matrix Z^T Z of the data set ``pts`` (device copy ``Z``), formed on first sight of that
-        object and kept while the SAME object keeps coming back (``invalidate_cache()`` after an in-place edit).
-        Row-sharded: the shards' moments are all-reduced once.  None when this data set does not take the closed form."""
+    MOMENTS_RECHECK_EVERY = 64      # "auto": closed-form column sums are re-validated against the projection this often
+
+    def _moments_for(self, pts, Z, persistent=True):
+        """The (D+1) x (D+1) matrix Z^T Z of the data set ``pts`` (device copy ``Z``), kept while the SAME object keeps
+        coming back (``invalidate_cache()`` after an in-place edit).  None when this call does not take the closed form.
+
+        Every decision in here is the same on every rank of a row-sharded projector (the ranks call in lock step and
+        each branch below has its own collectives): it depends on the family, the column count, ``persistent``, the
+        GLOBAL row count and the call sequence -- never on the size of the local shard.
+          * "auto": formed on the SECOND sight of the same object: a transient array (a fresh ``data[sub]`` per ADAM step)
+            never pays for moments it cannot reuse;
+          * row-sharded: only for the caller's persistent data (``persistent``: SparseVI passes ``pts is self.data``);
+            per-step sub-samples always project;
+          * "auto": checked against the projection kernel when formed and again every MOMENTS_RECHECK_EVERY-th use --
+            theta moves with the weights, and the closed form (yy - 2 theta.X'y + theta'X'X theta) cancels as the
+            residuals shrink; a disagreement > 1e-9 of the largest column sum retires it for this data set."""
         torch = self._torch
-        if self.colsum_mode == "mfma" or self._fam != self.FAMILIES["linreg"] or Z.shape[0] < 4096 or Z.shape[1] > 1024:
+        if self.colsum_mode == "mfma" or self._fam != self.FAMILIES["linreg"] or Z.shape[1] > 1024:
+            return None
+        if self._world > 1 and not persistent:
             return None
         key = (Z.data_ptr(), tuple(Z.shape), Z.stride(0))
         if self._mom_ref is pts and self._mom_key == key:
+            if not self._mom_ok:
+                return None
+            self._mom_calls += 1
+            if self.colsum_mode == "auto" and self._mom_calls % self.MOMENTS_RECHECK_EVERY == 0:
+                self._moments_check(Z, "rechecks")
             return self._mom if self._mom_ok else None
+        if self.colsum_mode == "auto" and self._mom_seen is not pts:
+            self._mom_seen = pts          # first sight: this call projects ("moments" was asked for by name: formed at once)
+            return None
         import time
         t0 = time.perf_counter()
+        n_rows = float(Z.shape[0])
+        if self._world > 1:
+            cnt = torch.tensor([n_rows], dtype=torch.float64, device=self.device)
+            torch.distributed.all_reduce(cnt, op=torch.distributed.ReduceOp.SUM, group=self.group)
+            n_rows = float(cnt.item())
+        self._mom_ref, self._mom_key, self._mom_ok, self._mom_calls = pts, key, False, 0
+        if n_rows < 4096:
+            self._mom = None
+            return None
         C = Z.shape[1]
-        need = int(self._lib.bcx_project_moments_scratch_bytes(int(Z.shape[0]), int(C)))
-        work = torch.empty((need + 7) // 8, dtype=torch.float64, device=self.device)
-        M = torch.empty((C, C), dtype=torch.float64, device=self.device)
-        self._check(self._lib.bcx_project_moments(self._stream(), Z.data_ptr(), Z.shape[0], Z.stride(0), C, M.data_ptr(), C,
-                                                  work.data_ptr(), work.numel() * 8))
+        M = torch.zeros((C, C), dtype=torch.float64, device=self.device)
+        if Z.shape[0]:
+            need = int(self._lib.bcx_project_moments_scratch_bytes(int(Z.shape[0]), int(C)))
+            work = torch.empty((need + 7) // 8, dtype=torch.float64, device=self.device)
+            self._check(self._lib.bcx_project_moments(self._stream(), Z.data_ptr(), Z.shape[0], Z.stride(0), C, M.data_ptr(), C,
+                                                      work.data_ptr(), work.numel() * 8))
         if self._world > 1:
             torch.distributed.all_reduce(M, op=torch.distributed.ReduceOp.SUM, group=self.group)
         torch.cuda.synchronize(self.device)
-        del work
         t1 = time.perf_counter()
-        self._mom, self._mom_ref, self._mom_key, self._mom_ok = M, pts, key, True
-        self.moments_info = {"rows": int(Z.shape[0]), "columns": int(C), "setup_ms": (t1 - t0) * 1e3, "checked": False}
+        self._mom, self._mom_ok = M, True
+        self.moments_info = {"rows": int(n_rows), "columns": int(C), "setup_ms": (t1 - t0) * 1e3, "checked": False}
         if self.colsum_mode == "auto":
-            # one projection of this data set at the current samples, once: the closed form has to reproduce it
-            a = self._colsum_projected(Z)
-            b = self._colsum_from_moments(Z)
-            scale = float(np.max(np.abs(a))) if a.size else 0.0
-            dis = float(np.max(np.abs(a - b))) / scale if scale > 0 else 0.0
-            self._mom_ok = bool(np.isfinite(dis) and dis <= 1e-9)
-            self.moments_info.update({"checked": True, "disagreement": dis, "accepted": self._mom_ok,
-                                      "check_ms": (time.perf_counter() - t1) * 1e3})
+            self._moments_check(Z, "checks")
         return self._mom if self._mom_ok else None
+
+    def _moments_check(self, Z, counter):
+        """One projection of this data set at the current samples: the closed form has to reproduce it."""
+        import time
+        t1 = time.perf_counter()
+        a = self._colsum_projected(Z)
+        b = self._colsum_from_moments(Z)
+        scale = float(np.max(np.abs(a))) if a.size else 0.0
+        dis = float(np.max(np.abs(a - b))) / scale if scale > 0 else 0.0
+        self._mom_ok = bool(np.isfinite(dis) and dis <= 1e-9)
+        self.moments_info.update({"checked": True, "disagreement": dis, "accepted": self._mom_ok,
+                                  "check_ms": (time.perf_counter() - t1) * 1e3,
+                                  counter: int(self.moments_info.get(counter, 0)) + 1})
 
     def _colsum_from_moments(self, Z, out=None):
         torch = self._torch
@@ -298,10 +337,10 @@ class DeviceProjector(Projector):
             self._sel_work = self._torch.empty((need + 7) // 8, dtype=self._torch.float64, device=self.device)
         return self._sel_work
 
-    def project_colsum(self, pts):
-        """sum_n vecs[n, :] as a length-S ndarray, without forming vecs."""
+    def project_colsum(self, pts, persistent=True):
+        """sum_n vecs[n, :] as a length-S ndarray, without forming vecs.  ``persistent``: see ``_moments_for``."""
         Z = self._dev(pts)
-        if self._moments_for(pts, Z) is not None:
+        if self._moments_for(pts, Z, persistent) is not None:
             return self._colsum_from_moments(Z)        # (row-sharded: the moments are already the global ones)
         return self._colsum_projected(Z)
 
@@ -319,10 +358,10 @@ class DeviceProjector(Projector):
             torch.distributed.all_reduce(col, op=torch.distributed.ReduceOp.SUM, group=self.group)
         return col.cpu().numpy() if out is None else None
 
-    def colsum_and_core(self, pts, core):
+    def colsum_and_core(self, pts, core, persistent=True):
         """(project_colsum(pts), project(core) as an ndarray) with ONE device->host copy: what every ADAM step of SparseVI
         reads back (sparsevi.py:35-41, 70-74).  ``core`` is the k x (D+1) array of coreset points (ndarray or device tensor),
-        k may be 0."""
+        k may be 0.  ``persistent``: ``pts`` is the caller's standing data set, not a per-call sub-sample (``_moments_for``)."""
         torch = self._torch
         Z = self._dev(pts)
         S = self.theta.shape[0]
@@ -332,12 +371,10 @@ class DeviceProjector(Projector):
             self._cc_buf = torch.empty(S * (max(k, 7) + 1), dtype=torch.float64, device=self.device)
         buf = self._cc_buf[:S * (k + 1)]
         col = buf[:S]
-        if not Z.shape[0]:
-            col.zero_()
-        elif self._moments_for(pts, Z) is not None:
+        if self._moments_for(pts, Z, persistent) is not None:
             self._colsum_from_moments(Z, out=col)
         else:
-            self._colsum_projected(Z, out=col)
+            self._colsum_projected(Z, out=col)      # (a shard without rows: zeros, and still the all-reduce its peers join)
         if k:
             self._launch(self._lib.bcx_project_write, self._common(C) + [buf[S:].data_ptr(), S, None], C)
         h = buf.cpu().numpy()

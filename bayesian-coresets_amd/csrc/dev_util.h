@@ -3,6 +3,15 @@
 // v_permlane32_swap across rows (lane mappings verified with tools/probe/lane_probe.hip).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <stdlib.h>
+
+// Development / test switches (kernel A/B selection, forced code paths) are read ONLY when the process exports
+// BCX_DEV=1 (tests/conftest.py and the tools/ scripts do): a production process never changes behaviour because of
+// a stray variable.  Every switch in csrc/*.hip goes through this one function.
+inline const char* bcx_dev_env(const char* name) {
+  static const bool on = [] { const char* e = getenv("BCX_DEV"); return e && e[0] == '1'; }();
+  return on ? getenv(name) : nullptr;
+}
 
 #define BCX_WAVE 64
 #define BCX_SCRATCH 64   // doubles of LDS scratch for block reductions (NV <= 4, <= 16 waves)

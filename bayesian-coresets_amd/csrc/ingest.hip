@@ -264,7 +264,7 @@ int bcx_launch_ingest(bcx_solver* s, const void* src, int src_dtype, int64_t ld_
   dim3 grid((unsigned)nblk), block(64 * nw);
   const int esz = src_dtype == BCX_F64 ? 8 : 4, eps = 16 / esz;
   const bool vec_ok = d % eps == 0 && ld_src % eps == 0 && ((uintptr_t)src % 16 == 0) && d / eps <= 64 * 16 &&
-                      !getenv("BCX_INGEST_SCALAR");
+                      !bcx_dev_env("BCX_INGEST_SCALAR");
   int chi = 1;
   while (vec_ok && chi * 64 < d / eps) chi <<= 1;
 #define LAUNCH_K(KFN)                                                                                         \

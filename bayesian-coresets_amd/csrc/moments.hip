@@ -450,8 +450,8 @@ static void gram_plan(int k, int d, int* nblk, int* nslices, int64_t* len_per_sl
   int cus = 256, dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
   const int64_t chunks = ((int64_t)d + MOM_ROWS - 1) / MOM_ROWS;
-  static const int force = [] { const char* e = getenv("BCX_GRAM_SLICES"); return e ? atoi(e) : 0; }();    // dev knobs
-  static const int force_p = [] { const char* e = getenv("BCX_GRAM_PATCH"); return e ? atoi(e) : -1; }();
+  static const int force = [] { const char* e = bcx_dev_env("BCX_GRAM_SLICES"); return e ? atoi(e) : 0; }();    // dev knobs
+  static const int force_p = [] { const char* e = bcx_dev_env("BCX_GRAM_PATCH"); return e ? atoi(e) : -1; }();
   int64_t sl = 1;
   if (npairs < 2 * cus) {
     sl = ((int64_t)3 * cus + npairs - 1) / npairs;

@@ -618,8 +618,8 @@ int bcx_launch_apply_omp(bcx_solver* s, const double* recv_dev) {
   const int64_t kub = s->k_ub;
   // default: the incremental multi-workgroup step of omp_lh.hip; beyond its LDS budget (or with BCX_OMP_MULTI=1 /
   // BCX_OMP_FORM=multi, dev) the multi-kernel form below (plain-double inverse)
-  static const char* form = getenv("BCX_OMP_FORM");
-  static const bool legacy = getenv("BCX_OMP_MULTI") != nullptr || (form && form[0] == 'm');
+  static const char* form = bcx_dev_env("BCX_OMP_FORM");
+  static const bool legacy = bcx_dev_env("BCX_OMP_MULTI") != nullptr || (form && form[0] == 'm');
   if (!legacy && s->grid_counter) {
     const int rc = bcx_launch_omp_lh(s, n, nullptr);
     if (rc <= 0) return rc;
@@ -642,8 +642,8 @@ int bcx_launch_apply_omp(bcx_solver* s, const double* recv_dev) {
 // Lawson-Hanson step) as ONE launch of omp_lh_kernel.  1 = not applicable (its LDS budget, or the dev knobs that select the
 // multi-kernel form): the caller launches resolve_kernel and bcx_launch_apply instead.
 int bcx_launch_omp_fused(bcx_solver* s, int exact) {
-  static const char* form = getenv("BCX_OMP_FORM");
-  static const bool off = getenv("BCX_OMP_MULTI") != nullptr || (form && form[0] == 'm') || getenv("BCX_OMP_UNFUSED") != nullptr;
+  static const char* form = bcx_dev_env("BCX_OMP_FORM");
+  static const bool off = bcx_dev_env("BCX_OMP_MULTI") != nullptr || (form && form[0] == 'm') || bcx_dev_env("BCX_OMP_UNFUSED") != nullptr;
   if (off || !s->grid_counter) return 1;
   NnlsArgs n;
   fill_nnls_args(s, n, nullptr);
@@ -777,7 +777,7 @@ int bcx_launch_optimize(bcx_solver* s, double tol) {
   BCX_HIP(hipMemcpy(&h, s->st, sizeof h, hipMemcpyDeviceToHost));
   const int k = h.k;
   if (k > 0) {
-    static const bool old_gram = getenv("BCX_GRAM_DIRECT") != nullptr;     // dev: round 2's kernel (operands straight from L2)
+    static const bool old_gram = bcx_dev_env("BCX_GRAM_DIRECT") != nullptr;     // dev: round 2's kernel (operands straight from L2)
     const size_t need = (size_t)bcx_gram_rows_scratch_bytes(k, s->cfg.d);
     if (!old_gram && s->gram_work_bytes < need) {
       if (s->gram_work) BCX_HIP(hipFree(s->gram_work));

@@ -221,7 +221,7 @@ __global__ __launch_bounds__(NN_THREADS) void optimize_grid_kernel(NnlsArgs n, G
 }
 
 int bcx_launch_optimize_grid(bcx_solver* s, double tol, int k) {
-  if (k >= OPT_MAX_K || getenv("BCX_OPT_SINGLE")) return 1;   // caller uses the single-workgroup kernel
+  if (k >= OPT_MAX_K || bcx_dev_env("BCX_OPT_SINGLE")) return 1;   // caller uses the single-workgroup kernel
   if (!s->grid_counter) {
     BCX_HIP(hipMalloc((void**)&s->grid_counter, 2 * sizeof(unsigned long long)));
   }

@@ -963,12 +963,12 @@ __global__ __launch_bounds__(THREADS) void optimize_lh_kernel(NnlsArgs n, GridSy
 
 // 1 = not applicable (LDS budget, dev knob BCX_OPT_GRID=1): the caller takes nnls_grid.hip's kernel
 int bcx_launch_optimize_lh(bcx_solver* s, double tol, int k) {
-  if (getenv("BCX_OPT_GRID") || getenv("BCX_OPT_SINGLE")) return 1;
+  if (bcx_dev_env("BCX_OPT_GRID") || bcx_dev_env("BCX_OPT_SINGLE")) return 1;
   // Small independent supports (k <= d, k <= 512) stay with nnls_grid.hip: all their columns join the passive set by
   // bordering, one barrier each and no dual passes (k = 400, d = 512: 3.9 ms against 7.8 here); from there on -- and for
   // every k > d, where that kernel has to take Lawson-Hanson's order with a refined solve per column -- this one is
   // faster (k = 999, d = 512: 12.7 against 28.3 ms; k = 1497, d = 1024: 45 against 191 ms).  BCX_OPT_LH=1 forces it (tests).
-  if (k <= s->cfg.d && k <= 512 && !getenv("BCX_OPT_LH")) return 1;
+  if (k <= s->cfg.d && k <= 512 && !bcx_dev_env("BCX_OPT_LH")) return 1;
   const int kcap = (k + 1 + 63) / 64 * 64;
   const size_t lds = (size_t)kcap * (8 * sizeof(double) + 3 * sizeof(int));
   if (lds > OMPL_LDS_MAX) return 1;
@@ -981,7 +981,7 @@ int bcx_launch_optimize_lh(bcx_solver* s, double tol, int k) {
   gs.counter = s->grid_counter;
   gs.base = 0;
   gs.timeout_ticks = 1000000000LL;     // 10 s
-  static const int forced_wgs = getenv("BCX_OPT_WGS") ? atoi(getenv("BCX_OPT_WGS")) : 0;     // dev
+  static const int forced_wgs = bcx_dev_env("BCX_OPT_WGS") ? atoi(bcx_dev_env("BCX_OPT_WGS")) : 0;     // dev
   const int wgs = forced_wgs > 0 ? forced_wgs : (k <= 256 ? 16 : (k <= 1024 ? 32 : OPTL_MAX_WGS));
   const int threads = k <= 192 ? 256 : (k <= 768 ? 512 : 1024);
 #define OPTL_LAUNCH(T)                                                                                                          \
@@ -997,7 +997,7 @@ int bcx_launch_optimize_lh(bcx_solver* s, double tol, int k) {
 }
 
 int bcx_launch_omp_lh(bcx_solver* s, NnlsArgs& n, const ResolveArgs* fused) {
-  static const int force = getenv("BCX_OMP_FORCE_RESOLVE") ? atoi(getenv("BCX_OMP_FORCE_RESOLVE")) : 0;   // tests: re-solve every N-th step
+  static const int force = bcx_dev_env("BCX_OMP_FORCE_RESOLVE") ? atoi(bcx_dev_env("BCX_OMP_FORCE_RESOLVE")) : 0;   // tests: re-solve every N-th step
   const int64_t kub = s->k_ub;
   const int kcap = (int)((kub + 1 + 63) / 64 * 64);
   const int dpad = (s->cfg.d + 63) / 64 * 64;
@@ -1023,7 +1023,7 @@ int bcx_launch_omp_lh(bcx_solver* s, NnlsArgs& n, const ResolveArgs* fused) {
   // reductions, whose cost grows with the number of waves; the parallel work (one wave per slot row / per row of H) is
   // 16 workgroups x waves.  Measured on the configs[2] vectors (tools/omp_hist.py, k <= 140): closed-form step 43.6 us
   // with 1024 threads, 30.2 with 512, 28.8 with 256.  Wider workgroups once a wave would own more than ~3 rows.
-  static const int forced_threads = getenv("BCX_OMP_THREADS") ? atoi(getenv("BCX_OMP_THREADS")) : 0;   // dev: 256 / 512 / 1024
+  static const int forced_threads = bcx_dev_env("BCX_OMP_THREADS") ? atoi(bcx_dev_env("BCX_OMP_THREADS")) : 0;   // dev: 256 / 512 / 1024
   const int threads = forced_threads ? forced_threads : (kub <= 192 ? 256 : (kub <= 448 ? 512 : NN_THREADS));
   ResolveArgs rsv;
   if (fused) rsv = *fused; else memset(&rsv, 0, sizeof(rsv));

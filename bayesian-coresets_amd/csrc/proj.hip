@@ -1093,7 +1093,7 @@ static int proj_nct(int mode, int family, int S, bool aligned, int D) {
   // loads per launch-long loop body, none between the MFMAs of a group) and is the faster one: N = 5M, D = 301, S = 256
   // 13.80 against 15.08 ms per call (55.8 against 51.1 TFLOP/s).  The transcendental families stay at 64 columns
   // (logistic SELECT at 128: 231 spilled VGPRs).  BCX_PROJ_SEL_NCT=4 selects the 64-column tile (dev).
-  static const bool sel8 = [] { const char* e = getenv("BCX_PROJ_SEL_NCT"); return !(e && atoi(e) == 4); }();
+  static const bool sel8 = [] { const char* e = bcx_dev_env("BCX_PROJ_SEL_NCT"); return !(e && atoi(e) == 4); }();
   // (round 4, with the table forms: logistic / Poisson SELECT on the 128-column tile still spill 225 / 208 VGPRs and run at 16 /
   // 32 TFLOP/s against 48 / 45 on the 64-column tile.  Tried for the registers they would need: the residual in LDS instead
   // of per-column global loads (no change in the spills; Poisson + 1 %, linreg - 0.5 %), and recomputing the request pointers
@@ -1104,7 +1104,7 @@ static int proj_nct(int mode, int family, int S, bool aligned, int D) {
   // box, N = 2M, S = 256, D = 300 / 301: linreg 56.3 against 51.5 TFLOP/s, logistic 51.6 / 48.6, Poisson 48.3 / 43.9.  Short
   // rows (D < 64) are bound by the stores of the N x S output, and there the 64-column tile's 128-byte pieces are the
   // better ones (logistic D = 10, S = 512: 1.22 against 1.25 ms).  BCX_PROJ_WRITE_NCT=4 selects the 64-column tile (dev).
-  static const bool wr8 = [] { const char* e = getenv("BCX_PROJ_WRITE_NCT"); return !(e && atoi(e) == 4); }();
+  static const bool wr8 = [] { const char* e = bcx_dev_env("BCX_PROJ_WRITE_NCT"); return !(e && atoi(e) == 4); }();
   if (mode == PMODE_WRITE && aligned && wr8 && D >= 64) return (S + 127) / 128 * 128 == (S + 63) / 64 * 64 ? 8 : 4;
   if (mode != PMODE_COLSUM) return 4;
   // the 128-column tile exists for the column sums of the linear-regression family and, on 16-byte aligned rows, of the
@@ -1112,16 +1112,16 @@ static int proj_nct(int mode, int family, int S, bool aligned, int D) {
   // +8 % at D = 300) and the Poisson one (round 4, below); the unaligned transcendental instantiations are not built
   // Poisson COLSUM on the 128-column tile parks 16 VGPRs (request pointers, outside the MFMA groups) and is the faster one
   // on 16-byte aligned rows: N = 2M, D = 301, S = 256 6.15 against 6.72 ms (50.1 against 45.9 TFLOP/s).  BCX_PROJ_POIS_NCT=4: dev.
-  static const bool pois8 = [] { const char* e = getenv("BCX_PROJ_POIS_NCT"); return !(e && atoi(e) == 4); }();
+  static const bool pois8 = [] { const char* e = bcx_dev_env("BCX_PROJ_POIS_NCT"); return !(e && atoi(e) == 4); }();
   if ((family == FAM_POISSON && !(pois8 && aligned)) || (family == FAM_LOGISTIC && !aligned)) return 4;
-  static const int forced = [] { const char* e = getenv("BCX_PROJ_NCT"); return e ? atoi(e) : 0; }();   // dev knob
+  static const int forced = [] { const char* e = bcx_dev_env("BCX_PROJ_NCT"); return e ? atoi(e) : 0; }();   // dev knob
   if (forced == 4 || forced == 8) return forced;
   return (S + 127) / 128 * 128 == (S + 63) / 64 * 64 ? 8 : 4;
 }
 // XCD teams (COLSUM, WRITE) need a grid that covers the 8 XCDs evenly; workgroups of an XCD that do not fill a team stay
 // idle (at most a fifth of them).  Returns the team size = number of column groups, 0 for the one-workgroup walk.
 static int proj_team(int mode, int family, int S, int grid, bool aligned, int D) {
-  static const bool no_team = getenv("BCX_PROJ_NO_TEAM") != nullptr;   // dev knob
+  static const bool no_team = bcx_dev_env("BCX_PROJ_NO_TEAM") != nullptr;   // dev knob
   const int cols = 16 * proj_nct(mode, family, S, aligned, D), ngc = (S + cols - 1) / cols;
   return (!no_team && ngc > 1 && grid % 8 == 0 && grid / 8 >= 4 * ngc) ? ngc : 0;
 }
@@ -1133,7 +1133,7 @@ static int proj_team(int mode, int family, int S, int grid, bool aligned, int D)
 static void proj_plan(int mode, int family, int64_t N, int S, bool aligned, int D, int* grid, int* team) {
   *grid = proj_grid(N);
   *team = proj_team(mode, family, S, *grid, aligned, D);
-  static const bool no_team = getenv("BCX_PROJ_NO_TEAM") != nullptr;   // dev knob
+  static const bool no_team = bcx_dev_env("BCX_PROJ_NO_TEAM") != nullptr;   // dev knob
   const int cols = 16 * proj_nct(mode, family, S, aligned, D), ngc = (S + cols - 1) / cols;
   const int64_t nblk = (N + PJ_ROWS - 1) / PJ_ROWS;
   if (!no_team && *team == 0 && ngc > 1 && N > 0 && nblk * ngc <= 2 * 256) {
@@ -1201,7 +1201,7 @@ static int project_write(void* stream, int32_t family, const void* Z_dev, int64_
   if (N == 0) return BCX_OK;
   p.out = (double*)out_dev; p.ldo = ldo; p.rowsum = (double*)rowsum_dev;
   hipStream_t st = (hipStream_t)stream;
-  static const bool no_small = getenv("BCX_PROJ_NO_SMALL") != nullptr;    // dev: the tiled kernel for every N
+  static const bool no_small = bcx_dev_env("BCX_PROJ_NO_SMALL") != nullptr;    // dev: the tiled kernel for every N
   if (N <= PJ_SMALL_ROWS && S <= 1024 && D <= 4096 && !no_small) {
     // a handful of rows: one workgroup per row, likelihood and centring in the same launch (proj_small_kernel)
     const size_t tabd = family == FAM_POISSON ? PJT_DOUBLES : family == FAM_LOGISTIC ? PJT_DOUBLES_LOGISTIC : 0;

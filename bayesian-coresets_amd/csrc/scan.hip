@@ -642,7 +642,7 @@ static int scan_grid_for(int64_t n, int rows_per_block, double loads_per_lane, b
   int64_t cap = (int64_t)floor(2048.0 / loads_per_lane / 256.0 + 0.5) * 256;
   if (cap < 256) cap = 256;
   if (heavy) cap = BCX_MAX_PARTIALS;   // fp64 GIGA is VALU-heavy (fp64 sqrt/divide per row): it wants the occupancy
-  if (const char* e = getenv("BCX_SCAN_GRID")) { const long v = atol(e); if (v > 0) cap = v; }
+  if (const char* e = bcx_dev_env("BCX_SCAN_GRID")) { const long v = atol(e); if (v > 0) cap = v; }
   if (cap > BCX_MAX_PARTIALS) cap = BCX_MAX_PARTIALS;
   if (want > cap) want = cap;
   return (int)want;
@@ -717,7 +717,7 @@ int bcx_launch_scan(bcx_solver* s, int exact) {
   // slots carry data (idle lanes in the last chunk / in the row group)
   int ur = (CH >= BCX_LOADS_IN_FLIGHT) ? 1 : (BCX_LOADS_IN_FLIGHT / CH > BCX_UR_MAX ? BCX_UR_MAX : BCX_LOADS_IN_FLIGHT / CH);
   const double util = (double)nvec / ((double)G * CH);
-  static const int deep_env = getenv("BCX_SCAN_DEEP") ? atoi(getenv("BCX_SCAN_DEEP")) : -1;   // dev: force 0 / 1
+  static const int deep_env = bcx_dev_env("BCX_SCAN_DEEP") ? atoi(bcx_dev_env("BCX_SCAN_DEEP")) : -1;   // dev: force 0 / 1
   // Row lengths that leave lanes of the group idle (util < 0.85; d = 100: 25 of 32 lanes, d = 300: 75 of 128 slots) run
   // best with TWO workgroups per CU and 4.5 - 6 USEFUL loads in flight per lane: the row steps are doubled only when
   // the base depth carries fewer than 4.5 (interleaved A/B on one box, tools/scan_knobs.sh, % of 8 TB/s, FW / GIGA:
@@ -732,7 +732,7 @@ int bcx_launch_scan(bcx_solver* s, int exact) {
   if (deep) ur *= 2;
   const int rpb = (BCX_SCAN_THREADS / 64) * (64 / G) * ur;
   int grid = scan_grid_for(a.n, rpb, CH * ur * util, f64 && dual);   // idle lanes do not count as loads in flight
-  if (ragged && !(f64 && dual) && !getenv("BCX_SCAN_GRID")) {
+  if (ragged && !(f64 && dual) && !bcx_dev_env("BCX_SCAN_GRID")) {
     const int64_t want = (a.n + rpb - 1) / rpb;
     grid = (int)(want < 512 ? (want < 1 ? 1 : want) : 512);
   }

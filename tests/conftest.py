@@ -12,6 +12,10 @@ if not os.environ.get("BCX_KEEP_IPC_MODE"):
 if not os.environ.get("BCX_NO_FAULTHANDLER"):   # (crash hunts preload tools/probe/abort_trace.so instead)
     faulthandler.enable(all_threads=True)
 
+# the library reads its development / test switches (BCX_OPT_LH, BCX_PROJ_NCT, BCX_INGEST_SCALAR ... : forced code
+# paths some tests compare against each other) only under BCX_DEV=1 (csrc/dev_util.h bcx_dev_env)
+os.environ.setdefault("BCX_DEV", "1")
+
 import numpy as np
 import pytest
 

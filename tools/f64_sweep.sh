@@ -1,4 +1,5 @@
 #!/bin/bash
+export BCX_DEV=1   # the library reads its dev switches only under this gate (csrc/dev_util.h)
 cd $GRAFT_REPO_ROOT
 for g in 256 512 1024 2048; do
   echo "== grid cap $g"

@@ -1,3 +1,4 @@
+export BCX_DEV=1   # the library reads its dev switches only under this gate (csrc/dev_util.h)
 cd /tmp && export TMPDIR=/tmp; R=$GRAFT_REPO_ROOT
 for f in 0 1; do
 rm -rf /tmp/fc$f

@@ -3,6 +3,7 @@ kernel time by hipEvents over `reps` back-to-back calls, upper-triangle flops k 
 peak; beside it round 2's direct kernel through optimize() is selected with BCX_GRAM_DIRECT=1 (tools/optimize_bench.py).
     python tools/gram_bench.py [k,d ...]"""
 import os, sys
+os.environ.setdefault("BCX_DEV", "1")   # dev switches are read only under this gate (csrc/dev_util.h)
 import numpy as np
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "bayesian-coresets_amd"))
 import torch

@@ -1,4 +1,5 @@
 #!/bin/bash
+export BCX_DEV=1   # the library reads its dev switches only under this gate (csrc/dev_util.h)
 # dev: A/B the non-temporal row loads of the scan kernel
 cd $GRAFT_REPO_ROOT/bayesian-coresets_amd
 for rep in 1 2; do

@@ -1,4 +1,5 @@
 #!/bin/bash
+export BCX_DEV=1   # the library reads its dev switches only under this gate (csrc/dev_util.h)
 # ONE final pass of round 4 at the final kernel sources: GPU suite (one process per file), smoke, the suite in one process as the
 # driver runs it, then every profile part (tools/profile_round.sh r04).  Output: gpurun_out/final, gpurun_out/prof_r04;
 # tools/collect_r04.sh copies the summaries into profiles/.

@@ -1,4 +1,5 @@
 #!/bin/bash
+export BCX_DEV=1   # the library reads its dev switches only under this gate (csrc/dev_util.h)
 # dev: launch-width / depth knobs of the scan kernel at lane-wasting row lengths, interleaved repetitions
 cd "$(dirname "$0")/.."
 for rep in 1 2 3; do

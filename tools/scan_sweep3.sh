@@ -1,4 +1,5 @@
 #!/bin/bash
+export BCX_DEV=1   # the library reads its dev switches only under this gate (csrc/dev_util.h)
 cd $GRAFT_REPO_ROOT/bayesian-coresets_amd
 for v in "8 8" "16 16" "32 16"; do
   set -- $v
