@@ -48,13 +48,17 @@ def shard_bounds(n_global, world_size, align=CHUNK_ROWS):
 class ShardedSolver(object):
     """Collective object: construct / call on every rank of ``group`` with the same arguments."""
 
-    def __init__(self, alg, n_global, d, group=None, device=None, engine_factory=None, **engine_kw):
+    def __init__(self, alg, n_global, d, group=None, device=None, engine_factory=None, solo=False, **engine_kw):
+        """``solo``: this process alone holds all ``n_global`` rows as ONE shard even though a process group is
+        initialised (not a collective object then: no rank but the caller takes part) -- bench.py's one-shard leg
+        inside a multi-rank run."""
         import torch
         import torch.distributed as dist
         self.torch, self.dist = torch, dist
         self.group = group
-        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
-        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        spans = dist.is_initialized() and not solo
+        self.rank = dist.get_rank(group) if spans else 0
+        self.world = dist.get_world_size(group) if spans else 1
         self.alg, self.n_global, self.d = alg, int(n_global), int(d)
         bounds, self.chunks_per_rank = shard_bounds(self.n_global, self.world)
         self.row_begin, self.row_end = bounds[self.rank]

@@ -66,10 +66,19 @@ def parse():
     ap.add_argument("--no-exact-rows", action="store_true", help="do not keep the raw fp64 rows resident")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-exact-mode", action="store_true", help="skip the fp64-stored-rows figure of the c4 line")
-    ap.add_argument("--cpu-rows", type=int, default=1_000_000,
-                    help="rows of the CPU-baseline sample (SURVEY 8d: N = 1e6 when host memory allows; halved until "
-                         "three copies of the fp64 sample fit the free memory)")
+    ap.add_argument("--cpu-rows", type=int, default=None,
+                    help="rows of the CPU-baseline sample.  Default: a 1,000,000-row sample first (halved until three copies "
+                         "of the fp64 sample fit the free memory), then -- single-GPU runs, host memory and --cpu-wall-cap "
+                         "permitting -- the oracle on ALL rows (SURVEY 8d); given explicitly: that sample only")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    ap.add_argument("--cpu-wall-cap", type=float, default=300.0,
+                    help="wall-clock cap of the full-N CPU baseline (generation + constructor + iterations); the number of "
+                         "timed iterations is cut to fit, and below 2 the leg is skipped (the scaled sample stands)")
+    ap.add_argument("--cpu-full", default="auto", choices=["auto", "always", "never"],
+                    help="full-N CPU baseline: auto = single-GPU runs only (a multi-rank line carries the scaled sample)")
+    ap.add_argument("--no-one-rank-leg", action="store_true",
+                    help="multi-rank synthetic runs: skip the one-shard run of the same workload on rank 0's GPU "
+                         "(one_rank_its / scaling_efficiency on the line)")
     ap.add_argument("--no-f16-leg", action="store_true", help="c4: skip the extra leg with fp16-stored rows")
     ap.add_argument("--opt-itrs", type=int, default=100, help="c5: ADAM steps per greedy step (sparsevi.py:7)")
     ap.add_argument("--no-side-legs", action="store_true", help="default line only: skip the compact c2 / c3 / c5 legs")
@@ -127,41 +136,138 @@ def blas_info():
         return "unknown", os.cpu_count() or 0
 
 
-def cpu_baseline_snnls(args, X, what):
-    """The oracle's faithful mode (reference op sequence: 5 passes of OpenBLAS dgemv/dgemm per iteration, fp64) timed on
-    this box's host cores on a bounded sample X (n_s x d) of the same workload, scaled linearly in N."""
+def host_rows(torch, args, n_s):
+    """The first n_s rows of the synthetic matrix as a C-contiguous fp64 host array: generated on the device per seeded block
+    exactly as load_synthetic does (same block sizes, so the same numbers) and copied block by block into one allocation."""
+    X = np.empty((n_s, args.dim))
+    for b0 in range(0, n_s, GEN_BLOCK):
+        m = min(GEN_BLOCK, args.rows - b0)
+        blk = gen_block(torch, args.seed, b0 // GEN_BLOCK, m, args.dim, "cuda")
+        k = min(m, n_s - b0)
+        X[b0:b0 + k] = blk[:k].cpu().numpy()
+    return X
+
+
+def _time_oracle(args, X, mode, seconds, warm, stride, cap_its):
+    """(iterations, elapsed s, constructor s) of the oracle in `mode` on X: `warm` untimed iterations, then `stride` at a time
+    until `seconds` have passed or `cap_its` are done."""
     from oracle.snnls_oracle import SnnlsOracle
-    n_s = X.shape[0]
-    o = SnnlsOracle(X.T, X.sum(axis=0), alg=args.alg, mode="faithful")
-    o.build(3)  # warm-up
-    done, t0 = 0, time.perf_counter()
+    t0 = time.perf_counter()
+    o = SnnlsOracle(X.T, X.sum(axis=0), alg=args.alg, mode=mode)
+    ctor = time.perf_counter() - t0
+    if warm:
+        o.build(warm)
+    done, t1 = 0, time.perf_counter()
     while True:
-        o.build(2)
-        done += 2
-        el = time.perf_counter() - t0
-        if el > args.cpu_seconds or done >= 200:
+        o.build(stride)
+        done += stride
+        el = time.perf_counter() - t1
+        if el > seconds or done >= cap_its:
             break
+    del o
+    return done, el, ctor
+
+
+def cpu_baseline_snnls(args, torch, world, what, sample=None):
+    """The oracle's faithful mode (reference op sequence: 5 passes of OpenBLAS dgemv/dgemm per iteration, fp64) timed on
+    this box's host cores.  First on a bounded sample of the same workload (scaled linearly in N); then, when the host can
+    hold it and the wall-clock cap allows, on ALL rows -- that figure replaces the scaled one and the scaled
+    one stays beside it (`sample_value_scaled`: how linear the cost is in N).  `sample`: ready-made host rows (config 3)."""
+    t_leg = time.perf_counter()
+    explicit = args.cpu_rows is not None
+    if sample is not None:
+        X, gen_s = sample, 0.0
+    else:
+        n_s = min(args.cpu_rows if explicit else 1_000_000, args.rows)
+        try:      # the oracle holds A, An and temporaries: three copies of the fp64 sample
+            import psutil
+            while n_s > 8 * GEN_BLOCK and 3.5 * n_s * args.dim * 8 > 0.6 * psutil.virtual_memory().available:
+                n_s //= 2
+        except ImportError:
+            n_s = min(n_s, 200_000)
+        if n_s < args.rows:
+            n_s = (n_s // GEN_BLOCK) * GEN_BLOCK or n_s
+        t0 = time.perf_counter()
+        X = host_rows(torch, args, n_s)
+        gen_s = time.perf_counter() - t0
+    n_s = X.shape[0]
+    done, el, ctor_s = _time_oracle(args, X, "faithful", args.cpu_seconds, 3, 2, 200)
     its_sample = done / el
     scale = n_s / float(args.rows)   # cost per iteration is linear in N
     # the fairer CPU number (SURVEY 8d): the same arithmetic with A.dot(w) maintained incrementally -- one pass over the
     # matrix per iteration instead of the reference's five
-    o1 = SnnlsOracle(X.T, X.sum(axis=0), alg=args.alg, mode="onepass")
-    o1.build(3)
-    done1, t1 = 0, time.perf_counter()
-    while True:
-        o1.build(4)
-        done1 += 4
-        el1 = time.perf_counter() - t1
-        if el1 > args.cpu_seconds / 2 or done1 >= 200:
-            break
+    done1, el1, _ = _time_oracle(args, X, "onepass", args.cpu_seconds / 2, 3, 4, 200)
     blas, ncpu = blas_info()
-    return {
+    out = {
         "value": its_sample * scale, "unit": "iterations/s", "cores": int(host_threads()), "kind": "port",
         "sample": "oracle faithful mode (NumPy/OpenBLAS fp64, reference op sequence), %s, %s, first %d of %d rows, d=%d, "
                   "%d iterations in %.1f s = %.2f it/s on the sample, scaled linearly in N (x%.4f)"
                   % (args.alg, what, n_s, args.rows, X.shape[1], done, el, its_sample, scale),
         "onepass_value": done1 / el1 * scale, "blas": blas, "host_cpus": ncpu, "sample_rows": int(n_s),
+        "sample_value_scaled": its_sample * scale, "full_n": None,
     }
+    want_full = (args.cpu_full == "always" or (args.cpu_full == "auto" and world == 1)) and not explicit \
+        and sample is None and n_s < args.rows
+    if not want_full:
+        if n_s < args.rows:
+            out["full_n"] = {"ran": False, "why": "--cpu-rows given" if explicit else
+                             ("multi-rank line: the scaled sample (--cpu-full always runs all rows)" if args.cpu_full == "auto"
+                              else "--cpu-full never")}
+        return out
+    del X
+    full = {"ran": False, "rows": int(args.rows), "wall_cap_s": args.cpu_wall_cap}
+    out["full_n"] = full
+    try:
+        import psutil
+        avail = float(psutil.virtual_memory().available)
+    except ImportError:
+        avail = 0.0
+    need = 3.3 * args.rows * args.dim * 8.0       # rows + normalised copy + the constructor's transient square
+    full.update({"host_free_GB": avail / 1e9, "host_need_GB": need / 1e9})
+    if need > 0.85 * avail:
+        full["why"] = "host memory: the oracle on all rows needs %.0f GB, %.0f GB are free" % (need / 1e9, avail / 1e9)
+        return out
+    t_it = 1.0 / max(its_sample * scale, 1e-12)                       # predicted seconds per faithful iteration at full N
+    setup = (gen_s + ctor_s) / scale                                   # predicted generation + constructor
+    spent = time.perf_counter() - t_leg
+    n_it = int((args.cpu_wall_cap - setup) / t_it) - 1                 # one warm-up iteration
+    full.update({"predicted_s_per_iteration": t_it, "predicted_setup_s": setup, "sample_leg_s": spent})
+    if n_it < 2:
+        full["why"] = "wall cap: set-up %.0f s + 3 iterations of %.1f s exceed %.0f s" % (setup, t_it, args.cpu_wall_cap)
+        return out
+    n_it = min(n_it, 20)
+    try:
+        t0 = time.perf_counter()
+        X = host_rows(torch, args, args.rows)
+        gen_full = time.perf_counter() - t0
+        done, el, ctor_full = _time_oracle(args, X, "faithful", 1e30, 1, 1, n_it)
+        del X
+    except MemoryError as e:
+        full["why"] = "MemoryError on the host (%s)" % e
+        return out
+    full.update({"ran": True, "iterations": done, "elapsed_s": el, "generation_s": gen_full, "constructor_s": ctor_full,
+                 "iterations_per_s": done / el, "leg_wall_s": time.perf_counter() - t_leg})
+    out["value"] = done / el
+    out["sample_rows"] = int(args.rows)
+    out["sample"] = ("oracle faithful mode (NumPy/OpenBLAS fp64, reference op sequence), %s, %s, ALL %d rows, d=%d: %d iterations "
+                     "in %.1f s after 1 warm-up (constructor %.0f s, generation + copy %.0f s, %.0f GB free host memory before); "
+                     "the %d-row sample scaled linearly gives %.4f it/s"
+                     % (args.alg, what, args.rows, args.dim, done, el, ctor_full, gen_full, avail / 1e9, n_s, its_sample * scale))
+    return out
+
+
+def wait_for_rank0(dist, rank, key):
+    """Ranks other than 0 block on the rendezvous store (a socket wait: off the CPU, unlike a spinning NCCL barrier that
+    would take cores from rank 0's BLAS threads) until rank 0 has finished its host-only legs and set `key`."""
+    from datetime import timedelta
+    try:
+        store = dist.distributed_c10d._get_default_store()
+        if rank == 0:
+            store.set(key, "1")
+        else:
+            store.wait([key], timedelta(hours=3))
+    except Exception as e:      # (no store: the barrier that follows still orders the ranks, just not off the CPU)
+        sys.stderr.write("bench.py: rank %d: store wait unavailable (%s)\n" % (rank, e))
 
 
 # =====================================================================================================================
@@ -238,7 +344,7 @@ def load_logistic(args, torch, dist, world, solver, info):
     info.update({"laplace_fit_s": t1 - t0, "projection_s": t2 - t1, "ingest_s": t3 - t2, "features": args.features,
                  "projection_kernel_ms": pms, "projection_kernel_gelem_per_s": (hi - lo) * args.dim / max(pms, 1e-9) / 1e6,
                  "row_norm_min": float(nrm.min()), "row_norm_max": float(nrm.max())})
-    sample = vecs[:min(args.cpu_rows, hi - lo)].cpu().numpy() if lo == 0 else None
+    sample = vecs[:min(args.cpu_rows or 1_000_000, hi - lo)].cpu().numpy() if lo == 0 else None
     del vecs, Z
     return sample
 
@@ -260,7 +366,7 @@ def run_snnls(args, torch, dist, nat, world, rank, local_rank):
     if rc != nat.OK:
         raise SystemExit("finalize failed: %d" % rc)
 
-    def sync():
+    def sync_all():
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
@@ -281,8 +387,10 @@ def run_snnls(args, torch, dist, nat, world, rank, local_rank):
             s.engine.reset()
             return s.build(n)
 
-    def timed(s, warmup, steps):
-        """(elapsed seconds over ranks, trace, scan ms total, scan launches, events-every) for exactly `steps` iterations"""
+    def timed(s, warmup, steps, solo=False):
+        """(elapsed seconds over ranks, trace, scan ms total, scan launches, events-every) for exactly `steps` iterations
+        (solo: `s` lives on this rank alone -- no barrier, no reduction over ranks)"""
+        sync = (lambda: torch.cuda.synchronize()) if solo else sync_all
         if warmup > 0:
             build(s, warmup)
         if os.environ.get("BENCH_TEST_EXPIRE_MAILBOX") and s.exchange == "mailbox":
@@ -299,7 +407,7 @@ def run_snnls(args, torch, dist, nat, world, rank, local_rank):
         tr = build(s, steps)
         sync()
         el = time.perf_counter() - t0
-        if world > 1:
+        if world > 1 and not solo:
             t = torch.tensor([el], dtype=torch.float64, device="cuda")
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             el = float(t.item())
@@ -321,10 +429,20 @@ def run_snnls(args, torch, dist, nat, world, rank, local_rank):
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dist.all_reduce(lo_t, op=dist.ReduceOp.MIN)
         xstat = {"n": xs["exchanges"], "max": [float(v) for v in t.tolist()], "min": [float(v) for v in lo_t.tolist()]}
+    # every rank's scan kernel (HIP events on its own stream): rows held and average launch duration
+    per_rank = [[float(solver.n_local), scan_ms / max(scan_launches, 1), float(scan_launches)]]
+    if world > 1:
+        mine = torch.tensor(per_rank[0], dtype=torch.float64, device="cuda")
+        allr = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allr, mine)
+        per_rank = [[float(v) for v in t.tolist()] for t in allr]
     if rank == 0:
         bytes_per_launch = float(solver.n_local) * args.dim * elem
         avg_ms = scan_ms / max(scan_launches, 1)
         achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+        # all shards together: the whole matrix's bytes over the SLOWEST shard's scan, against world x the HBM peak
+        slowest_ms = max(r[1] for r in per_rank)
+        agg = float(args.rows) * args.dim * elem / (slowest_ms * 1e-3) / 1e9 if slowest_ms > 0 else 0.0
         names = {"fw": "Frank-Wolfe", "giga": "GIGA", "omp": "OMP"}
         ran = ("M=%d greedy iterations" % steps_done if steps_done == args.steps else
                "%d of the requested M=%d greedy iterations (numeric limit reached, as in the reference)" % (steps_done, args.steps))
@@ -369,6 +487,10 @@ def run_snnls(args, torch, dist, nat, world, rank, local_rank):
                 "frac": achieved / HBM_PEAK_GBS, "traffic": measured_traffic(args, solver.n_local),
                 "avg_launch_ms": avg_ms, "launches": int(scan_launches), "timed_every": every,
                 "algorithmic_bytes_per_launch": bytes_per_launch,
+                # achieved / peak / frac above: rank 0's GPU.  All `world` GPUs: N d sizeof over the slowest shard's scan
+                "achieved_aggregate": agg, "peak_aggregate": HBM_PEAK_GBS * world, "frac_aggregate": agg / (HBM_PEAK_GBS * world),
+                "per_gpu_rows": [int(r[0]) for r in per_rank], "per_gpu_avg_launch_ms": [r[1] for r in per_rank],
+                "per_gpu_frac": [(r[0] * args.dim * elem / (r[1] * 1e-3) / 1e9 / HBM_PEAK_GBS) if r[1] > 0 else 0.0 for r in per_rank],
             },
         }
     # ---- row shards: the same iterations over the OTHER exchange mode (RCCL all-gather of the records per iteration, host
@@ -386,6 +508,36 @@ def run_snnls(args, torch, dist, nat, world, rank, local_rank):
                         "instead of the device-side peer mailbox; %d iterations after a reset" % len(tr_c[0]),
                 "ms_per_step": out["collective_ms_per_step"], "iterations_per_s": len(tr_c[0]) / el_c,
                 "final_error": float(tr_c[1][-1]) if len(tr_c[1]) else None}
+    # ---- row shards: the same workload as ONE shard on rank 0's GPU, in the same run (the other ranks wait off the CPU, see
+    # the end of this function): the line then carries its own 1-GPU figure and the scaling efficiency against it ----------
+    if world > 1 and rank == 0 and args.kind == "synthetic" and not args.no_side_legs and not args.no_one_rank_leg:
+        try:
+            keep = not args.no_exact_rows
+            need = float(args.rows) * args.dim * (elem + (8 if keep else 0)) + float(32 * GEN_BLOCK) * args.dim * 8 + 4e9
+            free = float(torch.cuda.mem_get_info()[0])
+            if free < need:
+                out["one_rank_error"] = "device memory: one shard of all rows needs %.0f GB, %.0f GB are free" % (need / 1e9, free / 1e9)
+            else:
+                one = ShardedSolver(alg, args.rows, args.dim, device=local_rank, store_dtype=store, keep_exact_rows=keep, solo=True)
+                load_synthetic(args, torch, one)
+                if one.finalize(None) != nat.OK:
+                    raise RuntimeError("finalize failed")
+                n1 = min(args.steps, 100)
+                el1, tr1, ms1, l1, _ = timed(one, args.warmup, n1, solo=True)
+                its1 = len(tr1[0]) / el1
+                b1 = float(args.rows) * args.dim * elem
+                out["one_rank_its"] = its1
+                out["one_rank_ms_per_step"] = el1 / max(len(tr1[0]), 1) * 1e3
+                out["one_rank_scan_frac"] = (b1 / (ms1 / max(l1, 1) * 1e-3) / 1e9 / HBM_PEAK_GBS) if ms1 > 0 else None
+                out["one_rank_same_selections"] = bool(all(int(x) == int(y) for x, y in zip(tr1[0], sel)))
+                out["speedup_vs_one_rank"] = out["value"] / its1
+                out["scaling_efficiency"] = out["value"] / its1 / world
+                out["config"]["one_rank_leg"] = ("the same rows as one shard on rank 0's GPU, %d iterations after the same %d warm-up "
+                                                 "iterations, while the other ranks wait off the CPU" % (len(tr1[0]), args.warmup))
+                del one
+                torch.cuda.empty_cache()
+        except Exception as e:      # the headline line must survive a broken side leg
+            out["one_rank_error"] = "%s: %s" % (type(e).__name__, e)
     # ---- the same workload with fp64-stored rows (the reference's own arithmetic end to end), c4 line only ----------
     if args.config == "c4" and not args.adhoc and store == nat.F32 and not args.no_exact_mode and world == 1:
         del solver
@@ -437,25 +589,17 @@ def run_snnls(args, torch, dist, nat, world, rank, local_rank):
                                "resolves": int(st3.get("resolves", 0))},
                 }
             del hs
-    if rank == 0 and not args.no_cpu_baseline and world == 1:
+    # ---- the reference's arithmetic on this box's host cores, on EVERY line (1, 2, 4, 8 ranks): rank 0 computes, the other
+    # ranks sleep on the rendezvous store meanwhile ----------------------------------------------------------------------
+    if rank == 0 and not args.no_cpu_baseline:
         if args.kind == "logistic":
-            X = cpu_sample
-            what = "Laplace-projected logistic vectors"
+            out["cpu_baseline"] = cpu_baseline_snnls(args, torch, world, "Laplace-projected logistic vectors", sample=cpu_sample)
         else:
-            n_s = min(args.cpu_rows, args.rows)
-            try:      # the oracle holds A, An and temporaries: three copies of the fp64 sample
-                import psutil
-                while n_s > 8 * GEN_BLOCK and 3.5 * n_s * args.dim * 8 > 0.6 * psutil.virtual_memory().available:
-                    n_s //= 2
-            except ImportError:
-                n_s = min(n_s, 200_000)
-            n_s = (n_s // GEN_BLOCK) * GEN_BLOCK or n_s
-            parts = [gen_block(torch, args.seed, blk, min(GEN_BLOCK, n_s - blk * GEN_BLOCK), args.dim, "cuda").cpu().numpy()
-                     for blk in range((n_s + GEN_BLOCK - 1) // GEN_BLOCK)]
-            X = np.concatenate(parts, axis=0)
-            what = "synthetic randn"
-        out["cpu_baseline"] = cpu_baseline_snnls(args, X, what)
+            out["cpu_baseline"] = cpu_baseline_snnls(args, torch, world, "synthetic randn")
         out["cpu_baseline_onepass"] = out["cpu_baseline"]["onepass_value"]      # flat: it/s, scaled to N like `value`
+        out["speedup_vs_cpu_baseline"] = out["value"] / max(out["cpu_baseline"]["value"], 1e-300)
+    if world > 1:
+        wait_for_rank0(dist, rank, "bench_host_legs_done_%s" % args.config)
     return out
 
 
@@ -552,7 +696,10 @@ def run_sparsevi(args, torch, dist, nat, world, rank, local_rank):
         elapsed = float(t.item())
     kms, launches, flops = prj.profile_read()
     prj.profile(False)
+    host_leg = world > 1 and not args.no_cpu_baseline
     if rank != 0:
+        if host_leg:
+            wait_for_rank0(dist, rank, "bench_host_legs_done_c5_%s" % args.colsum)      # (rank 0 times the oracle meanwhile)
         return None
     # (the k-point core projections are launches too: their flops and time are in the totals, weight ~1e-5)
     per_launch_flops = 2.0 * (hi - lo) * D * S
@@ -589,8 +736,11 @@ def run_sparsevi(args, torch, dist, nat, world, rank, local_rank):
                                "profiles/r02_mfma_f64_probe.txt)",
         },
     }
-    if not args.no_cpu_baseline and world == 1:
+    if not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline_sparsevi(args, Z, mu0, Sig0, sigsq, S)
+        out["speedup_vs_cpu_baseline"] = out["value"] / max(out["cpu_baseline"]["value"], 1e-300)
+    if host_leg:
+        wait_for_rank0(dist, rank, "bench_host_legs_done_c5_%s" % args.colsum)
     return out
 
 

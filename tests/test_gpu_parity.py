@@ -304,6 +304,12 @@ def _graded_error_trace(err, ref):
     np.testing.assert_allclose(err[:n], ref[:n], rtol=1e-9, atol=2e-14 * ref[0])
 
 
+def _graded_close(value, ref, scale):
+    """One error value in the floor regime under the same graded bound: 1e-9 relative + 2e-14 of `scale` (the size of the
+    vectors whose difference the error is: ||b||, or the first error of the run where the iterate starts far from b)."""
+    np.testing.assert_allclose(value, ref, rtol=1e-9, atol=2e-14 * scale)
+
+
 def test_F4_giga_latch(bc, golden, normal_inputs):
     """GIGA driven to the numeric limit: same 429 selections, then select fails twice in a row
     (cdirnrm < TOL, giga.py:28) and the solver latches (snnls.py:63-72) at the same place."""
@@ -314,7 +320,7 @@ def test_F4_giga_latch(bc, golden, normal_inputs):
     assert len(sel) == len(golden["F4_giga_sel"]) + 2 and list(status[-2:]) == [1, 1] and list(sel[-2:]) == [-1, -1]
     assert s.reached_numeric_limit is True and bool(golden["F4_giga_limit"])
     assert s.size() == int(golden["F4_giga_size"])
-    np.testing.assert_allclose(s.error(), float(golden["F4_giga_final_err"]), rtol=1e-3)
+    _graded_close(s.error(), float(golden["F4_giga_final_err"]), float(np.linalg.norm(X.sum(axis=0))))
     _graded_error_trace(err[status == 0], golden["F4_giga_err"])
     w = s.weights()
     assert np.array_equal(np.flatnonzero(w > 0), golden["F4_giga_idx"])
@@ -331,8 +337,9 @@ def test_F4_fw_400(bc, golden, normal_inputs):
     sel, err, status = s.last_trace
     assert np.array_equal(sel, golden["F4_fw_sel"])
     assert s.size() == int(golden["F4_fw_size"]) and not s.reached_numeric_limit
-    np.testing.assert_allclose(s.error(), float(golden["F4_fw_final_err"]), rtol=1e-4)
-    np.testing.assert_allclose(err, golden["F4_fw_err"], rtol=1e-4)
+    # (Frank-Wolfe's iterate starts at a polytope vertex of size sum(norms): the first error, 9.9e4, is the scale of the
+    #  vectors its error is the difference of)
+    _graded_close(s.error(), float(golden["F4_fw_final_err"]), float(golden["F4_fw_err"][0]))
     _graded_error_trace(err, golden["F4_fw_err"])
 
 
@@ -344,7 +351,16 @@ def test_F4_omp_past_k_equals_d(bc, golden, normal_inputs):
     sel = s.last_trace[0]
     assert np.array_equal(sel[:100], golden["F4_omp_sel"][:100])
     assert s.size() == 100 and not s.reached_numeric_limit
-    assert s.error() < 1e-10
+    # past k = d the weights are determined only up to the solver's tolerance: compare through A w.
+    # Both solutions reproduce b; their images differ by no more than the two errors, each under the graded floor bound
+    bn = float(np.linalg.norm(X.sum(axis=0)))
+    gw = np.zeros(X.shape[0])
+    gw[golden["F4_omp_idx"]] = golden["F4_omp_w"]
+    w = s.weights()
+    assert (w >= 0).all()
+    gap = float(np.linalg.norm(X.T.dot(w) - X.T.dot(gw)))
+    assert gap <= 2e-14 * bn + float(golden["F4_omp_final_err"]) * (1 + 1e-9), (gap, s.error(), bn)
+    assert s.error() <= 2e-14 * bn, (s.error(), bn)
 
 
 @pytest.mark.parametrize("alg", ("giga", "fw", "omp"))
@@ -628,7 +644,8 @@ def test_F10_giga_without_monotone_check(bc, host_golden, normal_inputs, how):
     assert np.array_equal(sel[sel >= 0], host_golden["F10_giga_sel"])
     assert not (status == 3).any()                                   # no monotone failures can be reported
     assert s.reached_numeric_limit == bool(host_golden["F10_giga_limit"]) and s.size() == int(host_golden["F10_giga_size"])
-    np.testing.assert_allclose(s.error(), float(host_golden["F10_giga_final_err"]), rtol=1e-3)
+    _graded_close(s.error(), float(host_golden["F10_giga_final_err"]), float(np.linalg.norm(X.sum(axis=0))))
+    _graded_error_trace(err[status == 0], host_golden["F10_giga_err"])
 
 
 def test_F10_fw_without_monotone_check(bc, host_golden, normal_inputs):
@@ -639,7 +656,7 @@ def test_F10_fw_without_monotone_check(bc, host_golden, normal_inputs):
     n_ok = int((status == 0).sum())
     assert np.array_equal(sel[sel >= 0][:400], host_golden["F10_fw_sel"][:400])
     assert not (status == 3).any() and s.reached_numeric_limit == bool(host_golden["F10_fw_limit"])
-    np.testing.assert_allclose(err[status == 0][:400], host_golden["F10_fw_err"][:400], rtol=1e-4)
+    _graded_error_trace(err[status == 0][:400], host_golden["F10_fw_err"][:400])
     assert n_ok >= 400
 
 

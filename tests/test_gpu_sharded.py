@@ -540,6 +540,32 @@ def test_bench_contract_eight_ranks():
     assert eight["config"]["exchange_probe"]["result"] == 1
 
 
+def test_multi_rank_line_carries_cpu_baseline_and_both_rooflines():
+    """`BENCH_SHARE_GPU=1 python bench.py --gpus 2 --steps 10` with NO launcher: the line of a multi-rank run carries the CPU
+    baseline (rank 0 times the oracle while the other rank waits on the rendezvous store), the per-GPU and the aggregate
+    roofline, and the same workload as one shard with the scaling efficiency against it."""
+    import json
+    import subprocess
+    bench = os.path.join(ROOT, "bench.py")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    out = subprocess.run([sys.executable, bench, "--gpus", "2", "--steps", "10", "--warmup", "5", "--rows", "300000", "--dim", "64",
+                          "--cpu-seconds", "2"], capture_output=True, text=True, timeout=900, env=dict(env, BENCH_SHARE_GPU="1"), cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    two = json.loads(lines[0])
+    assert two["n_gpus"] == 2
+    cb = two["cpu_baseline"]
+    assert cb["value"] > 0 and cb["cores"] >= 1 and cb["kind"] == "port" and cb["onepass_value"] > 0
+    assert cb["sample_rows"] == 300000        # the whole (small) workload fits the sample: nothing scaled
+    rf = two["roofline"]
+    assert 0.0 < rf["frac"] and 0.0 < rf["frac_aggregate"] <= 1.0 and rf["peak_aggregate"] == 2 * rf["peak"]
+    assert len(rf["per_gpu_frac"]) == 2 and sum(rf["per_gpu_rows"]) == 300000
+    assert two["one_rank_its"] > 0 and two["one_rank_same_selections"] is True
+    assert abs(two["scaling_efficiency"] - two["value"] / two["one_rank_its"] / 2) < 1e-12
+    assert two["speedup_vs_cpu_baseline"] > 1.0
+
+
 # ---- one rank per DEVICE over RCCL: runs only where the box has >= 2 GPUs (the 1-GPU test boxes skip it) ------------
 def _multi_device_worker(rank, world, port, alg, itrs, N, d, out_dir, exchange):
     os.environ["BCX_EXCHANGE"] = exchange
