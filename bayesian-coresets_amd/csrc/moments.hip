@@ -466,13 +466,17 @@ static void gram_plan(int k, int d, int* nblk, int* nslices, int64_t* len_per_sl
   *pshift = *nblk >= 32 ? 1 : 0;
   if (force_p >= 0 && force_p <= 3) *pshift = force_p;
 }
+int64_t bcx_gram_sk_scratch_bytes(int k, int d);      // gram.hip: the chip-balanced kernel (16-byte aligned rows, k >= 192)
+int bcx_gram_sk(hipStream_t st, const double* rows, int k, int d, int64_t ld, double* G, int64_t ldg, double* work);
 int64_t bcx_gram_rows_scratch_bytes(int k, int d) {
   int nblk, nslices, ps; int64_t lps;
   gram_plan(k, d, &nblk, &nslices, &lps, &ps);
-  if (nslices == 1) return 8;                                    // (unused)
-  return (int64_t)nslices * (nblk * (nblk + 1) / 2) * MOM_BLK * MOM_BLK * (int64_t)sizeof(double);
+  const int64_t tiled = nslices == 1 ? 8 : (int64_t)nslices * (nblk * (nblk + 1) / 2) * MOM_BLK * MOM_BLK * (int64_t)sizeof(double);
+  return std::max<int64_t>(tiled, bcx_gram_sk_scratch_bytes(k, d));     // (which kernel runs depends on the rows' alignment)
 }
 int bcx_gram_rows(hipStream_t st, const double* rows, int k, int d, int64_t ld, double* G, int64_t ldg, double* work) {
+  const int sk = bcx_gram_sk(st, rows, k, d, ld, G, ldg, work);
+  if (sk <= 0) return sk;
   int nblk, nslices, ps; int64_t lps;
   gram_plan(k, d, &nblk, &nslices, &lps, &ps);
   const int npairs = nblk * (nblk + 1) / 2;

@@ -828,11 +828,16 @@ for family, S in (("linreg", 200), ("poisson", 256), ("logistic", 128)):
 
 
 @pytest.mark.parametrize("k,d,pad", ((1, 1, 0), (5, 3, 1), (64, 32, 0), (65, 33, 0), (100, 100, 0), (130, 257, 1), (200, 129, 0), (333, 1000, 2),
-                                     (1497, 1024, 0), (700, 8192, 0), (2100, 64, 0)))
+                                     (1497, 1024, 0), (700, 8192, 0), (2100, 64, 0),
+                                     # the chip-balanced kernel (csrc/gram.hip: 16-byte aligned rows, k >= 192, d >= 64): 128 x 64 tiles ...
+                                     (192, 64, 0), (193, 70, 2), (257, 1000, 0), (1025, 333, 1), (2559, 96, 0),
+                                     # ... and 128 x 128 tiles from k = 2560, ragged row lengths, tiles hanging over the edge
+                                     (2560, 200, 0), (3000, 1030, 2), (4096, 1024, 0), (4100, 65, 1)))
 def test_gram_operator_matches_numpy(bc, k, d, pad):
-    """bcx_gram (csrc/moments.hip, the transposed-layout instance of the second-moment kernel): G = V V^T of k rows of d
-    doubles against NumPy -- block edges (k around multiples of 64), slice edges (d around multiples of 32), odd row strides
-    (8-byte staging loads) and padded ones, both triangles written, nothing outside the k x k block touched."""
+    """bcx_gram: G = V V^T of k rows of d doubles against NumPy, through both kernels -- csrc/gram.hip (tiles cut into equal
+    ranges of stages over all workgroups; partial tiles added by the finisher) and csrc/moments.hip gram_tile_kernel (odd
+    row strides, small supports): block edges, ragged row lengths, odd and padded row strides, both triangles written and
+    bit-identical, nothing outside the k x k block touched."""
     import torch
     from bayesiancoresets_amd import _native as nat
     lib = nat.load()

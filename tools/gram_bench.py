@@ -1,4 +1,5 @@
-"""dev: the Gram operator of the dense re-weight (bcx_gram: csrc/moments.hip moments_kernel<true> + moments_reduce_kernel) --
+"""dev: the Gram operator of the dense re-weight (bcx_gram: csrc/gram.hip gram_sk_kernel; BCX_GRAM_NCT=-1: csrc/moments.hip
+gram_tile_kernel + moments_reduce_kernel; BCX_GRAM_NCT=4 / 8 forces the tile width) --
 kernel time by hipEvents over `reps` back-to-back calls, upper-triangle flops k (k + 1) d over that time against the fp64 MFMA
 peak; beside it round 2's direct kernel through optimize() is selected with BCX_GRAM_DIRECT=1 (tools/optimize_bench.py).
     python tools/gram_bench.py [k,d ...]"""
@@ -11,7 +12,7 @@ from bayesiancoresets_amd import _native as nat
 
 PEAK = 78.6
 lib = nat.load()
-shapes = [tuple(int(v) for v in a.split(",")) for a in sys.argv[1:]] or [(400, 512), (999, 512), (1497, 1024), (1024, 1024), (2048, 2048), (4096, 1024), (512, 4096)]
+shapes = [tuple(int(v) for v in a.split(",")) for a in sys.argv[1:]] or [(400, 512), (999, 512), (1497, 1024), (1024, 1024), (2048, 2048), (4096, 1024), (512, 4096), (8192, 1024)]
 for k, d in shapes:
     V = torch.randn(k, d, dtype=torch.float64, device="cuda")
     G = torch.empty(k, k, dtype=torch.float64, device="cuda")
