@@ -2,26 +2,32 @@
 // orthopursuit.py:37-42) on the fp64 matrix cores, balanced over the whole chip ("stream-K").
 //
 // Why a second Gram kernel (the first one, gram_tile_kernel in moments.hip, stays as the path for rows that are not
-// 16-byte aligned and for small supports): that kernel hands out whole 64 x 64 blocks of the upper triangle, stages both
-// operands through registers with two workgroup barriers per 32 values, and uses v_mfma_f64_16x16x4_f64, which tops out
-// at 47.6 TFLOP/s on this chip (tools/probe/mfma_f64_peak.hip).  At k = 4096 that is 528 x 4 block pairs for 512
-// resident workgroups -- a ragged last round -- and 0.51 of the fp64 MFMA peak.  Here:
-//   * the inner loop is the projection kernel's (csrc/proj.hip): 128 x 64 workgroup tiles, operands fetched by LDS-DMA
-//     (global_load_lds_dwordx4, no staging registers) TWO 16-value stages ahead into three-slot rings, one counted wait +
-//     one bare barrier per stage, v_mfma_f64_4x4x4_4b_f64 (72.8 TFLOP/s register-only) with one operand natural and one
-//     replicated, rotated 128-byte LDS lines so that every ds_read_b128 is conflict free;
+// 16-byte aligned and for small supports): that kernel hands out whole 64 x 64 blocks of the upper triangle (at k = 4096:
+// 528 x 4 block pairs for 512 resident workgroups -- a ragged last round), stages both operands through registers with two
+// workgroup barriers per 32 values, gives a wave 32 x 32 entries (one operand read per MFMA) and stores the mirror image as
+// 8-byte entries 32 KiB apart: 0.34 / 0.51 of the fp64 MFMA peak at k = 1497 / 4096 (d = 1024).  Here:
+//   * 128 x 128 workgroup tiles (128 x 64 below k = 3072), a wave multiplies 64 rows by 64 (32) columns with
+//     v_mfma_f64_16x16x4_f64: 8 (6) ds_read_b128 feed 32 (16) MFMAs per 8 values of the row length.  Operands come by
+//     LDS-DMA (global_load_lds_dwordx4, no staging registers) one stage of 16 values ahead into two-slot rings (two ahead,
+//     three slots, for the narrow tile), one wait + one bare barrier per stage; 128-byte LDS lines rotated so that every
+//     ds_read_b128 is conflict free (SQ_LDS_BANK_CONFLICT = 0, layout of csrc/proj.hip);
 //   * the work is the SEQUENCE of (tile, stage) units of the upper triangle, cut into equal contiguous ranges, one per
 //     resident workgroup: every workgroup multiplies for the same time whatever k is.  A tile whose stages span several
 //     workgroups is finished by the one that holds its last stage: the others leave their partial accumulators in
-//     scratch (register layout, 512-byte coalesced) and raise a flag; the finisher adds them in a fixed order (its own
+//     scratch (register layout, 16-byte pieces, coalesced) and raise a flag; the finisher adds them in a fixed order (its own
 //     part first, then the contributors from the nearest to the farthest), so the result is deterministic for a given
-//     (k, d, workgroup count);
+//     (k, d, workgroup count).  Every workgroup takes the piece its successors finish FIRST and the piece its predecessors
+//     began LAST, so nobody waits for a workgroup that has not started yet;
 //   * the tile sequence is cut into eight contiguous pieces, one per XCD (workgroups b, b + 8, ... share an XCD under
 //     round-robin dispatch: a speed assumption, not a correctness one), so the workgroups of an XCD walk neighbouring tiles
 //     of the same block rows and find one of the two row panels in their L2; a workgroup only ever waits for workgroups
-//     with a LOWER blockIdx (b - 8, b - 16, ...), which were dispatched before it.
-// Both triangles are written, every entry pair from ONE accumulator (the one on or above the diagonal, stored together with
-// its mirror image): G is symmetric bit for bit.
+//     with a LOWER blockIdx (b - 8, b - 16, ...), which were dispatched before it;
+//   * both triangles are written, every entry pair from ONE accumulator (the one on or above the diagonal): G is symmetric
+//     bit for bit; the mirror image leaves the wave transposed in registers, as 16-byte pieces that fill 128-byte lines.
+// Measured (tools/gram_bench.py, d = 1024): k = 4096 306 us = 0.72 of the peak on the triangle's k (k + 1) d flops (the
+// steady state of the stage loop is 0.78; launch, prologue, partial tiles and stores are ~28 us), k = 8192 0.76,
+// k = 1497 81 us = 0.36 (19.5 stages per workgroup: the fixed costs dominate).  An earlier version of this kernel on the
+// projection kernel's v_mfma_f64_4x4x4_4b_f64 loop (one operand replicated: 4.5 times the LDS reads per flop) reached 0.62.
 #include <algorithm>
 #include <atomic>
 #include <chrono>
@@ -32,15 +38,16 @@ typedef double gk4d __attribute__((ext_vector_type(4)));
 typedef double gk2d __attribute__((ext_vector_type(2)));
 
 #define GK_KC 16                      // values of the row length per stage
-#define GK_ROWS 128                   // rows of G per tile (4 waves x 32)
+#define GK_ROWS 128                   // rows of G per tile: 2 x 2 waves, 64 rows x (16 NTB) columns each
 #define GK_IBYTES (GK_ROWS * GK_KC * 8)
-#define GK_COLS(NCT) (16 * (NCT))
-#define GK_JBYTES(NCT) (GK_COLS(NCT) * GK_KC * 8)
-#define GK_RING 3                     // stages of rows resident in LDS (requests run two stages ahead)
-#define GK_JBASE (GK_RING * GK_IBYTES)
-#define GK_LDS_BYTES(NCT) (GK_JBASE + GK_RING * GK_JBYTES(NCT))
-#define GK_NCT 4                      // 16-column tiles per workgroup tile: 128 x 64 (128 x 128 needs 96 KiB for the three-slot
-                                      // rings -- one workgroup per CU -- and measured slower with two slots: 0.52 against 0.59 at k = 4096)
+// NTB = 16-column tiles per wave: 4 (a 128 x 128 workgroup tile; rows requested one stage ahead into two-slot rings: 64 KiB,
+// two workgroups per CU) or 2 (128 x 64 for smaller supports -- more tiles to balance, half the partial tile; two stages ahead
+// into three-slot rings: 72 KiB)
+#define GK_COLS(NTB) (32 * (NTB))
+#define GK_JBYTES(NTB) (GK_COLS(NTB) * GK_KC * 8)
+#define GK_RING(NTB) ((NTB) == 4 ? 2 : 3)
+#define GK_JBASE(NTB) (GK_RING(NTB) * GK_IBYTES)
+#define GK_LDS_BYTES(NTB) (GK_JBASE(NTB) + GK_RING(NTB) * GK_JBYTES(NTB))
 #define GK_MIN_STAGES 6               // a workgroup is not started for fewer stages than this (prologue + fix-up cost)
 
 struct GramSkArgs {
@@ -53,6 +60,7 @@ struct GramSkArgs {
   int64_t ld, ldg;
   long long timeout_ticks;
   int k, d, nI, nJ, ntiles, nst;
+  int dbg;                // dev (BCX_GRAM_DBG): 1 = no row requests after the first stage, 2 = no partial tiles / fix-up (timing experiments: wrong results)
 };
 
 // One LDS-DMA request: 64 lanes x 16 bytes, each lane's own global address -> lds_dst + 16 * lane (csrc/proj.hip pj_glds16:
@@ -74,14 +82,37 @@ static __device__ __forceinline__ gk2d gk_ld2(const double* p) {
   return v;
 }
 
+// Exchanges between the four 16-lane rows of a wave (lane >> 4 = 0 .. 3), on doubles:
+//   gk_swap16(a, b): rows (r0 r1 r2 r3) of a and b -> a = (a.r0, b.r0, a.r2, b.r2), b = (a.r1, b.r1, a.r3, b.r3)
+//   gk_swap32(a, b):                                 a = (a.r0, a.r1, b.r0, b.r1), b = (a.r2, a.r3, b.r2, b.r3)
+// (v_permlane16_swap / v_permlane32_swap on the two halves of the value; element reads through named scalars, see scan.hip)
+typedef unsigned gk_v2u __attribute__((ext_vector_type(2)));
+static __device__ __forceinline__ void gk_swap16(double& a, double& b) {
+  const unsigned long long ua = (unsigned long long)__double_as_longlong(a), ub = (unsigned long long)__double_as_longlong(b);
+  const gk_v2u lo = __builtin_amdgcn_permlane16_swap((unsigned)ua, (unsigned)ub, false, false);
+  const gk_v2u hi = __builtin_amdgcn_permlane16_swap((unsigned)(ua >> 32), (unsigned)(ub >> 32), false, false);
+  const unsigned al = lo.x, bl = lo.y, ah = hi.x, bh = hi.y;
+  a = __longlong_as_double((long long)(((unsigned long long)ah << 32) | al));
+  b = __longlong_as_double((long long)(((unsigned long long)bh << 32) | bl));
+}
+static __device__ __forceinline__ void gk_swap32(double& a, double& b) {
+  const unsigned long long ua = (unsigned long long)__double_as_longlong(a), ub = (unsigned long long)__double_as_longlong(b);
+  const gk_v2u lo = __builtin_amdgcn_permlane32_swap((unsigned)ua, (unsigned)ub, false, false);
+  const gk_v2u hi = __builtin_amdgcn_permlane32_swap((unsigned)(ua >> 32), (unsigned)(ub >> 32), false, false);
+  const unsigned al = lo.x, bl = lo.y, ah = hi.x, bh = hi.y;
+  a = __longlong_as_double((long long)(((unsigned long long)ah << 32) | al));
+  b = __longlong_as_double((long long)(((unsigned long long)bh << 32) | bl));
+}
+
 struct GkPos { int tile, s, I, J; };
 
 // first column block of block row I that holds an entry on or above the diagonal
-template <int NCT> static __host__ __device__ __forceinline__ int gk_jmin(int I) { return (I * GK_ROWS) / GK_COLS(NCT); }
+template <int NTB> static __host__ __device__ __forceinline__ int gk_jmin(int I) { return (I * GK_ROWS) / GK_COLS(NTB); }
 
-template <int NCT>
+template <int NTB>
 __global__ __launch_bounds__(256, 2) void gram_sk_kernel(GramSkArgs p) {
-  constexpr int COLS = GK_COLS(NCT), JBYTES = GK_JBYTES(NCT), TCH = NCT / 2, NREQ = 4 + TCH;
+  constexpr int COLS = GK_COLS(NTB), JBYTES = GK_JBYTES(NTB), JBASE = GK_JBASE(NTB), RING = GK_RING(NTB), AHEAD = RING - 1;
+  constexpr int TCH = NTB, NREQ = 4 + TCH;     // LDS-DMA requests per wave and stage: 4 chunks of the row block, TCH of the column block
   extern __shared__ __attribute__((aligned(16))) unsigned char gk_lds[];
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int li = lane & 15, lk = lane >> 4;
@@ -96,14 +127,14 @@ __global__ __launch_bounds__(256, 2) void gram_sk_kernel(GramSkArgs p) {
     GkPos a;
     a.tile = t_lo + (int)(v / nst); a.s = (int)(v % nst);
     int t = a.tile, I = 0;
-    while (t >= p.nJ - gk_jmin<NCT>(I)) { t -= p.nJ - gk_jmin<NCT>(I); ++I; }
-    a.I = I; a.J = gk_jmin<NCT>(I) + t;
+    while (t >= p.nJ - gk_jmin<NTB>(I)) { t -= p.nJ - gk_jmin<NTB>(I); ++I; }
+    a.I = I; a.J = gk_jmin<NTB>(I) + t;
     return a;
   };
   auto advance = [&](GkPos a) {
     if (++a.s == nst) {
       a.s = 0; a.tile += 1;
-      if (++a.J == p.nJ) { a.I += 1; a.J = gk_jmin<NCT>(a.I); }
+      if (++a.J == p.nJ) { a.I += 1; a.J = gk_jmin<NTB>(a.I); }
     }
     return a;
   };
@@ -172,7 +203,7 @@ __global__ __launch_bounds__(256, 2) void gram_sk_kernel(GramSkArgs p) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) gk_glds16(p.V + (ip[j] + kc), lds0 + (unsigned)(rs * GK_IBYTES + (4 * wave + j) * 1024));
 #pragma unroll
-    for (int j = 0; j < TCH; ++j) gk_glds16(p.V + (jp[j] + kc), lds0 + (unsigned)(GK_JBASE + rs * JBYTES + (TCH * wave + j) * 1024));
+    for (int j = 0; j < TCH; ++j) gk_glds16(p.V + (jp[j] + kc), lds0 + (unsigned)(JBASE + rs * JBYTES + (TCH * wave + j) * 1024));
   };
   // pieces beyond the row length (last stage, d not a multiple of 16): zeroed by the lane that requested them, after its
   // requests have landed and before the barrier.  Rows beyond k are copies of row k - 1: their products are never stored.
@@ -182,84 +213,87 @@ __global__ __launch_bounds__(256, 2) void gram_sk_kernel(GramSkArgs p) {
 #pragma unroll
     for (int j = 0; j < NREQ; ++j) {
       unsigned char* dst = j < 4 ? gk_lds + rs * GK_IBYTES + (4 * wave + j) * 1024 + lane * 16
-                                 : gk_lds + GK_JBASE + rs * JBYTES + (TCH * wave + j - 4) * 1024 + lane * 16;
+                                 : gk_lds + JBASE + rs * JBYTES + (TCH * wave + j - 4) * 1024 + lane * 16;
       if (k0 >= p.d) *(gk2d*)dst = (gk2d){0.0, 0.0};
       else *(double*)(dst + 8) = 0.0;
     }
   };
   const bool ragged = (p.d & (GK_KC - 1)) != 0;
-  // read-side bases of this lane inside a 16-row operand tile (csrc/proj.hip): natural piece (row li, k-slot lk) and replicated
-  // piece (row lane & 3 of the strip, k-slot lk) of an even 8-value step; ^ 64 for an odd step
+  // Read side.  v_mfma_f64_16x16x4_f64 takes one double per lane from each operand: lane (li = lane & 15, lk = lane >> 4)
+  // supplies A[row li][k lk] and B[k lk][column li], and D[row (lane >> 4) + 4 reg][column lane & 15] comes back.  Both operands are
+  // read in the "natural" form of csrc/proj.hip: one ds_read_b128 gives the lane the two consecutive values {2 lk, 2 lk + 1}
+  // of an 8-value step of its row li -- the .x halves of the eight lanes groups form one 4-value MFMA step (values 0, 2, 4, 6),
+  // the .y halves the next (1, 3, 5, 7); any assignment of values to steps is fine as long as both operands use the same one.
+  // Byte offset inside a 16-row tile (2 chunks) for an even 8-value step; ^ 64 for an odd one.  A wave multiplies 64 rows by
+  // 16 NTB columns: 4 + NTB reads per 8-value step feed 8 NTB MFMAs (the 4x4x4 form of the projection kernel needs 4.5 times
+  // the LDS traffic per flop: it replicates one operand).
   const unsigned nat0 = (unsigned)((li >> 3) * 1024 + (li & 7) * 128 + ((lk + 2 * ((li >> 1) & 3)) & 7) * 16);
-  const unsigned rep0 = (unsigned)((lane & 3) * 128 + ((lk + 2 * ((lane >> 1) & 1)) & 7) * 16);
-  // acc[i][t][r] at lane (li, lk) = C[row 128 I + 32 wave + 16 i + li][column COLS J + 16 t + 4 r + lk]
-  gk4d acc[2][NCT];
+  const int wi = wave >> 1, wj = wave & 1;     // this wave's 64 rows / 16 NTB columns of the workgroup tile
+  // acc[ta][tb][r] at lane (li, lk) = C[row 128 I + 64 wi + 16 ta + lk + 4 r][column COLS J + 16 NTB wj + 16 tb + li]
+  gk4d acc[4][NTB];
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int ta = 0; ta < 4; ++ta)
 #pragma unroll
-    for (int t = 0; t < NCT; ++t) acc[i][t] = (gk4d){0.0, 0.0, 0.0, 0.0};
+    for (int tb = 0; tb < NTB; ++tb) acc[ta][tb] = (gk4d){0.0, 0.0, 0.0, 0.0};
   double* const mypart = p.part + (size_t)blockIdx.x * (GK_ROWS * COLS);
 
-  // ---- the stage pipeline: rows are requested TWO stages ahead into a ring of three slots (the panels come from L2 / the
-  // infinity cache, a microsecond or two away under load; one stage of this tile is ~1.5 us) ----
+  // ---- the stage pipeline: rows are requested AHEAD stages ahead into rings of RING slots ----
   It cur = seg_start(0), n1 = succ(cur), n2 = succ(n1);
   int rs = 0;
   issue_all(cur.g, 0);
-  if (n1.seg < 3) { issue_all(n1.g, 1); asm volatile("s_waitcnt vmcnt(%0)" :: "n"(NREQ) : "memory"); }
+  if (AHEAD == 2 && n1.seg < 3) { issue_all(n1.g, 1); asm volatile("s_waitcnt vmcnt(%0)" :: "n"(NREQ) : "memory"); }
   else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   if (ragged && cur.g.s == nst - 1) zero_tail(cur.g, 0);
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
   int piece_s0 = cur.g.s;                     // stage of its tile at which the current piece began
   for (;;) {
-    const int rs1 = rs == GK_RING - 1 ? 0 : rs + 1, rs2 = rs1 == GK_RING - 1 ? 0 : rs1 + 1;
-    const bool ahead = n2.seg < 3;
-    int kc2 = 0;
+    const int rs1 = rs == RING - 1 ? 0 : rs + 1, rsq = AHEAD == 2 ? (rs1 == RING - 1 ? 0 : rs1 + 1) : rs1;
+    const It& rq = AHEAD == 2 ? n2 : n1;       // the stage whose rows are requested while this one is multiplied
+    const bool ahead = rq.seg < 3 && !(p.dbg & 1);
+    int kcq = 0;
     if (ahead) {
-      if (n2.g.I != ip_I) set_i(n2.g.I);
-      if (n2.g.J != jp_J) set_j(n2.g.J);
-      kc2 = min(n2.g.s * GK_KC + 2 * fq, kmax);
+      if (rq.g.I != ip_I) set_i(rq.g.I);
+      if (rq.g.J != jp_J) set_j(rq.g.J);
+      kcq = min(rq.g.s * GK_KC + 2 * fq, kmax);
     }
     {
-      const unsigned char* ib = gk_lds + rs * GK_IBYTES + wave * 4096;          // this wave's two row tiles (natural operand)
-      const unsigned char* jb = gk_lds + GK_JBASE + rs * JBYTES;                // the column block's NCT tiles (replicated operand)
-      const unsigned char* natb[2] = {ib + nat0, ib + (nat0 ^ 64u)};
-      const unsigned char* repb[2] = {jb + rep0, jb + (rep0 ^ 64u)};
-      constexpr int NU = GK_KC / 8, NG = NCT * NU;
-      auto nat_ptr = [&](int uu, int t) { return (const gk2d*)(natb[uu & 1] + t * 2048); };
-      auto rep_ptr = [&](int g, int r) {
-        const int uu = g / NCT, t = g % NCT;
-        return (const gk2d*)(repb[(uu + r) & 1] + t * 2048 + (r >> 1) * 1024 + (r & 1) * 512);
-      };
-      gk2d rp[2][4];
+      const unsigned char* ibase = gk_lds + rs * GK_IBYTES + wi * 8192;                   // this wave's four row tiles
+      const unsigned char* jbase = gk_lds + JBASE + rs * JBYTES + wj * (NTB * 2048);      // and its NTB column tiles
+      const unsigned char* ib[2] = {ibase + nat0, ibase + (nat0 ^ 64u)};                  // even / odd 8-value step
+      const unsigned char* jb[2] = {jbase + nat0, jbase + (nat0 ^ 64u)};
+      gk2d av[2][4], bv[2][NTB];
 #pragma unroll
-      for (int r = 0; r < 4; ++r) rp[0][r] = *rep_ptr(0, r);
-      gk2d nt[2];
+      for (int t = 0; t < 4; ++t) av[0][t] = *(const gk2d*)(ib[0] + t * 2048);
 #pragma unroll
-      for (int g = 0; g < NG; ++g) {
-        const int uu = g / NCT, t = g % NCT;
-        if (t == 0) {
+      for (int t = 0; t < NTB; ++t) bv[0][t] = *(const gk2d*)(jb[0] + t * 2048);
 #pragma unroll
-          for (int i = 0; i < 2; ++i) nt[i] = *nat_ptr(uu, i);
+      for (int u = 0; u < GK_KC / 8; ++u) {
+        if (u + 1 < GK_KC / 8) {              // the other 8-value step's operands are on their way while this one is multiplied
+#pragma unroll
+          for (int t = 0; t < 4; ++t) av[(u + 1) & 1][t] = *(const gk2d*)(ib[(u + 1) & 1] + t * 2048);
+#pragma unroll
+          for (int t = 0; t < NTB; ++t) bv[(u + 1) & 1][t] = *(const gk2d*)(jb[(u + 1) & 1] + t * 2048);
         }
-        if (g + 1 < NG) {
+        // this step's share of the LDS-DMA requests for the stage ahead
+        if (ahead) {
 #pragma unroll
-          for (int r = 0; r < 4; ++r) rp[(g + 1) & 1][r] = *rep_ptr(g + 1, r);
-        }
-        // this group's share of the LDS-DMA requests of the stage after next
-        if (ahead && g < NREQ) {
-          if (g < 4) gk_glds16(p.V + (ip[g < 4 ? g : 0] + kc2), lds0 + (unsigned)(rs2 * GK_IBYTES + (4 * wave + g) * 1024));
-          else gk_glds16(p.V + (jp[g >= 4 && g < NREQ ? g - 4 : 0] + kc2), lds0 + (unsigned)(GK_JBASE + rs2 * JBYTES + (TCH * wave + g - 4) * 1024));
+          for (int q = u * (NREQ / 2); q < (u + 1) * (NREQ / 2) + (u == GK_KC / 8 - 1 ? NREQ % 2 : 0); ++q) {
+            if (q < 4) gk_glds16(p.V + (ip[q < 4 ? q : 0] + kcq), lds0 + (unsigned)(rsq * GK_IBYTES + (4 * wave + q) * 1024));
+            else gk_glds16(p.V + (jp[q >= 4 && q < NREQ ? q - 4 : 0] + kcq), lds0 + (unsigned)(JBASE + rsq * JBYTES + (TCH * wave + q - 4) * 1024));
+          }
         }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int r = 0; r < 4; ++r)
+        for (int ta = 0; ta < 4; ++ta)
 #pragma unroll
-          for (int i = 0; i < 2; ++i) acc[i][t][r] = __builtin_amdgcn_mfma_f64_4x4x4f64(rp[g & 1][r].x, nt[i].x, acc[i][t][r], 0, 0, 0);
+          for (int tb = 0; tb < NTB; ++tb)
+            acc[ta][tb] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[u & 1][ta].x, bv[u & 1][tb].x, acc[ta][tb], 0, 0, 0);
 #pragma unroll
-        for (int r = 0; r < 4; ++r)
+        for (int ta = 0; ta < 4; ++ta)
 #pragma unroll
-          for (int i = 0; i < 2; ++i) acc[i][t][r] = __builtin_amdgcn_mfma_f64_4x4x4f64(rp[g & 1][r].y, nt[i].y, acc[i][t][r], 0, 0, 0);
+          for (int tb = 0; tb < NTB; ++tb)
+            acc[ta][tb] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[u & 1][ta].y, bv[u & 1][tb].y, acc[ta][tb], 0, 0, 0);
         __builtin_amdgcn_sched_barrier(0);
       }
     }
@@ -268,7 +302,7 @@ __global__ __launch_bounds__(256, 2) void gram_sk_kernel(GramSkArgs p) {
     bool stored = false;
     if (tile_done) {
       // ---- this workgroup holds the tile's last stage: add what the holders of its earlier stages left, then store ----
-      if (piece_s0 > 0) {
+      if (piece_s0 > 0 && !(p.dbg & 2)) {
         const int64_t tile_u0 = (int64_t)(cur.g.tile - t_lo) * nst;
         for (int j = slot - 1; j >= 0; --j) {
           const int64_t ju0 = units * j / per, ju1 = units * (j + 1) / per;
@@ -283,61 +317,87 @@ __global__ __launch_bounds__(256, 2) void gram_sk_kernel(GramSkArgs p) {
               }
             }
             __syncthreads();
-            // (partial tile in register order: [wave][i][t][register pair][lane] pairs of doubles; all 4 NCT loads of the
-            // workgroup's share in flight together: one trip to the memory side per contributor)
-            const double* src = p.part + (size_t)b * (GK_ROWS * COLS) + (size_t)wave * (2 * NCT * 4 * 64) + 2 * lane;
+            // (partial tile in register order: [wave][ta][tb][register pair][lane] pairs of doubles; half of the wave's share
+            // in flight at a time: two trips to the memory side per contributor)
+            const double* src = p.part + (size_t)b * (GK_ROWS * COLS) + (size_t)wave * (4 * NTB * 4 * 64) + 2 * lane;
             asm volatile("" : "+v"(src));
-            gk2d v[2][NCT][2];
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
+            for (int half = 0; half < 2; ++half) {
+              gk2d v[2][NTB][2];
 #pragma unroll
-              for (int t = 0; t < NCT; ++t)
+              for (int ta = 0; ta < 2; ++ta)
 #pragma unroll
-                for (int h = 0; h < 2; ++h) v[i][t][h] = gk_ld2(src + ((i * NCT + t) * 2 + h) * 128);
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                for (int tb = 0; tb < NTB; ++tb)
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
+                  for (int h = 0; h < 2; ++h) v[ta][tb][h] = gk_ld2(src + (((2 * half + ta) * NTB + tb) * 2 + h) * 128);
+              asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #pragma unroll
-              for (int t = 0; t < NCT; ++t)
+              for (int ta = 0; ta < 2; ++ta)
 #pragma unroll
-                for (int h = 0; h < 2; ++h) {
-                  asm volatile("" : "+v"(v[i][t][h]));      // (volatile asms keep their order: the values are read after the wait)
-                  acc[i][t][2 * h] += v[i][t][h].x; acc[i][t][2 * h + 1] += v[i][t][h].y;
-                }
+                for (int tb = 0; tb < NTB; ++tb)
+#pragma unroll
+                  for (int h = 0; h < 2; ++h) {
+                    asm volatile("" : "+v"(v[ta][tb][h]));      // (volatile asms keep their order: the values are read after the wait)
+                    acc[2 * half + ta][tb][2 * h] += v[ta][tb][h].x; acc[2 * half + ta][tb][2 * h + 1] += v[ta][tb][h].y;
+                  }
+            }
           }
           if (ju0 <= tile_u0) break;
         }
       }
       // Only the entries on or above the diagonal are taken from the accumulators, each together with its mirror image: an
-      // entry below the diagonal of a block on the diagonal is also formed (with its operands swapped) in ANOTHER tile, whose
+      // entry below the diagonal of a block on the diagonal may also be formed (with its operands swapped) in ANOTHER tile, whose
       // stages may be split differently -- same products, other rounding.  One source per entry pair keeps G symmetric bit for bit.
-      const int row0 = cur.g.I * GK_ROWS + 32 * wave + li, col0 = cur.g.J * COLS + lk;
+      // The entries themselves go out as the accumulators hold them: 16 consecutive columns of a row per 16-lane row (128-byte
+      // lines).  For the mirror image the 16 x 16 tile is transposed inside the wave first -- register r of lane row lk holds
+      // row lk + 4 r; after exchanging registers with lane rows (a 4 x 4 transpose: two permlane swaps per pair) lane row lk
+      // holds rows 4 lk .. 4 lk + 3 of its column, i.e. four CONSECUTIVE entries of a row of the mirror image: two 16-byte
+      // stores, the four lane rows of a column filling one 128-byte line (as 8-byte stores 32 KiB apart -- one entry per line
+      // and instruction -- the mirror images of all workgroups' tiles took ~45 us of the call at k = 4096).
+      const int rowb = cur.g.I * GK_ROWS + 64 * wi, col0 = cur.g.J * COLS + 16 * NTB * wj + li;
+      const bool vec_ok = (p.ldg & 1) == 0 && ((uintptr_t)p.G & 15) == 0;
 #pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        const int row = row0 + 16 * i;
+      for (int ta = 0; ta < 4; ++ta)
 #pragma unroll
-        for (int t = 0; t < NCT; ++t)
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const int col = col0 + 16 * t + 4 * r;
-            if (row <= col && col < p.k) {
-              const double v = acc[i][t][r];
-              p.G[(size_t)row * p.ldg + col] = v;
-              p.G[(size_t)col * p.ldg + row] = v;
+        for (int tb = 0; tb < NTB; ++tb) {
+          const int col = col0 + 16 * tb;
+          double x0 = acc[ta][tb][0], x1 = acc[ta][tb][1], x2 = acc[ta][tb][2], x3 = acc[ta][tb][3];
+          {
+            const int row = rowb + 16 * ta + lk;
+            if (col < p.k) {
+              double* g = p.G + (size_t)row * p.ldg + col;
+              if (row <= col) g[0] = x0;
+              if (row + 4 <= col) g[4 * p.ldg] = x1;
+              if (row + 8 <= col) g[8 * p.ldg] = x2;
+              if (row + 12 <= col) g[12 * p.ldg] = x3;
             }
           }
-      }
+          gk_swap16(x0, x1); gk_swap16(x2, x3); gk_swap32(x0, x2); gk_swap32(x1, x3);
+          {
+            const int row = rowb + 16 * ta + 4 * lk;      // x0 .. x3: rows row .. row + 3 of column col
+            if (col < p.k && row <= col) {
+              double* g = p.G + (size_t)col * p.ldg + row;
+              if (vec_ok && row + 3 <= col) { *(gk2d*)g = (gk2d){x0, x1}; *(gk2d*)(g + 2) = (gk2d){x2, x3}; }
+              else {
+                g[0] = x0;
+                if (row + 1 <= col) g[1] = x1;
+                if (row + 2 <= col) g[2] = x2;
+                if (row + 3 <= col) g[3] = x3;
+              }
+            }
+          }
+        }
       stored = true;
-    } else if (seg_ends) {
+    } else if (seg_ends && !(p.dbg & 2)) {
       // ---- the piece ends inside a tile: leave the partial accumulators for the workgroup that finishes it, raise the flag ----
-      double* dst = mypart + (size_t)wave * (2 * NCT * 4 * 64) + 2 * lane;
+      double* dst = mypart + (size_t)wave * (4 * NTB * 4 * 64) + 2 * lane;
       asm volatile("" : "+v"(dst));           // (formed here: not hoisted out of the stage loop)
 #pragma unroll
-      for (int i = 0; i < 2; ++i)
+      for (int ta = 0; ta < 4; ++ta)
 #pragma unroll
-        for (int t = 0; t < NCT; ++t)
+        for (int tb = 0; tb < NTB; ++tb)
 #pragma unroll
-          for (int h = 0; h < 2; ++h) gk_st2(dst + ((i * NCT + t) * 2 + h) * 128, (gk2d){acc[i][t][2 * h], acc[i][t][2 * h + 1]});
+          for (int h = 0; h < 2; ++h) gk_st2(dst + ((ta * NTB + tb) * 2 + h) * 128, (gk2d){acc[ta][tb][2 * h], acc[ta][tb][2 * h + 1]});
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
       if (tid == 0) __hip_atomic_store(&p.flags[blockIdx.x], p.epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
@@ -346,14 +406,14 @@ __global__ __launch_bounds__(256, 2) void gram_sk_kernel(GramSkArgs p) {
     if (n1.seg == 3) break;
     if (tile_done || seg_ends) {
 #pragma unroll
-      for (int i = 0; i < 2; ++i)
+      for (int ta = 0; ta < 4; ++ta)
 #pragma unroll
-        for (int t = 0; t < NCT; ++t) acc[i][t] = (gk4d){0.0, 0.0, 0.0, 0.0};
+        for (int tb = 0; tb < NTB; ++tb) acc[ta][tb] = (gk4d){0.0, 0.0, 0.0, 0.0};
       piece_s0 = n1.g.s;
     }
-    // the NEXT stage's rows have to have landed; the requests of the stage after it stay in flight (they complete in issue
-    // order).  After an epilogue the queue also holds stores, which do not: drain it all.
-    if (ahead && !stored) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(NREQ) : "memory");
+    // the NEXT stage's rows have to have landed; with two stages ahead the requests of the stage after it stay in flight
+    // (they complete in issue order).  After an epilogue the queue also holds stores, which do not: drain it all.
+    if (AHEAD == 2 && ahead && !stored) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(NREQ) : "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if (ragged && n1.g.s == nst - 1) zero_tail(n1.g, rs1);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -365,14 +425,14 @@ __global__ __launch_bounds__(256, 2) void gram_sk_kernel(GramSkArgs p) {
 }
 
 // ---- host side -----------------------------------------------------------------------------------------------------
-struct GramSkPlan { int nct, nI, nJ, ntiles, nst, wgs; };
+struct GramSkPlan { int ntb, nI, nJ, ntiles, nst, wgs; };
 
-template <int NCT> static int gk_resident_wgs() {
+template <int NTB> static int gk_resident_wgs() {
   static const int n = [] {
     int dev = 0, cus = 256, per_cu = 0;
     if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
-    (void)hipFuncSetAttribute((const void*)gram_sk_kernel<NCT>, hipFuncAttributeMaxDynamicSharedMemorySize, GK_LDS_BYTES(NCT));
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)gram_sk_kernel<NCT>, 256, GK_LDS_BYTES(NCT)) != hipSuccess || per_cu < 1)
+    (void)hipFuncSetAttribute((const void*)gram_sk_kernel<NTB>, hipFuncAttributeMaxDynamicSharedMemorySize, GK_LDS_BYTES(NTB));
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)gram_sk_kernel<NTB>, 256, GK_LDS_BYTES(NTB)) != hipSuccess || per_cu < 1)
       per_cu = 1;
     if (per_cu > 2) per_cu = 2;
     return std::max(8, cus * per_cu / 8 * 8);
@@ -383,18 +443,17 @@ template <int NCT> static int gk_resident_wgs() {
 // Applies to rows that the LDS-DMA can fetch (16-byte pieces) and supports large enough to be worth a chip-wide launch.
 static bool gram_sk_plan(int k, int d, GramSkPlan* pl) {
   if (k < 192 || d < 4 * GK_KC) return false;
-  // (the kernel keeps row offsets as 32-bit element offsets; the caller checks k * ld)
-  static const bool tiled = bcx_dev_env("BCX_GRAM_TILED") != nullptr;      // dev: gram_tile_kernel for everything
-  if (tiled) return false;
-  pl->nct = GK_NCT;
-  const int cols = 16 * pl->nct;
+  static const int forced = [] { const char* e = bcx_dev_env("BCX_GRAM_NTB"); return e ? atoi(e) : 0; }();      // dev: 2 / 4 / -1 (gram_tile_kernel)
+  if (forced < 0) return false;
+  pl->ntb = forced == 2 || forced == 4 ? forced : (k >= 3072 ? 4 : 2);
+  const int cols = GK_COLS(pl->ntb);
   pl->nI = (k + GK_ROWS - 1) / GK_ROWS;
   pl->nJ = (k + cols - 1) / cols;
   pl->ntiles = 0;
   for (int I = 0; I < pl->nI; ++I) pl->ntiles += pl->nJ - (I * GK_ROWS) / cols;
   pl->nst = (d + GK_KC - 1) / GK_KC;
   const int64_t units = (int64_t)pl->ntiles * pl->nst;
-  const int resident = gk_resident_wgs<GK_NCT>();
+  const int resident = pl->ntb == 4 ? gk_resident_wgs<4>() : gk_resident_wgs<2>();
   const int64_t want = std::max<int64_t>(1, units / GK_MIN_STAGES);
   pl->wgs = (int)std::min<int64_t>(resident, (want + 7) / 8 * 8);
   return true;
@@ -404,7 +463,7 @@ static bool gram_sk_plan(int k, int d, GramSkPlan* pl) {
 int64_t bcx_gram_sk_scratch_bytes(int k, int d) {
   GramSkPlan pl;
   if (!gram_sk_plan(k, d, &pl)) return 0;
-  return (int64_t)pl.wgs * GK_ROWS * 16 * pl.nct * 8 + (int64_t)pl.wgs * 8 + 64;
+  return (int64_t)pl.wgs * GK_ROWS * GK_COLS(pl.ntb) * 8 + (int64_t)pl.wgs * 8 + 64;
 }
 
 // Flag words carry the number of the call that raised them: it starts from the clock, so the stale contents of a scratch
@@ -422,10 +481,13 @@ int bcx_gram_sk(hipStream_t st, const double* rows, int k, int d, int64_t ld, do
   a.V = rows; a.G = G; a.ld = ld; a.ldg = ldg; a.k = k; a.d = d;
   a.nI = pl.nI; a.nJ = pl.nJ; a.ntiles = pl.ntiles; a.nst = pl.nst;
   a.part = work;
-  a.flags = (unsigned long long*)(work + (size_t)pl.wgs * GK_ROWS * 16 * pl.nct);
+  a.flags = (unsigned long long*)(work + (size_t)pl.wgs * GK_ROWS * GK_COLS(pl.ntb));
   a.status = a.flags + pl.wgs;
   a.epoch = gram_next_epoch();                      // (never 0)
+  static const int dbg = [] { const char* e = bcx_dev_env("BCX_GRAM_DBG"); return e ? atoi(e) : 0; }();
+  a.dbg = dbg;
   a.timeout_ticks = 500000000LL;                    // 5 s of the 100 MHz wall clock
-  hipLaunchKernelGGL(gram_sk_kernel<GK_NCT>, dim3(pl.wgs), dim3(256), GK_LDS_BYTES(GK_NCT), st, a);
+  if (pl.ntb == 4) hipLaunchKernelGGL(gram_sk_kernel<4>, dim3(pl.wgs), dim3(256), GK_LDS_BYTES(4), st, a);
+  else hipLaunchKernelGGL(gram_sk_kernel<2>, dim3(pl.wgs), dim3(256), GK_LDS_BYTES(2), st, a);
   return hipGetLastError() == hipSuccess ? BCX_OK : BCX_ERR_HIP;
 }
