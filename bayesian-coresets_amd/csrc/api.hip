@@ -35,7 +35,7 @@ static void free_all(bcx_solver* s) {
     if (p) (void)hipFree(p);
   for (size_t w = 0; w < s->peer_mbox.size(); ++w)
     if (s->peer_mbox[w] && s->peer_mbox[w] != s->mbox) (void)hipIpcCloseMemHandle(s->peer_mbox[w]);
-  void* xptrs[] = {s->mbox, s->peer_tab, s->xseq, s->xprobe, s->rec_gather, s->grid_counter, s->fin_part, s->gram_work};
+  void* xptrs[] = {s->mbox, s->peer_tab, s->xseq, s->xprobe, s->rec_gather, s->grid_counter, s->fin_part, s->gram_work, s->warm_buf};
   for (void* p : xptrs)
     if (p) (void)hipFree(p);
   for (auto& ev : s->prof_events) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }

@@ -157,6 +157,9 @@ struct bcx_solver {
   int64_t gram_cap = 0;
   double* gram_work = nullptr;   // optimize(): slice partials of the Gram kernel (moments.hip), grown on demand
   size_t gram_work_bytes = 0;
+  void* warm_buf = nullptr;      // optimize(): buffers of the warm start (csrc/warm.hip), grown on demand
+  size_t warm_bytes = 0;
+  int64_t opt_warm = 0, opt_warm_failed = 0;   // optimize() calls that started warm / whose warm start was rejected by the closing check
   int64_t k_ub = 0;              // host upper bound of the slot count (grid sizing of the multi-kernel OMP step)
   unsigned long long* grid_counter = nullptr;   // [0] arrival counter of the grid barriers, [1] barrier base of the next OMP step
   uint64_t grid_epoch = 0;       // fused OMP launches since the counter was reset (bcx_build_begin)

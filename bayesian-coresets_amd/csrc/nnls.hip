@@ -778,7 +778,8 @@ int bcx_launch_optimize(bcx_solver* s, double tol) {
   const int k = h.k;
   if (k > 0) {
     static const bool old_gram = bcx_dev_env("BCX_GRAM_DIRECT") != nullptr;     // dev: round 2's kernel (operands straight from L2)
-    const size_t need = (size_t)bcx_gram_rows_scratch_bytes(k, s->cfg.d);
+    const int kp64 = (k + 63) / 64 * 64;       // (the warm start forms the inverse of a kp64 x kp64 block with the same kernel)
+    const size_t need = std::max((size_t)bcx_gram_rows_scratch_bytes(k, s->cfg.d), (size_t)bcx_gram_rows_scratch_bytes(kp64, kp64));
     if (!old_gram && s->gram_work_bytes < need) {
       if (s->gram_work) BCX_HIP(hipFree(s->gram_work));
       s->gram_work = nullptr; s->gram_work_bytes = 0;
@@ -797,10 +798,36 @@ int bcx_launch_optimize(bcx_solver* s, double tol) {
     }
   }
   if (k > 0) {
-    // incremental Lawson-Hanson on the double-double inverse (omp_lh.hip); where its closing Newton check fails -- or its
-    // LDS budget does not hold k slots -- the refined multi-workgroup solve of nnls_grid.hip, then the single-workgroup form
-    int rc = bcx_launch_optimize_lh(s, tol, k);
+    // incremental Lawson-Hanson on the double-double inverse (omp_lh.hip), started WARM from the largest independent part of
+    // the support (warm.hip: blocked Cholesky + fp64-MFMA inverse) where that applies; where the closing Newton check of
+    // the warm run fails, the same kernel from the empty passive set; where that one's fails -- or its LDS budget does not
+    // hold k slots -- the refined multi-workgroup solve of nnls_grid.hip, then the single-workgroup form
+    static const bool cold_only = bcx_dev_env("BCX_OPT_COLD") != nullptr;      // dev / tests: never start warm
+    const int32_t* warm_p = nullptr;
+    if (!cold_only && s->gram_work) {
+      const size_t need_w = bcx_warm_bytes(k);
+      if (s->warm_bytes < need_w) {
+        if (s->warm_buf) BCX_HIP(hipFree(s->warm_buf));
+        s->warm_buf = nullptr; s->warm_bytes = 0;
+        BCX_HIP(hipMalloc(&s->warm_buf, need_w));
+        s->warm_bytes = need_w;
+      }
+      const int wrc = bcx_warm_start(s, k, s->warm_buf, s->gram_work, &warm_p);
+      if (wrc < 0) return wrc;
+      if (wrc != 0) warm_p = nullptr;
+    }
+    int rc = bcx_launch_optimize_lh(s, tol, k, warm_p);
     if (rc < 0) return rc;
+    if (rc == 0 && warm_p) {
+      s->opt_warm += 1;
+      BCX_HIP(hipStreamSynchronize(s->stream));
+      BCX_HIP(hipMemcpy(&h, s->st, sizeof h, hipMemcpyDeviceToHost));
+      if (h.omp_mode != OMP_OPT_FALLBACK) return BCX_OK;
+      s->opt_warm_failed += 1;
+      BCX_HIP(hipMemsetAsync((char*)s->st + offsetof(DevState, omp_mode), 0, sizeof(int32_t), s->stream));
+      rc = bcx_launch_optimize_lh(s, tol, k, nullptr);
+      if (rc < 0) return rc;
+    }
     if (rc == 0) {
       BCX_HIP(hipStreamSynchronize(s->stream));
       BCX_HIP(hipMemcpy(&h, s->st, sizeof h, hipMemcpyDeviceToHost));

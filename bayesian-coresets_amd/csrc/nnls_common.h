@@ -139,4 +139,6 @@ void fill_nnls_args(bcx_solver* s, NnlsArgs& n, const double* recs);   // nnls.h
 struct ResolveArgs;
 int bcx_launch_omp_lh(bcx_solver* s, NnlsArgs& n, const ResolveArgs* fused);   // omp_lh.hip; 1 = not applicable (LDS budget)
 int bcx_launch_optimize_grid(bcx_solver* s, double tol, int k);         // nnls_grid.hip
-int bcx_launch_optimize_lh(bcx_solver* s, double tol, int k);           // omp_lh.hip; 1 = not applicable
+int bcx_launch_optimize_lh(bcx_solver* s, double tol, int k, const int32_t* warm_p);   // omp_lh.hip; 1 = not applicable; warm_p: csrc/warm.hip ran
+size_t bcx_warm_bytes(int k);                                            // warm.hip
+int bcx_warm_start(bcx_solver* s, int k, void* buf, double* gram_work, const int32_t** p_dev);   // 1 = not applicable

@@ -740,8 +740,12 @@ __global__ __launch_bounds__(THREADS) void omp_lh_kernel(NnlsArgs n, GridSync gs
 // refined solve of nnls_grid.hip instead.
 #define OPTL_MAX_WGS 64
 #define OPTL_BATCH 8
+// warm_p != null (csrc/warm.hip ran on the stream before this launch): the passive set does not start empty -- n.plist holds
+// *warm_p slots in order, n.hinv the (plain-double) inverse of their Gram block, low words zero.  The feasible point is the
+// current weights on those slots, z = H c their least-squares solution; the columns whose solution is not positive leave
+// through the same inner loop as after any entering column, and the iteration goes on from there.
 template <int THREADS>
-__global__ __launch_bounds__(THREADS) void optimize_lh_kernel(NnlsArgs n, GridSync gs, double tol, int kcap) {
+__global__ __launch_bounds__(THREADS) void optimize_lh_kernel(NnlsArgs n, GridSync gs, double tol, int kcap, const int32_t* warm_p) {
   const ApplyArgs& a = n.a;
   DevState* st = a.st;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = blockDim.x >> 6, d = a.d;
@@ -786,8 +790,35 @@ __global__ __launch_bounds__(THREADS) void optimize_lh_kernel(NnlsArgs n, GridSy
   const double tolscale = 10.0 * eps * (double)(d > k ? d : k) * bnorm;
   int p = 0;
   const int max_outer = 3 * k + 16;
+  int dg_p0 = 0, dg_p1 = 0, dg_in = 0, dg_out = 0, dg_outer = 0;      // diagnostics of the call (DevState::dbg_t[20..], bcx_debug_stamps)
+  if (warm_p) {
+    p = *warm_p;
+    if (p > k) p = 0;                                        // (never: guards the LDS arrays)
+    for (int q = tid; q < p; q += blockDim.x) {
+      const int slot = n.plist[q];
+      L.cs[q] = slot; L.pos[slot] = q;
+      L.xs[q] = a.act_w[slot];
+      L.g[q] = xld(&n.cvec[slot]);
+    }
+    __syncthreads();
+    n_out -= p;
+    if (p > 0) {
+      double* Zh = xbuf(n, G);
+      double* Zl = xbuf(n, G);
+      ompl_mv_rows(n, p, L.g, nullptr, Zh, Zl, nullptr);     // z = H c
+      gsync(G);
+      for (int q = tid; q < p; q += blockDim.x) L.z[q] = xld(&Zh[q]);
+      __syncthreads();
+      dg_p0 = p;
+      dg_out += ompl_inner(n, L, p, -1, max_outer, n_out, G, scratch);
+      dg_p1 = p;
+      for (int q = tid; q < p; q += blockDim.x) { L.xs[q] = L.x[L.cs[q]]; L.z[q] = L.xs[q]; }
+      __syncthreads();
+    }
+  }
   bool more = true;
   for (int outer = 0; outer < max_outer && G.ok && n_out > 0 && more; ++outer) {
+    ++dg_outer;
     // duals w_j = c_j - G[j, P] x of the members without weight: one wave per candidate, dealt over all workgroups
     double* D = xbuf(n, G);
     for (int j = wg * nw + wave; j < k; j += nwg * nw) {
@@ -863,8 +894,9 @@ __global__ __launch_bounds__(THREADS) void optimize_lh_kernel(NnlsArgs n, GridSy
       if (tid == 0) { L.z[p] = t; L.xs[p] = 0.0; L.cs[p] = cand; L.pos[cand] = p; }
       p += 1;
       --n_out;
+      ++dg_in;
       __syncthreads();
-      ompl_inner(n, L, p, cand, max_outer, n_out, G, scratch);
+      dg_out += ompl_inner(n, L, p, cand, max_outer, n_out, G, scratch);
       for (int q = tid; q < p; q += blockDim.x) { L.xs[q] = L.x[L.cs[q]]; L.z[q] = L.xs[q]; }
       __syncthreads();
     }
@@ -895,36 +927,42 @@ __global__ __launch_bounds__(THREADS) void optimize_lh_kernel(NnlsArgs n, GridSy
       __syncthreads();
     }
   };
-  combine(a.tmp);
-  gsync(G);
-  double* GV = xbuf(n, G);
-  for (int q = wg * nw + wave; q < p; q += nwg * nw) {
-    const double* row = a.act_rows + (size_t)L.cs[q] * d;
-    double acc = 0.0;
-    for (int i = lane; i < d; i += 64) acc += row[i] * (a.b[i] - xld(&a.tmp[i]));
-    acc = wave_allsum(acc);
-    if (lane == 0) xst(&GV[q], acc);
-  }
-  gsync(G);
-  for (int q = tid; q < p; q += blockDim.x) L.g[q] = xld(&GV[q]);
-  __syncthreads();
-  double* Zh = xbuf(n, G);
-  double* Zl = xbuf(n, G);
-  ompl_mv_rows(n, p, L.g, nullptr, Zh, Zl, nullptr);
-  gsync(G);
-  double dm = 0.0, xm = 0.0;
-  int neg = 0;
-  for (int q = tid; q < p; q += blockDim.x) {
-    const double dz = xld(&Zh[q]), xq = L.z[q];
-    dm = fmax(dm, fabs(dz)); xm = fmax(xm, fabs(xq));
-    L.u[q] = xq + dz;
-    if (!(xq + dz > 0.0)) neg = 1;
-  }
-  dm = block_allmax(dm, scratch);
-  xm = block_allmax(xm, scratch);
-  const double negs = block_allmax((double)neg, scratch);
-  const bool fallback = !G.ok || (p > 0 && (!(dm <= 1e-3 * xm) || negs > 0.0));
-  if (!fallback) {
+  // (after a warm start H began as a plain-double inverse: a second step takes what the first left -- each contracts the
+  // error by ~cond(G) eps -- and costs three barriers)
+  bool fallback = false;
+  double dm = 0.0, xm = 0.0, negs = 0.0;
+  for (int pass = 0; pass < (warm_p ? 2 : 1); ++pass) {
+    combine(a.tmp);
+    gsync(G);
+    double* GV = xbuf(n, G);
+    for (int q = wg * nw + wave; q < p; q += nwg * nw) {
+      const double* row = a.act_rows + (size_t)L.cs[q] * d;
+      double acc = 0.0;
+      for (int i = lane; i < d; i += 64) acc += row[i] * (a.b[i] - xld(&a.tmp[i]));
+      acc = wave_allsum(acc);
+      if (lane == 0) xst(&GV[q], acc);
+    }
+    gsync(G);
+    for (int q = tid; q < p; q += blockDim.x) L.g[q] = xld(&GV[q]);
+    __syncthreads();
+    double* Zh = xbuf(n, G);
+    double* Zl = xbuf(n, G);
+    ompl_mv_rows(n, p, L.g, nullptr, Zh, Zl, nullptr);
+    gsync(G);
+    double dm1 = 0.0, xm1 = 0.0;
+    int neg = 0;
+    for (int q = tid; q < p; q += blockDim.x) {
+      const double dz = xld(&Zh[q]), xq = L.z[q];
+      dm1 = fmax(dm1, fabs(dz)); xm1 = fmax(xm1, fabs(xq));
+      L.u[q] = xq + dz;
+      if (!(xq + dz > 0.0)) neg = 1;
+    }
+    dm1 = block_allmax(dm1, scratch);
+    xm1 = block_allmax(xm1, scratch);
+    const double negs1 = block_allmax((double)neg, scratch);
+    const bool bad = !G.ok || (p > 0 && (!(dm1 <= 1e-3 * xm1) || negs1 > 0.0));      // (the same in every workgroup)
+    if (pass == 0) { fallback = bad; dm = dm1; xm = xm1; negs = negs1; }
+    if (bad) break;
     for (int q = tid; q < p; q += blockDim.x) { L.z[q] = L.u[q]; L.x[L.cs[q]] = L.u[q]; }
     __syncthreads();
   }
@@ -932,6 +970,12 @@ __global__ __launch_bounds__(THREADS) void optimize_lh_kernel(NnlsArgs n, GridSy
   if (wg != 0) { if (G.ok) grid_arrive(G.gs, 1); return; }
   gsync(G);
   // ---- workgroup 0: publish the passive data, new weights, accept / revert (snnls.py:88-97) ------------------------------
+  if (tid == 0) {
+    st->dbg_t[20] = warm_p ? 1 : 0; st->dbg_t[21] = dg_p0; st->dbg_t[22] = dg_p1; st->dbg_t[23] = dg_in; st->dbg_t[24] = dg_out;
+    st->dbg_t[25] = p; st->dbg_t[26] = fallback; st->dbg_t[27] = (long long)(1e15 * (xm > 0.0 ? dm / xm : 0.0)); st->dbg_t[28] = (long long)negs;
+    st->dbg_t[29] = dg_outer; st->dbg_t[30] = n_out;
+    if (warm_p) for (int i = 0; i < 11; ++i) st->dbg_t[8 + i] = st->dbg_t[20 + i];       // (kept when a cold run follows)
+  }
   if (!G.ok) { if (tid == 0) { st->hvalid = 0; st->halt = HALT_GRID_TIMEOUT; } return; }
   if (fallback) {
     if (tid == 0) { st->omp_mode = OMP_OPT_FALLBACK; st->hvalid = 0; }
@@ -955,20 +999,20 @@ __global__ __launch_bounds__(THREADS) void optimize_lh_kernel(NnlsArgs n, GridSy
     refresh_state(a, scratch, false);
     if (tid == 0) { st->limit = 1; st->hvalid = 0; }
   } else if (tid == 0) {
-    st->hvalid = 1;
-    st->hlo_valid = 1;                                       // H is the double-double inverse of gram[P, P]
+    st->hvalid = warm_p ? 0 : 1;                             // (a warm start's H began as a plain-double inverse: the next OMP step re-solves)
+    st->hlo_valid = warm_p ? 0 : 1;                          // H is the double-double inverse of gram[P, P]
     st->since_refresh = 0;
   }
 }
 
 // 1 = not applicable (LDS budget, dev knob BCX_OPT_GRID=1): the caller takes nnls_grid.hip's kernel
-int bcx_launch_optimize_lh(bcx_solver* s, double tol, int k) {
+int bcx_launch_optimize_lh(bcx_solver* s, double tol, int k, const int32_t* warm_p) {
   if (bcx_dev_env("BCX_OPT_GRID") || bcx_dev_env("BCX_OPT_SINGLE")) return 1;
   // Small independent supports (k <= d, k <= 512) stay with nnls_grid.hip: all their columns join the passive set by
   // bordering, one barrier each and no dual passes (k = 400, d = 512: 3.9 ms against 7.8 here); from there on -- and for
   // every k > d, where that kernel has to take Lawson-Hanson's order with a refined solve per column -- this one is
   // faster (k = 999, d = 512: 12.7 against 28.3 ms; k = 1497, d = 1024: 45 against 191 ms).  BCX_OPT_LH=1 forces it (tests).
-  if (k <= s->cfg.d && k <= 512 && !bcx_dev_env("BCX_OPT_LH")) return 1;
+  if (!warm_p && k <= s->cfg.d && k <= 512 && !bcx_dev_env("BCX_OPT_LH")) return 1;
   const int kcap = (k + 1 + 63) / 64 * 64;
   const size_t lds = (size_t)kcap * (8 * sizeof(double) + 3 * sizeof(int));
   if (lds > OMPL_LDS_MAX) return 1;
@@ -987,7 +1031,7 @@ int bcx_launch_optimize_lh(bcx_solver* s, double tol, int k) {
 #define OPTL_LAUNCH(T)                                                                                                          \
   do {                                                                                                                          \
     if (lds > 48 * 1024) BCX_HIP(hipFuncSetAttribute((const void*)optimize_lh_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
-    hipLaunchKernelGGL(optimize_lh_kernel<T>, dim3(wgs), dim3(T), lds, s->stream, n, gs, tol, kcap);                          \
+    hipLaunchKernelGGL(optimize_lh_kernel<T>, dim3(wgs), dim3(T), lds, s->stream, n, gs, tol, kcap, warm_p);                  \
   } while (0)
   if (threads == 256) OPTL_LAUNCH(256); else if (threads == 512) OPTL_LAUNCH(512); else OPTL_LAUNCH(1024);
 #undef OPTL_LAUNCH

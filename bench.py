@@ -829,6 +829,7 @@ def side_legs(args, out, torch, dist, nat):
             out["c5_moments_same_idcs"] = r["config"]["coreset_idcs"] == out.get("c5_coreset_idcs")
             out["c5_moments_setup_ms"] = r["config"].get("moments_setup_ms")
     gram_leg(out, torch, nat)
+    optimize_leg(out, torch, nat)
 
 
 def gram_leg(out, torch, nat):
@@ -867,6 +868,73 @@ def gram_leg(out, torch, nat):
             del V, G, work
     except Exception as e:      # the headline line must survive a broken side leg
         out["reweight_gram_error"] = "%s: %s" % (type(e).__name__, e)
+
+
+def optimize_leg(out, torch, nat):
+    """optimize() (snnls.py:82-97) on the driver's clock: Frank-Wolfe supports of ~1500 points on synthetic randn rows, N = 1e6 --
+    d = 1024 (k > d: dependent columns, hundreds of pivots after the warm start) and d = 2048 (k < d: the warm start is the
+    answer).  Flat keys reweight_optimize_*: wall ms of the call, the warm start's passive set and the pivots after it, and
+    the share of the call spent in the fp64-MFMA kernels that form the two Gram matrices (the support's and the inverse's),
+    timed on their own on the same shapes."""
+    import ctypes
+    try:
+        lib = nat.load()
+        lib.bcx_debug_stamps.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
+        for d in (1024, 2048):
+            N, its = 1_000_000, 1500
+            eng = nat.Engine(nat.ALG_FW, N, d)
+            g = torch.Generator(device="cuda")
+            g.manual_seed(1)
+            for r0 in range(0, N, 250_000):
+                x = torch.randn(250_000, d, device="cuda", dtype=torch.float64, generator=g)
+                eng.load_device_rows(x.data_ptr(), 250_000, d, True, r0)
+                torch.cuda.synchronize()
+            del x
+            if eng.finalize(None) != 0:
+                raise RuntimeError("finalize failed")
+            eng.run_build(its, 1e-12)
+            k = len(eng.sparse_weights()[0])
+            e0 = eng.error()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            ok = eng.optimize(1e-12)
+            torch.cuda.synchronize()
+            ms = (time.perf_counter() - t0) * 1e3
+            st = (ctypes.c_longlong * 32)()
+            lib.bcx_debug_stamps(eng.h, st)
+            # the two Gram operators of the call, alone: k x d (the support) and kp x kp (Y Y^T = the inverse)
+            kp = (k + 63) // 64 * 64
+            gram_us = 0.0
+            for (kk, dd) in ((k, d), (kp, kp)):
+                V = torch.randn(kk, dd, dtype=torch.float64, device="cuda")
+                G = torch.empty(kk, kk, dtype=torch.float64, device="cuda")
+                work = torch.empty((int(lib.bcx_gram_scratch_bytes(kk, dd)) + 7) // 8, dtype=torch.float64, device="cuda")
+                stream = int(torch.cuda.current_stream().cuda_stream)
+                call = lambda: lib.bcx_gram(stream, V.data_ptr(), kk, dd, dd, G.data_ptr(), kk, work.data_ptr(), work.numel() * 8)
+                call()
+                e_0, e_1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e_0.record()
+                for _ in range(10):
+                    call()
+                e_1.record()
+                torch.cuda.synchronize()
+                gram_us += e_0.elapsed_time(e_1) * 1e3 / 10
+                del V, G, work
+            key = "reweight_optimize_k%d_d%d" % (round(k, -2), d)
+            out[key + "_ms"] = ms
+            out[key + "_k"] = int(k)
+            out[key + "_accepted"] = bool(ok)
+            out[key + "_error_before"] = e0
+            out[key + "_error_after"] = eng.error()
+            out[key + "_warm"] = {"started_warm": int(st[20]), "passive_set": int(st[21]), "entered": int(st[23]), "left": int(st[24]),
+                                  "closing_check_failed": int(st[26])}
+            out[key + "_gram_us"] = gram_us
+            out[key + "_mfma_share"] = gram_us / (ms * 1e3)
+            eng.close()
+            del eng
+            torch.cuda.empty_cache()
+    except Exception as e:      # the headline line must survive a broken side leg
+        out["reweight_optimize_error"] = "%s: %s" % (type(e).__name__, e)
 
 
 def mailbox_preflight_child():

@@ -238,10 +238,24 @@ def test_F7_optimize(bc, golden, normal_inputs, alg, kernel, monkeypatch):
         assert s.reached_numeric_limit == bool(golden["F7_%s_limit" % alg])
 
 
-@pytest.mark.parametrize("alg,N,d,itrs", (("fw", 8000, 640, 700), ("fw", 8000, 256, 700), ("giga", 6000, 200, 500)))
+def _optimize_stats(s):
+    """(started warm, warm passive set, columns entered, columns left, closing check failed) of the last optimize_lh launch
+    (DevState::dbg_t[20..], read through the unlisted debug entry point bcx_debug_stamps)."""
+    import ctypes
+    st = (ctypes.c_longlong * 32)()
+    lib = s._eng.lib
+    lib.bcx_debug_stamps.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
+    assert lib.bcx_debug_stamps(s._eng.h, st) == 0
+    return int(st[20]), int(st[21]), int(st[23]), int(st[24]), int(st[26])
+
+
+@pytest.mark.parametrize("alg,N,d,itrs", (("fw", 8000, 640, 700), ("fw", 8000, 256, 700), ("giga", 6000, 200, 500),
+                                          ("fw", 20000, 1024, 600), ("giga", 20000, 768, 700)))
 def test_optimize_large_supports_against_the_oracle(bc, alg, N, d, itrs):
-    """optimize() on supports beyond 512 columns and beyond d columns (the incremental double-double Lawson-Hanson kernel by
-    default): error against the oracle's scipy.optimize.nnls re-solve; weights too where the minimiser is unique (k <= d)."""
+    """optimize() on supports beyond 512 columns and beyond d columns: the incremental double-double Lawson-Hanson kernel
+    started WARM from the largest independent part of the support (csrc/warm.hip: blocked Cholesky with pivot rejection,
+    inverse on the fp64 matrix cores) -- error against the oracle's scipy.optimize.nnls re-solve; support and weights too
+    where the minimiser is unique (k <= d).  The warm start has to have been taken and accepted (no second, cold run)."""
     from oracle.snnls_oracle import SnnlsOracle
     X = np.random.RandomState(1000 + d).randn(N, d)
     o = SnnlsOracle(X.T, X.sum(axis=0), alg=alg, mode="onepass")
@@ -253,6 +267,9 @@ def test_optimize_large_supports_against_the_oracle(bc, alg, N, d, itrs):
     s.optimize()
     o.optimize()
     assert s._eng.omp_stats()["resolves"] == 0
+    warm, p0, entered, left, failed = _optimize_stats(s)
+    assert warm == 1 and failed == 0 and 0 < p0 <= min(k, d), (warm, p0, entered, left, failed)
+    assert entered + left < k, (entered, left, k)            # pivots from the warm state, not a rebuild of the set
     assert s.error() <= e0 * (1 + 1e-12)
     np.testing.assert_allclose(s.error(), o.error(), rtol=1e-6, atol=1e-9 * np.sqrt((X.sum(axis=0) ** 2).sum()))
     if k <= d:

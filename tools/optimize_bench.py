@@ -1,5 +1,6 @@
 """dev: time optimize() (fp64-MFMA Gram + cold-start NNLS) after a greedy build."""
 import sys, os, time
+os.environ.setdefault("BCX_DEV", "1")   # BCX_OPT_COLD=1 (never start warm) is a dev switch (csrc/dev_util.h)
 import numpy as np
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "bayesian-coresets_amd"))
 import torch
@@ -19,10 +20,25 @@ def run(alg, N, d, its):
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     k = len(idx)
+    import ctypes
+    st = (ctypes.c_longlong * 32)()
+    eng.lib.bcx_debug_stamps.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
+    eng.lib.bcx_debug_stamps(eng.h, st)
+    print("   last optimize_lh launch: warm %d p0 %d after-inner %d entered %d left %d p %d fallback %d newton-step/weights %.2e nonpositive %d dual passes %d candidates left %d"
+          % (st[20], st[21], st[22], st[23], st[24], st[25], st[26], st[27] / 1e15, st[28], st[29], st[30]))
+    if not st[20]:
+        print("   the warm launch before it:  p0 %d after-inner %d entered %d left %d p %d fallback %d newton-step/weights %.2e nonpositive %d dual passes %d candidates left %d"
+              % (st[9], st[10], st[11], st[12], st[13], st[14], st[15] / 1e15, st[16], st[17], st[18]))
     print("alg %d N=%d d=%d k=%d: optimize %.2f ms accepted=%s err %.6g -> %.10g  (Gram flops %.2e; refined-solve fallbacks %d)"
           % (alg, N, d, k, dt * 1e3, ok, e0, eng.error(), 2.0 * k * k * d, eng.omp_stats()["resolves"]))
 
 if __name__ == "__main__":
+    print("BCX_OPT_COLD =", os.environ.get("BCX_OPT_COLD"))
+    if len(sys.argv) > 1:      # alg,N,d,its
+        a, N, d, its = (int(v) for v in sys.argv[1].split(","))
+        run(a, N, d, its)
+        sys.exit(0)
     run(nat.ALG_FW, 1000000, 512, 400)
     run(nat.ALG_GIGA, 1000000, 512, 1000)
     run(nat.ALG_FW, 1000000, 1024, 1500)
+    run(nat.ALG_FW, 1000000, 2048, 1500)
