@@ -279,27 +279,27 @@ __global__ __launch_bounds__(256, 2) void proj_kernel(ProjArgs p) {
   // this lane's share of a stage: slot `lane` of Z chunks 4 wave + j (rows 32 wave + 8 j + fr) and of Theta chunks
   // 2 wave + j (columns 16 wave + 8 j + fr), piece fq of the row's 128-byte line
   const int fr = lane >> 3, fq = ((lane & 7) - 2 * ((fr >> 1) & 3)) & 7;
-  const double* zp[4];                       // row pointers of the Z tile being requested (they change once per row block)
-  int tp[TCH];                               // element offsets (into Theta: S x ldt < 2^31) of the columns being requested --
-                                             // one VGPR each instead of a pointer pair: what the 128-column transcendental tiles lacked
+  // What a lane asks for is ONE offset per operand plus scalars: row 8 j + fr of a tile is 8 j ldz (8 j ldt) elements
+  // behind row fr, clamped to the matrix's last row (zmax / tmax: only the block that hangs over the edge ever reaches
+  // them), from the row block's own base pointer (scalar).  Four row pointers and TCH offsets held 8 + TCH VGPRs here: what
+  // the 128-column transcendental tiles and the SELECT epilogue lacked.
+  int zp0 = 0, zmax = 0, tp0 = 0;
+  const double* zbase = p.Z;
+  const int zstep = 8 * (int)p.ldz, tstep = 8 * p.ldt, tmax = (S - 1) * p.ldt;
+  auto zp = [&](int j) { return min(zp0 + j * zstep, zmax); };
+  auto tp = [&](int j) { return min(tp0 + j * tstep, tmax); };
   int64_t zp_br = -1;
   int tp_cg = -1;
   const int kmax = ALIGNED ? ((D - 1) & ~1) : (D - 1);
   auto set_z = [&](int64_t fbr) {
     zp_br = fbr;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int64_t row = fbr * PJ_ROWS + 32 * wave + 8 * j + fr;
-      zp[j] = p.Z + (row < p.N ? row : p.N - 1) * p.ldz;
-    }
+    zbase = p.Z + fbr * PJ_ROWS * p.ldz;
+    zp0 = (32 * wave + fr) * (int)p.ldz;
+    zmax = (int)((p.N - 1 - fbr * PJ_ROWS) * p.ldz);      // (>= 0: the block's first row exists)
   };
   auto set_t = [&](int fcg) {
     tp_cg = fcg;
-#pragma unroll
-    for (int j = 0; j < TCH; ++j) {
-      const int col = fcg * COLS + 8 * (TCH * wave + j) + fr;
-      tp[j] = (col < S ? col : S - 1) * p.ldt;
-    }
+    tp0 = (fcg * COLS + 8 * TCH * wave + fr) * p.ldt;
   };
   auto advance = [&](PjPos a) {
     if (++a.s == nst) {
@@ -320,21 +320,22 @@ __global__ __launch_bounds__(256, 2) void proj_kernel(ProjArgs p) {
     const int kc = min(a.s * PJ_KC + 2 * fq, kmax);
 #pragma unroll
     for (int j = 0; j < 4; ++j)
-      pj_glds16(zp[j] + kc, lds0 + (unsigned)(zslot * PJ_ZBYTES + (4 * wave + j) * 1024));
+      pj_glds16(zbase + (zp(j) + kc), lds0 + (unsigned)(zslot * PJ_ZBYTES + (4 * wave + j) * 1024));
   };
   auto issue_t = [&](const PjPos& a, int tslot) {
     if (a.cg != tp_cg) set_t(a.cg);
     const int kc = min(a.s * PJ_KC + 2 * fq, kmax);
 #pragma unroll
     for (int j = 0; j < TCH; ++j)
-      pj_glds16(p.theta + (tp[j] + kc), lds0 + (unsigned)(TBASE + tslot * TBYTES + (TCH * wave + j) * 1024));
+      pj_glds16(p.theta + (tp(j) + kc), lds0 + (unsigned)(TBASE + tslot * TBYTES + (TCH * wave + j) * 1024));
   };
   // zero-fill of this lane's own slots of a stage that is not plain (after its DMA has landed)
   auto zero_fill = [&](const PjPos& a, int zslot, int tslot) {
     const int k = a.s * PJ_KC + 2 * fq;
+    const int zrows = (int)min((int64_t)PJ_ROWS, p.N - a.br * PJ_ROWS);      // rows of the block that exist (a scalar: the row test stays on 32 bits)
 #pragma unroll
     for (int j = 0; j < 4 + TCH; ++j) {
-      const bool valid = j < 4 ? a.br * PJ_ROWS + 32 * wave + 8 * j + fr < p.N : a.cg * COLS + 8 * (TCH * wave + j - 4) + fr < S;
+      const bool valid = j < 4 ? 32 * wave + 8 * j + fr < zrows : a.cg * COLS + 8 * (TCH * wave + j - 4) + fr < S;
       unsigned char* dst = j < 4 ? pj_lds + zslot * PJ_ZBYTES + (4 * wave + j) * 1024 + lane * 16
                                  : pj_lds + TBASE + tslot * TBYTES + (TCH * wave + j - 4) * 1024 + lane * 16;
       if (!valid || k >= D) *(pv2d*)dst = (pv2d){0.0, 0.0};
@@ -350,16 +351,17 @@ __global__ __launch_bounds__(256, 2) void proj_kernel(ProjArgs p) {
     const int k0 = min(k, D - 1), k1 = min(k + 1, D - 1);
 #pragma unroll
     for (int j = 0; j < 4 + TCH; ++j) {
-      const double* src = j < 4 ? zp[j] : p.theta + tp[j < 4 ? 0 : j - 4];
+      const double* src = j < 4 ? zbase + zp(j) : p.theta + tp(j < 4 ? 0 : j - 4);
       sreg[ALIGNED ? 0 : j].x = src[k0];
       sreg[ALIGNED ? 0 : j].y = src[k1];
     }
   };
   auto park_regs = [&](const PjPos& a, int zslot, int tslot) {
     const int k = a.s * PJ_KC + 2 * fq;
+    const int zrows = (int)min((int64_t)PJ_ROWS, p.N - a.br * PJ_ROWS);
 #pragma unroll
     for (int j = 0; j < 4 + TCH; ++j) {
-      const bool valid = j < 4 ? a.br * PJ_ROWS + 32 * wave + 8 * j + fr < p.N : a.cg * COLS + 8 * (TCH * wave + j - 4) + fr < S;
+      const bool valid = j < 4 ? 32 * wave + 8 * j + fr < zrows : a.cg * COLS + 8 * (TCH * wave + j - 4) + fr < S;
       unsigned char* dst = j < 4 ? pj_lds + zslot * PJ_ZBYTES + (4 * wave + j) * 1024 + lane * 16
                                  : pj_lds + TBASE + tslot * TBYTES + (TCH * wave + j - 4) * 1024 + lane * 16;
       *(pv2d*)dst = mask_piece(sreg[ALIGNED ? 0 : j], valid, k, D);
@@ -400,14 +402,14 @@ __global__ __launch_bounds__(256, 2) void proj_kernel(ProjArgs p) {
     const bool last = s == nst - 1;
     const int zs1 = zs == ZRING - 1 ? 0 : zs + 1, zs2 = zs1 == ZRING - 1 ? 0 : zs1 + 1, ts1 = ts ^ 1;
     // requests for the stages ahead fly while this stage's MFMAs run
-    int kct = 0, kcz = 0;
+    int kts = 0, kzs = 0;                      // (scalar stage bases: the lane's piece offset is added where a request is formed)
     if (ALIGNED) {
       // (the requests themselves are spread over the first groups of the compute loop)
-      if (more) { if (n1.cg != tp_cg) set_t(n1.cg); kct = min(n1.s * PJ_KC + 2 * fq, kmax); }
+      if (more) { if (n1.cg != tp_cg) set_t(n1.cg); kts = n1.s * PJ_KC; }
       if (ZRING == 3 ? more2 : more) {
         const PjPos& zn = ZRING == 3 ? n2 : n1;
         if (zn.br != zp_br) set_z(zn.br);
-        kcz = min(zn.s * PJ_KC + 2 * fq, kmax);
+        kzs = zn.s * PJ_KC;
       }
     } else if (more) {
       fetch_regs(n1);
@@ -461,9 +463,9 @@ __global__ __launch_bounds__(256, 2) void proj_kernel(ProjArgs p) {
 #pragma unroll
           for (int q = 0; q < TCH + 4; ++q) {
             if ((NG >= 8 ? q : q * NG / 8) != g) continue;
-            if (q < TCH) { if (more) pj_glds16(p.theta + (tp[q] + kct), lds0 + (unsigned)(TBASE + ts1 * TBYTES + (TCH * wave + q) * 1024)); }
+            if (q < TCH) { if (more) pj_glds16(p.theta + (tp(q) + min(kts + 2 * fq, kmax)), lds0 + (unsigned)(TBASE + ts1 * TBYTES + (TCH * wave + q) * 1024)); }
             else if (ZRING == 3 ? more2 : more)
-              pj_glds16(zp[q - TCH] + kcz, lds0 + (unsigned)((ZRING == 3 ? zs2 : zs1) * PJ_ZBYTES + (4 * wave + q - TCH) * 1024));
+              pj_glds16(zbase + (zp(q - TCH) + min(kzs + 2 * fq, kmax)), lds0 + (unsigned)((ZRING == 3 ? zs2 : zs1) * PJ_ZBYTES + (4 * wave + q - TCH) * 1024));
           }
         }
         __builtin_amdgcn_sched_barrier(0);
@@ -488,6 +490,7 @@ __global__ __launch_bounds__(256, 2) void proj_kernel(ProjArgs p) {
     if (last) {
       // ---- epilogue of tile (br, cg).  f64 C/D layout: D[i = (lane >> 4) + 4 * reg][j = lane & 15] ---------------
       const int64_t r0 = br * PJ_ROWS + 32 * wave;
+      const int rows_left = (int)min((int64_t)32, p.N - r0);      // rows of this wave's 32 that exist (<= 0: none)
       if constexpr (!TRP) {
         // i = data row (lk + 4 reg), j = column (li)
         if (cg == 0 || teamed) {
@@ -613,8 +616,10 @@ __global__ __launch_bounds__(256, 2) void proj_kernel(ProjArgs p) {
         if (LOCAL || cg == 0 || teamed) {
 #pragma unroll
           for (int tr = 0; tr < 2; ++tr) {
-            const int64_t row = r0 + 16 * tr + li;
-            const double y = (p.ycol >= 0 && row < p.N) ? p.Z[row * p.ldz + p.ycol] : 0.0;
+            // (the row test on 32-bit numbers -- rows left in the matrix from this wave's first one, a scalar -- so that no 64-bit
+            // lane value has to live across the k loop)
+            const int rl = 16 * tr + li;
+            const double y = (p.ycol >= 0 && rl < rows_left) ? p.Z[(r0 + rl) * p.ldz + p.ycol] : 0.0;
             yq[tr] = (FAM == FAM_LINREG) ? 2.0 * y : y;      // (loglik_shifted)
             cq[tr] = (FAM == FAM_POISSON) ? 0.0 : clin;   // (Poisson: gammaln(y + 1) is constant along the row and cancels in value - shift)
             rs[tr] = 0.0; rq[tr] = 0.0; rd[tr] = 0.0;
@@ -727,10 +732,10 @@ __global__ __launch_bounds__(256, 2) void proj_kernel(ProjArgs p) {
             s1 += bcx_xor16_f64(s1); s1 += bcx_xor32_f64(s1);
             s2 += bcx_xor16_f64(s2); s2 += bcx_xor32_f64(s2);
             sd += bcx_xor16_f64(sd); sd += bcx_xor32_f64(sd);
-            const long long row = r0 + 16 * tr + li;
+            const int rl = 16 * tr + li;
             // this column group's share of the row's moments, about the group's own shift (its first column)
-            if (lk == 0 && row < p.N) {
-              double* rec = p.part + ((size_t)cg * (size_t)p.N + (size_t)row) * 4;
+            if (lk == 0 && rl < rows_left) {
+              double* rec = p.part + ((size_t)cg * (size_t)p.N + (size_t)(r0 + rl)) * 4;
               *(pv2d*)rec = (pv2d){pq[tr], s1};
               *(pv2d*)(rec + 2) = (pv2d){s2, sd};
             }
@@ -1089,9 +1094,10 @@ extern "C" int bcx_project_profile_read(double* ms_total, int64_t* launches, dou
 // measured slower (logistic D=300: 29 against 35 TFLOP/s), WRITE holds eight rows per lane.
 static int proj_nct(int mode, int family, int S, bool aligned, int D) {
   // SELECT on the 128-column tile spilled ~200 registers in every family in round 2.  Since the row moments moved to
-  // per-column-group records the linear-regression instantiation parks 24 VGPRs of request-pointer state (12 stores, 13
-  // loads per launch-long loop body, none between the MFMAs of a group) and is the faster one: N = 5M, D = 301, S = 256
-  // 13.80 against 15.08 ms per call (55.8 against 51.1 TFLOP/s).  The transcendental families stay at 64 columns
+  // per-column-group records the linear-regression instantiation is the faster one: N = 5M, D = 301, S = 256
+  // 13.80 against 15.08 ms per call (55.8 against 51.1 TFLOP/s); since round 5 (one request offset + scalar strides instead
+  // of four row pointers and TCH offsets, row tests on 32-bit numbers) it fits 250 VGPRs without scratch (rounds 3-4: 24
+  // VGPRs of request state parked in scratch around the loop).  The transcendental families stay at 64 columns
   // (logistic SELECT at 128: 231 spilled VGPRs).  BCX_PROJ_SEL_NCT=4 selects the 64-column tile (dev).
   static const bool sel8 = [] { const char* e = bcx_dev_env("BCX_PROJ_SEL_NCT"); return !(e && atoi(e) == 4); }();
   // (round 4, with the table forms: logistic / Poisson SELECT on the 128-column tile still spill 225 / 208 VGPRs and run at 16 /
@@ -1110,7 +1116,7 @@ static int proj_nct(int mode, int family, int S, bool aligned, int D) {
   // the 128-column tile exists for the column sums of the linear-regression family and, on 16-byte aligned rows, of the
   // logistic one (round 3: with the series' constants in scalar registers and 32-bit Theta offsets it fits 255 VGPRs;
   // +8 % at D = 300) and the Poisson one (round 4, below); the unaligned transcendental instantiations are not built
-  // Poisson COLSUM on the 128-column tile parks 16 VGPRs (request pointers, outside the MFMA groups) and is the faster one
+  // Poisson COLSUM on the 128-column tile (249 VGPRs, no scratch since round 5; it parked 16 VGPRs before) is the faster one
   // on 16-byte aligned rows: N = 2M, D = 301, S = 256 6.15 against 6.72 ms (50.1 against 45.9 TFLOP/s).  BCX_PROJ_POIS_NCT=4: dev.
   static const bool pois8 = [] { const char* e = bcx_dev_env("BCX_PROJ_POIS_NCT"); return !(e && atoi(e) == 4); }();
   if ((family == FAM_POISSON && !(pois8 && aligned)) || (family == FAM_LOGISTIC && !aligned)) return 4;

@@ -885,9 +885,11 @@ def optimize_leg(out, torch, nat):
             eng = nat.Engine(nat.ALG_FW, N, d)
             g = torch.Generator(device="cuda")
             g.manual_seed(1)
-            for r0 in range(0, N, 250_000):
-                x = torch.randn(250_000, d, device="cuda", dtype=torch.float64, generator=g)
-                eng.load_device_rows(x.data_ptr(), 250_000, d, True, r0)
+            piece = 256 * 1024                     # (pieces start on the engine's 1024-row chunk boundaries)
+            for r0 in range(0, N, piece):
+                m = min(piece, N - r0)
+                x = torch.randn(m, d, device="cuda", dtype=torch.float64, generator=g)
+                eng.load_device_rows(x.data_ptr(), m, d, True, r0)
                 torch.cuda.synchronize()
             del x
             if eng.finalize(None) != 0:
