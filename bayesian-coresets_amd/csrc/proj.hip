@@ -279,27 +279,41 @@ __global__ __launch_bounds__(256, 2) void proj_kernel(ProjArgs p) {
   // this lane's share of a stage: slot `lane` of Z chunks 4 wave + j (rows 32 wave + 8 j + fr) and of Theta chunks
   // 2 wave + j (columns 16 wave + 8 j + fr), piece fq of the row's 128-byte line
   const int fr = lane >> 3, fq = ((lane & 7) - 2 * ((fr >> 1) & 3)) & 7;
-  // What a lane asks for is ONE offset per operand plus scalars: row 8 j + fr of a tile is 8 j ldz (8 j ldt) elements
-  // behind row fr, clamped to the matrix's last row (zmax / tmax: only the block that hangs over the edge ever reaches
-  // them), from the row block's own base pointer (scalar).  Four row pointers and TCH offsets held 8 + TCH VGPRs here: what
-  // the 128-column transcendental tiles and the SELECT epilogue lacked.
-  int zp0 = 0, zmax = 0, tp0 = 0;
+  // Request state.  What a lane asks for is, per operand, row 8 j + fr of a tile = 8 j ldz (8 j ldt) elements behind row fr,
+  // clamped to the matrix's last row, from the row block's own base pointer (a scalar): 32-bit element offsets, one VGPR per
+  // request (rounds 3-4 carried four row POINTERS: 8 VGPRs).  LEAN instantiations -- the three 128-column ones that sat at the
+  // 256-VGPR limit and parked up to 24 registers in scratch around the k loop -- carry only the offset of row fr and form
+  // the others (stride, clamp: zmax / tmax are only ever reached in the block that hangs over the edge) where a request is
+  // issued, and add the lane's piece offset there too: ~1 % slower per call than carrying them, and no scratch.
+  constexpr bool LEAN = NCT == 8 && (MODE == PMODE_SELECT || (MODE == PMODE_COLSUM && FAM != FAM_LINREG));
+  int zpv[LEAN ? 1 : 4], tpv[LEAN ? 1 : TCH];
+  int zmax = 0;
   const double* zbase = p.Z;
   const int zstep = 8 * (int)p.ldz, tstep = 8 * p.ldt, tmax = (S - 1) * p.ldt;
-  auto zp = [&](int j) { return min(zp0 + j * zstep, zmax); };
-  auto tp = [&](int j) { return min(tp0 + j * tstep, tmax); };
+  auto zp = [&](int j) { return LEAN ? min(zpv[0] + j * zstep, zmax) : zpv[LEAN ? 0 : j]; };
+  auto tp = [&](int j) { return LEAN ? min(tpv[0] + j * tstep, tmax) : tpv[LEAN ? 0 : j]; };
   int64_t zp_br = -1;
   int tp_cg = -1;
   const int kmax = ALIGNED ? ((D - 1) & ~1) : (D - 1);
   auto set_z = [&](int64_t fbr) {
     zp_br = fbr;
     zbase = p.Z + fbr * PJ_ROWS * p.ldz;
-    zp0 = (32 * wave + fr) * (int)p.ldz;
     zmax = (int)((p.N - 1 - fbr * PJ_ROWS) * p.ldz);      // (>= 0: the block's first row exists)
+    const int z0 = (32 * wave + fr) * (int)p.ldz;
+    if (LEAN) zpv[0] = z0;
+    else {
+#pragma unroll
+      for (int j = 0; j < (LEAN ? 1 : 4); ++j) zpv[j] = min(z0 + j * zstep, zmax);
+    }
   };
   auto set_t = [&](int fcg) {
     tp_cg = fcg;
-    tp0 = (fcg * COLS + 8 * TCH * wave + fr) * p.ldt;
+    const int t0 = (fcg * COLS + 8 * TCH * wave + fr) * p.ldt;
+    if (LEAN) tpv[0] = t0;
+    else {
+#pragma unroll
+      for (int j = 0; j < (LEAN ? 1 : TCH); ++j) tpv[j] = min(t0 + j * tstep, tmax);
+    }
   };
   auto advance = [&](PjPos a) {
     if (++a.s == nst) {
@@ -402,14 +416,16 @@ __global__ __launch_bounds__(256, 2) void proj_kernel(ProjArgs p) {
     const bool last = s == nst - 1;
     const int zs1 = zs == ZRING - 1 ? 0 : zs + 1, zs2 = zs1 == ZRING - 1 ? 0 : zs1 + 1, ts1 = ts ^ 1;
     // requests for the stages ahead fly while this stage's MFMAs run
-    int kts = 0, kzs = 0;                      // (scalar stage bases: the lane's piece offset is added where a request is formed)
+    int kts = 0, kzs = 0;                      // stage bases (scalars); LEAN: the lane's piece offset is added where a request is formed,
+    int kct = 0, kcz = 0;                      // otherwise it is carried through the stage
     if (ALIGNED) {
       // (the requests themselves are spread over the first groups of the compute loop)
-      if (more) { if (n1.cg != tp_cg) set_t(n1.cg); kts = n1.s * PJ_KC; }
+      if (more) { if (n1.cg != tp_cg) set_t(n1.cg); kts = n1.s * PJ_KC; if (!LEAN) kct = min(kts + 2 * fq, kmax); }
       if (ZRING == 3 ? more2 : more) {
         const PjPos& zn = ZRING == 3 ? n2 : n1;
         if (zn.br != zp_br) set_z(zn.br);
         kzs = zn.s * PJ_KC;
+        if (!LEAN) kcz = min(kzs + 2 * fq, kmax);
       }
     } else if (more) {
       fetch_regs(n1);
@@ -463,9 +479,9 @@ __global__ __launch_bounds__(256, 2) void proj_kernel(ProjArgs p) {
 #pragma unroll
           for (int q = 0; q < TCH + 4; ++q) {
             if ((NG >= 8 ? q : q * NG / 8) != g) continue;
-            if (q < TCH) { if (more) pj_glds16(p.theta + (tp(q) + min(kts + 2 * fq, kmax)), lds0 + (unsigned)(TBASE + ts1 * TBYTES + (TCH * wave + q) * 1024)); }
+            if (q < TCH) { if (more) pj_glds16(p.theta + (tp(q) + (LEAN ? min(kts + 2 * fq, kmax) : kct)), lds0 + (unsigned)(TBASE + ts1 * TBYTES + (TCH * wave + q) * 1024)); }
             else if (ZRING == 3 ? more2 : more)
-              pj_glds16(zbase + (zp(q - TCH) + min(kzs + 2 * fq, kmax)), lds0 + (unsigned)((ZRING == 3 ? zs2 : zs1) * PJ_ZBYTES + (4 * wave + q - TCH) * 1024));
+              pj_glds16(zbase + (zp(q - TCH) + (LEAN ? min(kzs + 2 * fq, kmax) : kcz)), lds0 + (unsigned)((ZRING == 3 ? zs2 : zs1) * PJ_ZBYTES + (4 * wave + q - TCH) * 1024));
           }
         }
         __builtin_amdgcn_sched_barrier(0);
