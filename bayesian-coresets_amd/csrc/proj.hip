@@ -4,7 +4,7 @@
 //   logistic regression   examples/common/model_lr.py:25-32
 //   Poisson (softplus)    examples/common/model_poiss.py:25-38
 //   Gaussian linear regr. examples/common/model_linreg.py:4-10
-// as one fused kernel: Z . Theta^T on the fp64 matrix cores (v_mfma_f64_4x4x4_4b_f64; operands staged through LDS by
+// as one fused kernel: Z . Theta^T on the fp64 matrix cores (v_mfma_f64_16x16x4_f64; operands staged through LDS by
 // LDS-DMA, 128 x 64 or 128 x 128 workgroup tiles) with the likelihood as the epilogue, and three
 // consumers that never need the N x S matrix twice:
 //   WRITE   : store the uncentred values (a second pass forms the row means and subtracts them)
@@ -400,7 +400,9 @@ __global__ __launch_bounds__(256, 2) void proj_kernel(ProjArgs p) {
   // read-side bases of this lane inside a 16-row operand tile (2 chunks): natural piece (row li, k-slot lk) and
   // replicated piece (row lane & 3 of the strip, k-slot lk) of an even step; ^ 64 for an odd step
   const unsigned nat0 = (unsigned)((li >> 3) * 1024 + (li & 7) * 128 + ((lk + 2 * ((li >> 1) & 3)) & 7) * 16);
+#ifdef PJ_USE_4X4X4
   const unsigned rep0 = (unsigned)((lane & 3) * 128 + ((lk + 2 * ((lane >> 1) & 1)) & 7) * 16);
+#endif
   // Orientation of the wave's 32 rows x 64 columns on the MFMA tiles.  WRITE: A = Z, B = Theta -- a lane holds 8 rows
   // x 4 columns, the 16 lanes of a DPP row hold 16 consecutive columns of one data row (128-byte stores).
   // COLSUM / SELECT: A = Theta, B = Z (the transposed product) -- a lane holds only 2 data rows (li, li + 16) x 16
@@ -437,16 +439,19 @@ __global__ __launch_bounds__(256, 2) void proj_kernel(ProjArgs p) {
         for (int tc = 0; tc < NCT; ++tc) acc[tr][tc] = (pv4d){0.0, 0.0, 0.0, 0.0};
     }
     {
-      // v_mfma_f64_4x4x4_4b_f64: four independent 4x4x4 products per instruction (lanes 16k + 4b + i hold A_b[i][k],
-      // lanes 16k + 4b + j hold B_b[k][j], D_b[i][j] comes back in lane 16i + 4b + j).  It sustains 72 TFLOP/s on this
-      // chip where the 16x16x4 form tops out at 47.6 (tools/probe/mfma_f64_peak.hip), so the 16x16 tile is built from it:
+      // (-DPJ_USE_4X4X4, rounds 2-4; kept for A/B runs, tools/proj_ab.sh)  v_mfma_f64_4x4x4_4b_f64: four independent 4x4x4
+      // products per instruction (lanes 16k + 4b + i hold A_b[i][k], lanes 16k + 4b + j hold B_b[k][j], D_b[i][j] comes back
+      // in lane 16i + 4b + j).  A register-only probe put it at 72 TFLOP/s and the 16x16x4 form at 47.6
+      // (tools/probe/mfma_f64_peak.hip), so the 16x16 tile was built from it:
       // the "B" operand is a natural 16-wide tile (block b = its columns 4b .. 4b+3), the "A" operand four rows replicated
       // into all four blocks -- D is then a 4 x 16 strip, and register r of the old 16x16 accumulator IS the strip of rows
       // 4r .. 4r+3, so accumulator layout and epilogue are those of the 16x16x4 version.
       const unsigned char* zb = pj_lds + zs * PJ_ZBYTES + wave * 4096;       // this wave's two Z tiles
       const unsigned char* tb = pj_lds + TBASE + ts * TBYTES;
       const unsigned char* natb[2] = {(TRP ? zb : tb) + nat0, (TRP ? zb : tb) + (nat0 ^ 64u)};
+#ifdef PJ_USE_4X4X4
       const unsigned char* repb[2] = {(TRP ? tb : zb) + rep0, (TRP ? tb : zb) + (rep0 ^ 64u)};
+#endif
       // Operand registers are double-buffered by hand: the four replicated pieces of group g + 1 are requested before the
       // 16 MFMAs of group g are issued (an LDS read takes ~130 cycles, four MFMAs 64), and within a group the .x MFMAs of
       // all accumulators precede their dependent .y MFMAs.  A group = one column tile (TRP) / one row tile (WRITE) of one
@@ -455,10 +460,58 @@ __global__ __launch_bounds__(256, 2) void proj_kernel(ProjArgs p) {
       auto nat_ptr = [&](int u, int t) {      // natural operand tile t of 8-k step u
         return (const pv2d*)(natb[u & 1] + t * 2048);
       };
+#ifdef PJ_USE_4X4X4
       auto rep_ptr = [&](int g, int r) {      // replicated operand, group g = (u, tile), rows 4 r .. 4 r + 3
         const int u = g / NA, t = g % NA;
         return (const pv2d*)(repb[(u + r) & 1] + t * 2048 + (r >> 1) * 1024 + (r & 1) * 512);
       };
+#endif
+#ifndef PJ_USE_4X4X4
+      // Round 5: v_mfma_f64_16x16x4_f64 with BOTH operands natural.  The 4x4x4 form below was chosen in round 2 on a probe that
+      // put the 16x16x4 form at 47.6 TFLOP/s; the Gram kernel of csrc/gram.hip runs it at 0.78-0.87 of the 78.6 TFLOP/s peak
+      // in its stage loop and a vendor GEMM in the round-4 traces at 0.93 MFMA-busy, so that probe was wrong.  The
+      // accumulator layout is the same (register r of lane row lk = row lk + 4 r of the A tile, column li of the B tile), so
+      // the epilogues do not change; the "A" tile is simply read like the "B" tile (one ds_read_b128 per tile and 8-value
+      // step instead of four replicated ones: 6 instead of 36 LDS reads per 32 x 64 wave tile and stage), and its double
+      // buffer shrinks from 32 to 8 VGPRs.  Measured A/B at the configs[4] shard shape, all nine family x consumer pairs:
+      // the same to 0.5 % (the kernel is not bound by its operand reads) -- kept for the registers and the simpler loop.
+      const unsigned char* nata[2] = {(TRP ? tb : zb) + nat0, (TRP ? tb : zb) + (nat0 ^ 64u)};
+      auto a_ptr = [&](int g) { return (const pv2d*)(nata[(g / NA) & 1] + (g % NA) * 2048); };
+      pv2d ap[2];
+      ap[0] = *a_ptr(0);
+      pv2d nt[NB];
+#pragma unroll
+      for (int g = 0; g < NG; ++g) {
+        const int u = g / NA, t = g % NA;
+        if (t == 0) {
+#pragma unroll
+          for (int i = 0; i < NB; ++i) nt[i] = *nat_ptr(u, i);
+        }
+        if (g + 1 < NG) ap[(g + 1) & 1] = *a_ptr(g + 1);
+        if (ALIGNED) {
+          // this group's share of the LDS-DMA requests (Theta first: the stage-end wait counts on the order)
+#pragma unroll
+          for (int q = 0; q < TCH + 4; ++q) {
+            if ((NG >= 8 ? q : q * NG / 8) != g) continue;
+            if (q < TCH) { if (more) pj_glds16(p.theta + (tp(q) + (LEAN ? min(kts + 2 * fq, kmax) : kct)), lds0 + (unsigned)(TBASE + ts1 * TBYTES + (TCH * wave + q) * 1024)); }
+            else if (ZRING == 3 ? more2 : more)
+              pj_glds16(zbase + (zp(q - TCH) + (LEAN ? min(kzs + 2 * fq, kmax) : kcz)), lds0 + (unsigned)((ZRING == 3 ? zs2 : zs1) * PJ_ZBYTES + (4 * wave + q - TCH) * 1024));
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < NB; ++i) {
+          pv4d& a4 = TRP ? acc[i][t] : acc[t][i];
+          a4 = __builtin_amdgcn_mfma_f64_16x16x4f64(ap[g & 1].x, nt[i].x, a4, 0, 0, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < NB; ++i) {
+          pv4d& a4 = TRP ? acc[i][t] : acc[t][i];
+          a4 = __builtin_amdgcn_mfma_f64_16x16x4f64(ap[g & 1].y, nt[i].y, a4, 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+#else
       pv2d rp[2][4];
 #pragma unroll
       for (int r = 0; r < 4; ++r) rp[0][r] = *rep_ptr(0, r);
@@ -502,6 +555,7 @@ __global__ __launch_bounds__(256, 2) void proj_kernel(ProjArgs p) {
           }
         __builtin_amdgcn_sched_barrier(0);
       }
+#endif
     }
     if (last) {
       // ---- epilogue of tile (br, cg).  f64 C/D layout: D[i = (lane >> 4) + 4 * reg][j = lane & 15] ---------------
