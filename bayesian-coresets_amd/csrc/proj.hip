@@ -281,11 +281,11 @@ __global__ __launch_bounds__(256, 2) void proj_kernel(ProjArgs p) {
   const int fr = lane >> 3, fq = ((lane & 7) - 2 * ((fr >> 1) & 3)) & 7;
   // Request state.  What a lane asks for is, per operand, row 8 j + fr of a tile = 8 j ldz (8 j ldt) elements behind row fr,
   // clamped to the matrix's last row, from the row block's own base pointer (a scalar): 32-bit element offsets, one VGPR per
-  // request (rounds 3-4 carried four row POINTERS: 8 VGPRs).  LEAN instantiations -- the three 128-column ones that sat at the
-  // 256-VGPR limit and parked up to 24 registers in scratch around the k loop -- carry only the offset of row fr and form
-  // the others (stride, clamp: zmax / tmax are only ever reached in the block that hangs over the edge) where a request is
-  // issued, and add the lane's piece offset there too: ~1 % slower per call than carrying them, and no scratch.
-  constexpr bool LEAN = NCT == 8 && (MODE == PMODE_SELECT || (MODE == PMODE_COLSUM && FAM != FAM_LINREG));
+  // request (rounds 3-4 carried four row POINTERS: 8 VGPRs, and the three 128-column instantiations at the 256-VGPR limit
+  // parked up to 24 registers in scratch around the k loop).  LEAN (off: with the 16x16x4 loop's smaller operand buffers
+  // every instantiation fits without it; measured ~1-2 % slower per call where it was on) carries only the offset of row
+  // fr and forms the others -- stride, clamp, the lane's piece offset -- where a request is issued.
+  constexpr bool LEAN = false;
   int zpv[LEAN ? 1 : 4], tpv[LEAN ? 1 : TCH];
   int zmax = 0;
   const double* zbase = p.Z;
