@@ -136,6 +136,17 @@ def blas_info():
         return "unknown", os.cpu_count() or 0
 
 
+def blas_threads_for_baseline():
+    """A launcher may have pinned the BLAS pool to one thread per rank (torch.distributed.run exports OMP_NUM_THREADS=1): the
+    CPU baseline is timed on the host's cores, as many as the BLAS build takes (NumPy's OpenBLAS: 64), whatever the launcher
+    set for the GPU ranks.  Stays in force for the rest of the process (only rank 0 computes on the host afterwards)."""
+    try:
+        from threadpoolctl import threadpool_limits
+        threadpool_limits(limits=max(1, min(os.cpu_count() or 1, 64)), user_api="blas")
+    except Exception:
+        pass
+
+
 def host_rows(torch, args, n_s):
     """The first n_s rows of the synthetic matrix as a C-contiguous fp64 host array: generated on the device per seeded block
     exactly as load_synthetic does (same block sizes, so the same numbers) and copied block by block into one allocation."""
@@ -174,6 +185,7 @@ def cpu_baseline_snnls(args, torch, world, what, sample=None):
     hold it and the wall-clock cap allows, on ALL rows -- that figure replaces the scaled one and the scaled
     one stays beside it (`sample_value_scaled`: how linear the cost is in N).  `sample`: ready-made host rows (config 3)."""
     t_leg = time.perf_counter()
+    blas_threads_for_baseline()
     explicit = args.cpu_rows is not None
     if sample is not None:
         X, gen_s = sample, 0.0
@@ -753,6 +765,7 @@ def cpu_baseline_sparsevi(args, Z, mu0, Sig0, sigsq, S):
     Zs = Z[:n_s].cpu().numpy()
     np.random.seed(args.seed)
     itrs = min(args.opt_itrs, 25)      # keep the sample to tens of seconds; cost is linear in 1 + opt_itrs
+    blas_threads_for_baseline()
     o = SparseVIOracle(Zs, model_linreg.posterior_sampler(mu0, Sig0, sigsq), lambda z, th: linreg_loglik(z, th, sigsq), S,
                        opt_itrs=itrs)
     o.step()

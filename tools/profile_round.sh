@@ -63,7 +63,9 @@ xch) # the two exchange modes, two ranks sharing this GPU (what a 1-GPU box can 
 opt) kt optimize python $R/tools/optimize_bench.py
      pmc optimize_mfma "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE" python $R/tools/optimize_bench.py
      kt gram python $R/tools/gram_bench.py 400,512 999,512 1497,1024 2048,2048 4096,1024
-     pmc gram_mfma "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE" python $R/tools/gram_bench.py 1497,1024 4096,1024 ;;
+     pmc gram_mfma "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE" python $R/tools/gram_bench.py 1497,1024 4096,1024
+     pmc gram_lds "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS" python $R/tools/gram_bench.py 4096,1024
+     kt optimize_k1500_d2048 python $R/tools/optimize_bench.py 1,1000000,2048,1500 ;;
 probe) [ -x $R/tools/probe/mfma_f64_peak ] || /opt/rocm/bin/hipcc -O3 --offload-arch=gfx950 -o $R/tools/probe/mfma_f64_peak $R/tools/probe/mfma_f64_peak.hip
        $R/tools/probe/mfma_f64_peak > $O/mfma_f64_probe.txt 2>&1
        pmc mfma_f64_probe_pmc "GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES" $R/tools/probe/mfma_f64_peak ;;
