@@ -303,23 +303,44 @@ __global__ __launch_bounds__(256, 2) void gram_sk_kernel(GramSkArgs p) {
     if (tile_done) {
       // ---- this workgroup holds the tile's last stage: add what the holders of its earlier stages left, then store ----
       if (piece_s0 > 0 && !(p.dbg & 2)) {
+        // the contributors are the slots j_last .. slot - 1 of this XCD (every workgroup has a non-empty range: gram_sk_plan)
         const int64_t tile_u0 = (int64_t)(cur.g.tile - t_lo) * nst;
-        for (int j = slot - 1; j >= 0; --j) {
-          const int64_t ju0 = units * j / per, ju1 = units * (j + 1) / per;
-          if (ju1 <= tile_u0) break;
-          if (ju0 < ju1) {
-            const int b = 8 * j + xcd;
-            if (tid == 0) {
-              const long long t0 = wall_clock64();
-              while (__hip_atomic_load(&p.flags[b], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != p.epoch) {
-                __builtin_amdgcn_s_sleep(8);
-                if (wall_clock64() - t0 > p.timeout_ticks) { atomicExch(p.status, (unsigned long long)p.epoch); break; }
-              }
+        int j_last = slot - 1;
+        while (j_last > 0 && units * j_last / per > tile_u0) --j_last;
+        const int nc = slot - j_last;
+        // Few contributors (the usual case): they are taken one at a time, nearest first -- wait for its flag, add its share --
+        // so that a late one does not hold up the others.  Many (a small support with long rows: tens per tile): lane c of
+        // wave 0 polls contributor c, all at once.  (A/B on one box, us per call, all flags at once + shares requested one
+        // contributor ahead: 20.6 / 50 / 71 against 24.2 / 53.7 / 87 at k, d = 400, 512 / 1024, 1024 / 512, 4096, but 89.5 against
+        // 79.7 at 1497, 1024 with its 3-4 contributors; the request-ahead form also cost the narrow tile 80 VGPRs.)
+        const bool many = nc > 4;
+        auto wait_for = [&](int c) {            // thread 0: contributor c's flag
+          const int b = 8 * (slot - 1 - c) + xcd;
+          const long long t0 = wall_clock64();
+          while (__hip_atomic_load(&p.flags[b], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != p.epoch) {
+            __builtin_amdgcn_s_sleep(8);
+            if (wall_clock64() - t0 > p.timeout_ticks) { atomicExch(p.status, (unsigned long long)p.epoch); break; }
+          }
+        };
+        if (many) {
+          if (wave == 0) {
+            for (int c0 = 0; c0 < nc; c0 += 64)
+              if (c0 + lane < nc) wait_for(c0 + lane);
+          }
+          __syncthreads();
+        }
+        // partial tiles in register order ([wave][ta][tb][register pair][lane] pairs of doubles), added nearest contributor
+        // first, half a share (8 NTB 16-byte loads per lane) in flight at a time
+        auto part_of = [&](int c) {
+          return p.part + (size_t)(8 * (slot - 1 - c) + xcd) * (GK_ROWS * COLS) + (size_t)wave * (4 * NTB * 4 * 64) + 2 * lane;
+        };
+        {
+          for (int c = 0; c < nc; ++c) {
+            if (!many) {
+              if (tid == 0) wait_for(c);
+              __syncthreads();
             }
-            __syncthreads();
-            // (partial tile in register order: [wave][ta][tb][register pair][lane] pairs of doubles; half of the wave's share
-            // in flight at a time: two trips to the memory side per contributor)
-            const double* src = p.part + (size_t)b * (GK_ROWS * COLS) + (size_t)wave * (4 * NTB * 4 * 64) + 2 * lane;
+            const double* src = part_of(c);
             asm volatile("" : "+v"(src));
 #pragma unroll
             for (int half = 0; half < 2; ++half) {
@@ -342,7 +363,6 @@ __global__ __launch_bounds__(256, 2) void gram_sk_kernel(GramSkArgs p) {
                   }
             }
           }
-          if (ju0 <= tile_u0) break;
         }
       }
       // Only the entries on or above the diagonal are taken from the accumulators, each together with its mirror image: an

@@ -249,8 +249,11 @@ int bcx_project_colsum_moments(void* stream, const void* M_dev, int64_t ldm, int
 /* The dense re-weight's Gram matrix as an operator of its own (optimize() forms it over the active rows, snnls.py:82-97:
  * `nnls(A[:, active], b)` solves the normal equations of that k-column block): G_dev (k x ldg doubles, both triangles) =
  * V V^T for the k rows of d doubles at rows_dev (row stride ld >= d), on the fp64 matrix cores; the d products of an entry
- * are summed in a fixed order (64 x 64 blocks of G, slices of the row length added in slice order).  k <= BCX_GRAM_MAX_ROWS;
- * work_dev: bcx_gram_scratch_bytes(k, d) bytes.  Errors: bcx_project_last_error(). */
+ * are summed in a fixed order for a given (k, d) on a given device (csrc/gram.hip: tiles of G cut into equal ranges of
+ * 16-value stages over the resident workgroups, partial tiles added by the workgroup that finishes the tile; rows that are
+ * not 16-byte aligned and k < 192: 64 x 64 blocks, slices of the row length added in slice order), G is symmetric bit for
+ * bit.  Asynchronous on `stream`.  k <= BCX_GRAM_MAX_ROWS; work_dev: bcx_gram_scratch_bytes(k, d) bytes (up to one 128 x 128
+ * tile of doubles per resident workgroup).  Errors: bcx_project_last_error(). */
 #define BCX_GRAM_MAX_ROWS 16384
 int64_t bcx_gram_scratch_bytes(int32_t k, int32_t d);
 int bcx_gram(void* stream, const void* rows_dev, int32_t k, int32_t d, int64_t ld, void* G_dev, int64_t ldg,
