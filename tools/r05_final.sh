@@ -20,5 +20,5 @@ fi
 python tools/optimize_bench.py 2>&1 | grep -v amdgpu.ids > gpurun_out/prof_r05/optimize_times.txt
 BCX_OPT_COLD=1 python tools/optimize_bench.py 2>&1 | grep -v amdgpu.ids | sed "s/^/[BCX_OPT_COLD=1: from the empty passive set] /" >> gpurun_out/prof_r05/optimize_times.txt
 BCX_OPT_GRID=1 python tools/optimize_bench.py 2>&1 | grep -v amdgpu.ids | sed "s/^/[nnls_grid.hip only] /" >> gpurun_out/prof_r05/optimize_times.txt
-BCX_GRAM_TILED=1 python tools/gram_bench.py 2>&1 | grep -v amdgpu.ids | sed "s/^/[BCX_GRAM_TILED=1: gram_tile_kernel of rounds 3-4] /" >> gpurun_out/prof_r05/gram_times.txt
+BCX_GRAM_NTB=-1 python tools/gram_bench.py 2>&1 | grep -v amdgpu.ids | sed "s/^/[BCX_GRAM_NTB=-1: gram_tile_kernel of rounds 3-4] /" >> gpurun_out/prof_r05/gram_times.txt
 ls gpurun_out/prof_r05 | wc -l
