@@ -5,7 +5,7 @@ O=gpurun_out/prof_r05
 D=$(python tools/stamp.py); H=$(cat bayesian-coresets_amd/lib/HEAD.txt 2>/dev/null)
 S=$(python -c "import json;print(json.load(open('$O/scan_traffic.json')).get('_stamp'))")
 [ "$S" = "$D" ] || { echo "scan_traffic.json is stamped $S, the tree is $D: run tools/r05_final.sh on this tree first"; exit 1; }
-for f in $(ls $O | grep -v "\.err$"); do
+for f in $(ls $O | grep -v "\.err$" | grep -v "_under_pmc.json$" | grep -v "omp_hist_c3\|tail_phases\|proj_c5shard_lds\|proj_c5shard_cache\|proj_c5shard_fetch\|_mfma_under\|bench_c4_8ranks"); do
   case $f in
     scan_traffic.json) cp $O/$f profiles/scan_traffic.json;;
     proj_bench_kernel_times.txt|optimize_times.txt|exchange_modes_2ranks.txt|gram_times.txt|upload_rate.txt|scan_row_lengths.txt|omp_hist_c3.txt|tail_phases.txt)
