@@ -40,11 +40,11 @@ struct WarmBufs {
 // perm: slots ordered by (weight desc, slot asc); slots without weight come last and are rejected from the start.
 // (Ordering by weight x row norm -- the size of the column's term in A w -- was tried: a quarter fewer pivots on a saved
 // N = 200k support, but 536 instead of 282 entering columns on the N = 1M, k = 1497, d = 1024 one.  Plain weights stay.)
-__global__ __launch_bounds__(1024) void warm_order_kernel(const double* __restrict__ w, const double* __restrict__ nrm, int k, int kp, WarmBufs wb) {
-  extern __shared__ double sw[];
+__global__ __launch_bounds__(256) void warm_order_kernel(const double* __restrict__ w, const double* __restrict__ nrm, int k, int kp, WarmBufs wb) {
+  extern __shared__ double sw[];               // (every workgroup holds all k weights and ranks its own 256 slots)
   for (int j = threadIdx.x; j < k; j += blockDim.x) sw[j] = w[j];
   __syncthreads();
-  for (int j = threadIdx.x; j < kp; j += blockDim.x) {
+  for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < kp; j += gridDim.x * blockDim.x) {
     if (j < k) {
       const double wj = sw[j];
       int rank = 0;
@@ -86,11 +86,12 @@ __global__ __launch_bounds__(64) void warm_diag_kernel(int kp, int jj, int d, Wa
   __shared__ double sL[WM_NB][WM_NB + 1];      // L11 for the inverse
   const int r = threadIdx.x;
   double a[WM_NB];
-  {
-    const double* src = wb.A + (size_t)(jj + r) * kp + jj;
+  // the block comes in row by row (lane = column: 512 contiguous bytes per load) and is handed to its row owners through LDS
+  for (int rr = 0; rr < WM_NB; ++rr) sL[rr][r] = wb.A[(size_t)(jj + rr) * kp + jj + r];
+  __syncthreads();
 #pragma unroll
-    for (int c = 0; c < WM_NB; ++c) a[c] = c <= r ? src[c] : 0.0;
-  }
+  for (int c = 0; c < WM_NB; ++c) a[c] = c <= r ? sL[r][c] : 0.0;
+  __syncthreads();
   int my_rej = wb.rej[jj + r];
   const double my_d0 = wb.diag0[jj + r];
   int accepted = wb.p[1];                      // columns accepted by the panels before this one
@@ -122,28 +123,30 @@ __global__ __launch_bounds__(64) void warm_diag_kernel(int kp, int jj, int d, Wa
   }
 #pragma unroll
   for (int c = 0; c < WM_NB; ++c) sL[r][c] = a[c];
-  {
-    double* dst = wb.A + (size_t)(jj + r) * kp + jj;
-#pragma unroll
-    for (int c = 0; c < WM_NB; ++c) dst[c] = a[c];          // (upper part of the block: zeros)
-  }
   __syncthreads();
+  for (int rr = 0; rr < WM_NB; ++rr) wb.A[(size_t)(jj + rr) * kp + jj + r] = sL[rr][r];      // (upper part of the block: zeros)
   // T = L11^-1: lane j forms column j by forward substitution -- x[t] = 0 above the diagonal, so the sums can start at 0 and
   // every operand L11[i][t] is a broadcast read
   double x[WM_NB];
   const int j = r;
 #pragma unroll
   for (int i = 0; i < WM_NB; ++i) {
-    double acc = 0.0;
+    double acc[4] = {0.0, 0.0, 0.0, 0.0};       // (four partial sums: the dependent chain of a row is a quarter as long)
 #pragma unroll
-    for (int t = 0; t < i; ++t) acc += sL[i][t] * x[t];
+    for (int t = 0; t < i; ++t) acc[t & 3] += sL[i][t] * x[t];
     const double lii = sL[i][i];
-    x[i] = i < j ? 0.0 : (i == j ? 1.0 / lii : -acc / lii);
+    x[i] = i < j ? 0.0 : (i == j ? 1.0 / lii : -((acc[0] + acc[1]) + (acc[2] + acc[3])) / lii);
   }
-  double* Tj = wb.T + (size_t)(jj / WM_NB) * WM_NB * WM_NB;
-  double* yr = wb.Y + (size_t)(jj + j) * kp + jj;           // Y_jj = T^T: row j of Y's block is column j of T
+  // T[i][j] = x[i] (lane j): through LDS so that the stores are rows (T) and columns-as-rows (Y_jj = T^T) of 512 bytes
+  __syncthreads();
 #pragma unroll
-  for (int i = 0; i < WM_NB; ++i) { Tj[i * WM_NB + j] = x[i]; yr[i] = x[i]; }
+  for (int i = 0; i < WM_NB; ++i) sL[i][j] = x[i];
+  __syncthreads();
+  double* Tj = wb.T + (size_t)(jj / WM_NB) * WM_NB * WM_NB;
+  for (int rr = 0; rr < WM_NB; ++rr) {
+    Tj[rr * WM_NB + r] = sL[rr][r];                                      // T row rr
+    wb.Y[(size_t)(jj + rr) * kp + jj + r] = sL[r][rr];                   // Y row rr = T column rr
+  }
   wb.rej[jj + r] = my_rej;
   if (r == 0) wb.p[1] = accepted;
 }
@@ -243,17 +246,33 @@ __global__ __launch_bounds__(256) void warm_gemm_kernel(const double* __restrict
   for (int a = 0; a < 2; ++a)
 #pragma unroll
     for (int b = 0; b < 2; ++b) acc[a][b] = (wm4d){0.0, 0.0, 0.0, 0.0};
-  for (int k0 = 0; k0 < K; k0 += 16) {
-    for (int e = tid; e < 16 * WM_NB; e += 256) {
-      // consecutive threads along whichever index is contiguous in memory
+  // this thread's four elements of each operand per 16-deep step (consecutive threads along whichever index is contiguous in
+  // memory); the next step's are in flight while this one is multiplied
+  double ra[4], rb[4];
+  auto fetch = [&](int k0) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int e = tid + 256 * q;
       const int kk = sa_k == 1 ? (e & 15) : (e >> 6), ii = sa_k == 1 ? (e >> 4) : (e & 63);
       const int gi = i0 + ii, gk = k0 + kk;
-      sAt[kk][ii] = (gi < M && gk < K) ? A[(size_t)gi * sa_i + (size_t)gk * sa_k] : 0.0;
+      ra[q] = (gi < M && gk < K) ? A[(size_t)gi * sa_i + (size_t)gk * sa_k] : 0.0;
       const int kb = sb_j == 1 ? (e >> 6) : (e & 15), jb = sb_j == 1 ? (e & 63) : (e >> 4);
       const int gj = j0 + jb, gkb = k0 + kb;
-      sBt[kb][jb] = (gj < N && gkb < K) ? B[(size_t)gkb * sb_k + (size_t)gj * sb_j] : 0.0;
+      rb[q] = (gj < N && gkb < K) ? B[(size_t)gkb * sb_k + (size_t)gj * sb_j] : 0.0;
+    }
+  };
+  fetch(0);
+  for (int k0 = 0; k0 < K; k0 += 16) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int e = tid + 256 * q;
+      const int kk = sa_k == 1 ? (e & 15) : (e >> 6), ii = sa_k == 1 ? (e >> 4) : (e & 63);
+      sAt[kk][ii] = ra[q];
+      const int kb = sb_j == 1 ? (e >> 6) : (e & 15), jb = sb_j == 1 ? (e & 63) : (e >> 4);
+      sBt[kb][jb] = rb[q];
     }
     __syncthreads();
+    if (k0 + 16 < K) fetch(k0 + 16);
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
       double av[2], bv[2];
@@ -368,7 +387,7 @@ int bcx_warm_start(bcx_solver* s, int k, void* buf, double* gram_work, const int
   wb.p = (int32_t*)base;                          // [0] size of the passive set, [1] columns accepted so far (Cholesky)
   if (hipMemsetAsync(wb.p, 0, 2 * sizeof(int32_t), s->stream) != hipSuccess) return BCX_ERR_HIP;
   hipStream_t st = s->stream;
-  hipLaunchKernelGGL(warm_order_kernel, dim3(1), dim3(1024), (size_t)k * 8, st, (const double*)s->act_w, (const double*)s->act_norm, k, kp, wb);
+  hipLaunchKernelGGL(warm_order_kernel, dim3((kp + 255) / 256), dim3(256), (size_t)k * 8, st, (const double*)s->act_w, (const double*)s->act_norm, k, kp, wb);
   hipLaunchKernelGGL(warm_gather_kernel, dim3((kp + 255) / 256, kp), dim3(256), 0, st, (const double*)s->gram, (int64_t)s->gram_cap, k, kp, wb);
   const int np = kp / WM_NB;
   for (int j = 0; j < np; ++j) {
