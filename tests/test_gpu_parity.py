@@ -279,6 +279,30 @@ def test_optimize_large_supports_against_the_oracle(bc, alg, N, d, itrs):
     assert s.reached_numeric_limit == o.reached_numeric_limit
 
 
+@pytest.mark.parametrize("alg,rank", (("fw", 40), ("fw", 90)))
+def test_optimize_on_a_support_of_low_rank(bc, alg, rank):
+    """optimize() where the support's Gram matrix is numerically singular long before k reaches d (rows of rank `rank` in
+    d = 128 dimensions, as the projected log-likelihoods of a small model are): the warm start's Cholesky has to leave out
+    every column that depends on the ones before it (pivot rule, not the d-column cap), the incremental kernel carries on
+    from that independent set, and the error equals the oracle's scipy.optimize.nnls re-solve."""
+    from oracle.snnls_oracle import SnnlsOracle
+    rs = np.random.RandomState(77 + rank)
+    X = rs.randn(6000, rank).dot(rs.randn(rank, 128))
+    o = SnnlsOracle(X.T, X.sum(axis=0), alg=alg, mode="onepass")
+    o.build(260)
+    s = _run(bc, X, alg, 260)
+    k = int((s.weights() > 0).sum())
+    assert k >= 128 and k > rank                           # (the warm start takes supports of 128 columns and more)
+    e0 = s.error()
+    s.optimize()
+    o.optimize()
+    warm, p0, entered, left, failed = _optimize_stats(s)
+    assert 0 < p0 <= rank + 2, (p0, rank)                  # the independent part of the support: about `rank` columns
+    assert s.error() <= e0 * (1 + 1e-12)
+    np.testing.assert_allclose(s.error(), o.error(), rtol=1e-6, atol=1e-9 * np.sqrt((X.sum(axis=0) ** 2).sum()))
+    assert s.reached_numeric_limit == o.reached_numeric_limit
+
+
 def test_hilbert_coreset_api(bc, golden, normal_inputs):
     """Drop-in surface of examples/synthetic_vectors/main.py:82-99."""
     X = normal_inputs(7, 3000, 64, "F9_input_sha256")

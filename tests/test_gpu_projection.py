@@ -831,6 +831,7 @@ for family, S in (("linreg", 200), ("poisson", 256), ("logistic", 128)):
                                      (1497, 1024, 0), (700, 8192, 0), (2100, 64, 0),
                                      # the chip-balanced kernel (csrc/gram.hip: 16-byte aligned rows, k >= 192, d >= 64): 128 x 64 tiles ...
                                      (192, 64, 0), (193, 70, 2), (257, 1000, 0), (1025, 333, 1), (2559, 96, 0),
+                                     (512, 4096, 0),      # tens of contributors per tile: their flags are polled all at once
                                      # ... and 128 x 128 tiles from k = 2560, ragged row lengths, tiles hanging over the edge
                                      (2560, 200, 0), (3000, 1030, 2), (4096, 1024, 0), (4100, 65, 1)))
 def test_gram_operator_matches_numpy(bc, k, d, pad):
