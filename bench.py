@@ -247,7 +247,7 @@ def cpu_baseline_snnls(args, torch, world, what, sample=None):
     if n_it < 2:
         full["why"] = "wall cap: set-up %.0f s + 3 iterations of %.1f s exceed %.0f s" % (setup, t_it, args.cpu_wall_cap)
         return out
-    n_it = min(n_it, 20)
+    n_it = min(n_it, 12)
     try:
         t0 = time.perf_counter()
         X = host_rows(torch, args, args.rows)
