@@ -8,6 +8,7 @@ Namespace mirrors bayesiancoresets/__init__.py:1-2 for the classes on the greedy
 ``BatchPSVICoreset`` is out of scope and is not provided."""
 from .coreset import Coreset, HilbertCoreset, UniformSamplingCoreset, SparseVICoreset, ShardedHilbertCoreset
 from .projector import BlackBoxProjector, Projector, DeviceProjector
+from .linreg_sampler import LinregPosteriorSampler
 from . import snnls
 from . import util
 

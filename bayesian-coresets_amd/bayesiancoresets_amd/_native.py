@@ -30,6 +30,7 @@ SYMBOLS = (
     "bcx_set_check_monotone", "bcx_project_profile", "bcx_project_profile_read", "bcx_exchange_stats", "bcx_load_rows_flags", "bcx_project_write_raw", "bcx_omp_stats", "bcx_project_select_ws", "bcx_project_select_scratch_bytes",
     "bcx_project_moments", "bcx_project_colsum_moments", "bcx_project_moments_scratch_bytes",
     "bcx_project_colsum_moments_scratch_bytes", "bcx_gram", "bcx_gram_scratch_bytes",
+    "bcx_project_colsum_moments_at", "bcx_linreg_posterior_draw", "bcx_sparsevi_adam_step",
 )
 
 
@@ -145,6 +146,9 @@ def load():
     sigs["bcx_project_profile_read"] = [P(dbl), P(i64), P(dbl)]
     sigs["bcx_project_moments"] = [vp, vp, i64, i64, i32, vp, i64, vp, i64]
     sigs["bcx_project_colsum_moments"] = [vp, vp, i64, i32, i32, vp, i32, i32, dbl, vp, vp]
+    sigs["bcx_project_colsum_moments_at"] = [vp, vp, i64, i32, i32, vp, i32, i32, dbl, vp, vp, vp]
+    sigs["bcx_linreg_posterior_draw"] = [vp, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, dbl, vp, i32, vp, vp]
+    sigs["bcx_sparsevi_adam_step"] = [vp, i32, i32, vp, dbl, vp, i64, vp, vp, vp, vp, i32, dbl, dbl, dbl, vp]
     sigs["bcx_gram"] = [vp, vp, i32, i32, i64, vp, i64, vp, i64]
     lib.bcx_gram_scratch_bytes.restype = ctypes.c_int64
     lib.bcx_gram_scratch_bytes.argtypes = [i32, i32]

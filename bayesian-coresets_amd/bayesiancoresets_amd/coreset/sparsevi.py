@@ -173,10 +173,49 @@ class SparseVICoreset(Coreset):
 
     # ---- sparsevi.py:69-76 ------------------------------------------------------------
     def _optimize(self):
+        plan = self._enqueue_plan()
+        if plan is not None:
+            self.wts = self._optimize_enqueued(plan)
+            return
+
         def grd(w):
             resid, sub, pts, eng, corevecs = self._residual(self.n_subsample_opt, w)
             return -corevecs.dot(resid) / corevecs.shape[1]
         self.wts = nn_opt(self.wts, grd, opt_itrs=self.opt_itrs, step_sched=self.step_sched)
+
+    # ---- the same loop with the weights resident on the device (csrc/svi.hip) -----------------------------------------------
+    ENQUEUE = True      # False: always the host loop above (tests compare the two)
+
+    def _enqueue_plan(self):
+        """A draw plan when the whole ADAM loop can be enqueued: device projector, the full data set at every step
+        (a per-step sub-sample is drawn on the host, sparsevi.py:33), a non-empty coreset, and a sampler that can draw from
+        device-resident weights (``enqueue_plan``: ``bc.LinregPosteriorSampler``).  Same decision on every rank."""
+        prj = self.ll_projector
+        if not (self.ENQUEUE and isinstance(prj, DeviceProjector) and self.n_subsample_opt is None and self.opt_itrs > 0
+                and 0 < self.wts.shape[0] <= 64 and prj.projection_dimension <= 8192):
+            return None
+        make = getattr(prj.sampler, "enqueue_plan", None)
+        return None if make is None else make(prj.projection_dimension, self.pts, self.opt_itrs)
+
+    def _optimize_enqueued(self, plan, b1=0.9, b2=0.999, eps=1e-8):
+        """nn_opt (util/opt.py:4-28) with grd = sparsevi.py:69-76, enqueued: per step the sampler's draw kernel at the current
+        device weights, the two projections (column sums of the data, the coreset points), and one kernel for
+        resid / gradient / ADAM moments / step / clamp.  The host evaluates the schedule up front and reads the weights once."""
+        prj = self.ll_projector
+        torch = prj._torch
+        k, S, T = self.wts.shape[0], prj.projection_dimension, self.opt_itrs
+        sched = np.array([(self.step_sched(i), 1.0 - b1 ** (i + 1), 1.0 - b2 ** (i + 1)) for i in range(T)], dtype=np.float64)
+        state = torch.from_numpy(np.concatenate((np.asarray(self.wts, dtype=np.float64), np.zeros(2 * k), sched.ravel()))).to(prj.device)
+        w, m1, m2, sched_d = state[:k], state[k:2 * k], state[2 * k:3 * k], state[3 * k:]
+        core = self._core_points_device()
+        lib = prj._lib
+        for i in range(T):
+            theta, mean = plan.draw(w, i)                                         # sparsevi.py:25
+            prj.use_draws(theta, mean=mean)
+            buf, _ = prj.colsum_and_core_enqueue(self.data, core, persistent=True)    # sparsevi.py:35-41
+            prj._check(lib.bcx_sparsevi_adam_step(prj._stream(), k, S, buf.data_ptr(), 1.0, buf[S:].data_ptr(), S, w.data_ptr(),
+                                                  m1.data_ptr(), m2.data_ptr(), sched_d.data_ptr(), i, b1, b2, eps, None))
+        return w.cpu().numpy()
 
     def error(self):
         return 0.0   # as in the reference (sparsevi.py:78-79: KL estimate not implemented)

@@ -236,7 +236,9 @@ class DeviceProjector(Projector):
                                   "check_ms": (time.perf_counter() - t1) * 1e3,
                                   counter: int(self.moments_info.get(counter, 0)) + 1})
 
-    def _colsum_from_moments(self, Z, out=None):
+    def _colsum_from_moments(self, Z, out=None, tbar=None):
+        """``tbar`` (optional device vector, D doubles): the point the quadratic is expanded around -- the mean of the
+        draws when their producer already has it (csrc/svi.hip); otherwise the library forms it."""
         torch = self._torch
         S, D = self.theta.shape[0], Z.shape[1] - 1
         if self.theta.shape[1] != D:
@@ -245,9 +247,10 @@ class DeviceProjector(Projector):
         if self._mom_work is None or self._mom_work.numel() != need:
             self._mom_work = torch.zeros(need, dtype=torch.float64, device=self.device)     # (zero: the arrival counter)
         col = torch.empty(S, dtype=torch.float64, device=self.device) if out is None else out
-        self._check(self._lib.bcx_project_colsum_moments(self._stream(), self._mom.data_ptr(), self._mom.stride(0), D, D,
-                                                         self.theta.data_ptr(), S, self.theta.stride(0), self.sigsq,
-                                                         col.data_ptr(), self._mom_work.data_ptr()))
+        self._check(self._lib.bcx_project_colsum_moments_at(self._stream(), self._mom.data_ptr(), self._mom.stride(0), D, D,
+                                                            self.theta.data_ptr(), S, self.theta.stride(0), self.sigsq,
+                                                            col.data_ptr(), self._mom_work.data_ptr(),
+                                                            None if tbar is None else tbar.data_ptr()))
         return col.cpu().numpy() if out is None else None
 
     def _dims(self, Z):
@@ -268,8 +271,14 @@ class DeviceProjector(Projector):
         """``samples = sampler(S, wts, pts)`` (projector.py:23-24).  A sampler may return a torch tensor that is
         already on the GPU (S x D): it is then used in place -- no host round trip on the per-ADAM-step path of
         SparseVI, where a host sampler otherwise dominates (examples/common/model_linreg.py)."""
+        self.use_draws(self.sampler(self.projection_dimension, wts, pts))
+
+    def use_draws(self, drawn, mean=None):
+        """Install ``drawn`` (S x D: ndarray or device tensor) as the current samples -- what ``update`` does with the
+        sampler's return value.  A producer that enqueues its draws on the device (``SparseVICoreset``'s device-resident
+        weight optimisation) calls this directly; ``mean`` is then the mean of the draws as a device vector, if it has it."""
         torch = self._torch
-        drawn = self.sampler(self.projection_dimension, wts, pts)
+        self.theta_mean = mean
         if isinstance(drawn, torch.Tensor):
             t = drawn.to(self.device, dtype=torch.float64)
             if t.dim() == 1:
@@ -362,6 +371,14 @@ class DeviceProjector(Projector):
         """(project_colsum(pts), project(core) as an ndarray) with ONE device->host copy: what every ADAM step of SparseVI
         reads back (sparsevi.py:35-41, 70-74).  ``core`` is the k x (D+1) array of coreset points (ndarray or device tensor),
         k may be 0.  ``persistent``: ``pts`` is the caller's standing data set, not a per-call sub-sample (``_moments_for``)."""
+        buf, k = self.colsum_and_core_enqueue(pts, core, persistent)
+        S = self.theta.shape[0]
+        h = buf.cpu().numpy()
+        return h[:S], h[S:].reshape(k, S)
+
+    def colsum_and_core_enqueue(self, pts, core, persistent=True):
+        """The same two projections left ON THE DEVICE, nothing read back: (buf, k) with buf[:S] the column sums and
+        buf[S:] the k x S projected coreset points (one buffer, reused by the next call; valid in stream order)."""
         torch = self._torch
         Z = self._dev(pts)
         S = self.theta.shape[0]
@@ -372,13 +389,12 @@ class DeviceProjector(Projector):
         buf = self._cc_buf[:S * (k + 1)]
         col = buf[:S]
         if self._moments_for(pts, Z, persistent) is not None:
-            self._colsum_from_moments(Z, out=col)
+            self._colsum_from_moments(Z, out=col, tbar=getattr(self, "theta_mean", None))
         else:
             self._colsum_projected(Z, out=col)      # (a shard without rows: zeros, and still the all-reduce its peers join)
         if k:
             self._launch(self._lib.bcx_project_write, self._common(C) + [buf[S:].data_ptr(), S, None], C)
-        h = buf.cpu().numpy()
-        return h[:S], h[S:].reshape(k, S)
+        return buf, k
 
     def project_select(self, pts, resid, row_ids=None):
         """(max_n corr_n, arg-max row) with corr_n = vecs[n].resid / ||vecs[n]|| / S (first maximum).

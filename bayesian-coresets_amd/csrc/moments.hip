@@ -519,9 +519,11 @@ extern "C" int64_t bcx_project_colsum_moments_scratch_bytes(int32_t D, int32_t S
 // colsum_dev[s] = sum_n vecs[n][s] of the linear-regression projection of the data whose moments are M_dev (features in
 // rows/columns [0, D), response in row/column ycol), for the S parameter rows of theta_dev.  work_dev:
 // bcx_project_colsum_moments_scratch_bytes(D, S) bytes, ZERO before the first call (the kernel leaves its counter zero).
-extern "C" int bcx_project_colsum_moments(void* stream, const void* M_dev, int64_t ldm, int32_t D, int32_t ycol,
-                                          const void* theta_dev, int32_t S, int32_t ldt, double sigsq, void* colsum_dev,
-                                          void* work_dev) {
+// tbar_dev: the point the quadratic is expanded around, D doubles (any point near the draws serves -- the expansion is exact;
+// csrc/svi.hip leaves the mean of the draws it makes), or NULL: their mean is formed here.
+extern "C" int bcx_project_colsum_moments_at(void* stream, const void* M_dev, int64_t ldm, int32_t D, int32_t ycol,
+                                             const void* theta_dev, int32_t S, int32_t ldt, double sigsq, void* colsum_dev,
+                                             void* work_dev, const void* tbar_dev) {
   if (!M_dev || !theta_dev || !colsum_dev || !work_dev || D < 1 || D >= MOM_MAX_COLS || ycol < 0 || ycol >= ldm || ldm < D ||
       S < 1 || ldt < D || !(sigsq > 0.0)) {
     bcx_project_set_error("bcx_project_colsum_moments: bad arguments");
@@ -530,9 +532,13 @@ extern "C" int bcx_project_colsum_moments(void* stream, const void* M_dev, int64
   int nct, Spad;
   colsum_plan(D, S, &nct, &Spad);
   double* work = (double*)work_dev;
-  double* tbar = work + (size_t)nct * Spad + 1;
+  const double* tbar = (const double*)tbar_dev;
   hipStream_t st = (hipStream_t)stream;
-  hipLaunchKernelGGL(moments_mean_kernel, dim3((D + 63) / 64), dim3(256), 0, st, (const double*)theta_dev, (int)S, (int)ldt, (int)D, tbar);
+  if (!tbar) {
+    double* own = work + (size_t)nct * Spad + 1;
+    hipLaunchKernelGGL(moments_mean_kernel, dim3((D + 63) / 64), dim3(256), 0, st, (const double*)theta_dev, (int)S, (int)ldt, (int)D, own);
+    tbar = own;
+  }
   const int tiles = nct * (Spad / 16);
   const bool al = ((uintptr_t)theta_dev % 16 == 0) && ldt % 2 == 0;
   if (al)
@@ -543,4 +549,10 @@ extern "C" int bcx_project_colsum_moments(void* stream, const void* M_dev, int64
                        (const double*)theta_dev, (int)S, (int)ldt, (const double*)tbar, sigsq, (double*)colsum_dev, work, nct, Spad);
   MOM_HIP(hipGetLastError());
   return BCX_OK;
+}
+
+extern "C" int bcx_project_colsum_moments(void* stream, const void* M_dev, int64_t ldm, int32_t D, int32_t ycol,
+                                          const void* theta_dev, int32_t S, int32_t ldt, double sigsq, void* colsum_dev,
+                                          void* work_dev) {
+  return bcx_project_colsum_moments_at(stream, M_dev, ldm, D, ycol, theta_dev, S, ldt, sigsq, colsum_dev, work_dev, nullptr);
 }

@@ -5,8 +5,9 @@ examples/common/model_linreg.py).  Rows are z = [x, y]; prior theta ~ N(mu0, Sig
     Sigma_w^-1 = Sig0^-1 + X^T diag(w) X / sigsq,    mu_w = Sigma_w (Sig0^-1 mu0 + X^T diag(w) y / sigsq)
 
 ``posterior_sampler(..., device=None)`` is the host (NumPy) sampler; with ``device=`` a torch device the same
-posterior is formed on the GPU (for up to 32 weighted points as a low-rank update of the prior's factor, otherwise by a
-Cholesky of the D x D system) and the draws come back as a device tensor, which ``bc.DeviceProjector`` uses in place.
+posterior is formed on the GPU (for up to 64 weighted points as a low-rank update of the prior's factor by
+``bc.LinregPosteriorSampler``, otherwise by a Cholesky of the D x D system) and the draws come back as a device tensor,
+which ``bc.DeviceProjector`` uses in place.
 SparseVI calls the sampler once per ADAM step (sparsevi.py:25 via projector.update); at D = 301 the host
 version costs ~29 ms per call on a 128-thread box (SciPy triangular solve + Cholesky of a 301 x 301 matrix)
 against 2.9 ms for the whole N = 625k projection it feeds, so the sampler is what one moves next.
@@ -141,7 +142,20 @@ def posterior_sampler(mu0, Sig0, sigsq, device=None, seed=None):
         U = torch.linalg.solve_triangular(L, eye, upper=False).T
         return U @ (U.T @ rhs), U
 
+    # On a GPU the draws for up to 64 weighted points come from the library's own kernel (bc.LinregPosteriorSampler,
+    # csrc/svi.hip: the same rank-k correction through a k x k Cholesky instead of the eigenproblem, one launch, and -- through
+    # `enqueue_plan` -- from weights that never leave the device: SparseVI then enqueues its whole ADAM loop).  The torch
+    # forms below remain for torch's CPU device, for more points and for more than 1024 draws per call.
+    fast = None
+    if dev.type == "cuda":
+        import bayesiancoresets_amd as bc
+        fast = bc.LinregPosteriorSampler(mu0, Sig0, sigsq, device=dev)
+        fast.gen = gen                                              # one random stream whichever form serves a call
+
     def sampler(n, wts, pts):
+        k = 0 if wts is None else len(wts)
+        if fast is not None and fast.supports(n, k) and (k == 0 or np.all(np.asarray(wts) >= 0)):
+            return fast(n, wts, pts)
         if use_lowrank(wts):
             # draws = mu + R U^T with U = U0 (I + W diag(d) W^T), never forming U:  (R + ((R W) d) W^T) U0^T + mu
             W, d_d, e_d, t = lowrank_factors(wts, pts)
@@ -155,6 +169,8 @@ def posterior_sampler(mu0, Sig0, sigsq, device=None, seed=None):
         out[:, :D] = mu + torch.randn(n, D, dtype=torch.float64, device=dev, generator=gen) @ U.T
         return out[:, :D]
     sampler.posterior = posterior
+    if fast is not None:
+        sampler.enqueue_plan = fast.enqueue_plan
     return sampler
 
 

@@ -246,6 +246,36 @@ int bcx_project_moments(void* stream, const void* Z_dev, int64_t N, int64_t ldz,
                         void* work_dev, int64_t work_bytes);
 int bcx_project_colsum_moments(void* stream, const void* M_dev, int64_t ldm, int32_t D, int32_t ycol,
                                const void* theta_dev, int32_t S, int32_t ldt, double sigsq, void* colsum_dev, void* work_dev);
+/* ... expanded around a point the caller supplies: tbar_dev = D doubles near the draws (the expansion is exact around any
+ * point; bcx_linreg_posterior_draw leaves the mean of its draws), NULL = bcx_project_colsum_moments. */
+int bcx_project_colsum_moments_at(void* stream, const void* M_dev, int64_t ldm, int32_t D, int32_t ycol,
+                                  const void* theta_dev, int32_t S, int32_t ldt, double sigsq, void* colsum_dev, void* work_dev,
+                                  const void* tbar_dev);
+/* SparseVI's weight optimisation with the weights resident on the device (sparsevi.py:69-76 -> util/opt.py:4-28): the
+ * reference's loop body is projector.update(w, pts) [sampler call, sparsevi.py:25], two projections [sparsevi.py:35-41],
+ * the gradient [sparsevi.py:72-74] and one projected-ADAM update [opt.py:19-25]; with these two entry points and the
+ * projection calls above a host enqueues opt_itrs such steps and reads the k weights back once (csrc/svi.hip).
+ *   bcx_linreg_posterior_draw  theta_dev (S x ld) = S draws from the posterior of the weighted coreset under the Gaussian
+ *                              linear-regression model with a N(mu0, Sig0) prior (the sampler of the reference's
+ *                              examples/linear_regression/main.py:124-147), theta = mu_w + R_dev Uw^T for the standard-normal
+ *                              R_dev (S x ld, 16-byte aligned), as a rank-k correction of the prior's factor Sig0 = U0 U0^T
+ *                              through a k x k Cholesky; tbar_dev (D) = the mean of the draws.  Per-point inputs (formed
+ *                              by the caller when the points change): K0 = (X U0)(X U0)^T (k x k), xmu0 = X mu0, y (k),
+ *                              XU0 = X U0 and XS0 = X Sig0 (k x ld); per-model: U0T = U0^T (D x ld), mu0 (D).  w_dev: the
+ *                              k weights (negative entries count as 0).  k <= 64, S <= 1024, ld even.
+ *   bcx_sparsevi_adam_step     resid = scaling colsum - w corevecs, g = -corevecs resid / S, then opt.py:19-25 on w_dev /
+ *                              mom1_dev / mom2_dev (k doubles each) with every weight clamped at 0 (nn_idcs = None).
+ *                              core_dev: k x ldc projected coreset points; sched_dev: 3 doubles per step -- step_sched(i),
+ *                              1 - b1^(i+1), 1 - b2^(i+1), evaluated by the host; step: i; trace_dev: NULL or steps x k
+ *                              doubles receiving the weights after each step.
+ * Asynchronous on `stream`; errors: bcx_project_last_error(). */
+int bcx_linreg_posterior_draw(void* stream, int32_t k, int32_t D, int32_t ld, const void* w_dev, const void* K0_dev,
+                              const void* xmu0_dev, const void* y_dev, const void* XU0_dev, const void* XS0_dev,
+                              const void* U0T_dev, const void* mu0_dev, double sigsq, const void* R_dev, int32_t S,
+                              void* theta_dev, void* tbar_dev);
+int bcx_sparsevi_adam_step(void* stream, int32_t k, int32_t S, const void* colsum_dev, double scaling, const void* core_dev,
+                           int64_t ldc, void* w_dev, void* mom1_dev, void* mom2_dev, const void* sched_dev, int32_t step,
+                           double b1, double b2, double eps, void* trace_dev);
 /* The dense re-weight's Gram matrix as an operator of its own (optimize() forms it over the active rows, snnls.py:82-97:
  * `nnls(A[:, active], b)` solves the normal equations of that k-column block): G_dev (k x ldg doubles, both triangles) =
  * V V^T for the k rows of d doubles at rows_dev (row stride ld >= d), on the fp64 matrix cores; the d products of an entry

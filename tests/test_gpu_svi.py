@@ -1,0 +1,198 @@
+"""GPU: SparseVI's weight optimisation with the weights resident on the device (csrc/svi.hip; reference:
+coreset/sparsevi.py:69-76, util/opt.py:4-28, the sampler of examples/linear_regression/main.py:124-147).
+
+* the posterior-draw kernel against the NumPy restatement of the model's weighted conjugate posterior
+  (tests/models.py linreg_weighted_post, pinned to reference outputs by tests/test_host_golden.py F12);
+* the ADAM-step kernel against the package's ``nn_opt`` (bit-for-bit restatement of util/opt.py, tests/test_host_golden.py);
+* the enqueued loop of ``SparseVICoreset`` against its host loop (the reference's own sequence) on the same draws."""
+import numpy as np
+import pytest
+
+from models import make_linreg_data, linreg_weighted_post
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def bc():
+    import bayesiancoresets_amd as bc
+    return bc
+
+
+def _model(rs, D):
+    mu0 = rs.randn(D)
+    A0 = rs.randn(D, D)
+    Sig0 = A0.dot(A0.T) / D + np.eye(D)
+    return mu0, Sig0, 0.37
+
+
+@pytest.mark.parametrize("D,k,S", ((7, 3, 16), (30, 1, 40), (31, 12, 64), (301, 4, 320), (301, 33, 320), (100, 64, 300),
+                                   (302, 0, 310), (129, 17, 1024)))
+def test_posterior_draw_kernel(bc, D, k, S):
+    """theta = mu_w + R Uw^T with Uw Uw^T = Sigma_w: the rows of R are the unit vectors (they return Uw itself), a zero row
+    (the mean) and standard-normal rows (compared with mu_w + R Uw^T for the Uw just read)."""
+    import torch
+    rs = np.random.RandomState(1000 * D + k)
+    mu0, Sig0, sigsq = _model(rs, D)
+    pts = rs.randn(k, D + 1)
+    wts = np.abs(rs.randn(k)) * 30.0
+    if k > 1:
+        wts[0] = 0.0                       # a point that has just entered the coreset
+    smp = bc.LinregPosteriorSampler(mu0, Sig0, sigsq, seed=3)
+    ld = D + D % 2
+    R = np.zeros((S, ld))
+    R[:D, :D] = np.eye(D)
+    R[D + 1:, :] = rs.randn(S - D - 1, ld)          # (row D stays zero; the padding column holds noise: it must not matter)
+    Rd = torch.from_numpy(R).cuda()
+    smp._noise = lambda n: Rd
+    theta = smp(S, wts, pts)
+    assert tuple(theta.shape) == (S, D) and theta.stride(0) == ld and theta.data_ptr() % 16 == 0
+    th = theta.cpu().numpy()
+    if k:
+        mu_ref, U_ref = linreg_weighted_post(mu0, np.linalg.inv(Sig0), sigsq, pts, wts)
+    else:
+        mu_ref, U_ref = mu0, np.linalg.cholesky(Sig0)
+    cov_ref = U_ref.dot(U_ref.T)
+    mu = th[D]
+    np.testing.assert_allclose(mu, mu_ref, rtol=1e-9, atol=1e-10 * np.abs(mu_ref).max())
+    UwT = th[:D] - mu
+    cov = UwT.T.dot(UwT)
+    assert np.abs(cov - cov_ref).max() <= 1e-10 * np.abs(cov_ref).max()
+    want = mu + R[:, :D].dot(UwT)
+    assert np.abs(th - want).max() <= 1e-12 * max(1.0, np.abs(want).max())
+    np.testing.assert_allclose(smp.mean.cpu().numpy(), th.mean(axis=0), rtol=1e-12, atol=1e-13 * np.abs(th).max())
+    # the same points again with other weights (cached point state), then other points of the same shape: nothing stale
+    if k:
+        w2 = wts * 0.5 + 1.0
+        mu2 = smp(S, w2, pts).cpu().numpy()[D]
+        np.testing.assert_allclose(mu2, linreg_weighted_post(mu0, np.linalg.inv(Sig0), sigsq, pts, w2)[0], rtol=1e-9, atol=1e-10)
+        p3 = pts + 0.25
+        mu3 = smp(S, w2, p3).cpu().numpy()[D]
+        np.testing.assert_allclose(mu3, linreg_weighted_post(mu0, np.linalg.inv(Sig0), sigsq, p3, w2)[0], rtol=1e-9, atol=1e-10)
+        # from device-resident weights: the same kernel, the same numbers
+        plan = smp.enqueue_plan(S, p3, 2)
+        assert plan is not None
+        plan.noise = Rd[None, :, :]
+        t4, m4 = plan.draw(torch.from_numpy(w2).cuda(), 0)
+        assert np.array_equal(t4.cpu().numpy()[D], mu3)
+
+
+def test_posterior_sampler_limits(bc):
+    rs = np.random.RandomState(0)
+    mu0, Sig0, sigsq = _model(rs, 6)
+    smp = bc.LinregPosteriorSampler(mu0, Sig0, sigsq)
+    assert smp.enqueue_plan(16, rs.randn(65, 7), 3) is None and smp.enqueue_plan(2048, rs.randn(3, 7), 3) is None
+    with pytest.raises(ValueError):
+        smp(16, np.ones(65), rs.randn(65, 7))
+    with pytest.raises(ValueError):
+        smp(16, np.ones(2), rs.randn(2, 9))
+    assert tuple(smp(5, np.array([]), np.array([])).shape) == (5, 6)
+    # draws have the posterior's first two moments
+    pts, wts = rs.randn(4, 7), rs.rand(4) * 5
+    mu, U = linreg_weighted_post(mu0, np.linalg.inv(Sig0), sigsq, pts, wts)
+    big = np.vstack([smp(1024, wts, pts).cpu().numpy() for _ in range(20)])
+    sd = np.sqrt(np.diag(U.dot(U.T)).max())
+    np.testing.assert_allclose(big.mean(axis=0), mu, atol=6 * sd / np.sqrt(big.shape[0]))
+    np.testing.assert_allclose(np.cov(big.T), U.dot(U.T), atol=0.08 * sd ** 2)
+
+
+@pytest.mark.parametrize("k,S", ((1, 16), (5, 256), (64, 100), (17, 1000)))
+def test_adam_step_kernel_against_nn_opt(bc, k, S):
+    import ctypes
+    import torch
+    from bayesiancoresets_amd import _native
+    from bayesiancoresets_amd.util.opt import nn_opt
+    lib = _native.load()
+    rs = np.random.RandomState(k * 7 + S)
+    core = rs.randn(k, S)
+    colsum = 3.0 * rs.randn(S)
+    w0 = np.abs(rs.randn(k))
+    T, scaling = 25, 1.7
+    sched_fn = lambda i: 0.3 / (1.0 + i)
+    b1, b2, eps = 0.9, 0.999, 1e-8
+
+    def grd(w):
+        return -core.dot(scaling * colsum - w.dot(core)) / S
+    want = nn_opt(w0, grd, opt_itrs=T, step_sched=sched_fn)
+    sched = np.array([(sched_fn(i), 1.0 - b1 ** (i + 1), 1.0 - b2 ** (i + 1)) for i in range(T)])
+    d = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float64)).cuda()
+    core_d, col_d, w, m1, m2, sc, tr = d(core), d(colsum), d(w0), d(np.zeros(k)), d(np.zeros(k)), d(sched), d(np.zeros((T, k)))
+    stream = int(torch.cuda.current_stream().cuda_stream)
+    for i in range(T):
+        assert lib.bcx_sparsevi_adam_step(stream, k, S, col_d.data_ptr(), scaling, core_d.data_ptr(), S, w.data_ptr(), m1.data_ptr(),
+                                          m2.data_ptr(), sc.data_ptr(), i, b1, b2, eps, tr.data_ptr()) == 0
+    got = w.cpu().numpy()
+    np.testing.assert_allclose(got, want, rtol=1e-10, atol=1e-13)
+    assert np.array_equal(tr.cpu().numpy()[-1], got)
+    assert (got >= 0).all()
+    assert lib.bcx_sparsevi_adam_step(stream, 65, S, col_d.data_ptr(), scaling, core_d.data_ptr(), S, w.data_ptr(), m1.data_ptr(),
+                                      m2.data_ptr(), sc.data_ptr(), 0, b1, b2, eps, None) == _native.ERR_ARG
+
+
+class _ReplaySampler(object):
+    """Wraps the package sampler so that the call form and the enqueued form consume the SAME pre-drawn normal numbers."""
+
+    def __init__(self, inner, noise):
+        self.inner, self.noise, self.at = inner, noise, 0
+        inner._noise = self._one
+        inner._noise_block = self._block
+
+    def _one(self, n):
+        r = self.noise[self.at]
+        self.at += 1
+        return r
+
+    def _block(self, steps, n):
+        r = self.noise[self.at:self.at + steps]
+        self.at += steps
+        return r
+
+    def __call__(self, n, wts, pts):
+        return self.inner(n, wts, pts)
+
+    def enqueue_plan(self, n, pts, steps):
+        return self.inner.enqueue_plan(n, pts, steps)
+
+
+@pytest.mark.parametrize("colsum", ("mfma", "moments"))
+def test_enqueued_loop_matches_the_host_loop(bc, colsum):
+    """Three greedy steps of SparseVICoreset, opt_itrs = 30: the ADAM loop enqueued on the device-resident weights against the
+    host loop (nn_opt around projector.update + two projections, the reference's sequence) on the same normal draws."""
+    import torch
+    D, N, S, T, steps = 12, 20000, 64, 30, 3
+    rs = np.random.RandomState(11)
+    Z = make_linreg_data(11, N, D)
+    mu0, Sig0, sigsq = np.zeros(D), 4.0 * np.eye(D), 1.0
+    g = torch.Generator(device="cuda")
+    g.manual_seed(17)
+    noise = torch.randn(steps * (T + 1) + 4, S, D + D % 2, dtype=torch.float64, device="cuda", generator=g)
+    out = {}
+    for mode in (True, False):
+        smp = _ReplaySampler(bc.LinregPosteriorSampler(mu0, Sig0, sigsq), noise)
+        prj = bc.DeviceProjector("linreg", smp, S, sigsq=sigsq, colsum=colsum)
+        alg = bc.SparseVICoreset(Z, prj, opt_itrs=T)
+        alg.ENQUEUE = mode
+        alg.build(steps)
+        out[mode] = (alg.wts.copy(), alg.idcs.copy(), smp.at)
+    assert out[True][2] == out[False][2] == 1 + steps * (T + 1)      # (the constructor's draw, then select + T per step)
+    assert np.array_equal(out[True][1], out[False][1]) and out[True][1].shape[0] >= 2
+    np.testing.assert_allclose(out[True][0], out[False][0], rtol=1e-8, atol=1e-12)
+    assert (out[True][0] > 0).any()
+
+
+def test_enqueue_is_declined_where_the_host_has_to_act(bc):
+    """Per-step sub-samples are drawn on the host (sparsevi.py:33) and a plain sampler has no device form: host loop."""
+    D, N, S = 6, 5000, 32
+    Z = make_linreg_data(3, N, D)
+    mu0, Sig0, sigsq = np.zeros(D), np.eye(D), 1.0
+    smp = bc.LinregPosteriorSampler(mu0, Sig0, sigsq, seed=1)
+    np.random.seed(4)
+    alg = bc.SparseVICoreset(Z, bc.DeviceProjector("linreg", smp, S, sigsq=sigsq), n_subsample_opt=1000, opt_itrs=5)
+    alg.build(2)
+    assert alg._enqueue_plan() is None and alg.size() >= 1
+    alg2 = bc.SparseVICoreset(Z, bc.DeviceProjector("linreg", lambda n, w, p: smp(n, w, p), S, sigsq=sigsq), opt_itrs=5)
+    alg2.build(2)
+    assert alg2._enqueue_plan() is None
+    alg3 = bc.SparseVICoreset(Z, bc.DeviceProjector("linreg", smp, S, sigsq=sigsq), opt_itrs=5)
+    alg3.build(2)
+    assert alg3._enqueue_plan() is not None
