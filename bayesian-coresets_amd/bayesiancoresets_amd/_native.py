@@ -31,6 +31,7 @@ SYMBOLS = (
     "bcx_project_moments", "bcx_project_colsum_moments", "bcx_project_moments_scratch_bytes",
     "bcx_project_colsum_moments_scratch_bytes", "bcx_gram", "bcx_gram_scratch_bytes",
     "bcx_project_colsum_moments_at", "bcx_linreg_posterior_draw", "bcx_sparsevi_adam_step",
+    "bcx_linreg_posterior_apply", "bcx_linreg_posterior_apply_ok",
 )
 
 
@@ -147,8 +148,10 @@ def load():
     sigs["bcx_project_moments"] = [vp, vp, i64, i64, i32, vp, i64, vp, i64]
     sigs["bcx_project_colsum_moments"] = [vp, vp, i64, i32, i32, vp, i32, i32, dbl, vp, vp]
     sigs["bcx_project_colsum_moments_at"] = [vp, vp, i64, i32, i32, vp, i32, i32, dbl, vp, vp, vp]
-    sigs["bcx_linreg_posterior_draw"] = [vp, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, dbl, vp, i32, vp, vp]
-    sigs["bcx_sparsevi_adam_step"] = [vp, i32, i32, vp, dbl, vp, i64, vp, vp, vp, vp, i32, dbl, dbl, dbl, vp]
+    sigs["bcx_linreg_posterior_draw"] = [vp, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, dbl, vp, vp, i32, vp, vp]
+    sigs["bcx_linreg_posterior_apply"] = [vp, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, dbl, vp, vp, i32, vp, vp]
+    sigs["bcx_linreg_posterior_apply_ok"] = [i32, i32]
+    sigs["bcx_sparsevi_adam_step"] = [vp, i32, i32, vp, dbl, vp, i64, vp, vp, vp, vp, i32, dbl, dbl, dbl, vp, i32]
     sigs["bcx_gram"] = [vp, vp, i32, i32, i64, vp, i64, vp, i64]
     lib.bcx_gram_scratch_bytes.restype = ctypes.c_int64
     lib.bcx_gram_scratch_bytes.argtypes = [i32, i32]

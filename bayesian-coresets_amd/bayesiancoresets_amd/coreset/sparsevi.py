@@ -207,14 +207,15 @@ class SparseVICoreset(Coreset):
         sched = np.array([(self.step_sched(i), 1.0 - b1 ** (i + 1), 1.0 - b2 ** (i + 1)) for i in range(T)], dtype=np.float64)
         state = torch.from_numpy(np.concatenate((np.asarray(self.wts, dtype=np.float64), np.zeros(2 * k), sched.ravel()))).to(prj.device)
         w, m1, m2, sched_d = state[:k], state[k:2 * k], state[2 * k:3 * k], state[3 * k:]
-        core = self._core_points_device()
-        lib = prj._lib
+        theta, mean = plan.buffers()
+        run, buf, _ = prj.enqueue_step_plan(self.data, self._core_points_device(), True, theta, mean)    # sparsevi.py:35-41
+        adam, args = prj._lib.bcx_sparsevi_adam_step, [prj._stream(), k, S, buf.data_ptr(), 1.0, buf[S:].data_ptr(), S, w.data_ptr(),
+                                                       m1.data_ptr(), m2.data_ptr(), sched_d.data_ptr(), 0, b1, b2, eps, None, 1]
         for i in range(T):
-            theta, mean = plan.draw(w, i)                                         # sparsevi.py:25
-            prj.use_draws(theta, mean=mean)
-            buf, _ = prj.colsum_and_core_enqueue(self.data, core, persistent=True)    # sparsevi.py:35-41
-            prj._check(lib.bcx_sparsevi_adam_step(prj._stream(), k, S, buf.data_ptr(), 1.0, buf[S:].data_ptr(), S, w.data_ptr(),
-                                                  m1.data_ptr(), m2.data_ptr(), sched_d.data_ptr(), i, b1, b2, eps, None))
+            plan.draw(w, i)                                                       # sparsevi.py:25
+            run()
+            args[11] = i
+            prj._check(adam(*args))
         return w.cpu().numpy()
 
     def error(self):

@@ -45,6 +45,8 @@ class LinregPosteriorSampler(object):
         self._pts_key, self._pts_state = None, None
         self._theta, self._tbar = {}, torch.empty(D, dtype=torch.float64, device=self.device)
         self._none = torch.zeros(1, dtype=torch.float64, device=self.device)
+        self._zero_mu = torch.zeros(D, dtype=torch.float64, device=self.device)
+        self._scratch_mean = torch.empty(D, dtype=torch.float64, device=self.device)
 
     # -- noise: separate hooks so that a test can feed both entry points the same numbers --------------------------------
     def _noise(self, n):
@@ -71,24 +73,28 @@ class LinregPosteriorSampler(object):
         XU0[:, :self.D] = X.dot(self.U0)
         XS0[:, :self.D] = X.dot(self.Sig0)
         K0 = XU0.dot(XU0.T)
-        pad = (k * k + 2 * k) % 2                           # the two k x ld blocks start on 16-byte boundaries
-        blob = np.concatenate((K0.ravel(), X.dot(self.mu0), y, np.zeros(pad), XU0.ravel(), XS0.ravel()))
+        Xp = np.zeros((k, self.ld))
+        Xp[:, :self.D] = X
+        pad = (k * k + 2 * k) % 2                           # the k x ld blocks start on 16-byte boundaries
+        blob = np.concatenate((K0.ravel(), X.dot(self.mu0), y, np.zeros(pad), XU0.ravel(), XS0.ravel(), Xp.ravel()))
         d = torch.from_numpy(blob).to(self.device)
         o = k * k
         st = {"k": k, "K0": d[:o], "xmu0": d[o:o + k], "y": d[o + k:o + 2 * k]}
         o += 2 * k + pad
-        st["XU0"], st["XS0"] = d[o:o + k * self.ld], d[o + k * self.ld:o + 2 * k * self.ld]
+        n = k * self.ld
+        st["XU0"], st["XS0"], st["X"] = d[o:o + n], d[o + n:o + 2 * n], d[o + 2 * n:o + 3 * n]
         st["blob"] = d
         self._pts_key, self._pts_state = pts.copy(), st
         return st
 
-    def _launch(self, st, w_dev, R, theta):
+    def _launch(self, st, w_dev, R, rbar, theta, mu0=None, tbar=None):
         k = st["k"] if st is not None else 0
         lib, dp = self._lib, (lambda key: st[key].data_ptr() if k else None)
         stream = int(self._torch.cuda.current_stream(self.device).cuda_stream)
         rc = lib.bcx_linreg_posterior_draw(stream, k, self.D, self.ld, w_dev.data_ptr() if k else None, dp("K0"), dp("xmu0"), dp("y"),
-                                           dp("XU0"), dp("XS0"), self._U0T.data_ptr(), self._mu0.data_ptr(), self.sigsq,
-                                           R.data_ptr(), R.shape[0], theta.data_ptr(), self._tbar.data_ptr())
+                                           dp("XU0"), dp("XS0"), self._U0T.data_ptr(), (self._mu0 if mu0 is None else mu0).data_ptr(),
+                                           self.sigsq, R.data_ptr(), rbar.data_ptr(), R.shape[0], theta.data_ptr(),
+                                           (self._tbar if tbar is None else tbar).data_ptr())
         if rc != 0:
             raise self._nat.EngineError(rc, lib.bcx_project_last_error().decode())
 
@@ -109,7 +115,8 @@ class LinregPosteriorSampler(object):
             st = self._points(pts)
             w_dev = torch.from_numpy(np.ascontiguousarray(wts, dtype=np.float64)).to(self.device)
         theta = self._theta_buf(n)
-        self._launch(st, w_dev, self._noise(n), theta)
+        R = self._noise(n)
+        self._launch(st, w_dev, R, R.mean(dim=0), theta)
         self.mean = self._tbar
         return theta[:, :self.D]
 
@@ -123,11 +130,58 @@ class LinregPosteriorSampler(object):
 
 
 class _Plan(object):
+    """The draws of ``steps`` consecutive sampler calls at the same points, from weights that live on the device.  The
+    normal numbers of all steps are drawn up front; where the per-step kernel for a few points applies (k <= 32,
+    csrc/svi.hip lrs_apply_kernel) their image under the prior's factor, G = R U0^T, is formed for all steps in one launch
+    and a step is a rank-k correction of its rows."""
+
     def __init__(self, sampler, n, st, noise):
-        self.s, self.n, self.st, self.noise = sampler, n, st, noise
-        self.theta = sampler._theta_buf(n)
+        s, torch = sampler, sampler._torch
+        self.s, self.n, self.st = s, n, st
+        self.theta = s._theta_buf(n)
+        self._args = None
+        self.fast = bool(s._lib.bcx_linreg_posterior_apply_ok(st["k"], s.ld))
+        self.set_noise(noise)
+
+    def set_noise(self, noise):
+        s, torch, n = self.s, self.s._torch, self.n
+        steps = noise.shape[0]
+        self.noise, self._args = noise, None
+        self.rbar = noise.mean(dim=1)                       # steps x ld: the column means of every step's normal draws
+        if self.fast:
+            ext = torch.cat((noise.reshape(steps * n, s.ld), self.rbar))
+            G = torch.empty_like(ext)
+            s._launch(None, s._none, ext, ext, G, mu0=s._zero_mu, tbar=s._scratch_mean)     # k = 0, zero prior mean: R U0^T
+            self.G, self.Gbar = G[:steps * n].view(steps, n, s.ld), G[steps * n:]
+
+    def buffers(self):
+        """(draws S x D, their mean): the same two device buffers at every step, rewritten in stream order."""
+        return self.theta[:, :self.s.D], self.s._tbar
 
     def draw(self, w_dev, i):
-        """Enqueue the draws for ADAM step ``i`` at the device-resident weights; (draws S x D, their mean)."""
-        self.s._launch(self.st, w_dev, self.noise[i], self.theta)
-        return self.theta[:, :self.s.D], self.s._tbar
+        """Enqueue the draws for ADAM step ``i`` at the device-resident weights ``w_dev``; returns ``buffers()``."""
+        a = self._args
+        if a is None or a[4] != w_dev.data_ptr():
+            # the argument list, built once: per step only the two pointers into the noise (or its image) move
+            s, st = self.s, self.st
+            stream = int(s._torch.cuda.current_stream(s.device).cuda_stream)
+            if self.fast:
+                a = [stream, st["k"], s.D, s.ld, w_dev.data_ptr(), st["K0"].data_ptr(), st["xmu0"].data_ptr(), st["y"].data_ptr(),
+                     st["X"].data_ptr(), st["XS0"].data_ptr(), s._mu0.data_ptr(), s.sigsq, 0, 0, self.n, self.theta.data_ptr(),
+                     s._tbar.data_ptr()]
+                self._at, self._fn = (12, 13), s._lib.bcx_linreg_posterior_apply
+                rows, means = self.G, self.Gbar
+            else:
+                a = [stream, st["k"], s.D, s.ld, w_dev.data_ptr(), st["K0"].data_ptr(), st["xmu0"].data_ptr(), st["y"].data_ptr(),
+                     st["XU0"].data_ptr(), st["XS0"].data_ptr(), s._U0T.data_ptr(), s._mu0.data_ptr(), s.sigsq, 0, 0, self.n,
+                     self.theta.data_ptr(), s._tbar.data_ptr()]
+                self._at, self._fn = (13, 14), s._lib.bcx_linreg_posterior_draw
+                rows, means = self.noise, self.rbar
+            self._r0, self._rstep = rows.data_ptr(), rows.stride(0) * 8
+            self._b0, self._bstep = means.data_ptr(), means.stride(0) * 8
+            self._args = a
+        a[self._at[0]], a[self._at[1]] = self._r0 + i * self._rstep, self._b0 + i * self._bstep
+        rc = self._fn(*a)
+        if rc != 0:
+            raise self.s._nat.EngineError(rc, self.s._lib.bcx_project_last_error().decode())
+        return self.buffers()

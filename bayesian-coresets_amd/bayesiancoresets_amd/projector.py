@@ -396,6 +396,40 @@ class DeviceProjector(Projector):
             self._launch(self._lib.bcx_project_write, self._common(C) + [buf[S:].data_ptr(), S, None], C)
         return buf, k
 
+    def enqueue_step_plan(self, pts, core, persistent, draws, mean):
+        """For a loop that repeats ``colsum_and_core_enqueue(pts, core)`` at draws that are rewritten IN PLACE between the
+        repetitions (``SparseVICoreset``'s device-resident weight optimisation): installs ``draws`` / ``mean`` once and returns
+        ``(run, buf, k)`` -- ``run()`` enqueues the column sums of ``pts`` into buf[:S] and the k x S projected coreset
+        points into buf[S:], the latter as RAW log-likelihoods (uncentred: ``bcx_sparsevi_adam_step`` takes the row means),
+        from argument lists built once.  The decisions of ``_moments_for`` are taken at every repetition as before."""
+        self.use_draws(draws, mean=mean)
+        torch, lib = self._torch, self._lib
+        Z, C = self._dev(pts), self._dev(core)
+        S, k = self.theta.shape[0], C.shape[0]
+        if getattr(self, "_cc_buf", None) is None or self._cc_buf.numel() < S * (k + 1):
+            self._cc_buf = torch.empty(S * (max(k, 7) + 1), dtype=torch.float64, device=self.device)
+        buf = self._cc_buf[:S * (k + 1)]
+        col = buf[:S]
+        core_args = self._common(C) + [buf[S:].data_ptr(), S]
+        state = {"mom": None}
+
+        def run():
+            if self._moments_for(pts, Z, persistent) is not None:
+                a = state["mom"]
+                if a is None or a[1] != self._mom.data_ptr():
+                    D = Z.shape[1] - 1
+                    need = int(lib.bcx_project_colsum_moments_scratch_bytes(int(D), int(S))) // 8
+                    if self._mom_work is None or self._mom_work.numel() != need:
+                        self._mom_work = torch.zeros(need, dtype=torch.float64, device=self.device)
+                    a = state["mom"] = [core_args[0], self._mom.data_ptr(), self._mom.stride(0), D, D, self.theta.data_ptr(), S,
+                                        self.theta.stride(0), self.sigsq, col.data_ptr(), self._mom_work.data_ptr(),
+                                        None if mean is None else mean.data_ptr()]
+                self._check(lib.bcx_project_colsum_moments_at(*a))
+            else:
+                self._colsum_projected(Z, out=col)
+            self._check(lib.bcx_project_write_raw(*core_args))
+        return run, buf, k
+
     def project_select(self, pts, resid, row_ids=None):
         """(max_n corr_n, arg-max row) with corr_n = vecs[n].resid / ||vecs[n]|| / S (first maximum).
         ``row_ids`` (ascending, one per local row): the identity under which a local row competes -- its global row

@@ -176,6 +176,14 @@ __global__ __launch_bounds__(256) void moments_mean_kernel(const double* __restr
 // quarter as long as with one wave per tile (this kernel is all latency: 46 MFLOP).
 // Partials [column tile][sample] go to `work`; the last workgroup to arrive sums them in tile order, centres and scales.
 // work: nct * Spad partials, then one arrival counter (self-resetting).
+#define MQ_U 12
+// sc1 load without a wait of its own: the caller issues a batch, waits once (s_waitcnt vmcnt(0)) and ties the values
+// (atomic loads are issued and awaited one by one: nct round trips in the closing sum)
+static __device__ __forceinline__ double mom_ld_nowait(const double* p) {
+  double v;
+  asm volatile("global_load_dwordx2 %0, %1, off sc1" : "=v"(v) : "v"(p) : "memory");
+  return v;
+}
 template <bool AL>
 __global__ __launch_bounds__(256) void moments_quad_kernel(const double* __restrict__ M, int64_t ldm, int D, int ycol,
                                                            const double* __restrict__ theta, int S, int ldt,
@@ -194,12 +202,12 @@ __global__ __launch_bounds__(256) void moments_quad_kernel(const double* __restr
     const double* gc = M + (vb ? cb : 0);
     mv4d acc = (mv4d){0.0, 0.0, 0.0, 0.0};
     const int ksteps = (D + 7) / 8;
-    for (int t0 = wave; t0 < ksteps; t0 += 16) {
-      // four double-steps per trip (t0, t0 + 4, t0 + 8, t0 + 12): all their loads are issued before the first MFMA
-      // (addresses clamped, values masked)
-      double a0[4], a1[4], b0[4], b1[4];
+    for (int t0 = wave; t0 < ksteps; t0 += 4 * MQ_U) {
+      // MQ_U double-steps per trip (t0, t0 + 4, ...): all their loads are issued before the first MFMA (addresses clamped,
+      // values masked); D <= 384 is one trip -- one round of load latency instead of three
+      double a0[MQ_U], a1[MQ_U], b0[MQ_U], b1[MQ_U];
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
+      for (int u = 0; u < MQ_U; ++u) {
         const int k = 8 * (t0 + 4 * u) + 2 * lk;
         const bool k0 = k < D, k1 = k + 1 < D;
         const int kc = k0 ? k : 0, kd = k1 ? k + 1 : 0;
@@ -214,7 +222,7 @@ __global__ __launch_bounds__(256) void moments_quad_kernel(const double* __restr
         b1[u] = (vb && k1) ? g1 : 0.0;
       }
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
+      for (int u = 0; u < MQ_U; ++u) {
         acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[u], b0[u], acc, 0, 0, 0);
         acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[u], b1[u], acc, 0, 0, 0);
       }
@@ -257,7 +265,17 @@ __global__ __launch_bounds__(256) void moments_quad_kernel(const double* __restr
   double m[1] = {0.0};
   for (int u = tid; u < S; u += 256) {
     double t = 0.0;
-    for (int c = 0; c < nct; ++c) t += mom_ld(work + (size_t)c * Spad + u);
+    for (int c0 = 0; c0 < nct; c0 += 16) {
+      double v[16];
+#pragma unroll
+      for (int q = 0; q < 16; ++q) v[q] = mom_ld_nowait(work + (size_t)(c0 + q < nct ? c0 + q : c0) * Spad + u);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        asm volatile("" : "+v"(v[q]));
+        if (c0 + q < nct) t += v[q];
+      }
+    }
     mom_st(&work[u], t);
     m[0] += t;
   }

@@ -875,26 +875,29 @@ __global__ __launch_bounds__(256) void center_kernel(double* out, int64_t ldo, i
   }
 }
 
-// A handful of rows (the coreset points SparseVI projects at every ADAM step, sparsevi.py:38-39): one workgroup per row, a
-// thread per sample -- x_row in LDS, the sample's parameter row streamed with 16-byte loads (D = 301: 151 per thread, L2
-// resident), likelihood, row mean over the workgroup, centred values stored.  One ~6 us launch where the tiled MFMA kernel
-// (one 128-row block, D / 16 barrier-separated stages) takes 35 us plus 5 us for the centring pass; that call sits on the
-// critical path of every ADAM step.  Same arithmetic per value (loglik<FAM>); the dot product is summed in k order.
+// A handful of rows (the coreset points SparseVI projects at every ADAM step, sparsevi.py:38-39): one workgroup of sixteen
+// waves per row, x_row in LDS.  A WAVE takes a sample at a time (four in flight): its lanes read the sample's parameter row
+// as consecutive 16-byte pieces (D = 301: three loads per lane, 1 KiB contiguous per instruction -- a thread per sample walked
+// 64 rows 2.4 KB apart with every load: 13 us), the partial products meet in a wave sum, one lane evaluates the likelihood.
+// Row mean over the workgroup, centred values stored: one ~5 us launch where the tiled MFMA kernel (one 128-row block, D / 16
+// barrier-separated stages) takes 35 us plus 5 us for the centring pass; the call sits on the critical path of every ADAM
+// step.  Same arithmetic per value (loglik<FAM>); the dot product is summed lane-wise (values 2 lane + 128 i), then over lanes.
 #define PJ_SMALL_ROWS 32
 template <int FAM, bool AL>
-__global__ __launch_bounds__(256) void proj_small_kernel(ProjArgs p, int center) {
+__global__ __launch_bounds__(1024) void proj_small_kernel(ProjArgs p, int center) {
   extern __shared__ __attribute__((aligned(16))) unsigned char pj_lds[];
   __shared__ double scratch[BCX_SCRATCH];
+  __shared__ double svals[1024];                                       // S <= 1024
   double* xs = (double*)pj_lds;                                        // D (+1) doubles
-  const int tid = threadIdx.x, D = p.D, S = p.S;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, D = p.D, S = p.S;
   const int Dp = (D + 1) & ~1;
   constexpr int NTAB = FAM == FAM_POISSON ? PJT_DOUBLES : FAM == FAM_LOGISTIC ? PJT_DOUBLES_LOGISTIC : 0;
   double* tabw = xs + Dp;
   const pj_tab_t tab = (pj_tab_t)tabw;
   const int64_t row = blockIdx.x;
   const double* z = p.Z + row * p.ldz;
-  for (int k = tid; k < Dp; k += 256) xs[k] = k < D ? z[k] : 0.0;
-  if (NTAB) for (int k = tid; k < NTAB; k += 256) tabw[k] = p.tab[k];
+  for (int k = tid; k < Dp; k += 1024) xs[k] = k < D ? z[k] : 0.0;
+  if (NTAB) for (int k = tid; k < NTAB; k += 1024) tabw[k] = p.tab[k];
   const double y = p.ycol >= 0 ? z[p.ycol] : 0.0;
   const double clin = (FAM == FAM_LINREG) ? -0.5 * log(2.0 * 3.14159265358979323846 * p.param) : 0.0;
   const double parg = (FAM == FAM_LINREG) ? 1.0 / (2.0 * p.param) : p.param;
@@ -907,43 +910,41 @@ __global__ __launch_bounds__(256) void proj_small_kernel(ProjArgs p, int center)
     c0 = fma(-(y * y), parg, clin);
     yv = 2.0 * y;
   }
+  // the samples of this workgroup: all of them when the row is centred here, a slice (gridDim.y of them) when it is left raw
+  const int per = ((S + (int)gridDim.y - 1) / (int)gridDim.y + 3) & ~3;
+  const int s_begin = min(S, (int)blockIdx.y * per), s_end = min(S, s_begin + per);
   __syncthreads();
-  double part[1] = {0.0};
-  double vals[4];                                                      // up to 1024 samples per row stay in registers
-  for (int q = 0; q < 4; ++q) {
-    const int sidx = tid + 256 * q;
-    double m = 0.0;
-    if (sidx < S) {
-      const double* th = p.theta + (size_t)sidx * p.ldt;
-      if (AL) {
-        double m1 = 0.0;
-        int k = 0;
-        for (; k + 8 <= Dp; k += 8) {
-          pv2d t0 = *(const pv2d*)(th + k), t1 = *(const pv2d*)(th + k + 2), t2 = *(const pv2d*)(th + k + 4), t3 = *(const pv2d*)(th + k + 6);
-          m = fma(xs[k], t0.x, m); m1 = fma(xs[k + 1], t0.y, m1);
-          m = fma(xs[k + 2], t1.x, m); m1 = fma(xs[k + 3], t1.y, m1);
-          m = fma(xs[k + 4], t2.x, m); m1 = fma(xs[k + 5], t2.y, m1);
-          m = fma(xs[k + 6], t3.x, m); m1 = fma(xs[k + 7], t3.y, m1);
-        }
-        for (; k < D; ++k) m = fma(xs[k], th[k], m);                  // (the pad column is never read: its x is 0, its theta may be anything)
-        m += m1;
-      } else {
-        for (int k = 0; k < D; ++k) m = fma(xs[k], th[k], m);
+  for (int s0 = s_begin + 4 * wave; s0 < s_end; s0 += 64) {            // (wave-uniform trip count)
+    double m[4] = {0.0, 0.0, 0.0, 0.0};
+    for (int c = 2 * lane; c < Dp; c += 128) {
+      const pv2d x = *(const pv2d*)(xs + c);                           // (the pad column's x is 0; its theta may be anything: masked)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int sidx = s0 + q < s_end ? s0 + q : s_end - 1;
+        const double* th = p.theta + (size_t)sidx * p.ldt + c;
+        pv2d t;
+        if (AL) t = *(const pv2d*)th;
+        else { t.x = th[0]; t.y = c + 1 < D ? th[1] : 0.0; }
+        if (c + 1 >= D) t.y = 0.0;
+        m[q] = fma(x.x, t.x, m[q]);
+        m[q] = fma(x.y, t.y, m[q]);
       }
     }
-    vals[q] = sidx < S ? loglik<FAM>(m, yv, parg, c0, tab) : 0.0;
-    part[0] += vals[q];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) m[q] = wave_allsum(m[q]);
+    const double mine = lane == 0 ? m[0] : lane == 1 ? m[1] : lane == 2 ? m[2] : m[3];
+    if (lane < 4 && s0 + lane < s_end) svals[s0 + lane - s_begin] = loglik<FAM>(mine, yv, parg, c0, tab);
   }
+  __syncthreads();
+  const int mine_n = s_end - s_begin;
+  double part[1] = {tid < mine_n ? svals[tid] : 0.0};
+  const double v = part[0];
   double mean = 0.0;
-  if (center) {
+  if (center) {                                                        // (gridDim.y == 1)
     block_allsum<1>(part, scratch);
     mean = part[0] / (double)S;
   }
-  double* out = p.out + row * p.ldo;
-  for (int q = 0; q < 4; ++q) {
-    const int sidx = tid + 256 * q;
-    if (sidx < S) out[sidx] = vals[q] - mean;
-  }
+  if (tid < mine_n) p.out[row * p.ldo + s_begin + tid] = v - mean;
 }
 
 // colsum[s] = sum over the workgroup partials in a fixed order: one workgroup per 64 columns, four
@@ -1285,10 +1286,12 @@ static int project_write(void* stream, int32_t family, const void* Z_dev, int64_
     const size_t lds = ((size_t)((D + 1) & ~1) + tabd) * sizeof(double);
     const bool al = ((uintptr_t)p.theta % 16 == 0) && p.ldt % 2 == 0;
     const int cen = center ? 1 : 0;
+    // raw rows need no sum over the samples: four workgroups per row, every wave then has all its loads in flight at once
+    const dim3 sgrid((unsigned)N, center ? 1u : (unsigned)std::min(4, (S + 63) / 64));
 #define PJ_SMALL(F)                                                                                                   \
     do {                                                                                                                \
-      if (al) hipLaunchKernelGGL((proj_small_kernel<F, true>), dim3((unsigned)N), dim3(256), lds, st, p, cen);          \
-      else hipLaunchKernelGGL((proj_small_kernel<F, false>), dim3((unsigned)N), dim3(256), lds, st, p, cen);           \
+      if (al) hipLaunchKernelGGL((proj_small_kernel<F, true>), sgrid, dim3(1024), lds, st, p, cen);                     \
+      else hipLaunchKernelGGL((proj_small_kernel<F, false>), sgrid, dim3(1024), lds, st, p, cen);                      \
     } while (0)
     if (family == FAM_LOGISTIC) PJ_SMALL(FAM_LOGISTIC); else if (family == FAM_POISSON) PJ_SMALL(FAM_POISSON); else PJ_SMALL(FAM_LINREG);
 #undef PJ_SMALL

@@ -16,10 +16,11 @@
 //                         mu_w = mu0 + (X Sig0)^T (c - s * a'),  c = w y / sigsq,  a' = (L L^T)^-1 [s * (X mu0 + K0 c)],  K0 = (X U0)(X U0)^T
 //                     for standard-normal R (S x D).  Everything that depends on the points alone (X U0, X Sig0, K0, X mu0) is
 //                     formed once per greedy step by the caller; per ADAM step the kernel needs the k weights.  One workgroup
-//                     per 16 columns of theta (16 waves: one 16 x 16 tile of R Uw^T each per 256 draws, v_mfma_f64_16x16x4_f64;
-//                     every workgroup repeats the k x k factorisation -- k <= 64, one wave, cheaper than a launch), Uw^T formed
-//                     in LDS 128 rows at a time; the workgroup owns its columns for ALL draws and also leaves their mean
-//                     (thetabar: what the closed-form column sums are expanded around, csrc/moments.hip).
+//                     per 64 draws x 16 columns of theta (one 16 x 16 tile of R Uw^T per wave, v_mfma_f64_16x16x4_f64; every
+//                     workgroup repeats the k x k factorisation -- k <= 64, one wave, cheaper than a launch), Uw^T formed in LDS
+//                     160 rows at a time, itself on the matrix cores.  The column means of R ride along as one more row: their
+//                     "draw" is the mean of the draws (thetabar: what the closed-form column sums are expanded around,
+//                     csrc/moments.hip).
 //   svi_adam_kernel   resid = scaling colsum - w corevecs, g = -corevecs resid / S, the ADAM moments, the step and the clamp at
 //                     zero, on the device-resident weights; the step-size schedule and the bias corrections arrive as data
 //                     (the caller evaluates step_sched(i), 1 - b1^(i+1), 1 - b2^(i+1) on the host once per greedy step).
@@ -31,10 +32,10 @@
 typedef double sv4d __attribute__((ext_vector_type(4)));
 
 #define LRS_KMAX 64          // coreset points
-#define LRS_CH 128           // rows of Uw^T per LDS chunk
+#define LRS_CH 160           // rows of Uw^T per LDS chunk (a multiple of 16)
+#define LRS_CHD (LRS_CH / 8) // double-steps per chunk: 8 values of the inner dimension, two MFMAs
 #define LRS_LDB 24           // doubles per staged row of Uw^T (16 used): lane groups lk, lk + 1 of a ds_read_b64 on disjoint bank halves
-#define LRS_MAXT 4           // 16-draw tiles per wave: S <= 16 waves x 4 x 16 = 1024
-#define LRS_SMAX (16 * LRS_MAXT * 16)
+#define LRS_SMAX (1 << 22)   // rows per call
 
 struct LrsArgs {
   const double* w;      // k weights (device-resident, updated by svi_adam_kernel)
@@ -46,46 +47,115 @@ struct LrsArgs {
   const double* U0T;    // D x ld: U0^T (row i, column n = U0[n][i])
   const double* mu0;    // D
   const double* R;      // S x ld standard normal draws
+  const double* Rbar;   // ld: their column means (one more row of R: its "draw" is the mean of the draws)
   double* theta;        // S x ld
   double* tbar;         // D: mean over the draws
   double sigsq;
   int k, D, S, ld;
+  int dbg;              // dev (BCX_SVI_DBG): timing experiments that cut the kernel short (wrong results)
 };
 
-__global__ __launch_bounds__(1024) void lrs_draw_kernel(LrsArgs a) {
-  // one buffer, three lives: I + C C^T and its Cholesky factor (lower) -> the chunks of Uw^T -> the column-mean partials
+// Workgroup (x, y): columns 16 x .. 16 x + 15 of theta, rows 64 y .. 64 y + 63 of [R; Rbar] (one 16 x 16 tile per wave).
+// Everything is latency here (46 MFLOP per call; a dependent global load is ~1 us on this chip), so ALL requests that do not
+// depend on the factorisation go out first -- this wave's rows of R for two chunks of the inner dimension (registers), its
+// blocks of U0^T and (X U0)^T for the first chunk, the k x k inputs -- then: the k x k system (wave 0, LDS only; the others
+// wait) -> per chunk of the inner dimension: Uw^T = U0^T - (X U0)^T B2 on the matrix cores into LDS (the next chunk's blocks
+// requested meanwhile), the tile's MFMAs from it -> store.  Every workgroup repeats the k x k factorisation (cheaper than a
+// launch and a round trip).
+#define LRS_BPW ((LRS_CH / 16 + 3) / 4)            // 16-row blocks of a chunk per wave
+__global__ __launch_bounds__(256) void lrs_draw_kernel(LrsArgs a) {
+  // one buffer, two lives: I + C C^T and its Cholesky factor (lower) -> the chunks of Uw^T
   __shared__ double sbuf[LRS_KMAX * (LRS_KMAX + 1)];
   double (*sL)[LRS_KMAX + 1] = (double (*)[LRS_KMAX + 1])sbuf;
   double* sUw = sbuf;                               // LRS_CH x LRS_LDB
-  __shared__ double sB2[LRS_KMAX][16];              // s * X Sig0 [:, cols]  ->  diag(s) T^T diag(s) X Sig0 [:, cols]
+  __shared__ double sB2[LRS_KMAX][16];              // diag(s) T^T diag(s) X Sig0 [:, cols]
+  __shared__ double sXS[LRS_KMAX][16];              // X Sig0 [:, cols]
   __shared__ double ss[LRS_KMAX], sc[LRS_KMAX], sa[LRS_KMAX], smu[16];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int li = lane & 15, lk = lane >> 4;
   const int k = a.k, D = a.D, S = a.S, ld = a.ld;
+  const int k4 = (k + 3) & ~3;
   const int n0 = blockIdx.x * 16;
+  const int col = n0 + li;
+  const int row0 = (blockIdx.y * 4 + wave) * 16;    // rows of [R; Rbar] of this wave's tile
 
-  // ---- the k x k system ----
-  if (tid < k) {
-    const double wj = fmax(a.w[tid], 0.0);
-    ss[tid] = sqrt(wj / a.sigsq);
-    sc[tid] = wj * a.y[tid] / a.sigsq;
-  }
-  __syncthreads();
-  for (int e = tid; e < k * k; e += 1024) {
+  // this lane's row of the A operand: lane group lk feeds values kq = 8 t + 2 lk (+1) to MFMAs 2 t (2 t + 1): one 16-byte load
+  // per two steps
+  const int arow = row0 + li;
+  const bool arow_ok = arow <= S;
+  const double* rp = arow < S ? a.R + (size_t)arow * ld : (arow == S ? a.Rbar : a.R);
+  double xa[2][LRS_CHD], xb[2][LRS_CHD];            // two chunks in registers (D <= 320: the whole inner dimension)
+  auto load_A = [&](int kb, double (&va)[LRS_CHD], double (&vb)[LRS_CHD]) {
+#pragma unroll
+    for (int t = 0; t < LRS_CHD; ++t) {
+      const int kq = kb + 8 * t + 2 * lk;
+      const int kc = kq + 1 < ld ? kq : 0;           // (ld and kq are even: kq < ld implies kq + 1 < ld)
+      const double2 v = *(const double2*)(rp + kc);
+      va[t] = (arow_ok && kq < D) ? v.x : 0.0;
+      vb[t] = (arow_ok && kq + 1 < D) ? v.y : 0.0;
+    }
+  };
+  // this wave's blocks of a chunk: 16 rows of U0^T in the C layout (row lk + 4 r, column li) and, for the first four points,
+  // -(X U0)^T in the A layout (row li, point lk)
+  double pu[LRS_BPW][4], px[LRS_BPW];
+  auto load_U = [&](int kb) {
+#pragma unroll
+    for (int b = 0; b < LRS_BPW; ++b) {
+      const int rb = kb + 16 * (wave + 4 * b);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = rb + lk + 4 * r;
+        pu[b][r] = (row < D && col < D) ? a.U0T[(size_t)row * ld + col] : 0.0;
+      }
+      px[b] = (lk < k && rb + li < D) ? -a.XU0[(size_t)lk * ld + rb + li] : 0.0;
+    }
+  };
+  long long stamp[8];
+#define LRS_STAMP(i) do { if (a.dbg == 9) { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); stamp[i] = wall_clock64(); } } while (0)
+  LRS_STAMP(0);
+  const long long c0 = clock64();
+  load_A(0, xa[0], xb[0]);
+  if (LRS_CH < D) load_A(LRS_CH, xa[1], xb[1]);
+  load_U(0);
+  LRS_STAMP(1);
+  if (a.dbg == 1) { if (xa[0][0] == 1.2345e-300) a.tbar[0] = xa[1][3] + xb[0][7] + pu[0][0] + px[1]; return; }
+
+  // ---- the k x k system: every input straight from memory (no value waits for another) ----
+  for (int e = tid; e < k * k; e += 256) {
     const int i = e / k, j = e - i * k;
-    sL[i][j] = (i == j ? 1.0 : 0.0) + ss[i] * ss[j] * a.K0[e];
+    const double si = sqrt(fmax(a.w[i], 0.0) / a.sigsq), sj = sqrt(fmax(a.w[j], 0.0) / a.sigsq);
+    sL[i][j] = (i == j ? 1.0 : 0.0) + si * sj * a.K0[e];
   }
   if (tid < k) {
+    const double wi = fmax(a.w[tid], 0.0), si = sqrt(wi / a.sigsq);
+    ss[tid] = si;
+    sc[tid] = wi * a.y[tid] / a.sigsq;
     double t = a.xmu0[tid];
-    for (int j = 0; j < k; ++j) t += a.K0[tid * k + j] * sc[j];
-    sa[tid] = ss[tid] * t;
+    for (int j0 = 0; j0 < k; j0 += 8) {             // (eight points per round of loads)
+      double kk[8], ww[8], yy[8];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const int j = j0 + q < k ? j0 + q : k - 1;
+        kk[q] = a.K0[tid * k + j]; ww[q] = a.w[j]; yy[q] = a.y[j];
+      }
+#pragma unroll
+      for (int q = 0; q < 8; ++q)
+        if (j0 + q < k) t += kk[q] * (fmax(ww[q], 0.0) * yy[q] / a.sigsq);
+    }
+    sa[tid] = si * t;
   }
-  for (int e = tid; e < k * 16; e += 1024) {
+  for (int e = tid; e < k4 * 16; e += 256) {
     const int j = e >> 4, c = e & 15;
-    sB2[j][c] = n0 + c < D ? ss[j] * a.XS0[(size_t)j * ld + n0 + c] : 0.0;
+    const bool ok = j < k && n0 + c < D;
+    const double x = ok ? a.XS0[(size_t)j * ld + n0 + c] : 0.0;
+    sXS[j][c] = x;
+    sB2[j][c] = ok ? sqrt(fmax(a.w[j], 0.0) / a.sigsq) * x : 0.0;
   }
+  const double mu0c = (tid < 16 && n0 + tid < D) ? a.mu0[n0 + tid] : 0.0;
   __syncthreads();
-  if (wave == 0) {
+  LRS_STAMP(2);
+  if (a.dbg == 2) { if (sL[0][0] == 1.2345e-300) a.tbar[0] = xa[0][3] + xb[1][7]; return; }
+  if (wave == 0 && a.dbg != 3) {
     // right-looking Cholesky, lane = row (a wave runs in lock step and its LDS accesses complete in order: the exchanges
     // between lanes below need no barrier, only that the compiler keeps the order -- wave_barrier)
     for (int c = 0; c < k; ++c) {
@@ -102,106 +172,248 @@ __global__ __launch_bounds__(1024) void lrs_draw_kernel(LrsArgs a) {
     // lanes 0..15: B2[:, c] = diag(s) (I + L)^-T L^-1 (s * X Sig0[:, c]);  lane 16: the mean's coefficients c - s * (L L^T)^-1 a
     if (lane < 17) {
       const bool mean = lane == 16;
-      double* col = mean ? sa : &sB2[0][lane];
+      double* cl = mean ? sa : &sB2[0][lane];
       const int cs = mean ? 1 : 16;
       for (int i = 0; i < k; ++i) {                 // L u = rhs
-        double t = col[i * cs];
-        for (int u = 0; u < i; ++u) t -= sL[i][u] * col[u * cs];
-        col[i * cs] = t / sL[i][i];
+        double t = cl[i * cs];
+        for (int u = 0; u < i; ++u) t -= sL[i][u] * cl[u * cs];
+        cl[i * cs] = t / sL[i][i];
       }
       const double one = mean ? 0.0 : 1.0;          // ((I + L)^T v = u for the factor, L^T v = u for the mean)
       for (int i = k - 1; i >= 0; --i) {
-        double t = col[i * cs];
-        for (int u = i + 1; u < k; ++u) t -= sL[u][i] * col[u * cs];
-        col[i * cs] = t / (one + sL[i][i]);
+        double t = cl[i * cs];
+        for (int u = i + 1; u < k; ++u) t -= sL[u][i] * cl[u * cs];
+        cl[i * cs] = t / (one + sL[i][i]);
       }
-      for (int i = 0; i < k; ++i) col[i * cs] = mean ? sc[i] - ss[i] * col[i * cs] : ss[i] * col[i * cs];
+      for (int i = 0; i < k; ++i) cl[i * cs] = mean ? sc[i] - ss[i] * cl[i * cs] : ss[i] * cl[i * cs];
     }
   }
   __syncthreads();
+  LRS_STAMP(3);
   if (tid < 16) {
-    double m = 0.0;
-    if (n0 + tid < D) {
-      m = a.mu0[n0 + tid];
-      for (int j = 0; j < k; ++j) m += sa[j] * a.XS0[(size_t)j * ld + n0 + tid];
-    }
+    double m = mu0c;
+    for (int j = 0; j < k; ++j) m += sa[j] * sXS[j][tid];
     smu[tid] = m;
   }
+  if (a.dbg == 4) { if (smu[0] == 1.2345e-300) a.tbar[0] = xa[0][3] + xb[1][7]; return; }
 
-  // ---- R Uw^T, the inner dimension in chunks of LRS_CH rows of Uw^T ----
-  const int ntiles = (S + 15) / 16;
-  sv4d acc[LRS_MAXT];
+  // ---- [R; Rbar] Uw^T, the inner dimension in chunks of LRS_CH rows of Uw^T ----
+  sv4d acc = (sv4d){0.0, 0.0, 0.0, 0.0};
+  // Uw^T[rows of the chunk][16 columns] = U0^T - (X U0)^T B2, 16 rows per wave and block: v_mfma_f64_16x16x4_f64 with
+  // A = -(X U0)^T (lane: row li of the block, point m + lk), B = B2 (point m + lk, column li), C = U0^T; then the tile's MFMAs
+  auto chunk = [&](int kb, double (&va)[LRS_CHD], double (&vb)[LRS_CHD]) {
+    __syncthreads();                                // (the previous chunk has been read; first chunk: the factor is no longer needed)
+    const int crows = min(LRS_CH, (D - kb + 15) & ~15);      // rows >= D are formed as zeros (LDS may hold anything)
 #pragma unroll
-  for (int u = 0; u < LRS_MAXT; ++u) acc[u] = (sv4d){0.0, 0.0, 0.0, 0.0};
-  for (int kb = 0; kb < D; kb += LRS_CH) {
-    __syncthreads();                                // (the previous chunk has been read; first trip: smu / sB2 are complete)
-    for (int e = tid; e < LRS_CH * 16; e += 1024) {
-      const int r = e >> 4, c = e & 15, kq = kb + r;
-      double v = 0.0;
-      if (kq < D && n0 + c < D) {
-        v = a.U0T[(size_t)kq * ld + n0 + c];
-        for (int j = 0; j < k; ++j) v -= a.XU0[(size_t)j * ld + kq] * sB2[j][c];
-      }
-      sUw[r * LRS_LDB + c] = v;
-    }
-    __syncthreads();
-    const int nds = (min(LRS_CH, D - kb) + 7) / 8;  // double-steps (8 values of the inner dimension) with anything in them
-#pragma unroll
-    for (int u = 0; u < LRS_MAXT; ++u) {
-      const int rt = wave + 16 * u;
-      if (rt >= ntiles) break;                      // (wave-uniform)
-      const int row = rt * 16 + li;
-      const double* rp = a.R + (size_t)(row < S ? row : 0) * ld;
-      for (int t0 = 0; t0 < nds; t0 += 4) {
-        // lane group lk feeds values kq = 8 t + 2 lk (+1) to steps 2 t (2 t + 1): one 16-byte load per two steps
-        double x0[4], x1[4];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const int kq = kb + 8 * (t0 + q) + 2 * lk;
-          const int kc = kq + 1 < ld ? kq : 0;       // (ld is even, kq is even: kq < ld implies kq + 1 < ld)
-          const double2 v = *(const double2*)(rp + kc);
-          const bool ok = row < S && t0 + q < nds;
-          x0[q] = (ok && kq < D) ? v.x : 0.0;
-          x1[q] = (ok && kq + 1 < D) ? v.y : 0.0;
+    for (int b = 0; b < LRS_BPW; ++b) {
+      const int blk = wave + 4 * b;
+      if (16 * blk < crows) {                       // (wave-uniform)
+        const int rb = kb + 16 * blk;
+        sv4d u = (sv4d){pu[b][0], pu[b][1], pu[b][2], pu[b][3]};
+        if (k4) u = __builtin_amdgcn_mfma_f64_16x16x4f64(px[b], sB2[lk][li], u, 0, 0, 0);
+        const bool rok = rb + li < D;
+        for (int m = 4; m < k4; m += 4) {
+          const int j = m + lk;
+          const double x = (j < k && rok) ? -a.XU0[(size_t)j * ld + rb + li] : 0.0;
+          u = __builtin_amdgcn_mfma_f64_16x16x4f64(x, sB2[j][li], u, 0, 0, 0);
         }
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          if (t0 + q < nds) {
-            const int r = 8 * (t0 + q) + 2 * lk;
-            acc[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(x0[q], sUw[r * LRS_LDB + li], acc[u], 0, 0, 0);
-            acc[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(x1[q], sUw[(r + 1) * LRS_LDB + li], acc[u], 0, 0, 0);
+        for (int r = 0; r < 4; ++r) sUw[(16 * blk + lk + 4 * r) * LRS_LDB + li] = u[r];
+      }
+    }
+    if (kb + LRS_CH < D) load_U(kb + LRS_CH);       // (in flight during this chunk's MFMAs)
+    __syncthreads();
+    const int nds = (min(LRS_CH, D - kb) + 7) / 8;  // double-steps with anything in them
+#pragma unroll
+    for (int t = 0; t < LRS_CHD; ++t) {
+      if (t < nds) {
+        const int r = 8 * t + 2 * lk;
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(va[t], sUw[r * LRS_LDB + li], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(vb[t], sUw[(r + 1) * LRS_LDB + li], acc, 0, 0, 0);
+      }
+    }
+    if (kb + 2 * LRS_CH < D) load_A(kb + 2 * LRS_CH, va, vb);      // (D > 320: this register set's next chunk)
+  };
+  for (int kb = 0; kb < D; kb += 2 * LRS_CH) {
+    chunk(kb, xa[0], xb[0]);
+    LRS_STAMP(4);
+    if (kb + LRS_CH < D) chunk(kb + LRS_CH, xa[1], xb[1]);
+  }
+  LRS_STAMP(5);
+  // ---- theta = mu + R Uw^T (f64 C/D layout: column = lane & 15, row = (lane >> 4) + 4 reg); row S is the mean ----
+  const double mu = smu[li];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int row = row0 + lk + 4 * r;
+    const double v = col < D ? mu + acc[r] : 0.0;
+    if (row < S && col < ld) a.theta[(size_t)row * ld + col] = v;
+    else if (row == S && col < D) a.tbar[col] = v;
+  }
+  if (a.dbg == 9) {
+    LRS_STAMP(6);
+    const long long c1 = clock64();
+    if (tid == 0 && blockIdx.y == 2 && blockIdx.x < 8) {
+      double* o = (double*)a.Rbar + ld + 8 * blockIdx.x;      // (the next step's means: a debugging run draws once)
+      for (int i = 0; i < 7; ++i) o[i] = (double)(stamp[i] - (i ? stamp[0] : 0)) * 0.01;
+      o[7] = (double)(c1 - c0) / ((double)(stamp[6] - stamp[0]) * 0.01);      // shader-clock ticks per microsecond
+    }
+  }
+}
+
+// The same draws for a LOOP of calls at the same points (SparseVI: opt_itrs ADAM steps): G = R U0^T does not depend on the
+// weights, so the caller forms it for all steps at once (lrs_draw_kernel with k = 0, one launch per greedy step) and a step is
+//     theta = mu_w + G - (G X^T) B2,     B2 = diag(s) T^T diag(s) (X Sig0)   (k x D),
+// a rank-k correction of rows that are read once, contiguously -- the per-step kernel above spends 13 us waiting for its
+// 16 x 302 tiles of a fresh R (16 rows 2.4 KB apart per load instruction) and 5 us forming Uw^T.  One wave per row of
+// [G; Gbar] (Gbar: the column means of G -- its row gives the mean of the draws), four rows per workgroup; every workgroup
+// repeats the k x k factorisation and the 2 D triangular solves for B2 (a thread per column), X and B2 live in LDS.
+#define LRA_KMAX 32
+#define LRA_NI 8             // 16-byte pieces of a row per lane: ld <= 1024
+struct LraArgs {
+  const double* w; const double* K0; const double* xmu0; const double* y;
+  const double* X;      // k x ld: the points' features (padding 0)
+  const double* XS0;    // k x ld: X Sig0
+  const double* mu0;    // D
+  const double* G;      // S x ld: R U0^T
+  const double* Gbar;   // ld: column means of G
+  double* theta; double* tbar;
+  double sigsq;
+  int k, D, S, ld;
+};
+__global__ __launch_bounds__(256) void lrs_apply_kernel(LraArgs a) {
+  extern __shared__ __attribute__((aligned(16))) double lra_dyn[];   // X (k x ld), B2 (k x ld)
+  __shared__ double sL[LRA_KMAX][LRA_KMAX + 1];
+  __shared__ double ss[LRA_KMAX], sc[LRA_KMAX], sa[LRA_KMAX];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int k = a.k, D = a.D, S = a.S, ld = a.ld;
+  double* sX = lra_dyn;
+  double* sB2 = lra_dyn + (size_t)k * ld;
+  const int row = blockIdx.x * 4 + wave;            // of [G; Gbar]
+  const bool row_ok = row <= S;
+  const double* gp = row < S ? a.G + (size_t)row * ld : a.Gbar;
+  // ---- every request that depends on nothing: this wave's row, the prior mean, the points, the k x k inputs ----
+  double2 g[LRA_NI], m0[LRA_NI];
+#pragma unroll
+  for (int i = 0; i < LRA_NI; ++i) {
+    const int c = 2 * lane + 128 * i;
+    const bool ok = c < ld && row_ok;
+    g[i] = ok ? *(const double2*)(gp + c) : make_double2(0.0, 0.0);
+    m0[i].x = (ok && c < D) ? a.mu0[c] : 0.0;
+    m0[i].y = (ok && c + 1 < D) ? a.mu0[c + 1] : 0.0;
+  }
+  for (int e = tid; e < k * ld; e += 256) {
+    const int j = e / ld;
+    sX[e] = a.X[e];
+    sB2[e] = sqrt(fmax(a.w[j], 0.0) / a.sigsq) * a.XS0[e];
+  }
+  for (int e = tid; e < k * k; e += 256) {
+    const int i = e / k, j = e - i * k;
+    const double si = sqrt(fmax(a.w[i], 0.0) / a.sigsq), sj = sqrt(fmax(a.w[j], 0.0) / a.sigsq);
+    sL[i][j] = (i == j ? 1.0 : 0.0) + si * sj * a.K0[e];
+  }
+  if (tid < k) {
+    const double wi = fmax(a.w[tid], 0.0), si = sqrt(wi / a.sigsq);
+    ss[tid] = si;
+    sc[tid] = wi * a.y[tid] / a.sigsq;
+    double t = a.xmu0[tid];
+    for (int j0 = 0; j0 < k; j0 += 8) {
+      double kk[8], ww[8], yy[8];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const int j = j0 + q < k ? j0 + q : k - 1;
+        kk[q] = a.K0[tid * k + j]; ww[q] = a.w[j]; yy[q] = a.y[j];
+      }
+#pragma unroll
+      for (int q = 0; q < 8; ++q)
+        if (j0 + q < k) t += kk[q] * (fmax(ww[q], 0.0) * yy[q] / a.sigsq);
+    }
+    sa[tid] = si * t;
+  }
+  __syncthreads();
+  if (wave == 0) {                                  // right-looking Cholesky, lane = row (see lrs_draw_kernel)
+    for (int c = 0; c < k; ++c) {
+      const double l = sqrt(sL[c][c]);
+      __builtin_amdgcn_wave_barrier();
+      if (lane >= c && lane < k) sL[lane][c] = lane == c ? l : sL[lane][c] / l;
+      __builtin_amdgcn_wave_barrier();
+      if (lane > c && lane < k) {
+        const double lrc = sL[lane][c];
+        for (int c2 = c + 1; c2 <= lane; ++c2) sL[lane][c2] -= lrc * sL[c2][c];
+      }
+      __builtin_amdgcn_wave_barrier();
+    }
+  }
+  __syncthreads();
+  // a thread per column n < D: B2[:, n] = diag(s) (I + L)^-T L^-1 (s * X Sig0[:, n]); one more "column" is the mean's coefficient
+  // vector c - s * (L L^T)^-1 a
+  for (int n = tid; n <= D; n += 256) {             // (n == D: the mean's vector)
+    const bool mean = n == D;
+    double* cl = mean ? sa : sB2 + n;
+    const int cs = mean ? 1 : ld;
+    for (int i = 0; i < k; ++i) {                   // L u = rhs
+      double t = cl[(size_t)i * cs];
+      for (int u = 0; u < i; ++u) t -= sL[i][u] * cl[(size_t)u * cs];
+      cl[(size_t)i * cs] = t / sL[i][i];
+    }
+    const double one = mean ? 0.0 : 1.0;
+    for (int i = k - 1; i >= 0; --i) {
+      double t = cl[(size_t)i * cs];
+      for (int u = i + 1; u < k; ++u) t -= sL[u][i] * cl[(size_t)u * cs];
+      cl[(size_t)i * cs] = t / (one + sL[i][i]);
+    }
+    for (int i = 0; i < k; ++i) cl[(size_t)i * cs] = mean ? sc[i] - ss[i] * cl[i] : ss[i] * cl[(size_t)i * cs];
+  }
+  __syncthreads();
+  if (!row_ok) return;
+  // ---- this wave's row: theta = mu0 + (X Sig0)^T coef + g - sum_j (g . X_j) B2_j ----
+  double2 acc[LRA_NI];
+#pragma unroll
+  for (int i = 0; i < LRA_NI; ++i) acc[i] = make_double2(m0[i].x + g[i].x, m0[i].y + g[i].y);
+  for (int j0 = 0; j0 < k; j0 += 4) {
+    double2 xs[4][LRA_NI];                          // X Sig0, four points per round of loads (cached: every workgroup reads them)
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+      for (int i = 0; i < LRA_NI; ++i) {
+        const int c = 2 * lane + 128 * i;
+        xs[q][i] = (j0 + q < k && c < ld) ? *(const double2*)(a.XS0 + (size_t)(j0 + q) * ld + c) : make_double2(0.0, 0.0);
+      }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      if (j0 + q < k) {                             // (wave-uniform)
+        const int j = j0 + q;
+        double pj = 0.0;
+#pragma unroll
+        for (int i = 0; i < LRA_NI; ++i) {
+          const int c = 2 * lane + 128 * i;
+          if (c < ld) {
+            const double2 x = *(const double2*)(sX + (size_t)j * ld + c);
+            pj = fma(g[i].x, x.x, pj);
+            pj = fma(g[i].y, x.y, pj);
+          }
+        }
+        pj = wave_allsum(pj);
+        const double cj = sa[j];
+#pragma unroll
+        for (int i = 0; i < LRA_NI; ++i) {
+          const int c = 2 * lane + 128 * i;
+          if (c < ld) {
+            const double2 b = *(const double2*)(sB2 + (size_t)j * ld + c);
+            acc[i].x += cj * xs[q][i].x - pj * b.x;
+            acc[i].y += cj * xs[q][i].y - pj * b.y;
           }
         }
       }
     }
   }
-  // ---- theta = mu + R Uw^T (f64 C/D layout: column = lane & 15, row = (lane >> 4) + 4 reg), column means ----
-  const int col = n0 + li;
-  const double mu = smu[li];
-  double csum = 0.0;
 #pragma unroll
-  for (int u = 0; u < LRS_MAXT; ++u) {
-    const int rt = wave + 16 * u;
-    if (rt >= ntiles) break;
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int row = rt * 16 + lk + 4 * r;
-      if (row < S && col < ld) {
-        const double v = col < D ? mu + acc[u][r] : 0.0;
-        a.theta[(size_t)row * ld + col] = v;
-        csum += v;
-      }
+  for (int i = 0; i < LRA_NI; ++i) {
+    const int c = 2 * lane + 128 * i;
+    if (c < ld) {
+      if (c + 1 >= D) acc[i].y = 0.0;               // (the padding column)
+      if (row < S) *(double2*)(a.theta + (size_t)row * ld + c) = acc[i];
+      else { a.tbar[c] = acc[i].x; if (c + 1 < D) a.tbar[c + 1] = acc[i].y; }
     }
-  }
-  __syncthreads();                                  // (every wave has read its last chunk)
-  double* red = sbuf;                               // 16 waves x 64 partials
-  red[wave * 64 + lane] = csum;
-  __syncthreads();
-  if (tid < 16 && n0 + tid < D) {
-    double t = 0.0;
-    for (int wv = 0; wv < 16; ++wv)
-      for (int g = 0; g < 4; ++g) t += red[wv * 64 + g * 16 + tid];
-    a.tbar[n0 + tid] = t / (double)S;
   }
 }
 
@@ -210,21 +422,31 @@ __global__ __launch_bounds__(1024) void lrs_draw_kernel(LrsArgs a) {
 __global__ __launch_bounds__(256) void svi_adam_kernel(const double* __restrict__ colsum, double scaling, const double* __restrict__ core,
                                                        int64_t ldc, int k, int S, double* __restrict__ w, double* __restrict__ mom1,
                                                        double* __restrict__ mom2, const double* __restrict__ sched, int step,
-                                                       double b1, double b2, double eps, double* __restrict__ trace) {
-  __shared__ double sw[LRS_KMAX], sg[LRS_KMAX];
+                                                       double b1, double b2, double eps, double* __restrict__ trace, int raw_core) {
+  __shared__ double sw[LRS_KMAX], sg[LRS_KMAX], scm[LRS_KMAX];
   extern __shared__ double resid[];                 // S
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  if (tid < k) sw[tid] = w[tid];
+  if (tid < k) { sw[tid] = w[tid]; scm[tid] = 0.0; }
   __syncthreads();
+  if (raw_core) {
+    // the projected coreset points arrive as raw log-likelihoods: their row means (projector.py:21) are taken here
+    for (int j = wave; j < k; j += 4) {
+      double t = 0.0;
+      for (int s = lane; s < S; s += 64) t += core[(size_t)j * ldc + s];
+      t = wave_allsum(t);
+      if (lane == 0) scm[j] = t / (double)S;
+    }
+    __syncthreads();
+  }
   for (int s = tid; s < S; s += 256) {
     double t = 0.0;                                 // w.dot(corevecs) in NumPy's order of the k terms
-    for (int j = 0; j < k; ++j) t += sw[j] * core[(size_t)j * ldc + s];
+    for (int j = 0; j < k; ++j) t += sw[j] * (core[(size_t)j * ldc + s] - scm[j]);
     resid[s] = scaling * colsum[s] - t;             // sparsevi.py:72
   }
   __syncthreads();
   for (int j = wave; j < k; j += 4) {
     double t = 0.0;
-    for (int s = lane; s < S; s += 64) t += core[(size_t)j * ldc + s] * resid[s];
+    for (int s = lane; s < S; s += 64) t += (core[(size_t)j * ldc + s] - scm[j]) * resid[s];
     t = wave_allsum(t);
     if (lane == 0) sg[j] = -t / (double)S;          // sparsevi.py:74
   }
@@ -255,28 +477,60 @@ void bcx_project_set_error(const std::string& msg);   // proj.hip
 
 extern "C" int bcx_linreg_posterior_draw(void* stream, int32_t k, int32_t D, int32_t ld, const void* w_dev, const void* K0_dev,
                                          const void* xmu0_dev, const void* y_dev, const void* XU0_dev, const void* XS0_dev,
-                                         const void* U0T_dev, const void* mu0_dev, double sigsq, const void* R_dev, int32_t S,
-                                         void* theta_dev, void* tbar_dev) {
+                                         const void* U0T_dev, const void* mu0_dev, double sigsq, const void* R_dev,
+                                         const void* Rbar_dev, int32_t S, void* theta_dev, void* tbar_dev) {
   if (k < 0 || k > LRS_KMAX || D < 1 || ld < D || (ld & 1) || S < 1 || S > LRS_SMAX || !(sigsq > 0.0) || !U0T_dev || !mu0_dev ||
-      !R_dev || !theta_dev || !tbar_dev || (k > 0 && (!w_dev || !K0_dev || !xmu0_dev || !y_dev || !XU0_dev || !XS0_dev)) ||
-      ((uintptr_t)R_dev & 15)) {
-    bcx_project_set_error("bcx_linreg_posterior_draw: bad arguments (k <= 64 points, S <= 1024 draws, even leading dimension, "
+      !R_dev || !Rbar_dev || !theta_dev || !tbar_dev || (k > 0 && (!w_dev || !K0_dev || !xmu0_dev || !y_dev || !XU0_dev || !XS0_dev)) ||
+      ((uintptr_t)R_dev & 15) || ((uintptr_t)Rbar_dev & 15)) {
+    bcx_project_set_error("bcx_linreg_posterior_draw: bad arguments (k <= 64 points, even leading dimension, "
                           "16-byte aligned normal draws)");
     return BCX_ERR_ARG;
   }
   LrsArgs a;
   a.w = (const double*)w_dev; a.K0 = (const double*)K0_dev; a.xmu0 = (const double*)xmu0_dev; a.y = (const double*)y_dev;
   a.XU0 = (const double*)XU0_dev; a.XS0 = (const double*)XS0_dev; a.U0T = (const double*)U0T_dev; a.mu0 = (const double*)mu0_dev;
-  a.R = (const double*)R_dev; a.theta = (double*)theta_dev; a.tbar = (double*)tbar_dev;
+  a.R = (const double*)R_dev; a.Rbar = (const double*)Rbar_dev; a.theta = (double*)theta_dev; a.tbar = (double*)tbar_dev;
   a.sigsq = sigsq; a.k = k; a.D = D; a.S = S; a.ld = ld;
-  hipLaunchKernelGGL(lrs_draw_kernel, dim3((ld + 15) / 16), dim3(1024), 0, (hipStream_t)stream, a);
+  static const char* dbg = bcx_dev_env("BCX_SVI_DBG");
+  a.dbg = dbg ? atoi(dbg) : 0;
+  hipLaunchKernelGGL(lrs_draw_kernel, dim3((ld + 15) / 16, (S + 1 + 63) / 64), dim3(256), 0, (hipStream_t)stream, a);
+  SVI_HIP(hipGetLastError());
+  return BCX_OK;
+}
+
+// LDS bytes of lrs_apply_kernel's X and B2; the kernel serves k <= 32 points while they fit 128 KiB
+extern "C" int bcx_linreg_posterior_apply_ok(int32_t k, int32_t ld) {
+  return k >= 1 && k <= LRA_KMAX && ld >= 2 && ld <= 128 * LRA_NI && (int64_t)2 * k * ld * 8 <= 128 * 1024;
+}
+extern "C" int bcx_linreg_posterior_apply(void* stream, int32_t k, int32_t D, int32_t ld, const void* w_dev, const void* K0_dev,
+                                          const void* xmu0_dev, const void* y_dev, const void* X_dev, const void* XS0_dev,
+                                          const void* mu0_dev, double sigsq, const void* G_dev, const void* Gbar_dev, int32_t S,
+                                          void* theta_dev, void* tbar_dev) {
+  if (!bcx_linreg_posterior_apply_ok(k, ld) || D < 1 || ld < D || (ld & 1) || S < 1 || !(sigsq > 0.0) || !w_dev || !K0_dev || !xmu0_dev ||
+      !y_dev || !X_dev || !XS0_dev || !mu0_dev || !G_dev || !Gbar_dev || !theta_dev || !tbar_dev ||
+      (((uintptr_t)G_dev | (uintptr_t)Gbar_dev | (uintptr_t)XS0_dev | (uintptr_t)theta_dev) & 15)) {
+    bcx_project_set_error("bcx_linreg_posterior_apply: bad arguments (see bcx_linreg_posterior_apply_ok; 16-byte aligned rows)");
+    return BCX_ERR_ARG;
+  }
+  LraArgs a;
+  a.w = (const double*)w_dev; a.K0 = (const double*)K0_dev; a.xmu0 = (const double*)xmu0_dev; a.y = (const double*)y_dev;
+  a.X = (const double*)X_dev; a.XS0 = (const double*)XS0_dev; a.mu0 = (const double*)mu0_dev; a.G = (const double*)G_dev;
+  a.Gbar = (const double*)Gbar_dev; a.theta = (double*)theta_dev; a.tbar = (double*)tbar_dev;
+  a.sigsq = sigsq; a.k = k; a.D = D; a.S = S; a.ld = ld;
+  const size_t lds = (size_t)2 * k * ld * sizeof(double);
+  static size_t lds_max = 0;
+  if (lds > 32 * 1024 && lds > lds_max) {
+    SVI_HIP(hipFuncSetAttribute((const void*)lrs_apply_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    lds_max = lds;
+  }
+  hipLaunchKernelGGL(lrs_apply_kernel, dim3((S + 1 + 3) / 4), dim3(256), lds, (hipStream_t)stream, a);
   SVI_HIP(hipGetLastError());
   return BCX_OK;
 }
 
 extern "C" int bcx_sparsevi_adam_step(void* stream, int32_t k, int32_t S, const void* colsum_dev, double scaling, const void* core_dev,
                                       int64_t ldc, void* w_dev, void* mom1_dev, void* mom2_dev, const void* sched_dev, int32_t step,
-                                      double b1, double b2, double eps, void* trace_dev) {
+                                      double b1, double b2, double eps, void* trace_dev, int32_t core_is_raw) {
   if (k < 1 || k > LRS_KMAX || S < 1 || S > 8192 || ldc < S || step < 0 || !colsum_dev || !core_dev || !w_dev || !mom1_dev ||
       !mom2_dev || !sched_dev) {
     bcx_project_set_error("bcx_sparsevi_adam_step: bad arguments (1 <= k <= 64 weights, S <= 8192)");
@@ -284,7 +538,7 @@ extern "C" int bcx_sparsevi_adam_step(void* stream, int32_t k, int32_t S, const 
   }
   hipLaunchKernelGGL(svi_adam_kernel, dim3(1), dim3(256), (size_t)S * sizeof(double), (hipStream_t)stream, (const double*)colsum_dev,
                      scaling, (const double*)core_dev, ldc, (int)k, (int)S, (double*)w_dev, (double*)mom1_dev, (double*)mom2_dev,
-                     (const double*)sched_dev, (int)step, b1, b2, eps, (double*)trace_dev);
+                     (const double*)sched_dev, (int)step, b1, b2, eps, (double*)trace_dev, (int)core_is_raw);
   SVI_HIP(hipGetLastError());
   return BCX_OK;
 }

@@ -259,23 +259,35 @@ int bcx_project_colsum_moments_at(void* stream, const void* M_dev, int64_t ldm, 
  *                              linear-regression model with a N(mu0, Sig0) prior (the sampler of the reference's
  *                              examples/linear_regression/main.py:124-147), theta = mu_w + R_dev Uw^T for the standard-normal
  *                              R_dev (S x ld, 16-byte aligned), as a rank-k correction of the prior's factor Sig0 = U0 U0^T
- *                              through a k x k Cholesky; tbar_dev (D) = the mean of the draws.  Per-point inputs (formed
+ *                              through a k x k Cholesky; tbar_dev (D) = the mean of the draws, formed as the "draw" of
+ *                              Rbar_dev (ld doubles: the column means of R_dev, supplied by the caller).  Per-point inputs (formed
  *                              by the caller when the points change): K0 = (X U0)(X U0)^T (k x k), xmu0 = X mu0, y (k),
  *                              XU0 = X U0 and XS0 = X Sig0 (k x ld); per-model: U0T = U0^T (D x ld), mu0 (D).  w_dev: the
- *                              k weights (negative entries count as 0).  k <= 64, S <= 1024, ld even.
+ *                              k weights (negative entries count as 0).  k <= 64, ld even.
  *   bcx_sparsevi_adam_step     resid = scaling colsum - w corevecs, g = -corevecs resid / S, then opt.py:19-25 on w_dev /
  *                              mom1_dev / mom2_dev (k doubles each) with every weight clamped at 0 (nn_idcs = None).
- *                              core_dev: k x ldc projected coreset points; sched_dev: 3 doubles per step -- step_sched(i),
+ *                              core_dev: k x ldc projected coreset points (core_is_raw != 0: as bcx_project_write_raw leaves
+ *                              them -- the row means of projector.py:21 are then taken here); sched_dev: 3 doubles per step -- step_sched(i),
  *                              1 - b1^(i+1), 1 - b2^(i+1), evaluated by the host; step: i; trace_dev: NULL or steps x k
  *                              doubles receiving the weights after each step.
  * Asynchronous on `stream`; errors: bcx_project_last_error(). */
 int bcx_linreg_posterior_draw(void* stream, int32_t k, int32_t D, int32_t ld, const void* w_dev, const void* K0_dev,
                               const void* xmu0_dev, const void* y_dev, const void* XU0_dev, const void* XS0_dev,
-                              const void* U0T_dev, const void* mu0_dev, double sigsq, const void* R_dev, int32_t S,
-                              void* theta_dev, void* tbar_dev);
+                              const void* U0T_dev, const void* mu0_dev, double sigsq, const void* R_dev, const void* Rbar_dev,
+                              int32_t S, void* theta_dev, void* tbar_dev);
+/*   bcx_linreg_posterior_apply the same draws for a loop of calls at the same points: G_dev (S x ld) = R U0^T and Gbar_dev (ld, its
+ *                              column means) are formed once for all steps (bcx_linreg_posterior_draw with k = 0 and a zero
+ *                              prior mean returns R U0^T), a step is then the rank-k correction theta = mu_w + G - (G X^T) B2
+ *                              of rows read once.  X_dev: the points' features (k x ld, padding 0).  Serves the (k, ld) for which
+ *                              bcx_linreg_posterior_apply_ok is non-zero (k <= 32 and 16 k ld <= 128 KiB of LDS). */
+int bcx_linreg_posterior_apply_ok(int32_t k, int32_t ld);
+int bcx_linreg_posterior_apply(void* stream, int32_t k, int32_t D, int32_t ld, const void* w_dev, const void* K0_dev,
+                               const void* xmu0_dev, const void* y_dev, const void* X_dev, const void* XS0_dev,
+                               const void* mu0_dev, double sigsq, const void* G_dev, const void* Gbar_dev, int32_t S,
+                               void* theta_dev, void* tbar_dev);
 int bcx_sparsevi_adam_step(void* stream, int32_t k, int32_t S, const void* colsum_dev, double scaling, const void* core_dev,
                            int64_t ldc, void* w_dev, void* mom1_dev, void* mom2_dev, const void* sched_dev, int32_t step,
-                           double b1, double b2, double eps, void* trace_dev);
+                           double b1, double b2, double eps, void* trace_dev, int32_t core_is_raw);
 /* The dense re-weight's Gram matrix as an operator of its own (optimize() forms it over the active rows, snnls.py:82-97:
  * `nnls(A[:, active], b)` solves the normal equations of that k-column block): G_dev (k x ldg doubles, both triangles) =
  * V V^T for the k rows of d doubles at rows_dev (row stride ld >= d), on the fp64 matrix cores; the d products of an entry

@@ -72,9 +72,14 @@ def test_posterior_draw_kernel(bc, D, k, S):
         # from device-resident weights: the same kernel, the same numbers
         plan = smp.enqueue_plan(S, p3, 2)
         assert plan is not None
-        plan.noise = Rd[None, :, :]
+        plan.set_noise(Rd[None, :, :])
+        assert plan.fast == (k <= 32)
         t4, m4 = plan.draw(torch.from_numpy(w2).cuda(), 0)
-        assert np.array_equal(t4.cpu().numpy()[D], mu3)
+        t4, m4 = t4.cpu().numpy(), m4.cpu().numpy()
+        np.testing.assert_allclose(t4[D], mu3, rtol=1e-12, atol=1e-13 * np.abs(mu3).max())
+        U3 = smp(S, w2, p3).cpu().numpy()
+        assert np.abs(t4 - U3).max() <= 1e-12 * max(1.0, np.abs(U3).max())      # (the call form at the same noise)
+        np.testing.assert_allclose(m4, t4.mean(axis=0), rtol=1e-12, atol=1e-13 * np.abs(t4).max())
 
 
 def test_posterior_sampler_limits(bc):
@@ -96,15 +101,17 @@ def test_posterior_sampler_limits(bc):
     np.testing.assert_allclose(np.cov(big.T), U.dot(U.T), atol=0.08 * sd ** 2)
 
 
-@pytest.mark.parametrize("k,S", ((1, 16), (5, 256), (64, 100), (17, 1000)))
-def test_adam_step_kernel_against_nn_opt(bc, k, S):
+@pytest.mark.parametrize("k,S,raw", ((1, 16, 0), (5, 256, 1), (64, 100, 1), (17, 1000, 0), (4, 256, 1)))
+def test_adam_step_kernel_against_nn_opt(bc, k, S, raw):
+    """``raw``: the projected coreset points arrive uncentred (bcx_project_write_raw) and the kernel takes the row means."""
     import ctypes
     import torch
     from bayesiancoresets_amd import _native
     from bayesiancoresets_amd.util.opt import nn_opt
     lib = _native.load()
     rs = np.random.RandomState(k * 7 + S)
-    core = rs.randn(k, S)
+    core_raw = rs.randn(k, S) + 5.0 * rs.randn(k, 1)
+    core = core_raw - core_raw.mean(axis=1)[:, None]
     colsum = 3.0 * rs.randn(S)
     w0 = np.abs(rs.randn(k))
     T, scaling = 25, 1.7
@@ -116,17 +123,17 @@ def test_adam_step_kernel_against_nn_opt(bc, k, S):
     want = nn_opt(w0, grd, opt_itrs=T, step_sched=sched_fn)
     sched = np.array([(sched_fn(i), 1.0 - b1 ** (i + 1), 1.0 - b2 ** (i + 1)) for i in range(T)])
     d = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float64)).cuda()
-    core_d, col_d, w, m1, m2, sc, tr = d(core), d(colsum), d(w0), d(np.zeros(k)), d(np.zeros(k)), d(sched), d(np.zeros((T, k)))
+    core_d, col_d, w, m1, m2, sc, tr = d(core_raw if raw else core), d(colsum), d(w0), d(np.zeros(k)), d(np.zeros(k)), d(sched), d(np.zeros((T, k)))
     stream = int(torch.cuda.current_stream().cuda_stream)
     for i in range(T):
         assert lib.bcx_sparsevi_adam_step(stream, k, S, col_d.data_ptr(), scaling, core_d.data_ptr(), S, w.data_ptr(), m1.data_ptr(),
-                                          m2.data_ptr(), sc.data_ptr(), i, b1, b2, eps, tr.data_ptr()) == 0
+                                          m2.data_ptr(), sc.data_ptr(), i, b1, b2, eps, tr.data_ptr(), raw) == 0
     got = w.cpu().numpy()
     np.testing.assert_allclose(got, want, rtol=1e-10, atol=1e-13)
     assert np.array_equal(tr.cpu().numpy()[-1], got)
     assert (got >= 0).all()
     assert lib.bcx_sparsevi_adam_step(stream, 65, S, col_d.data_ptr(), scaling, core_d.data_ptr(), S, w.data_ptr(), m1.data_ptr(),
-                                      m2.data_ptr(), sc.data_ptr(), 0, b1, b2, eps, None) == _native.ERR_ARG
+                                      m2.data_ptr(), sc.data_ptr(), 0, b1, b2, eps, None, 0) == _native.ERR_ARG
 
 
 class _ReplaySampler(object):
