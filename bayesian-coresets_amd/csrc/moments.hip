@@ -188,10 +188,13 @@ template <bool AL>
 __global__ __launch_bounds__(256) void moments_quad_kernel(const double* __restrict__ M, int64_t ldm, int D, int ycol,
                                                            const double* __restrict__ theta, int S, int ldt,
                                                            const double* __restrict__ tbar, double sigsq,
-                                                           double* __restrict__ colsum, double* __restrict__ work, int nct, int Spad) {
+                                                           double* __restrict__ colsum, double* __restrict__ work, int nct, int Spad, int dbg) {
   __shared__ double scratch[BCX_SCRATCH];
   __shared__ double red[4][4][64];
   __shared__ int last;
+  long long stamp[8];
+#define MQ_STAMP(i) do { if (dbg) { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); stamp[i] = wall_clock64(); } } while (0)
+  MQ_STAMP(0);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int li = lane & 15, lk = lane >> 4;
   const int st = blockIdx.x / nct, ct = blockIdx.x - st * nct;
@@ -201,6 +204,17 @@ __global__ __launch_bounds__(256) void moments_quad_kernel(const double* __restr
     const double* th = theta + (size_t)(va ? sa : 0) * ldt;
     const double* gc = M + (vb ? cb : 0);
     mv4d acc = (mv4d){0.0, 0.0, 0.0, 0.0};
+    // what wave 0 needs after the products, requested now (f64 C/D layout: col = lane & 15, row = (lane >> 4) + 4 * reg)
+    double e_tb = 0.0, e_gy = 0.0, e_th[4] = {0.0, 0.0, 0.0, 0.0};
+    if (wave == 0 && vb) {
+      e_tb = tbar[cb];
+      e_gy = M[(size_t)ycol * ldm + cb];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int sr = st * 16 + lk + 4 * r;
+        e_th[r] = theta[(size_t)(sr < S ? sr : 0) * ldt + cb];
+      }
+    }
     const int ksteps = (D + 7) / 8;
     for (int t0 = wave; t0 < ksteps; t0 += 4 * MQ_U) {
       // MQ_U double-steps per trip (t0, t0 + 4, ...): all their loads are issued before the first MFMA (addresses clamped,
@@ -227,19 +241,20 @@ __global__ __launch_bounds__(256) void moments_quad_kernel(const double* __restr
         acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[u], b1[u], acc, 0, 0, 0);
       }
     }
+    MQ_STAMP(1);
 #pragma unroll
     for (int r = 0; r < 4; ++r) red[wave][r][lane] = acc[r];
     __syncthreads();
     if (wave == 0) {
       // f64 C/D layout: col = lane & 15, row = (lane >> 4) + 4 * reg
-      const double tb = vb ? tbar[cb] : 0.0, gy = vb ? M[(size_t)ycol * ldm + cb] : 0.0;
+      const double tb = e_tb, gy = e_gy;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const double y4 = ((red[0][r][lane] + red[1][r][lane]) + red[2][r][lane]) + red[3][r][lane];
         const int sr = st * 16 + lk + 4 * r;
         double v = 0.0;
         if (vb && sr < S) {
-          const double dl = theta[(size_t)sr * ldt + cb] - tb;
+          const double dl = e_th[r] - tb;
           v = y4 * (dl + 2.0 * tb) - 2.0 * dl * gy;
         }
         v += bcx_dpp_f64<0xB1>(v);     // sum over the 16 lanes (columns) of the row group
@@ -253,6 +268,7 @@ __global__ __launch_bounds__(256) void moments_quad_kernel(const double* __restr
   unsigned* counter = (unsigned*)(work + (size_t)nct * Spad);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
+  MQ_STAMP(2);
   if (tid == 0) {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -260,6 +276,7 @@ __global__ __launch_bounds__(256) void moments_quad_kernel(const double* __restr
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
   }
   __syncthreads();
+  MQ_STAMP(3);
   if (!last) return;
   // the last workgroup to arrive: every partial is in memory; tile order, then sample order -- the same bits whichever it is
   double m[1] = {0.0};
@@ -280,10 +297,18 @@ __global__ __launch_bounds__(256) void moments_quad_kernel(const double* __restr
     m[0] += t;
   }
   __syncthreads();
+  MQ_STAMP(4);
   block_allsum<1>(m, scratch);
   const double mean = m[0] / (double)S, f = -1.0 / (2.0 * sigsq);
   for (int u = tid; u < S; u += 256) colsum[u] = f * (mom_ld(work + u) - mean);
   if (tid == 0) __hip_atomic_store(counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (dbg) {
+    MQ_STAMP(5);
+    if (tid == 0) {
+      double* o = work + (size_t)nct * Spad + 1;      // (the space of the library's own thetabar: dev runs pass one)
+      for (int i = 0; i < 6; ++i) o[i] = (double)(stamp[i] - (i ? stamp[0] : 0)) * 0.01;
+    }
+  }
 }
 
 void bcx_project_set_error(const std::string& msg);   // proj.hip: the message bcx_project_last_error() returns
@@ -559,12 +584,13 @@ extern "C" int bcx_project_colsum_moments_at(void* stream, const void* M_dev, in
   }
   const int tiles = nct * (Spad / 16);
   const bool al = ((uintptr_t)theta_dev % 16 == 0) && ldt % 2 == 0;
+  static const int mqdbg = bcx_dev_env("BCX_MQ_DBG") != nullptr;     // dev: time stamps of the last workgroup (needs tbar_dev)
   if (al)
     hipLaunchKernelGGL(moments_quad_kernel<true>, dim3(tiles), dim3(256), 0, st, (const double*)M_dev, ldm, (int)D, (int)ycol,
-                       (const double*)theta_dev, (int)S, (int)ldt, (const double*)tbar, sigsq, (double*)colsum_dev, work, nct, Spad);
+                       (const double*)theta_dev, (int)S, (int)ldt, (const double*)tbar, sigsq, (double*)colsum_dev, work, nct, Spad, mqdbg);
   else
     hipLaunchKernelGGL(moments_quad_kernel<false>, dim3(tiles), dim3(256), 0, st, (const double*)M_dev, ldm, (int)D, (int)ycol,
-                       (const double*)theta_dev, (int)S, (int)ldt, (const double*)tbar, sigsq, (double*)colsum_dev, work, nct, Spad);
+                       (const double*)theta_dev, (int)S, (int)ldt, (const double*)tbar, sigsq, (double*)colsum_dev, work, nct, Spad, mqdbg);
   MOM_HIP(hipGetLastError());
   return BCX_OK;
 }

@@ -52,7 +52,7 @@ struct LrsArgs {
   double* tbar;         // D: mean over the draws
   double sigsq;
   int k, D, S, ld;
-  int dbg;              // dev (BCX_SVI_DBG): timing experiments that cut the kernel short (wrong results)
+  int dbg;              // dev (BCX_SVI_DBG=9): time stamps of workgroups (0..7, 2) into the next step's Rbar (tools/svi_step_bench.py)
 };
 
 // Workgroup (x, y): columns 16 x .. 16 x + 15 of theta, rows 64 y .. 64 y + 63 of [R; Rbar] (one 16 x 16 tile per wave).
@@ -118,7 +118,6 @@ __global__ __launch_bounds__(256) void lrs_draw_kernel(LrsArgs a) {
   if (LRS_CH < D) load_A(LRS_CH, xa[1], xb[1]);
   load_U(0);
   LRS_STAMP(1);
-  if (a.dbg == 1) { if (xa[0][0] == 1.2345e-300) a.tbar[0] = xa[1][3] + xb[0][7] + pu[0][0] + px[1]; return; }
 
   // ---- the k x k system: every input straight from memory (no value waits for another) ----
   for (int e = tid; e < k * k; e += 256) {
@@ -154,8 +153,7 @@ __global__ __launch_bounds__(256) void lrs_draw_kernel(LrsArgs a) {
   const double mu0c = (tid < 16 && n0 + tid < D) ? a.mu0[n0 + tid] : 0.0;
   __syncthreads();
   LRS_STAMP(2);
-  if (a.dbg == 2) { if (sL[0][0] == 1.2345e-300) a.tbar[0] = xa[0][3] + xb[1][7]; return; }
-  if (wave == 0 && a.dbg != 3) {
+  if (wave == 0) {
     // right-looking Cholesky, lane = row (a wave runs in lock step and its LDS accesses complete in order: the exchanges
     // between lanes below need no barrier, only that the compiler keeps the order -- wave_barrier)
     for (int c = 0; c < k; ++c) {
@@ -195,7 +193,6 @@ __global__ __launch_bounds__(256) void lrs_draw_kernel(LrsArgs a) {
     for (int j = 0; j < k; ++j) m += sa[j] * sXS[j][tid];
     smu[tid] = m;
   }
-  if (a.dbg == 4) { if (smu[0] == 1.2345e-300) a.tbar[0] = xa[0][3] + xb[1][7]; return; }
 
   // ---- [R; Rbar] Uw^T, the inner dimension in chunks of LRS_CH rows of Uw^T ----
   sv4d acc = (sv4d){0.0, 0.0, 0.0, 0.0};

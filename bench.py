@@ -732,9 +732,11 @@ def run_sparsevi(args, torch, dist, nat, world, rank, local_rank):
             # (csrc/moments.hip), the select step's projection stays
             "colsum": args.colsum, "moments": prj.moments_info or None,
             "moments_setup_ms": (prj.moments_info or {}).get("setup_ms"),
-            "sampler": "weighted conjugate posterior on the device (examples/common/model_linreg.py: rank-k update of the "
-                       "prior's %d x %d factor per ADAM step, k = coreset size: the user-callback side of the Projector "
-                       "interface)" % (D, D),
+            "sampler": "weighted conjugate posterior on the device (bc.LinregPosteriorSampler via examples/common/model_linreg.py: "
+                       "rank-k correction of the prior's %d x %d factor through a k x k Cholesky, k = coreset size, from "
+                       "weights that stay on the device)" % (D, D),
+            "adam_loop": "enqueued: opt_itrs x (draws, column sums, coreset projection, ADAM step) without host synchronisation, "
+                         "one read-back per greedy step (csrc/svi.hip)" if alg._enqueue_plan() is not None else "host loop (nn_opt)",
             "coreset_size": int(alg.size()), "coreset_idcs": [int(i) for i in alg.idcs],
             "projection_ms_per_step_kernels": kms / args.steps,
         },
@@ -841,6 +843,9 @@ def side_legs(args, out, torch, dist, nat):
             out["c5_moments_mfma_frac"] = r["roofline"]["frac"]
             out["c5_moments_same_idcs"] = r["config"]["coreset_idcs"] == out.get("c5_coreset_idcs")
             out["c5_moments_setup_ms"] = r["config"].get("moments_setup_ms")
+            out["c5_adam_loop"] = r["config"].get("adam_loop")
+            # everything of a closed-form greedy step that is not the select projection, per ADAM step
+            out["c5_moments_adam_step_us"] = (r["ms_per_step"] - r["config"]["projection_ms_per_step_kernels"]) / max(r["config"]["opt_itrs"], 1) * 1e3
     gram_leg(out, torch, nat)
     optimize_leg(out, torch, nat)
 

@@ -233,6 +233,48 @@ def test_sparsevi_two_shards_match_reference(tmp_path):
     np.testing.assert_allclose(r0["wts"], g["step2_wts"], rtol=1e-5, atol=1e-8)
 
 
+def _svi_enqueued_worker(rank, world, port, out_dir, colsum):
+    for p in (ROOT, os.path.join(ROOT, "bayesian-coresets_amd"), os.path.join(ROOT, "tests")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    import torch
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import bayesiancoresets_amd as bc
+    from models import make_linreg_data
+    N, D, S, sigsq = 30000, 9, 48, 1.0
+    Z = make_linreg_data(4, N, D)
+    per = (N + world - 1) // world
+    lo, hi = rank * per, min(N, (rank + 1) * per)
+    smp = bc.LinregPosteriorSampler(np.zeros(D), 2.0 * np.eye(D), sigsq, seed=9)      # (replicated: the same seed on every rank)
+    grp = dist.group.WORLD if world > 1 else None
+    prj = bc.DeviceProjector("linreg", smp, S, sigsq=sigsq, group=grp, row_offset=lo, colsum=colsum)
+    alg = bc.SparseVICoreset(Z[lo:hi], prj, opt_itrs=20, row_offset=lo, group=grp) if world > 1 else bc.SparseVICoreset(Z, prj, opt_itrs=20)
+    alg.build(3)
+    assert alg._enqueue_plan() is not None
+    np.savez(os.path.join(out_dir, "svie_w%d_r%d.npz" % (world, rank)), idcs=alg.idcs, wts=alg.wts, pts=alg.pts)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("colsum", ("mfma", "moments"))
+def test_sparsevi_enqueued_loop_on_two_shards(tmp_path, colsum):
+    """The device-resident weight optimisation (csrc/svi.hip) with the rows sharded over two ranks: every rank enqueues the same
+    loop (replicated sampler and weights), the column sums are all-reduced inside it; same coreset as one rank."""
+    import torch.multiprocessing as mp
+    for world in (1, 2):
+        mp.spawn(_svi_enqueued_worker, args=(world, _free_port(), str(tmp_path), colsum), nprocs=world, join=True)
+    one = np.load(tmp_path / "svie_w1_r0.npz")
+    r0, r1 = np.load(tmp_path / "svie_w2_r0.npz"), np.load(tmp_path / "svie_w2_r1.npz")
+    for k in ("idcs", "wts", "pts"):
+        assert np.array_equal(r0[k], r1[k]), k
+    assert np.array_equal(one["idcs"], r0["idcs"]) and one["idcs"].shape[0] >= 2
+    np.testing.assert_allclose(r0["wts"], one["wts"], rtol=1e-8, atol=1e-12)
+
+
 # ---- bench.py contract, single process and under torchrun (two ranks sharing the GPU) -------------------
 def _run_bench(extra_env, nproc, args):
     import json

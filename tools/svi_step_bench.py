@@ -84,3 +84,11 @@ if os.environ.get("BCX_SVI_DBG") == "9":
         print("workgroups (0..7, 2): start | us since start: loads issued+landed, k x k inputs, factor, chunk 0, chunk 1, stored | clock ticks / us")
         t[:, 0] -= t[:, 0].min()
         print(t)
+if os.environ.get("BCX_MQ_DBG"):
+    torch.cuda.synchronize()
+    for rep in range(3):
+        colsum(0)
+        torch.cuda.synchronize()
+        nct, Spad = (D + 15) // 16, (S + 15) // 16 * 16
+        print("quad, last workgroup: us since its start: products, partials stored, counter, closing loads, end:",
+              prj._mom_work[nct * Spad + 1: nct * Spad + 7].cpu().numpy()[1:])
