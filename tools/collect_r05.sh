@@ -8,7 +8,7 @@ S=$(python -c "import json;print(json.load(open('$O/scan_traffic.json')).get('_s
 for f in $(ls $O | grep -v "\.err$" | grep -v "_under_pmc.json$" | grep -v "omp_hist_c3\|tail_phases\|proj_c5shard_lds\|proj_c5shard_cache\|proj_c5shard_fetch\|_mfma_under\|bench_c4_8ranks"); do
   case $f in
     scan_traffic.json) cp $O/$f profiles/scan_traffic.json;;
-    proj_bench_kernel_times.txt|optimize_times.txt|exchange_modes_2ranks.txt|gram_times.txt|upload_rate.txt|scan_row_lengths.txt|omp_hist_c3.txt|tail_phases.txt)
+    proj_bench_kernel_times.txt|optimize_times.txt|exchange_modes_2ranks.txt|gram_times.txt|upload_rate.txt|scan_row_lengths.txt|omp_hist_c3.txt|tail_phases.txt|svi_adam_step_pieces.txt)
       { echo "# source digest $D, head $H"; cat $O/$f; } > profiles/r05_$f;;
     *) cp $O/$f profiles/r05_$f;;
   esac

@@ -21,4 +21,5 @@ python tools/optimize_bench.py 2>&1 | grep -v amdgpu.ids > gpurun_out/prof_r05/o
 BCX_OPT_COLD=1 python tools/optimize_bench.py 2>&1 | grep -v amdgpu.ids | sed "s/^/[BCX_OPT_COLD=1: from the empty passive set] /" >> gpurun_out/prof_r05/optimize_times.txt
 BCX_OPT_GRID=1 python tools/optimize_bench.py 2>&1 | grep -v amdgpu.ids | sed "s/^/[nnls_grid.hip only] /" >> gpurun_out/prof_r05/optimize_times.txt
 BCX_GRAM_NTB=-1 python tools/gram_bench.py 2>&1 | grep -v amdgpu.ids | sed "s/^/[BCX_GRAM_NTB=-1: gram_tile_kernel of rounds 3-4] /" >> gpurun_out/prof_r05/gram_times.txt
+{ python tools/svi_step_bench.py 4; BCX_SVI_DBG=9 BCX_MQ_DBG=1 python tools/svi_step_bench.py 4 | tail -9; } 2>&1 | grep -v amdgpu.ids > gpurun_out/prof_r05/svi_adam_step_pieces.txt
 ls gpurun_out/prof_r05 | wc -l
