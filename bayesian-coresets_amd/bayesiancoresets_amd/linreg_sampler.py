@@ -39,6 +39,12 @@ class LinregPosteriorSampler(object):
         U0T = np.zeros((D, self.ld))
         U0T[:, :D] = self.U0.T
         self._U0T = torch.from_numpy(U0T).to(self.device)
+        # an isotropic / diagonal prior (the reference's experiment: Sig0 = c I): R U0^T is a column scaling
+        self._U0_diag = None
+        if np.count_nonzero(self.U0 - np.diag(np.diag(self.U0))) == 0:
+            dg = np.zeros(self.ld)
+            dg[:D] = np.diag(self.U0)
+            self._U0_diag = torch.from_numpy(dg).to(self.device)
         self._mu0 = torch.from_numpy(self.mu0).to(self.device)
         self.gen = torch.Generator(device=self.device)
         self.gen.manual_seed(0 if seed is None else int(seed))
@@ -149,10 +155,13 @@ class _Plan(object):
         self.noise, self._args = noise, None
         self.rbar = noise.mean(dim=1)                       # steps x ld: the column means of every step's normal draws
         if self.fast:
-            ext = torch.cat((noise.reshape(steps * n, s.ld), self.rbar))
-            G = torch.empty_like(ext)
-            s._launch(None, s._none, ext, ext, G, mu0=s._zero_mu, tbar=s._scratch_mean)     # k = 0, zero prior mean: R U0^T
-            self.G, self.Gbar = G[:steps * n].view(steps, n, s.ld), G[steps * n:]
+            if s._U0_diag is not None:
+                self.G, self.Gbar = noise * s._U0_diag, self.rbar * s._U0_diag
+            else:
+                ext = torch.cat((noise.reshape(steps * n, s.ld), self.rbar))
+                G = torch.empty_like(ext)
+                s._launch(None, s._none, ext, ext, G, mu0=s._zero_mu, tbar=s._scratch_mean)     # k = 0, zero prior mean: R U0^T
+                self.G, self.Gbar = G[:steps * n].view(steps, n, s.ld), G[steps * n:]
 
     def buffers(self):
         """(draws S x D, their mean): the same two device buffers at every step, rewritten in stream order."""

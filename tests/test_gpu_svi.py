@@ -161,8 +161,8 @@ class _ReplaySampler(object):
         return self.inner.enqueue_plan(n, pts, steps)
 
 
-@pytest.mark.parametrize("colsum", ("mfma", "moments"))
-def test_enqueued_loop_matches_the_host_loop(bc, colsum):
+@pytest.mark.parametrize("colsum,prior", (("mfma", "iso"), ("moments", "iso"), ("moments", "dense")))
+def test_enqueued_loop_matches_the_host_loop(bc, colsum, prior):
     """Three greedy steps of SparseVICoreset, opt_itrs = 30: the ADAM loop enqueued on the device-resident weights against the
     host loop (nn_opt around projector.update + two projections, the reference's sequence) on the same normal draws."""
     import torch
@@ -170,6 +170,9 @@ def test_enqueued_loop_matches_the_host_loop(bc, colsum):
     rs = np.random.RandomState(11)
     Z = make_linreg_data(11, N, D)
     mu0, Sig0, sigsq = np.zeros(D), 4.0 * np.eye(D), 1.0
+    if prior == "dense":                   # (an isotropic prior takes a shortcut: R U0^T is a column scaling)
+        A0 = rs.randn(D, D)
+        mu0, Sig0 = 0.1 * rs.randn(D), 2.0 * (A0.dot(A0.T) / D + np.eye(D))
     g = torch.Generator(device="cuda")
     g.manual_seed(17)
     noise = torch.randn(steps * (T + 1) + 4, S, D + D % 2, dtype=torch.float64, device="cuda", generator=g)
