@@ -61,3 +61,42 @@ def test_sparsevi_host_loop_matches_reference():
     assert np.array_equal(pts, Z[idcs]) and alg.error() == 0.0
     alg.reset()
     assert alg.size() == 0 and alg.pts.shape == (0, D + 1)
+
+
+def test_enqueue_plan_is_offered_only_where_the_loop_needs_no_host():
+    """``SparseVICoreset._enqueue_plan`` (the switch between the device-resident ADAM loop and the host loop, csrc/svi.hip):
+    asked of the sampler only with a device projector, the full data set at every step, a non-empty coreset of at most 64
+    points and opt_itrs > 0; a sampler without ``enqueue_plan`` or one that declines (None) keeps the host loop."""
+    Z = make_linreg_data(3, 500, 4)
+    calls = []
+
+    class Sampler(object):
+        def __init__(self, answer):
+            self.answer = answer
+
+        def __call__(self, n, wts, pts):
+            return np.zeros((n, 4))
+
+        def enqueue_plan(self, n, pts, steps):
+            calls.append((n, np.asarray(pts).shape, steps))
+            return self.answer
+
+    def alg_for(sampler, k=2, **kw):
+        a = bc.SparseVICoreset(Z, NumpyFusedProjector(sampler, 8, 1.0), **kw)
+        a.wts, a.idcs, a.pts = np.ones(k), np.arange(k), Z[:k]
+        return a
+
+    assert alg_for(Sampler("plan"), opt_itrs=5)._enqueue_plan() == "plan" and calls == [(8, (2, 5), 5)]
+    assert alg_for(Sampler(None), opt_itrs=5)._enqueue_plan() is None                       # the sampler declines
+    assert alg_for(lambda n, w, p: np.zeros((n, 4)), opt_itrs=5)._enqueue_plan() is None    # no device form
+    n = len(calls)
+    assert alg_for(Sampler("plan"), opt_itrs=5, n_subsample_opt=100)._enqueue_plan() is None     # sub-sample drawn on the host
+    assert alg_for(Sampler("plan"), opt_itrs=0)._enqueue_plan() is None
+    assert alg_for(Sampler("plan"), k=0, opt_itrs=5)._enqueue_plan() is None
+    assert alg_for(Sampler("plan"), k=65, opt_itrs=5)._enqueue_plan() is None
+    off = alg_for(Sampler("plan"), opt_itrs=5)
+    off.ENQUEUE = False
+    assert off._enqueue_plan() is None and len(calls) == n                                  # none of these asked the sampler
+    other = bc.SparseVICoreset(Z, bc.BlackBoxProjector(Sampler("plan"), 8, lambda z, th: linreg_log_likelihood(z, th, 1.0)), opt_itrs=5)
+    other.wts, other.idcs, other.pts = np.ones(2), np.arange(2), Z[:2]
+    assert other._enqueue_plan() is None and len(calls) == n                                # host projector: host loop
