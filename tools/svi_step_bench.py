@@ -76,6 +76,7 @@ for name, fn in (("draw", draw), ("colsum (closed form)", colsum), ("coreset pro
     timed(name, fn)
 if os.environ.get("BCX_SVI_DBG") == "9":
     torch.cuda.synchronize()
+    plan.fast, plan._args = False, None         # (the per-call MFMA kernel: the one with the time stamps)
     for rep in range(3):
         plan.draw(w, 0)
         torch.cuda.synchronize()
