@@ -27,7 +27,7 @@ def _model(rs, D):
 
 
 @pytest.mark.parametrize("D,k,S", ((7, 3, 16), (30, 1, 40), (31, 12, 64), (301, 4, 320), (301, 33, 320), (100, 64, 300),
-                                   (302, 0, 310), (129, 17, 1024)))
+                                   (302, 0, 310), (129, 17, 1024), (1000, 3, 1010), (2, 2, 5), (511, 16, 520)))
 def test_posterior_draw_kernel(bc, D, k, S):
     """theta = mu_w + R Uw^T with Uw Uw^T = Sigma_w: the rows of R are the unit vectors (they return Uw itself), a zero row
     (the mean) and standard-normal rows (compared with mu_w + R Uw^T for the Uw just read)."""
