@@ -20,7 +20,7 @@ import numpy as np
 
 class LinregPosteriorSampler(object):
     KMAX = 64      # weighted points the kernel takes (csrc/svi.hip LRS_KMAX)
-    SMAX = 1024    # draws per call
+    SMAX = 4096    # draws per call (DeviceProjector's own limit on the projection dimension)
 
     def __init__(self, mu0, Sig0, sigsq, device="cuda", seed=None):
         import torch

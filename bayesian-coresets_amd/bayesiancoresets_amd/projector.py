@@ -403,6 +403,10 @@ class DeviceProjector(Projector):
         points into buf[S:], the latter as RAW log-likelihoods (uncentred: ``bcx_sparsevi_adam_step`` takes the row means),
         from argument lists built once.  The decisions of ``_moments_for`` are taken at every repetition as before."""
         self.use_draws(draws, mean=mean)
+        if self.theta.data_ptr() != draws.data_ptr():
+            # (use_draws copies rows that do not start on 16-byte boundaries: the copy would go stale at the next repetition)
+            raise ValueError("enqueue_step_plan: the draws must be usable in place (device tensor, fp64, unit column stride, "
+                             "even row stride, 16-byte aligned)")
         torch, lib = self._torch, self._lib
         Z, C = self._dev(pts), self._dev(core)
         S, k = self.theta.shape[0], C.shape[0]

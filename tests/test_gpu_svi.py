@@ -27,7 +27,7 @@ def _model(rs, D):
 
 
 @pytest.mark.parametrize("D,k,S", ((7, 3, 16), (30, 1, 40), (31, 12, 64), (301, 4, 320), (301, 33, 320), (100, 64, 300),
-                                   (302, 0, 310), (129, 17, 1024), (1000, 3, 1010), (2, 2, 5), (511, 16, 520)))
+                                   (302, 0, 310), (129, 17, 1024), (1000, 3, 1010), (2, 2, 5), (511, 16, 520), (40, 5, 3000)))
 def test_posterior_draw_kernel(bc, D, k, S):
     """theta = mu_w + R Uw^T with Uw Uw^T = Sigma_w: the rows of R are the unit vectors (they return Uw itself), a zero row
     (the mean) and standard-normal rows (compared with mu_w + R Uw^T for the Uw just read)."""
@@ -86,7 +86,7 @@ def test_posterior_sampler_limits(bc):
     rs = np.random.RandomState(0)
     mu0, Sig0, sigsq = _model(rs, 6)
     smp = bc.LinregPosteriorSampler(mu0, Sig0, sigsq)
-    assert smp.enqueue_plan(16, rs.randn(65, 7), 3) is None and smp.enqueue_plan(2048, rs.randn(3, 7), 3) is None
+    assert smp.enqueue_plan(16, rs.randn(65, 7), 3) is None and smp.enqueue_plan(4097, rs.randn(3, 7), 3) is None
     with pytest.raises(ValueError):
         smp(16, np.ones(65), rs.randn(65, 7))
     with pytest.raises(ValueError):
@@ -188,6 +188,21 @@ def test_enqueued_loop_matches_the_host_loop(bc, colsum, prior):
     assert np.array_equal(out[True][1], out[False][1]) and out[True][1].shape[0] >= 2
     np.testing.assert_allclose(out[True][0], out[False][0], rtol=1e-8, atol=1e-12)
     assert (out[True][0] > 0).any()
+
+
+def test_step_plan_refuses_draws_it_would_have_to_copy(bc):
+    import torch
+    D, S = 5, 16
+    prj = bc.DeviceProjector("linreg", lambda n, w, p: np.zeros((n, D)), S, sigsq=1.0)
+    Z = torch.randn(5000, D + 1, dtype=torch.float64, device="cuda")
+    odd = torch.zeros(S, D, dtype=torch.float64, device="cuda")           # rows of 5 doubles: not 16-byte aligned
+    with pytest.raises(ValueError):
+        prj.enqueue_step_plan(Z, Z[:2], True, odd, None)
+    even = torch.zeros(S, D + 1, dtype=torch.float64, device="cuda")[:, :D]
+    run, buf, k = prj.enqueue_step_plan(Z, Z[:2], True, even, None)
+    run()
+    torch.cuda.synchronize()
+    assert k == 2 and buf.numel() == S * 3 and bool(torch.isfinite(buf).all())
 
 
 def test_enqueue_is_declined_where_the_host_has_to_act(bc):
