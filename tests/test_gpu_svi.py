@@ -4,7 +4,8 @@ coreset/sparsevi.py:69-76, util/opt.py:4-28, the sampler of examples/linear_regr
 * the posterior-draw kernel against the NumPy restatement of the model's weighted conjugate posterior
   (tests/models.py linreg_weighted_post, pinned to reference outputs by tests/test_host_golden.py F12);
 * the ADAM-step kernel against the package's ``nn_opt`` (bit-for-bit restatement of util/opt.py, tests/test_host_golden.py);
-* the enqueued loop of ``SparseVICoreset`` against its host loop (the reference's own sequence) on the same draws."""
+* the enqueued loop of ``SparseVICoreset`` against its host loop (the reference's own sequence) and against
+  oracle/sparsevi_oracle.py, on the same draws."""
 import numpy as np
 import pytest
 
@@ -188,6 +189,34 @@ def test_enqueued_loop_matches_the_host_loop(bc, colsum, prior):
     assert np.array_equal(out[True][1], out[False][1]) and out[True][1].shape[0] >= 2
     np.testing.assert_allclose(out[True][0], out[False][0], rtol=1e-8, atol=1e-12)
     assert (out[True][0] > 0).any()
+
+
+@pytest.mark.parametrize("colsum", ("mfma", "moments"))
+def test_enqueued_loop_against_the_oracle(bc, colsum):
+    """The same loop against oracle/sparsevi_oracle.py (the NumPy restatement of sparsevi.py + projector.py + opt.py, pinned to
+    the reference's own runs F6 / F6b): the oracle's sampler callback is the device sampler's call form, fed the same normal
+    numbers the enqueued loop consumes, so both sides see the same parameter draws and differ only in who does the arithmetic."""
+    import torch
+    from oracle.sparsevi_oracle import SparseVIOracle, linreg_loglik
+    D, N, S, T, steps = 10, 12000, 48, 25, 3
+    rs = np.random.RandomState(5)
+    Z = make_linreg_data(7, N, D)
+    A0 = rs.randn(D, D)
+    mu0, Sig0, sigsq = 0.2 * rs.randn(D), 1.5 * (A0.dot(A0.T) / D + np.eye(D)), 0.8
+    g = torch.Generator(device="cuda")
+    g.manual_seed(23)
+    noise = torch.randn(steps * (T + 1) + 4, S, D + D % 2, dtype=torch.float64, device="cuda", generator=g)
+    ref_smp = _ReplaySampler(bc.LinregPosteriorSampler(mu0, Sig0, sigsq), noise)
+    orc = SparseVIOracle(Z, lambda n, w, p: ref_smp(n, np.asarray(w, dtype=np.float64), p).cpu().numpy().copy(),
+                         lambda z, th: linreg_loglik(z, th, sigsq), S, opt_itrs=T)
+    for _ in range(steps):
+        orc.step()
+    smp = _ReplaySampler(bc.LinregPosteriorSampler(mu0, Sig0, sigsq), noise)
+    alg = bc.SparseVICoreset(Z, bc.DeviceProjector("linreg", smp, S, sigsq=sigsq, colsum=colsum), opt_itrs=T)
+    alg.build(steps)
+    assert alg._enqueue_plan() is not None and smp.at - T == ref_smp.at == 1 + steps * (T + 1)      # (the probe above drew a plan's worth)
+    assert np.array_equal(alg.idcs, orc.idcs) and orc.idcs.shape[0] >= 2
+    np.testing.assert_allclose(alg.wts, orc.wts, rtol=1e-7, atol=1e-11)
 
 
 def test_step_plan_refuses_draws_it_would_have_to_copy(bc):
