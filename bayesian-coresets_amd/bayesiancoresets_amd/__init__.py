@@ -5,8 +5,8 @@
     alg.build(1000); wts, pts, idcs = alg.get()
 
 Namespace mirrors bayesiancoresets/__init__.py:1-2 for the classes on the greedy / SparseVI path (SURVEY.md section 8);
-``BatchPSVICoreset`` is out of scope and is not provided."""
-from .coreset import Coreset, HilbertCoreset, UniformSamplingCoreset, SparseVICoreset, ShardedHilbertCoreset
+``BatchPSVICoreset`` is out of scope: the name exists and raises NotImplementedError."""
+from .coreset import Coreset, HilbertCoreset, UniformSamplingCoreset, SparseVICoreset, BatchPSVICoreset, ShardedHilbertCoreset
 from .projector import BlackBoxProjector, Projector, DeviceProjector
 from .linreg_sampler import LinregPosteriorSampler
 from . import snnls

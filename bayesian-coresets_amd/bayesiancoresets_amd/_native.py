@@ -7,11 +7,14 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
+# a source checkout builds the library in-tree (make -C bayesian-coresets_amd); an installed package carries it inside (setup.py)
 LIB_PATH = os.path.join(os.path.dirname(_HERE), "lib", "libbcx.so")
+if not os.path.exists(LIB_PATH) and os.path.exists(os.path.join(_HERE, "_lib", "libbcx.so")):
+    LIB_PATH = os.path.join(_HERE, "_lib", "libbcx.so")
 
 ALG_GIGA, ALG_FW, ALG_OMP = 0, 1, 2
 F32, F64, F16 = 0, 1, 2
-OK, ERR_ARG, ERR_HIP, ERR_ZERO_ROW, ERR_ZERO_B, ERR_NOMEM, ERR_STATE = 0, -1, -2, -3, -4, -5, -6
+OK, ERR_ARG, ERR_HIP, ERR_ZERO_ROW, ERR_ZERO_B, ERR_NOMEM, ERR_STATE, ERR_EXCHANGE, ERR_TIMEOUT = 0, -1, -2, -3, -4, -5, -6, -7, -8
 IT_OK, IT_FAIL_SELECT, IT_FAIL_REWEIGHT, IT_FAIL_MONOTONE = 0, 1, 2, 3
 REC_HDR = 4
 LOAD_CENTER_ROWS = 1
@@ -29,7 +32,7 @@ SYMBOLS = (
     "bcx_build_enqueue_exact", "bcx_exchange_export", "bcx_exchange_attach", "bcx_exchange_probe", "bcx_exchange_disable", "bcx_exchange_set_timeout",
     "bcx_set_check_monotone", "bcx_project_profile", "bcx_project_profile_read", "bcx_exchange_stats", "bcx_load_rows_flags", "bcx_project_write_raw", "bcx_omp_stats", "bcx_project_select_ws", "bcx_project_select_scratch_bytes",
     "bcx_project_moments", "bcx_project_colsum_moments", "bcx_project_moments_scratch_bytes",
-    "bcx_project_colsum_moments_scratch_bytes", "bcx_gram", "bcx_gram_scratch_bytes",
+    "bcx_project_colsum_moments_scratch_bytes", "bcx_gram", "bcx_gram_scratch_bytes", "bcx_gram_check",
     "bcx_project_colsum_moments_at", "bcx_linreg_posterior_draw", "bcx_sparsevi_adam_step",
     "bcx_linreg_posterior_apply", "bcx_linreg_posterior_apply_ok",
 )
@@ -153,6 +156,7 @@ def load():
     sigs["bcx_linreg_posterior_apply_ok"] = [i32, i32]
     sigs["bcx_sparsevi_adam_step"] = [vp, i32, i32, vp, dbl, vp, i64, vp, vp, vp, vp, i32, dbl, dbl, dbl, vp, i32]
     sigs["bcx_gram"] = [vp, vp, i32, i32, i64, vp, i64, vp, i64]
+    sigs["bcx_gram_check"] = [vp, vp]
     lib.bcx_gram_scratch_bytes.restype = ctypes.c_int64
     lib.bcx_gram_scratch_bytes.argtypes = [i32, i32]
     lib.bcx_project_moments_scratch_bytes.restype = ctypes.c_int64

@@ -75,16 +75,12 @@ class ShardedHilbertCoreset(Coreset):
             raise ValueError("ShardedHilbertCoreset.__init__(): this rank holds %d projected rows, its solver shard %d"
                              % (int(vecs.shape[0]), self.snnls.n_local))
         if self.snnls.n_local:
-            try:
-                self.snnls.load_local(vecs, center=fold)
-            except TypeError:
-                # an engine built by a plain factory FUNCTION cannot be inspected before it exists: one written for the
-                # two-argument load_rows_any gets what project() would have given it (row means subtracted here)
-                if not fold:
-                    raise
+            # an engine built by a plain factory FUNCTION cannot be inspected before it exists: one written for the
+            # two-argument load_rows_any gets what project() would have given it (row means subtracted here)
+            if fold and not _H._accepts(self.snnls.engine.load_rows_any, "center"):
                 vecs = vecs - vecs.mean(axis=1)[:, None] if isinstance(vecs, np.ndarray) else vecs - vecs.mean(dim=1, keepdim=True)
                 fold = False
-                self.snnls.load_local(vecs)
+            self.snnls.load_local(vecs, center=fold)
         rc = self.snnls.finalize(None)                     # b = column sums over all shards (hilbert.py:24)
         if rc == nat.ERR_ZERO_ROW:
             raise ValueError("ShardedHilbertCoreset.__init__(): A must not have any 0 columns")   # giga.py:11-12

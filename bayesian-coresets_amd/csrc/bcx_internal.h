@@ -203,6 +203,9 @@ int bcx_launch_optimize(bcx_solver* s, double tol);
 // moments.hip: G = rows rows^T (k x k, both triangles) on the fp64 matrix cores; work: bcx_gram_rows_scratch_bytes(k, d) bytes
 int64_t bcx_gram_rows_scratch_bytes(int k, int d);
 int bcx_gram_rows(hipStream_t st, const double* rows, int k, int d, int64_t ld, double* G, int64_t ldg, double* work);
+// gram.hip: the call counter of the stream-K kernel and the check of its time-out word (first 8 bytes of the scratch)
+unsigned long long bcx_gram_sk_epoch_now();
+int bcx_gram_sk_timed_out(hipStream_t st, const double* work, unsigned long long since);
 int bcx_scan_grid(const bcx_solver* s);
 
 #ifdef BCX_TIMING

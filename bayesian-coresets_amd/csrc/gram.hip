@@ -450,16 +450,22 @@ __global__ __launch_bounds__(256, 2) void gram_sk_kernel(GramSkArgs p) {
 // ---- host side -----------------------------------------------------------------------------------------------------
 struct GramSkPlan { int ntb, nI, nJ, ntiles, nst, wgs; };
 
+// Resident workgroups of the kernel on the CURRENT device (the function attribute and the CU count are per device: a process
+// that drives several GPUs gets each one's own figure).
 template <int NTB> static int gk_resident_wgs() {
-  static const int n = [] {
-    int dev = 0, cus = 256, per_cu = 0;
-    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
-    (void)hipFuncSetAttribute((const void*)gram_sk_kernel<NTB>, hipFuncAttributeMaxDynamicSharedMemorySize, GK_LDS_BYTES(NTB));
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)gram_sk_kernel<NTB>, 256, GK_LDS_BYTES(NTB)) != hipSuccess || per_cu < 1)
-      per_cu = 1;
-    if (per_cu > 2) per_cu = 2;
-    return std::max(8, cus * per_cu / 8 * 8);
-  }();
+  static std::atomic<int> cache[64];                   // 0: not yet asked on that device
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+  int n = cache[dev].load(std::memory_order_acquire);
+  if (n > 0) return n;
+  int cus = 256, per_cu = 0;
+  if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
+  (void)hipFuncSetAttribute((const void*)gram_sk_kernel<NTB>, hipFuncAttributeMaxDynamicSharedMemorySize, GK_LDS_BYTES(NTB));
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)gram_sk_kernel<NTB>, 256, GK_LDS_BYTES(NTB)) != hipSuccess || per_cu < 1)
+    per_cu = 1;
+  if (per_cu > 2) per_cu = 2;
+  n = std::max(8, cus * per_cu / 8 * 8);
+  cache[dev].store(n, std::memory_order_release);
   return n;
 }
 
@@ -482,7 +488,7 @@ static bool gram_sk_plan(int k, int d, GramSkPlan* pl) {
   return true;
 }
 
-// scratch: partial tiles | flags | status
+// scratch: status (64 bytes, at a place that does not depend on the plan: bcx_gram_sk_timed_out) | partial tiles | flags
 int64_t bcx_gram_sk_scratch_bytes(int k, int d) {
   GramSkPlan pl;
   if (!gram_sk_plan(k, d, &pl)) return 0;
@@ -491,9 +497,25 @@ int64_t bcx_gram_sk_scratch_bytes(int k, int d) {
 
 // Flag words carry the number of the call that raised them: it starts from the clock, so the stale contents of a scratch
 // buffer (an earlier call, an earlier process) never match a later call's number.
-static unsigned long long gram_next_epoch() {
-  static std::atomic<unsigned long long> e{((unsigned long long)std::chrono::steady_clock::now().time_since_epoch().count() << 16) | 1ull};
-  return e.fetch_add(1) + 1;
+static const unsigned long long gram_epoch0 = ((unsigned long long)std::chrono::steady_clock::now().time_since_epoch().count() << 16) | 1ull;
+static std::atomic<unsigned long long>& gram_epoch_counter() {
+  static std::atomic<unsigned long long> e{gram_epoch0};
+  return e;
+}
+static unsigned long long gram_next_epoch() { return gram_epoch_counter().fetch_add(1) + 1; }
+// Every call launched after this value was read carries a later number (since == 0: every call of this process).
+unsigned long long bcx_gram_sk_epoch_now() { return gram_epoch_counter().load(); }
+// Did a workgroup of a call numbered after `since` that used the scratch `work` give up waiting for a peer's partial tile
+// (the GPU shared with another process, preemption, fewer resident workgroups than planned)?  Its G is then not valid.
+// Synchronises the stream.  1: yes, 0: no, < 0: HIP error.  (Differences, not magnitudes: the counter starts from the clock
+// and may wrap; stale contents of the scratch fall outside the few numbers issued since.)
+int bcx_gram_sk_timed_out(hipStream_t st, const double* work, unsigned long long since) {
+  unsigned long long v = 0;
+  if (hipMemcpyAsync(&v, work, sizeof v, hipMemcpyDeviceToHost, st) != hipSuccess) return BCX_ERR_HIP;
+  if (hipStreamSynchronize(st) != hipSuccess) return BCX_ERR_HIP;
+  if (since == 0) since = gram_epoch0;
+  const unsigned long long age = v - since, span = gram_epoch_counter().load() - since;
+  return age != 0 && age <= span ? 1 : 0;
 }
 
 // 1: not applicable (alignment, size: the caller uses gram_tile_kernel), 0: launched, < 0: error
@@ -503,9 +525,9 @@ int bcx_gram_sk(hipStream_t st, const double* rows, int k, int d, int64_t ld, do
   GramSkArgs a;
   a.V = rows; a.G = G; a.ld = ld; a.ldg = ldg; a.k = k; a.d = d;
   a.nI = pl.nI; a.nJ = pl.nJ; a.ntiles = pl.ntiles; a.nst = pl.nst;
-  a.part = work;
-  a.flags = (unsigned long long*)(work + (size_t)pl.wgs * GK_ROWS * GK_COLS(pl.ntb));
-  a.status = a.flags + pl.wgs;
+  a.status = (unsigned long long*)work;
+  a.part = work + 8;
+  a.flags = (unsigned long long*)(a.part + (size_t)pl.wgs * GK_ROWS * GK_COLS(pl.ntb));
   a.epoch = gram_next_epoch();                      // (never 0)
   static const int dbg = [] { const char* e = bcx_dev_env("BCX_GRAM_DBG"); return e ? atoi(e) : 0; }();
   a.dbg = dbg;

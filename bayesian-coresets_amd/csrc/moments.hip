@@ -550,6 +550,15 @@ extern "C" int bcx_gram(void* stream, const void* rows_dev, int32_t k, int32_t d
   return rc;
 }
 
+extern "C" int bcx_gram_check(void* stream, const void* work_dev) {
+  if (!work_dev) { bcx_project_set_error("bcx_gram_check: bad arguments"); return BCX_ERR_ARG; }
+  // (every call so far that used this scratch: the word only ever holds the number of a call that gave up a wait)
+  const int t = bcx_gram_sk_timed_out((hipStream_t)stream, (const double*)work_dev, 0ull);
+  if (t < 0) { bcx_project_set_error("bcx_gram_check: reading the status word failed"); return t; }
+  if (t) { bcx_project_set_error("bcx_gram: a workgroup timed out waiting for a peer's partial tile; G is not valid"); return BCX_ERR_TIMEOUT; }
+  return BCX_OK;
+}
+
 // Doubles of scratch bcx_project_colsum_moments needs: the (column tile, sample) partials, thetabar, the arrival counter.
 static void colsum_plan(int D, int S, int* nct, int* Spad) { *nct = (D + 15) / 16; *Spad = (S + 15) / 16 * 16; }
 extern "C" int64_t bcx_project_colsum_moments_scratch_bytes(int32_t D, int32_t S) {

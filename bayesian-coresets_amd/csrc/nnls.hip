@@ -776,6 +776,15 @@ int bcx_launch_optimize(bcx_solver* s, double tol) {
   BCX_HIP(hipStreamSynchronize(s->stream));
   BCX_HIP(hipMemcpy(&h, s->st, sizeof h, hipMemcpyDeviceToHost));
   const int k = h.k;
+  const unsigned long long gram_since = bcx_gram_sk_epoch_now();
+  // every place below that has synchronised the stream anyway: did a Gram launch of THIS call give up a wait (csrc/gram.hip)?
+  auto gram_ok = [&]() -> int {
+    if (!s->gram_work) return BCX_OK;
+    const int t = bcx_gram_sk_timed_out(s->stream, s->gram_work, gram_since);
+    if (t < 0) return t;
+    if (t) { s->err = "optimize: the Gram kernel timed out waiting for a peer workgroup's partial tile (GPU shared or preempted); result discarded"; return BCX_ERR_TIMEOUT; }
+    return BCX_OK;
+  };
   if (k > 0) {
     static const bool old_gram = bcx_dev_env("BCX_GRAM_DIRECT") != nullptr;     // dev: round 2's kernel (operands straight from L2)
     const int kp64 = (k + 63) / 64 * 64;       // (the warm start forms the inverse of a kp64 x kp64 block with the same kernel)
@@ -822,6 +831,7 @@ int bcx_launch_optimize(bcx_solver* s, double tol) {
       s->opt_warm += 1;
       BCX_HIP(hipStreamSynchronize(s->stream));
       BCX_HIP(hipMemcpy(&h, s->st, sizeof h, hipMemcpyDeviceToHost));
+      { const int g = gram_ok(); if (g != BCX_OK) return g; }
       if (h.omp_mode != OMP_OPT_FALLBACK) return BCX_OK;
       s->opt_warm_failed += 1;
       BCX_HIP(hipMemsetAsync((char*)s->st + offsetof(DevState, omp_mode), 0, sizeof(int32_t), s->stream));
@@ -831,10 +841,12 @@ int bcx_launch_optimize(bcx_solver* s, double tol) {
     if (rc == 0) {
       BCX_HIP(hipStreamSynchronize(s->stream));
       BCX_HIP(hipMemcpy(&h, s->st, sizeof h, hipMemcpyDeviceToHost));
+      { const int g = gram_ok(); if (g != BCX_OK) return g; }
       if (h.omp_mode != OMP_OPT_FALLBACK) return BCX_OK;
       s->opt_fallbacks += 1;
       BCX_HIP(hipMemsetAsync((char*)s->st + offsetof(DevState, omp_mode), 0, sizeof(int32_t), s->stream));
     }
+    { const int g = gram_ok(); if (g != BCX_OK) return g; }      // (the forms below read the same G)
     rc = bcx_launch_optimize_grid(s, tol, k);             // 1 = not applicable
     if (rc <= 0) return rc;
   }

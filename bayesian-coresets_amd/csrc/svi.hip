@@ -25,6 +25,7 @@
 //                     zero, on the device-resident weights; the step-size schedule and the bias corrections arrive as data
 //                     (the caller evaluates step_sched(i), 1 - b1^(i+1), 1 - b2^(i+1) on the host once per greedy step).
 // The host enqueues opt_itrs x (draw, column sums, coreset projection, ADAM) and reads the weights back once.
+#include <atomic>
 #include <string>
 #include "bcx_internal.h"
 #include "dev_util.h"
@@ -515,10 +516,15 @@ extern "C" int bcx_linreg_posterior_apply(void* stream, int32_t k, int32_t D, in
   a.Gbar = (const double*)Gbar_dev; a.theta = (double*)theta_dev; a.tbar = (double*)tbar_dev;
   a.sigsq = sigsq; a.k = k; a.D = D; a.S = S; a.ld = ld;
   const size_t lds = (size_t)2 * k * ld * sizeof(double);
-  static size_t lds_max = 0;
-  if (lds > 32 * 1024 && lds > lds_max) {
-    SVI_HIP(hipFuncSetAttribute((const void*)lrs_apply_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    lds_max = lds;
+  if (lds > 32 * 1024) {
+    // per DEVICE (a process may drive several): the largest request so far on the current one
+    static std::atomic<size_t> lds_max[64];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+    if (lds > lds_max[dev].load(std::memory_order_acquire)) {
+      SVI_HIP(hipFuncSetAttribute((const void*)lrs_apply_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      lds_max[dev].store(lds, std::memory_order_release);
+    }
   }
   hipLaunchKernelGGL(lrs_apply_kernel, dim3((S + 1 + 3) / 4), dim3(256), lds, (hipStream_t)stream, a);
   SVI_HIP(hipGetLastError());

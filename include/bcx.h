@@ -39,7 +39,8 @@ enum {
   BCX_ERR_ZERO_B = -4,     /* ||b|| == 0 for GIGA: reference raises NumericalPrecisionError (giga.py:16-17) */
   BCX_ERR_NOMEM = -5,
   BCX_ERR_STATE = -6,      /* solver not initialised / already latched where not allowed */
-  BCX_ERR_EXCHANGE = -7    /* peer mailbox: a shard's record did not arrive in time (see bcx_exchange_attach) */
+  BCX_ERR_EXCHANGE = -7,   /* peer mailbox: a shard's record did not arrive in time (see bcx_exchange_attach) */
+  BCX_ERR_TIMEOUT = -8     /* a wait between workgroups of one launch expired (GPU shared / preempted): the result is not valid */
 };
 
 /* per-iteration status written to the trace (snnls.py:41-74 outcome of one loop iteration) */
@@ -300,6 +301,12 @@ int bcx_sparsevi_adam_step(void* stream, int32_t k, int32_t S, const void* colsu
 int64_t bcx_gram_scratch_bytes(int32_t k, int32_t d);
 int bcx_gram(void* stream, const void* rows_dev, int32_t k, int32_t d, int64_t ld, void* G_dev, int64_t ldg,
              void* work_dev, int64_t work_bytes);
+/* bcx_gram is asynchronous; the kernel that balances the tiles over the chip hands partial tiles between workgroups and
+ * gives up a wait after 5 s (a GPU shared with another process, preemption).  bcx_gram_check synchronises `stream` and
+ * returns BCX_ERR_TIMEOUT if a call of this process that used the scratch `work_dev` gave up -- that call's G is
+ * not valid (zero the first 8 bytes of the scratch to re-arm); BCX_OK otherwise.  optimize() (bcx_optimize) makes the same
+ * check on its own Gram launches and returns BCX_ERR_TIMEOUT. */
+int bcx_gram_check(void* stream, const void* work_dev);
 const char* bcx_project_last_error(void);
 /* Measurement: hipEvents around the projection kernel alone, recorded on the stream the kernel is launched on.
  * bcx_project_profile(1) starts timing every later projection launch of the calling host thread, (0) stops;

@@ -857,7 +857,7 @@ def test_gram_operator_matches_numpy(bc, k, d, pad):
     st = int(torch.cuda.current_stream().cuda_stream)
     rc = lib.bcx_gram(st, buf.data_ptr(), k, d, ld, G.data_ptr(), ldg, work.data_ptr(), work.numel() * 8)
     assert rc == 0, lib.bcx_project_last_error()
-    torch.cuda.synchronize()
+    assert lib.bcx_gram_check(st, work.data_ptr()) == 0      # (synchronises; no hand-off between workgroups timed out)
     got = G.cpu().numpy()
     want = V @ V.T
     np.testing.assert_allclose(got[:, :k], want, rtol=1e-12, atol=1e-12 * np.abs(want).max())
@@ -866,3 +866,8 @@ def test_gram_operator_matches_numpy(bc, k, d, pad):
     # argument checks: scratch too small, too many rows
     assert lib.bcx_gram(st, buf.data_ptr(), k, d, ld, G.data_ptr(), ldg, work.data_ptr(), need - 8) != 0
     assert lib.bcx_gram_scratch_bytes(20000, 8) == -1
+    # the time-out word of the stream-K kernel: a call number of this process in the first 8 bytes of the scratch is reported,
+    # anything else (stale contents, an earlier process) is not
+    work[:1].view(torch.int64).fill_(0x1234567)
+    assert lib.bcx_gram_check(st, work.data_ptr()) == 0
+    assert lib.bcx_gram_check(st, None) == nat.ERR_ARG

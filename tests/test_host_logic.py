@@ -17,6 +17,9 @@ def test_namespace_matches_reference_surface():
     for name in ("nn_opt", "set_verbosity", "set_tolerance", "TOL"):
         assert hasattr(bc.util, name)
     assert issubclass(bc.util.errors.NumericalPrecisionError, Exception)
+    # the one exported name that is not on the accelerated path says so when constructed (bayesiancoresets/__init__.py:1)
+    with pytest.raises(NotImplementedError):
+        bc.BatchPSVICoreset(np.zeros((3, 2)), None, 10)
 
 
 def test_tolerance_global():
