@@ -192,7 +192,7 @@ class SparseVICoreset(Coreset):
         device-resident weights (``enqueue_plan``: ``bc.LinregPosteriorSampler``).  Same decision on every rank."""
         prj = self.ll_projector
         if not (self.ENQUEUE and isinstance(prj, DeviceProjector) and self.n_subsample_opt is None and self.opt_itrs > 0
-                and 0 < self.wts.shape[0] <= 64 and prj.projection_dimension <= 8192):
+                and 0 < self.wts.shape[0] <= 4096 and prj.projection_dimension <= 8192):
             return None
         make = getattr(prj.sampler, "enqueue_plan", None)
         return None if make is None else make(prj.projection_dimension, self.pts, self.opt_itrs)
@@ -209,14 +209,22 @@ class SparseVICoreset(Coreset):
         w, m1, m2, sched_d = state[:k], state[k:2 * k], state[2 * k:3 * k], state[3 * k:]
         theta, mean = plan.buffers()
         run, buf, _ = prj.enqueue_step_plan(self.data, self._core_points_device(), True, theta, mean)    # sparsevi.py:35-41
-        adam, args = prj._lib.bcx_sparsevi_adam_step, [prj._stream(), k, S, buf.data_ptr(), 1.0, buf[S:].data_ptr(), S, w.data_ptr(),
-                                                       m1.data_ptr(), m2.data_ptr(), sched_d.data_ptr(), 0, b1, b2, eps, None, 1]
+        # (more than 64 weights: the ADAM step is two launches over slabs of weights and needs scratch, csrc/svi.hip)
+        need = int(prj._lib.bcx_sparsevi_adam_scratch_bytes(k, S))
+        work = torch.empty(max(need // 8, 1), dtype=torch.float64, device=prj.device)
+        adam, args = prj._lib.bcx_sparsevi_adam_step_ws, [prj._stream(), k, S, buf.data_ptr(), 1.0, buf[S:].data_ptr(), S, w.data_ptr(),
+                                                          m1.data_ptr(), m2.data_ptr(), sched_d.data_ptr(), 0, b1, b2, eps, None, 1,
+                                                          work.data_ptr(), work.numel() * 8]
         for i in range(T):
             plan.draw(w, i)                                                       # sparsevi.py:25
             run()
             args[11] = i
             prj._check(adam(*args))
-        return w.cpu().numpy()
+        out = w.cpu().numpy()
+        check = getattr(plan, "check", None)
+        if check is not None:
+            check()                                                               # (a factorisation that lost its workgroups raises)
+        return out
 
     def error(self):
         return 0.0   # as in the reference (sparsevi.py:78-79: KL estimate not implemented)

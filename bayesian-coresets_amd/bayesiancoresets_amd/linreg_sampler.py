@@ -5,8 +5,10 @@ main.py:124-147: prior theta ~ N(mu0, Sig0), noise variance sigsq, rows z = [x, 
     Sigma_w^-1 = Sig0^-1 + X^T diag(w) X / sigsq,      mu_w = Sigma_w (Sig0^-1 mu0 + X^T diag(w) y / sigsq)
 
 SparseVI calls its sampler once per ADAM step (sparsevi.py:25 -> projector.update), 1 + opt_itrs times per greedy step,
-with the SAME points and new weights.  The draws are formed by one kernel (csrc/svi.hip: a rank-k correction of the
-prior's factor through a k x k Cholesky, k = number of weighted points <= 64), in two ways:
+with the SAME points and new weights.  The draws are formed on the device -- for a few points by one kernel (csrc/svi.hip: a
+rank-k correction of the prior's factor through a k x k Cholesky inside one workgroup), for more (the reference's experiment
+grows the coreset to 300 points at D = 301) by the reference's own arithmetic, theta = mu_w + R L^-1 with L L^T the D x D
+precision (csrc/lrpost.hip: one cooperative launch factors it and forms L^-1 and mu_w) -- in two ways:
 
 * ``sampler(n, wts, pts)``: the reference's sampler signature -- uploads the k weights, returns the draws as a device
   tensor (``DeviceProjector`` uses them in place);
@@ -19,8 +21,11 @@ import numpy as np
 
 
 class LinregPosteriorSampler(object):
-    KMAX = 64      # weighted points the kernel takes (csrc/svi.hip LRS_KMAX)
+    KMAX = 4096    # weighted points (csrc/lrpost.hip)
+    KLOW = 64      # ... that the rank-k form of csrc/svi.hip takes (LRS_KMAX)
+    DMAX = 1024    # features the D x D form takes (csrc/lrpost.hip LP_NB * LP_MAX_NT)
     SMAX = 4096    # draws per call (DeviceProjector's own limit on the projection dimension)
+    NOISE_BUDGET = 2 << 30      # bytes of pre-drawn normal numbers (+ their images) an enqueue plan may hold
 
     def __init__(self, mu0, Sig0, sigsq, device="cuda", seed=None):
         import torch
@@ -53,6 +58,9 @@ class LinregPosteriorSampler(object):
         self._none = torch.zeros(1, dtype=torch.float64, device=self.device)
         self._zero_mu = torch.zeros(D, dtype=torch.float64, device=self.device)
         self._scratch_mean = torch.empty(D, dtype=torch.float64, device=self.device)
+        # the D x D form (csrc/lrpost.hip): prior precision and Sig0^-1 mu0 once; scratch, L^-1 and mu_w on first use
+        self._S0inv_host = np.linalg.inv(self.Sig0)
+        self._factor = None
 
     # -- noise: separate hooks so that a test can feed both entry points the same numbers --------------------------------
     def _noise(self, n):
@@ -63,7 +71,45 @@ class LinregPosteriorSampler(object):
 
     # -- per-point state ------------------------------------------------------------------------------------------------------
     def supports(self, n, k):
-        return 0 <= k <= self.KMAX and 1 <= n <= self.SMAX
+        return 0 <= k <= (self.KMAX if self.D <= self.DMAX else self.KLOW) and 1 <= n <= self.SMAX
+
+    def _low_rank(self, k):
+        """Which form serves k points: the rank-k correction inside one workgroup while its per-step kernel applies
+        (csrc/svi.hip lrs_apply_kernel: X and B2 in LDS), the D x D factorisation beyond (measured at D = 301: the k x k
+        Cholesky every workgroup of lrs_draw_kernel repeats costs 140 us per call at k = 32 and 350 at k = 64)."""
+        if self.D > self.DMAX:
+            return True
+        return k == 0 or bool(self._lib.bcx_linreg_posterior_apply_ok(k, self.ld))
+
+    def _factor_state(self):
+        f = self._factor
+        if f is None:
+            torch, D = self._torch, self.D
+            need = int(self._lib.bcx_linreg_posterior_factor_scratch_bytes(D))
+            f = self._factor = {
+                "S0inv": torch.from_numpy(np.ascontiguousarray(self._S0inv_host)).to(self.device),
+                "rhs0": torch.from_numpy(self._S0inv_host.dot(self.mu0)).to(self.device),
+                "work": torch.empty((need + 7) // 8, dtype=torch.float64, device=self.device),
+                "Linv": torch.zeros(D, self.ld, dtype=torch.float64, device=self.device),     # (the upper triangle stays zero)
+                "mu": torch.zeros(D, dtype=torch.float64, device=self.device),
+            }
+        return f
+
+    def _factor_args(self, st, w_dev):
+        """Argument list of bcx_linreg_posterior_factor at the points ``st`` and the device-resident weights ``w_dev``."""
+        f = self._factor_state()
+        stream = int(self._torch.cuda.current_stream(self.device).cuda_stream)
+        return [stream, st["k"], self.D, self.ld, w_dev.data_ptr(), st["X"].data_ptr(), st["y"].data_ptr(), f["S0inv"].data_ptr(), self.D,
+                f["rhs0"].data_ptr(), self.sigsq, f["work"].data_ptr(), f["work"].numel() * 8, f["Linv"].data_ptr(), self.ld,
+                f["mu"].data_ptr()]
+
+    def factor_status(self):
+        """Synchronises; raises if the last factorisation's workgroups lost each other or met a non-positive pivot."""
+        if self._factor is not None:
+            stream = int(self._torch.cuda.current_stream(self.device).cuda_stream)
+            rc = self._lib.bcx_linreg_posterior_factor_status(stream, self.D, self._factor["work"].data_ptr())
+            if rc != 0:
+                raise self._nat.EngineError(rc, self._lib.bcx_project_last_error().decode())
 
     def _points(self, pts):
         """Device block [K0 (k x k) | X mu0 (k) | y (k) | X U0 (k x ld) | X Sig0 (k x ld)] of the points ``pts`` (k x (D+1))."""
@@ -75,17 +121,23 @@ class LinregPosteriorSampler(object):
         if self._pts_key is not None and self._pts_key.shape == pts.shape and np.array_equal(self._pts_key, pts):
             return self._pts_state
         X, y = pts[:, :-1], pts[:, -1]
+        Xp = np.zeros((k, self.ld))
+        Xp[:, :self.D] = X
+        if not self._low_rank(k):
+            # the D x D form needs the features and the responses only
+            d = torch.from_numpy(np.concatenate((y, np.zeros(k % 2), Xp.ravel()))).to(self.device)
+            st = {"k": k, "y": d[:k], "X": d[k + k % 2:], "blob": d, "low_rank": False}
+            self._pts_key, self._pts_state = pts.copy(), st
+            return st
         XU0, XS0 = np.zeros((k, self.ld)), np.zeros((k, self.ld))
         XU0[:, :self.D] = X.dot(self.U0)
         XS0[:, :self.D] = X.dot(self.Sig0)
         K0 = XU0.dot(XU0.T)
-        Xp = np.zeros((k, self.ld))
-        Xp[:, :self.D] = X
         pad = (k * k + 2 * k) % 2                           # the k x ld blocks start on 16-byte boundaries
         blob = np.concatenate((K0.ravel(), X.dot(self.mu0), y, np.zeros(pad), XU0.ravel(), XS0.ravel(), Xp.ravel()))
         d = torch.from_numpy(blob).to(self.device)
         o = k * k
-        st = {"k": k, "K0": d[:o], "xmu0": d[o:o + k], "y": d[o + k:o + 2 * k]}
+        st = {"k": k, "K0": d[:o], "xmu0": d[o:o + k], "y": d[o + k:o + 2 * k], "low_rank": True}
         o += 2 * k + pad
         n = k * self.ld
         st["XU0"], st["XS0"], st["X"] = d[o:o + n], d[o + n:o + 2 * n], d[o + 2 * n:o + 3 * n]
@@ -93,12 +145,14 @@ class LinregPosteriorSampler(object):
         self._pts_key, self._pts_state = pts.copy(), st
         return st
 
-    def _launch(self, st, w_dev, R, rbar, theta, mu0=None, tbar=None):
+    def _launch(self, st, w_dev, R, rbar, theta, mu0=None, tbar=None, U0T=None):
+        """lrs_draw_kernel: theta = mu + [R; rbar] Uw^T.  ``U0T`` / ``mu0`` override the prior's factor and mean (with st = None:
+        theta = mu0 + R U0T -- the D x D form passes L^-1 and mu_w)."""
         k = st["k"] if st is not None else 0
         lib, dp = self._lib, (lambda key: st[key].data_ptr() if k else None)
         stream = int(self._torch.cuda.current_stream(self.device).cuda_stream)
         rc = lib.bcx_linreg_posterior_draw(stream, k, self.D, self.ld, w_dev.data_ptr() if k else None, dp("K0"), dp("xmu0"), dp("y"),
-                                           dp("XU0"), dp("XS0"), self._U0T.data_ptr(), (self._mu0 if mu0 is None else mu0).data_ptr(),
+                                           dp("XU0"), dp("XS0"), (self._U0T if U0T is None else U0T).data_ptr(), (self._mu0 if mu0 is None else mu0).data_ptr(),
                                            self.sigsq, R.data_ptr(), rbar.data_ptr(), R.shape[0], theta.data_ptr(),
                                            (self._tbar if tbar is None else tbar).data_ptr())
         if rc != 0:
@@ -122,7 +176,15 @@ class LinregPosteriorSampler(object):
             w_dev = torch.from_numpy(np.ascontiguousarray(wts, dtype=np.float64)).to(self.device)
         theta = self._theta_buf(n)
         R = self._noise(n)
-        self._launch(st, w_dev, R, R.mean(dim=0), theta)
+        if k and not st["low_rank"]:
+            rc = self._lib.bcx_linreg_posterior_factor(*self._factor_args(st, w_dev))
+            if rc != 0:
+                raise self._nat.EngineError(rc, self._lib.bcx_project_last_error().decode())
+            f = self._factor
+            self._launch(None, self._none, R, R.mean(dim=0), theta, mu0=f["mu"], U0T=f["Linv"])
+            self.factor_status()
+        else:
+            self._launch(st, w_dev, R, R.mean(dim=0), theta)
         self.mean = self._tbar
         return theta[:, :self.D]
 
@@ -132,6 +194,8 @@ class LinregPosteriorSampler(object):
         pts = np.atleast_2d(np.asarray(pts, dtype=np.float64))
         if pts.shape[0] < 1 or not self.supports(n, pts.shape[0]):
             return None
+        if 3 * steps * (n + 1) * self.ld * 8 > self.NOISE_BUDGET:
+            return None                                     # (the caller's host loop draws step by step)
         return _Plan(self, n, self._points(pts), self._noise_block(steps, n))
 
 
@@ -145,8 +209,9 @@ class _Plan(object):
         s, torch = sampler, sampler._torch
         self.s, self.n, self.st = s, n, st
         self.theta = s._theta_buf(n)
-        self._args = None
-        self.fast = bool(s._lib.bcx_linreg_posterior_apply_ok(st["k"], s.ld))
+        self._args, self._w_ptr, self._pre = None, None, None
+        self.fast = bool(st["low_rank"] and s._lib.bcx_linreg_posterior_apply_ok(st["k"], s.ld))
+        self.factored = not st["low_rank"]
         self.set_noise(noise)
 
     def set_noise(self, noise):
@@ -170,16 +235,25 @@ class _Plan(object):
     def draw(self, w_dev, i):
         """Enqueue the draws for ADAM step ``i`` at the device-resident weights ``w_dev``; returns ``buffers()``."""
         a = self._args
-        if a is None or a[4] != w_dev.data_ptr():
-            # the argument list, built once: per step only the two pointers into the noise (or its image) move
+        if a is None or self._w_ptr != w_dev.data_ptr():
+            # the argument lists, built once: per step only the two pointers into the noise (or its image) move
             s, st = self.s, self.st
             stream = int(s._torch.cuda.current_stream(s.device).cuda_stream)
+            self._w_ptr, self._pre = w_dev.data_ptr(), None
             if self.fast:
                 a = [stream, st["k"], s.D, s.ld, w_dev.data_ptr(), st["K0"].data_ptr(), st["xmu0"].data_ptr(), st["y"].data_ptr(),
                      st["X"].data_ptr(), st["XS0"].data_ptr(), s._mu0.data_ptr(), s.sigsq, 0, 0, self.n, self.theta.data_ptr(),
                      s._tbar.data_ptr()]
                 self._at, self._fn = (12, 13), s._lib.bcx_linreg_posterior_apply
                 rows, means = self.G, self.Gbar
+            elif self.factored:
+                # the D x D form: factor at the current weights (csrc/lrpost.hip), then theta = mu_w + R L^-1
+                self._pre = (s._lib.bcx_linreg_posterior_factor, s._factor_args(st, w_dev))
+                f = s._factor
+                a = [stream, 0, s.D, s.ld, None, None, None, None, None, None, f["Linv"].data_ptr(), f["mu"].data_ptr(), s.sigsq, 0, 0,
+                     self.n, self.theta.data_ptr(), s._tbar.data_ptr()]
+                self._at, self._fn = (13, 14), s._lib.bcx_linreg_posterior_draw
+                rows, means = self.noise, self.rbar
             else:
                 a = [stream, st["k"], s.D, s.ld, w_dev.data_ptr(), st["K0"].data_ptr(), st["xmu0"].data_ptr(), st["y"].data_ptr(),
                      st["XU0"].data_ptr(), st["XS0"].data_ptr(), s._U0T.data_ptr(), s._mu0.data_ptr(), s.sigsq, 0, 0, self.n,
@@ -189,8 +263,17 @@ class _Plan(object):
             self._r0, self._rstep = rows.data_ptr(), rows.stride(0) * 8
             self._b0, self._bstep = means.data_ptr(), means.stride(0) * 8
             self._args = a
+        if self._pre is not None:
+            rc = self._pre[0](*self._pre[1])
+            if rc != 0:
+                raise self.s._nat.EngineError(rc, self.s._lib.bcx_project_last_error().decode())
         a[self._at[0]], a[self._at[1]] = self._r0 + i * self._rstep, self._b0 + i * self._bstep
         rc = self._fn(*a)
         if rc != 0:
             raise self.s._nat.EngineError(rc, self.s._lib.bcx_project_last_error().decode())
         return self.buffers()
+
+    def check(self):
+        """After the loop's read-back: did every factorisation of the loop complete (csrc/lrpost.hip's status word)?"""
+        if self.factored:
+            self.s.factor_status()

@@ -1,0 +1,613 @@
+// lrpost.hip -- the weighted conjugate posterior of Gaussian linear regression for ANY number of weighted points, from
+// weights that live on the device (reference: examples/common/model_linreg.py:26-41 weighted_post, the sampler of
+// examples/linear_regression/main.py:141-147):
+//
+//     P = Sig0^-1 + X^T diag(w) X / sigsq = L L^T,     U = L^-T  (Sigma_w = U U^T),     mu_w = Sigma_w (Sig0^-1 mu0 + X^T (w y) / sigsq),
+//     draws  theta = mu_w + R U^T = mu_w + R L^-1      for standard-normal R  -- the reference's own factor and arithmetic.
+//
+// csrc/svi.hip serves a few points as a rank-k correction of the prior's factor inside ONE workgroup; beyond that the
+// k x k system no longer fits a workgroup and, for k near D (the reference's experiment runs the coreset up to 300 points
+// at D = 301), the D x D form is the smaller one.  SparseVI needs this factorisation once per ADAM step, 100 times per
+// greedy step, each depending on the last (sparsevi.py:69-76), so what counts is the LATENCY of one D x D Cholesky +
+// inverse -- 19 MFLOP behind a chain of D dependent pivots -- not its throughput:
+//
+//   lrp_form_kernel   P (lower triangle, 32 x 32 tiles) on the fp64 matrix cores and the right-hand side; clears the flags of
+//                     the next kernel.  One workgroup per tile of P.
+//   lrp_chol_kernel   ONE launch of 3 + H co-resident workgroups: blocked Cholesky of the augmented matrix [P; I; rhs^T] --
+//                     the row operations that turn P into L turn I into L^-T and rhs^T into (L^-1 rhs)^T, a forward
+//                     substitution that rides along (no sweep after the factorisation).  LEFT-looking: tile (R, p) of block
+//                     column p is  (init - sum_{q<p} tile(R, q) L_{p,q}^T) W_pp^T,  W_pp = L_pp^-1, formed in one go when
+//                     column p's turn comes -- nothing is ever read-modified-written across steps.
+//                       * workgroup 0, the CHAIN, factors every diagonal tile (one wave, a row per lane; the identity rows
+//                         in the other 32 lanes give W_pp for free) and forms the sub-diagonal tile L_{p+1,p} and the next
+//                         diagonal tile itself, so the critical path diag(p) -> diag(p+1) never leaves the workgroup;
+//                       * workgroups 1 and 2, the ASSISTANTS, pre-accumulate for the chain the two sums over columns q <= p - 2
+//                         of those tiles (they are ready a step early); while wave 0 factors, the chain's waves 1-3 add the
+//                         one term of column p - 1;
+//                       * H helpers share the other tiles of column p: accumulate as soon as column p - 1 is complete
+//                         (counter C[p-1]) -- that overlaps diag(p) -- then wait for W_pp (flag F1[p]), multiply, publish
+//                         (C[p]); finished tiles of L^-T leave transposed, as L^-1 row-major for the draw kernel.
+//                     Every tile that crosses workgroups is stored WRITE-THROUGH (sc1) and read with sc1 loads: a hand-off is
+//                     "every storing wave drains its stores, workgroup barrier, one relaxed agent-scope flag / counter", no
+//                     release / acquire fence (a release fence behind 16 KB of fresh tiles costs ~6.5 us and sat twice per
+//                     step on the critical path of the first version: 146 us for D = 301).
+//                     At the end mu_w = L^-T (L^-1 rhs) from the finished tiles.
+//   the draws         theta = mu_w + [R; Rbar] L^-1: csrc/svi.hip's lrs_draw_kernel with L^-1 in the place of the prior's
+//                     factor (k = 0).
+//
+// Tiles are stored "k-grouped": element (row, col) of a 32 x 32 tile at (col / 4) * 128 + row * 4 + col % 4, so that the
+// 16 x 4 operand slices of v_mfma_f64_16x16x4_f64 -- lane l: row l % 16, k = l / 16 -- are 512 contiguous bytes per wave load;
+// every product here has the form C (+)= A B^T with both operands read that way.
+#include <atomic>
+#include <string>
+#include "bcx_internal.h"
+#include "dev_util.h"
+
+typedef double lp4d __attribute__((ext_vector_type(4)));
+
+#define LP_NB 32
+#define LP_TILE (LP_NB * LP_NB)
+#define LP_MAX_NT 32                 // D <= 1024
+#define LP_MAX_H 60
+#define LP_FIXED_WGS 3               // the chain and its two assistants
+
+struct LpArgs {
+  // inputs of the form kernel
+  const double* w; const double* X; const double* y;      // k weights, k x ldx features (padding columns zero), k responses
+  const double* S0inv; const double* rhs0;                 // D x lds0 prior precision, Sig0^-1 mu0
+  double sigsq;
+  int k, D, ldx, lds0;
+  // work
+  double* TT;     // nt * nt tiles of P (lower block triangle), [i * nt + j]: written by lrp_form_kernel, read-only afterwards
+  double* LT;     // finished tiles of L (strictly lower block triangle)
+  double* BL;     // (nt + 1) * nt finished tiles of the bottom part: rows 0 .. nt-1 L^-T (upper block triangle), row nt the row (L^-1 rhs)^T
+  double* XW;     // nt tiles: the inverses of the diagonal tiles, W_pp = L_pp^-1 (rows c, k)
+  double* AS;     // nt tiles: P_{p+1,p} - sum_{q <= p-2} L_{p+1,q} L_{p,q}^T        (assistant 1 -> chain)
+  double* AD;     // nt tiles: P_{p+1,p+1} - sum_{q <= p-2} L_{p+1,q} L_{p+1,q}^T    (assistant 2 -> chain)
+  double* rhs;    // 32 nt doubles: Sig0^-1 mu0 + X^T (w y) / sigsq, zero padded
+  int* flags;     // F1 [nt] | C [nt] | A1 [nt] | A2 [nt] | status
+  // outputs
+  double* Linv; int64_t ldl;   // D x ldl row-major, lower triangular (the upper triangle is never written: the caller zeroes it once)
+  double* mu;                  // D
+  int nt, H;
+  long long timeout_ticks;
+  long long* dbg;              // dev (BCX_LRP_DBG=1): wall-clock stamps [workgroup][step][8] (tools/lrp_timeline.py); else null
+};
+
+static __device__ __forceinline__ int lp_kg(int row, int col) { return (col >> 2) * 128 + row * 4 + (col & 3); }
+
+// write-through (sc1) store / sc1 load of one double: coherent across XCDs without fences (the reader bypasses its L1, the
+// writer's line leaves its L2)
+static __device__ __forceinline__ double lp_ld(const double* p) {
+  return __longlong_as_double((long long)__hip_atomic_load((const unsigned long long*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+}
+static __device__ __forceinline__ void lp_st(double* p, double v) {
+  __hip_atomic_store((unsigned long long*)p, (unsigned long long)__double_as_longlong(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// operand slice of a k-grouped tile: rows 16 half .. 16 half + 15, all 32 values of the contraction index.  COH: the tile is
+// (or may have been) written by another workgroup of this launch.
+template <bool COH>
+static __device__ __forceinline__ void lp_rows(const double* tile, int half, int lane, double (&v)[8]) {
+  const int o = (half * 16 + (lane & 15)) * 4 + (lane >> 4);
+#pragma unroll
+  for (int t = 0; t < 8; ++t) v[t] = COH ? lp_ld(tile + t * 128 + o) : tile[t * 128 + o];
+}
+static __device__ __forceinline__ lp4d lp_mma(const double (&a)[8], const double (&b)[8], lp4d acc) {
+#pragma unroll
+  for (int t = 0; t < 8; ++t) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[t], b[t], acc, 0, 0, 0);
+  return acc;
+}
+static __device__ __forceinline__ lp4d lp_mma_neg(const double (&a)[8], const double (&b)[8], lp4d acc) {
+#pragma unroll
+  for (int t = 0; t < 8; ++t) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-a[t], b[t], acc, 0, 0, 0);
+  return acc;
+}
+// quadrant (rb, cb) of a k-grouped tile in the accumulator layout: register r holds (row 16 rb + lane / 16 + 4 r, col 16 cb + lane % 16)
+template <bool COH>
+static __device__ __forceinline__ lp4d lp_quad_load(const double* tile, int rb, int cb, int lane) {
+  lp4d c;
+  const int col = cb * 16 + (lane & 15), row0 = rb * 16 + (lane >> 4);
+#pragma unroll
+  for (int r = 0; r < 4; ++r) c[r] = COH ? lp_ld(tile + lp_kg(row0 + 4 * r, col)) : tile[lp_kg(row0 + 4 * r, col)];
+  return c;
+}
+template <bool COH>
+static __device__ __forceinline__ void lp_quad_store(double* tile, int rb, int cb, int lane, lp4d c) {
+  const int col = cb * 16 + (lane & 15), row0 = rb * 16 + (lane >> 4);
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    if (COH) lp_st(tile + lp_kg(row0 + 4 * r, col), c[r]);
+    else tile[lp_kg(row0 + 4 * r, col)] = c[r];
+  }
+}
+
+// ---- P and the right-hand side ------------------------------------------------------------------------------------------
+// Workgroups 0 .. nt (nt + 1) / 2 - 1: tile (i, j), i >= j, of P = S0inv + X^T diag(w / sigsq) X (k-grouped, into TT); rows /
+// columns >= D are padded with the identity.  Workgroups after them, one per block of 32 columns: that block of the
+// right-hand side; the first of them clears the flags.
+__global__ __launch_bounds__(256) void lrp_form_kernel(LpArgs a) {
+  __shared__ double sw[4096];                       // w_j / sigsq (the second kind of workgroup: w_j y_j / sigsq)
+  __shared__ double sred[8][32];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int nt = a.nt, D = a.D, k = a.k;
+  const int ntop = nt * (nt + 1) / 2;
+  if ((int)blockIdx.x >= ntop) {
+    const int j = blockIdx.x - ntop;
+    if (j == 0) for (int e = tid; e < 4 * nt + 1; e += 256) a.flags[e] = 0;
+    for (int e = tid; e < k; e += 256) sw[e] = fmax(a.w[e], 0.0) / a.sigsq * a.y[e];
+    __syncthreads();
+    // rhs0 + X^T (w y) / sigsq for the 32 columns of block j: eight groups of points, added in group order
+    const int c = j * 32 + (tid & 31), g = tid >> 5;
+    double s = 0.0;
+    if (c < D) {
+      int jj = g;
+      for (; jj + 24 < k; jj += 32) {               // (four independent loads in flight)
+        const double x0 = a.X[(size_t)jj * a.ldx + c], x1 = a.X[(size_t)(jj + 8) * a.ldx + c];
+        const double x2 = a.X[(size_t)(jj + 16) * a.ldx + c], x3 = a.X[(size_t)(jj + 24) * a.ldx + c];
+        s += sw[jj] * x0; s += sw[jj + 8] * x1; s += sw[jj + 16] * x2; s += sw[jj + 24] * x3;
+      }
+      for (; jj < k; jj += 8) s += sw[jj] * a.X[(size_t)jj * a.ldx + c];
+    }
+    sred[g][tid & 31] = s;
+    __syncthreads();
+    if (tid < 32) {
+      double v = 0.0;
+      if (c < D) {
+        v = a.rhs0[c];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) v += sred[q][tid];
+      }
+      a.rhs[c] = v;
+    }
+    return;
+  }
+  int i = 0, t = blockIdx.x;
+  while (t >= i + 1) { t -= i + 1; ++i; }
+  const int j = t;                                  // tile (i, j), j <= i
+  for (int e = tid; e < k; e += 256) sw[e] = fmax(a.w[e], 0.0) / a.sigsq;
+  const int rb = wave >> 1, cb = wave & 1;
+  const int li = lane & 15, lk = lane >> 4;
+  const int ra = i * 32 + rb * 16 + li;             // the A operand's row of P (a feature), this lane
+  const int rbcol = j * 32 + cb * 16 + li;          // the B operand's
+  lp4d acc;
+  {
+    const int col = j * 32 + cb * 16 + li;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int row = i * 32 + rb * 16 + lk + 4 * r;
+      acc[r] = (row < D && col < D) ? a.S0inv[(size_t)row * a.lds0 + col] : (row == col ? 1.0 : 0.0);
+    }
+  }
+  const bool aok = ra < D, bok = rbcol < D;
+  // 32 points per round: the next round's features are requested before this round's products (two register sets)
+  auto fetch = [&](int j0, double (&xa)[8], double (&xb)[8]) {
+#pragma unroll
+    for (int tt = 0; tt < 8; ++tt) {
+      const int jj = j0 + 4 * tt + lk;
+      const bool ok = jj < k;
+      const size_t o = (size_t)(ok ? jj : 0) * a.ldx;
+      xa[tt] = (ok && aok) ? a.X[o + ra] : 0.0;
+      xb[tt] = (ok && bok) ? a.X[o + rbcol] : 0.0;
+    }
+  };
+  auto scale = [&](int j0, double (&xa)[8]) {
+#pragma unroll
+    for (int tt = 0; tt < 8; ++tt) { const int jj = j0 + 4 * tt + lk; xa[tt] *= jj < k ? sw[jj] : 0.0; }
+  };
+  double xa0[8], xb0[8], xa1[8], xb1[8];
+  if (k > 0) fetch(0, xa0, xb0);
+  __syncthreads();                                  // (sw)
+  for (int j0 = 0; j0 < k; j0 += 64) {
+    if (j0 + 32 < k) fetch(j0 + 32, xa1, xb1);
+    scale(j0, xa0);
+    acc = lp_mma(xa0, xb0, acc);
+    if (j0 + 32 < k) {
+      if (j0 + 64 < k) fetch(j0 + 64, xa0, xb0);
+      scale(j0 + 32, xa1);
+      acc = lp_mma(xa1, xb1, acc);
+    }
+  }
+  lp_quad_store<false>(a.TT + (size_t)(i * nt + j) * LP_TILE, rb, cb, lane, acc);
+}
+
+// ---- the factorisation ---------------------------------------------------------------------------------------------------
+#define LP_STAMP(slot) do { if (a.dbg && (threadIdx.x & 63) == 0) a.dbg[((size_t)blockIdx.x * a.nt + p) * 8 + (slot)] = wall_clock64(); } while (0)
+// one lane: relaxed polls until *p >= target (the payload behind it was stored write-through: no acquire fence)
+static __device__ __forceinline__ bool lp_poll(const int* p, int target, const LpArgs& a) {
+  const long long t0 = wall_clock64();
+  while (__hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+    __builtin_amdgcn_s_sleep(1);
+    if (wall_clock64() - t0 > a.timeout_ticks) { atomicExch(a.flags + 4 * a.nt, 1); return false; }
+  }
+  return true;
+}
+// all threads of the workgroup
+static __device__ __forceinline__ bool lp_wait(const int* p, int target, const LpArgs& a, int* s_ok) {
+  if (threadIdx.x == 0) *s_ok = lp_poll(p, target, a) ? 1 : 0;
+  __syncthreads();
+  const bool ok = *s_ok != 0;
+  __syncthreads();
+  return ok;
+}
+// all threads: every wave's write-through stores have left, then the counter moves
+static __device__ __forceinline__ void lp_signal(int* p, int add) {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (threadIdx.x == 0) __hip_atomic_fetch_add(p, add, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+static __device__ __forceinline__ int lp_panel_count(int nt, int p) {     // tiles of panel p: helpers' top, the chain's, bottom, rhs
+  return (nt - p - 2 > 0 ? nt - p - 2 : 0) + (p + 1 < nt ? 1 : 0) + (p + 1) + 1;
+}
+
+static __device__ __forceinline__ double lp_readlane(double v, int l) {
+  const unsigned long long b = (unsigned long long)__double_as_longlong(v);
+  const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)b, l), hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(b >> 32), l);
+  return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
+
+// One wave: Cholesky of the 32 x 32 tile in sdg (row-major, stride 33) and the inverse of its factor.  Lane l < 32 holds row l
+// of the tile, lane 32 + l row l of the identity; the column operations that produce L in the first turn the second into
+// X = L^-T.  Per column c the multipliers l_jc (j > c) reach all lanes by v_readlane; they are fetched EIGHT at a time into
+// distinct scalar registers before their multiply-adds, and the 30 - c updates of columns j >= c + 2 are issued beside the next
+// column's dependent chain (update of column c + 1 -> pivot -> rsqrt with two Newton steps -> scale).  Measured on this chip
+// (tools/probe/f64_chain_probe.hip, cycles per wave instruction): independent v_fma_f64 5, dependent 6.5, v_rsq_f64 18, a
+// v_readlane pair + fma 11 when the scalar pair is not reused back to back (29 when it is: the compiler's own schedule of the
+// plain loop, 6 us per tile), a readlane -> fma hop 25, a BROADCAST ds_read_b128 36 per wave (so multipliers through LDS are
+// slower than through v_readlane: 8 us per tile), a dependent v_mfma_f64_16x16x4 64.  The loop body is software-pipelined by
+// hand and pinned with scheduling barriers.  Writes W = L^-1 = X^T k-grouped into sw (LDS) and gw (global, write-through).
+// bad: a pivot was not positive.
+static __device__ __forceinline__ double lp_rsqrt(double d) {
+  double r = __builtin_amdgcn_rsq(d);
+  double e = fma(-d * r, r, 1.0);                   // two Newton steps for 1 / sqrt(d)
+  r = fma(0.5 * r, e, r);
+  e = fma(-d * r, r, 1.0);
+  return fma(0.5 * r, e, r);
+}
+static __device__ __forceinline__ void lp_diag(const double* sdg, double* sw, double* gw, int lane, int* bad) {
+  double a[32];
+  const int row = lane & 31;
+  const bool top = lane < 32;
+#pragma unroll
+  for (int c = 0; c < 32; ++c) a[c] = top ? (c <= row ? sdg[row * 33 + c] : 0.0) : (c == row ? 1.0 : 0.0);
+  double d = lp_readlane(a[0], 0);
+  double dmin = d;
+  double r = lp_rsqrt(d);
+#pragma unroll
+  for (int c = 0; c < 32; ++c) {
+    a[c] *= r;
+    if (c + 1 < 32) {
+      const double l1 = lp_readlane(a[c], c + 1);
+      a[c + 1] = fma(-a[c], l1, a[c + 1]);
+      __builtin_amdgcn_sched_barrier(0);
+      d = lp_readlane(a[c + 1], c + 1);
+      dmin = fmin(dmin, d);                         // (a non-positive pivot leaves NaNs behind; reported once, after the loop)
+      r = lp_rsqrt(d);
+#pragma unroll
+      for (int j0 = c + 2; j0 < 32; j0 += 8) {
+        double m[8];
+#pragma unroll
+        for (int b = 0; b < 8; ++b) if (j0 + b < 32) m[b] = lp_readlane(a[c], j0 + b);
+#pragma unroll
+        for (int b = 0; b < 8; ++b) if (j0 + b < 32) a[j0 + b] = fma(-a[c], m[b], a[j0 + b]);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+  if (!(dmin > 0.0)) *bad = 1;
+  if (!top) {
+    // lane 32 + kk holds X[kk][c] = W[c][kk]
+#pragma unroll
+    for (int c = 0; c < 32; ++c) {
+      const int o = lp_kg(c, row);
+      sw[o] = a[c];
+      lp_st(gw + o, a[c]);
+    }
+  }
+}
+
+// acc (quadrant rb, cb) -= sum_{q = q0}^{q1 - 1} tileA(q) tileB(q)^T, tiles stepping by strideA / strideB doubles; two terms'
+// operands in flight
+static __device__ __forceinline__ lp4d lp_accumulate(lp4d acc, const double* ta, size_t strideA, const double* tb, size_t strideB,
+                                                     int q0, int q1, int rb, int cb, int lane) {
+  int q = q0;
+  for (; q + 1 < q1; q += 2) {
+    double x0[8], y0[8], x1[8], y1[8];
+    lp_rows<true>(ta + (size_t)q * strideA, rb, lane, x0);
+    lp_rows<true>(tb + (size_t)q * strideB, cb, lane, y0);
+    lp_rows<true>(ta + (size_t)(q + 1) * strideA, rb, lane, x1);
+    lp_rows<true>(tb + (size_t)(q + 1) * strideB, cb, lane, y1);
+    acc = lp_mma_neg(x0, y0, acc);
+    acc = lp_mma_neg(x1, y1, acc);
+  }
+  if (q < q1) {
+    double x0[8], y0[8];
+    lp_rows<true>(ta + (size_t)q * strideA, rb, lane, x0);
+    lp_rows<true>(tb + (size_t)q * strideB, cb, lane, y0);
+    acc = lp_mma_neg(x0, y0, acc);
+  }
+  return acc;
+}
+
+__global__ __launch_bounds__(256) void lrp_chol_kernel(LpArgs a) {
+  __shared__ double s_dg[32 * 33];                  // the diagonal tile the chain factors next (row-major)
+  __shared__ double s_dgp[LP_TILE];                 // ... its value before the last update (k-grouped)
+  __shared__ double s_w[LP_TILE];                   // W_pp
+  __shared__ double s_a1[LP_TILE];                  // chain: sub-diagonal tile before the multiplication by W_pp^T; helpers: the same role
+  __shared__ double s_l1[2][LP_TILE];               // the chain's sub-diagonal tiles L_{p+1,p}, this step's and the last's
+  __shared__ double s_red[8][32];
+  __shared__ int s_ok, s_bad;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int nt = a.nt, H = a.H, D = a.D;
+  const int rb = wave >> 1, cb = wave & 1;
+  int* F1 = a.flags; int* C = a.flags + nt; int* A1 = a.flags + 2 * nt; int* A2 = a.flags + 3 * nt;
+  if (tid == 0) { s_ok = 1; s_bad = 0; }
+  __syncthreads();
+
+  if (blockIdx.x == 0) {
+    // ================= the chain =================
+    {
+      const lp4d c = lp_quad_load<false>(a.TT, rb, cb, lane);          // tile (0, 0), written by the kernel before
+      const int col = cb * 16 + (lane & 15), row0 = rb * 16 + (lane >> 4);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) s_dg[(row0 + 4 * r) * 33 + col] = c[r];
+    }
+    __syncthreads();
+    for (int p = 0; p < nt; ++p) {
+      const bool more = p + 1 < nt;
+      if (wave == 0) {
+        LP_STAMP(0);
+        lp_diag(s_dg, s_w, a.XW + (size_t)p * LP_TILE, lane, &s_bad);
+        LP_STAMP(1);
+        // the inverse of the diagonal tile is what every helper waits for: out at once (this wave wrote all of it)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (lane == 0) __hip_atomic_store(&F1[p], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        LP_STAMP(2);
+      } else if (more) {
+        // meanwhile: what does not depend on this diagonal tile -- tiles (p+1, p) and (p+1, p+1) up to and including the term
+        // of column p - 1.  Eight quadrant jobs over three waves (<= 3 each, their operands requested together); each wave
+        // waits for the assistants and for column p - 1 on its own.
+        bool ok = true;
+        if (lane == 0 && p >= 1) {
+          ok = lp_poll(&C[p - 1], lp_panel_count(nt, p - 1), a);
+          if (ok) ok = lp_poll(&A1[p], 1, a);
+          if (ok) ok = lp_poll(&A2[p], 1, a);
+        }
+        ok = __shfl(ok ? 1 : 0, 0, 64) != 0;
+        if (wave == 1) LP_STAMP(3);
+        const double* t_sub = p >= 1 ? a.AS + (size_t)p * LP_TILE : a.TT + (size_t)((p + 1) * nt + p) * LP_TILE;
+        const double* t_dg = p >= 1 ? a.AD + (size_t)p * LP_TILE : a.TT + (size_t)((p + 1) * nt + p + 1) * LP_TILE;
+        const double* l_far = p >= 1 ? a.LT + (size_t)((p + 1) * nt + p - 1) * LP_TILE : nullptr;      // L_{p+1,p-1}: a helper's
+        const double* l_prev = s_l1[(p + 1) & 1];                                                        // L_{p,p-1}: the chain's last
+        if (ok) {
+          lp4d c[3];
+          double x[3][8], y[3][8];
+#pragma unroll
+          for (int u = 0; u < 3; ++u) {
+            const int job = wave - 1 + 3 * u;
+            if (job < 8) {
+              const int q = job & 3, qr = q >> 1, qc = q & 1;
+              c[u] = p >= 1 ? lp_quad_load<true>(job < 4 ? t_sub : t_dg, qr, qc, lane) : lp_quad_load<false>(job < 4 ? t_sub : t_dg, qr, qc, lane);
+              if (p >= 1) {
+                lp_rows<true>(l_far, qr, lane, x[u]);
+                if (job < 4) lp_rows<false>(l_prev, qc, lane, y[u]);
+                else lp_rows<true>(l_far, qc, lane, y[u]);
+              }
+            }
+          }
+#pragma unroll
+          for (int u = 0; u < 3; ++u) {
+            const int job = wave - 1 + 3 * u;
+            if (job < 8) {
+              const int q = job & 3, qr = q >> 1, qc = q & 1;
+              if (p >= 1) c[u] = lp_mma_neg(x[u], y[u], c[u]);
+              lp_quad_store<false>(job < 4 ? s_a1 : s_dgp, qr, qc, lane, c[u]);
+            }
+          }
+        }
+        if (!ok && lane == 0) s_ok = 0;
+        if (wave == 1) LP_STAMP(4);
+      }
+      __syncthreads();
+      if (!more || !s_ok) break;
+      // L_{p+1,p} = (tile) W_pp^T
+      double* l1 = s_l1[p & 1];
+      {
+        double x[8], y[8];
+        lp_rows<false>(s_a1, rb, lane, x);
+        lp_rows<false>(s_w, cb, lane, y);
+        const lp4d c = lp_mma(x, y, (lp4d){0.0, 0.0, 0.0, 0.0});
+        lp_quad_store<false>(l1, rb, cb, lane, c);
+        lp_quad_store<true>(a.LT + (size_t)((p + 1) * nt + p) * LP_TILE, rb, cb, lane, c);
+      }
+      __syncthreads();
+      // the next diagonal tile: its last update
+      {
+        double x[8], y[8];
+        lp_rows<false>(l1, rb, lane, x);
+        lp_rows<false>(l1, cb, lane, y);
+        const lp4d c = lp_mma_neg(x, y, lp_quad_load<false>(s_dgp, rb, cb, lane));
+        const int col = cb * 16 + (lane & 15), row0 = rb * 16 + (lane >> 4);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) s_dg[(row0 + 4 * r) * 33 + col] = c[r];
+      }
+      lp_signal(&C[p], 1);                          // (its barrier also hands s_dg to wave 0)
+      if (wave == 0) LP_STAMP(5);
+    }
+    if (tid == 0 && s_bad) atomicExch(a.flags + 4 * nt, 2);
+    return;
+  }
+
+  if (blockIdx.x < LP_FIXED_WGS) {
+    // ================= an assistant: the chain's tile of step p, all terms of the columns q <= p - 2 =================
+    const bool sub = blockIdx.x == 1;               // 1: tile (p+1, p); 2: tile (p+1, p+1)
+    for (int p = 1; p + 1 < nt; ++p) {
+      if (p >= 2 && !lp_wait(&C[p - 2], lp_panel_count(nt, p - 2), a, &s_ok)) return;
+      if (wave == 0) LP_STAMP(0);
+      lp4d c = lp_quad_load<false>(a.TT + (size_t)((p + 1) * nt + (sub ? p : p + 1)) * LP_TILE, rb, cb, lane);
+      const double* ta = a.LT + (size_t)((p + 1) * nt) * LP_TILE;                     // row p + 1 of L
+      const double* tb = a.LT + (size_t)((sub ? p : p + 1) * nt) * LP_TILE;           // row p (or p + 1 again)
+      c = lp_accumulate(c, ta, LP_TILE, tb, LP_TILE, 0, p - 1, rb, cb, lane);
+      lp_quad_store<true>((sub ? a.AS : a.AD) + (size_t)p * LP_TILE, rb, cb, lane, c);
+      lp_signal(sub ? &A1[p] : &A2[p], 1);
+      if (wave == 0) LP_STAMP(1);
+    }
+    return;
+  }
+
+  // ================= a helper =================
+  const int h = blockIdx.x - LP_FIXED_WGS;
+  for (int p = 0; p < nt; ++p) {
+    // the jobs of block column p, in a fixed order: top rows p + 2 .. nt - 1, bottom rows 0 .. p, the right-hand side row;
+    // job n goes to helper (n + 3 p) mod H
+    const int ntopj = nt - p - 2 > 0 ? nt - p - 2 : 0;
+    const int njobs = ntopj + p + 2;
+    bool waited_c = p == 0, waited_f = false;
+    int done = 0;
+    for (int n = (h + H - (3 * p) % H) % H; n < njobs; n += H) {
+      if (!waited_c) { if (!lp_wait(&C[p - 1], lp_panel_count(nt, p - 1), a, &s_ok)) return; waited_c = true; }
+      if (wave == 0 && done == 0) LP_STAMP(0);
+      const bool is_top = n < ntopj;
+      const int R = is_top ? p + 2 + n : n - ntopj;                     // top row i, or bottom row r (r == p + 1 here means: the rhs row)
+      const bool is_rhs = !is_top && R == p + 1;
+      const int rrow = is_rhs ? nt : R;
+      // init - sum_{q < p} tile(R, q) L_{p,q}^T
+      lp4d c;
+      int q0 = 0;
+      const double* ta;
+      if (is_top) {
+        c = lp_quad_load<false>(a.TT + (size_t)(R * nt + p) * LP_TILE, rb, cb, lane);
+        ta = a.LT + (size_t)(R * nt) * LP_TILE;
+      } else {
+        const int col = cb * 16 + (lane & 15), row0 = rb * 16 + (lane >> 4);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int row = row0 + 4 * r;
+          c[r] = is_rhs ? (row == 0 ? a.rhs[p * 32 + col] : 0.0) : ((R == p && row == col) ? 1.0 : 0.0);
+        }
+        ta = a.BL + (size_t)(rrow * nt) * LP_TILE;
+        q0 = is_rhs ? 0 : R;                        // (row r of L^-T starts at column r)
+      }
+      c = lp_accumulate(c, ta, LP_TILE, a.LT + (size_t)(p * nt) * LP_TILE, LP_TILE, q0, p, rb, cb, lane);
+      __syncthreads();                              // (the previous job's reads of s_a1)
+      lp_quad_store<false>(s_a1, rb, cb, lane, c);
+      if (!waited_f) { if (!lp_wait(&F1[p], 1, a, &s_ok)) return; waited_f = true; } else __syncthreads();
+      if (wave == 0 && done == 0) LP_STAMP(1);
+      double x[8], wq[8];
+      lp_rows<true>(a.XW + (size_t)p * LP_TILE, cb, lane, wq);
+      lp_rows<false>(s_a1, rb, lane, x);
+      c = lp_mma(x, wq, (lp4d){0.0, 0.0, 0.0, 0.0});
+      if (is_top) lp_quad_store<true>(a.LT + (size_t)(R * nt + p) * LP_TILE, rb, cb, lane, c);
+      else {
+        lp_quad_store<true>(a.BL + (size_t)(rrow * nt + p) * LP_TILE, rb, cb, lane, c);
+        if (!is_rhs) {
+          // finished tile (r, p) of L^-T: its transpose is block (p, r) of L^-1, row-major for the draw kernel
+          const int orow = p * 32 + cb * 16 + (lane & 15);
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const int ocol = R * 32 + rb * 16 + (lane >> 4) + 4 * q;
+            if (orow < D && ocol < D) lp_st(a.Linv + (size_t)orow * a.ldl + ocol, c[q]);
+          }
+        }
+      }
+      ++done;
+    }
+    if (done) { lp_signal(&C[p], done); if (wave == 0) LP_STAMP(2); }
+  }
+  // ---- mu = L^-T u, u = L^-1 rhs (row 0 of the finished right-hand side tiles): 32 columns per workgroup ----
+  if (!lp_wait(&C[nt - 1], lp_panel_count(nt, nt - 1), a, &s_ok)) return;
+  for (int cbk = h; cbk < nt; cbk += H) {
+    const int c = cbk * 32 + (tid & 31), g = tid >> 5;                // eight groups of rows
+    double s = 0.0;
+    if (c < D)
+      for (int i = cbk * 32 + g; i < D; i += 8) {
+        const double u = lp_ld(a.BL + (size_t)(nt * nt + (i >> 5)) * LP_TILE + lp_kg(0, i & 31));
+        s += u * lp_ld(a.Linv + (size_t)i * a.ldl + c);
+      }
+    s_red[g][tid & 31] = s;
+    __syncthreads();
+    if (tid < 32 && c < D) {
+      double m = 0.0;
+#pragma unroll
+      for (int q = 0; q < 8; ++q) m += s_red[q][tid];
+      a.mu[c] = m;
+    }
+    __syncthreads();
+  }
+}
+
+// ---- host side --------------------------------------------------------------------------------------------------------------
+void bcx_project_set_error(const std::string& msg);   // proj.hip
+#define LRP_HIP(call)                                                             \
+  do {                                                                            \
+    hipError_t _e = (call);                                                       \
+    if (_e != hipSuccess) {                                                       \
+      bcx_project_set_error(std::string(#call) + ": " + hipGetErrorString(_e));   \
+      return BCX_ERR_HIP;                                                         \
+    }                                                                             \
+  } while (0)
+
+static int lrp_helpers(int nt) {
+  static const int forced = [] { const char* e = bcx_dev_env("BCX_LRP_HELPERS"); return e ? atoi(e) : 0; }();      // dev
+  if (forced >= 1 && forced <= LP_MAX_H) return forced;
+  int h = nt + 2;                                   // a block column has at most nt + 1 jobs for the helpers: one each
+  if (h > LP_MAX_H) h = LP_MAX_H;
+  return h;
+}
+static int64_t lrp_tiles(int nt) { return (int64_t)2 * nt * nt + (int64_t)(nt + 1) * nt + 3 * nt; }
+static int64_t lrp_flag_bytes(int nt) { return (int64_t)(4 * nt + 1 + 15) / 16 * 16 * 4; }
+#define LRP_DBG_BYTES(nt) ((int64_t)(LP_FIXED_WGS + LP_MAX_H) * (nt) * 8 * 8)
+
+extern "C" int64_t bcx_linreg_posterior_factor_scratch_bytes(int32_t D) {
+  if (D < 1 || D > LP_NB * LP_MAX_NT) return -1;
+  const int nt = (D + LP_NB - 1) / LP_NB;
+  return lrp_tiles(nt) * LP_TILE * 8 + (int64_t)nt * 32 * 8 + lrp_flag_bytes(nt) + LRP_DBG_BYTES(nt);
+}
+
+extern "C" int bcx_linreg_posterior_factor(void* stream, int32_t k, int32_t D, int32_t ldx, const void* w_dev, const void* X_dev,
+                                           const void* y_dev, const void* S0inv_dev, int32_t lds0, const void* rhs0_dev, double sigsq,
+                                           void* work_dev, int64_t work_bytes, void* Linv_dev, int64_t ldl, void* mu_dev) {
+  if (k < 0 || k > 4096 || D < 1 || D > LP_NB * LP_MAX_NT || ldx < D || lds0 < D || ldl < D || !(sigsq > 0.0) || !S0inv_dev || !rhs0_dev ||
+      !work_dev || !Linv_dev || !mu_dev || (k > 0 && (!w_dev || !X_dev || !y_dev)) ||
+      work_bytes < bcx_linreg_posterior_factor_scratch_bytes(D) || ((uintptr_t)work_dev & 15)) {
+    bcx_project_set_error("bcx_linreg_posterior_factor: bad arguments (k <= 4096 points, D <= 1024 features, scratch of "
+                          "bcx_linreg_posterior_factor_scratch_bytes(D) bytes)");
+    return BCX_ERR_ARG;
+  }
+  LpArgs a;
+  a.w = (const double*)w_dev; a.X = (const double*)X_dev; a.y = (const double*)y_dev;
+  a.S0inv = (const double*)S0inv_dev; a.rhs0 = (const double*)rhs0_dev;
+  a.sigsq = sigsq; a.k = k; a.D = D; a.ldx = ldx; a.lds0 = lds0;
+  const int nt = (D + LP_NB - 1) / LP_NB;
+  double* base = (double*)work_dev;
+  a.TT = base; base += (size_t)nt * nt * LP_TILE;
+  a.LT = base; base += (size_t)nt * nt * LP_TILE;
+  a.BL = base; base += (size_t)(nt + 1) * nt * LP_TILE;
+  a.XW = base; base += (size_t)nt * LP_TILE;
+  a.AS = base; base += (size_t)nt * LP_TILE;
+  a.AD = base; base += (size_t)nt * LP_TILE;
+  a.rhs = base; base += (size_t)nt * 32;
+  a.flags = (int*)base;
+  static const bool dbg = bcx_dev_env("BCX_LRP_DBG") != nullptr;
+  a.dbg = dbg ? (long long*)((char*)base + lrp_flag_bytes(nt)) : nullptr;
+  a.Linv = (double*)Linv_dev; a.ldl = ldl; a.mu = (double*)mu_dev;
+  a.nt = nt; a.H = lrp_helpers(nt);
+  a.timeout_ticks = 200000000LL;                    // 2 s of the 100 MHz wall clock
+  hipLaunchKernelGGL(lrp_form_kernel, dim3(nt * (nt + 1) / 2 + nt), dim3(256), 0, (hipStream_t)stream, a);
+  hipLaunchKernelGGL(lrp_chol_kernel, dim3(LP_FIXED_WGS + a.H), dim3(256), 0, (hipStream_t)stream, a);
+  LRP_HIP(hipGetLastError());
+  return BCX_OK;
+}
+
+// After a synchronisation of the stream: 0 ok, BCX_ERR_TIMEOUT a wait between the workgroups of lrp_chol_kernel expired (its
+// outputs are not valid), BCX_ERR_STATE a pivot was not positive (P not positive definite: NaN / negative weights upstream).
+extern "C" int bcx_linreg_posterior_factor_status(void* stream, int32_t D, const void* work_dev) {
+  if (D < 1 || D > LP_NB * LP_MAX_NT || !work_dev) { bcx_project_set_error("bcx_linreg_posterior_factor_status: bad arguments"); return BCX_ERR_ARG; }
+  const int nt = (D + LP_NB - 1) / LP_NB;
+  const int* flags = (const int*)((const double*)work_dev + lrp_tiles(nt) * LP_TILE + (int64_t)nt * 32);
+  int v = 0;
+  LRP_HIP(hipMemcpyAsync(&v, flags + 4 * nt, sizeof v, hipMemcpyDeviceToHost, (hipStream_t)stream));
+  LRP_HIP(hipStreamSynchronize((hipStream_t)stream));
+  if (v == 1) { bcx_project_set_error("linreg posterior factorisation: a wait between workgroups timed out (GPU shared or preempted)"); return BCX_ERR_TIMEOUT; }
+  if (v == 2) { bcx_project_set_error("linreg posterior factorisation: the precision matrix is not positive definite"); return BCX_ERR_STATE; }
+  return BCX_OK;
+}

@@ -947,6 +947,91 @@ __global__ __launch_bounds__(1024) void proj_small_kernel(ProjArgs p, int center
   if (tid < mine_n) p.out[row * p.ldo + s_begin + tid] = v - mean;
 }
 
+// ---- a few hundred rows (the coreset points of SparseVI once the coreset has grown: sparsevi.py:38-39 at k = 33 .. 4096) -------
+// The tiled kernel above starts at 128-row blocks with D / 16 barrier-separated LDS stages: for 300 rows it runs three
+// workgroups per column tile for 56 us, on the critical path of every ADAM step.  Here a workgroup forms a 32 x 32 block of
+// Z Theta^T -- one 16 x 16 tile per wave on v_mfma_f64_16x16x4_f64 -- with both operands straight from global memory (they are
+// L2-resident: k x D and S x D doubles): lane (i = lane % 16, g = lane / 16) feeds row i's values 8 g .. 8 g + 7 of each run
+// of 32 of the inner dimension, one per MFMA step (any assignment of the inner index to steps serves, as long as both
+// operands use the same one), i.e. four 16-byte loads per operand and run.  Raw log-likelihoods (the caller centres).
+#define PJ_MID_ROWS 4096
+typedef double pjm4d __attribute__((ext_vector_type(4)));
+template <int FAM, bool AL>
+__global__ __launch_bounds__(256) void proj_mid_kernel(ProjArgs p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char pj_lds[];
+  constexpr int NTAB = FAM == FAM_POISSON ? PJT_DOUBLES : FAM == FAM_LOGISTIC ? PJT_DOUBLES_LOGISTIC : 0;
+  double* tabw = (double*)pj_lds;
+  const pj_tab_t tab = (pj_tab_t)tabw;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 15, lk = lane >> 4, rb = wave >> 1, cb = wave & 1;
+  const int D = p.D, S = p.S;
+  if (NTAB) { for (int k = tid; k < NTAB; k += 256) tabw[k] = p.tab[k]; __syncthreads(); }
+  const int64_t arow = (int64_t)blockIdx.x * 32 + rb * 16 + li;
+  const int bcol = blockIdx.y * 32 + cb * 16 + li;
+  const double* zp = p.Z + (arow < p.N ? arow : 0) * p.ldz;
+  const double* tp = p.theta + (size_t)(bcol < S ? bcol : 0) * p.ldt;
+  const bool aok = arow < p.N, bok = bcol < S;
+  pjm4d acc = (pjm4d){0.0, 0.0, 0.0, 0.0};
+  auto fetch = [&](int kb, double (&xa)[8], double (&xb)[8]) {
+    const int k0 = kb + 8 * lk;
+    if (AL && k0 + 8 <= D) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const pv2d u = *(const pv2d*)(zp + k0 + 2 * q), v = *(const pv2d*)(tp + k0 + 2 * q);
+        xa[2 * q] = u.x; xa[2 * q + 1] = u.y; xb[2 * q] = v.x; xb[2 * q + 1] = v.y;
+      }
+    } else {
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const bool ok = k0 + q < D;
+        xa[q] = ok ? zp[ok ? k0 + q : 0] : 0.0;
+        xb[q] = ok ? tp[ok ? k0 + q : 0] : 0.0;
+      }
+    }
+    if (!aok) {
+#pragma unroll
+      for (int q = 0; q < 8; ++q) xa[q] = 0.0;
+    }
+    if (!bok) {
+#pragma unroll
+      for (int q = 0; q < 8; ++q) xb[q] = 0.0;
+    }
+  };
+  double xa0[8], xb0[8], xa1[8], xb1[8];
+  fetch(0, xa0, xb0);
+  for (int kb = 0; kb < D; kb += 64) {
+    if (kb + 32 < D) fetch(kb + 32, xa1, xb1);
+#pragma unroll
+    for (int t = 0; t < 8; ++t) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(xa0[t], xb0[t], acc, 0, 0, 0);
+    if (kb + 32 < D) {
+      if (kb + 64 < D) fetch(kb + 64, xa0, xb0);
+#pragma unroll
+      for (int t = 0; t < 8; ++t) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(xa1[t], xb1[t], acc, 0, 0, 0);
+    }
+  }
+  // accumulator layout: register r holds (row 16 rb + lane / 16 + 4 r, column 16 cb + lane % 16)
+  const double clin = (FAM == FAM_LINREG) ? -0.5 * log(2.0 * 3.14159265358979323846 * p.param) : 0.0;
+  const double parg = (FAM == FAM_LINREG) ? 1.0 / (2.0 * p.param) : p.param;
+  const int col = blockIdx.y * 32 + cb * 16 + li;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int64_t row = (int64_t)blockIdx.x * 32 + rb * 16 + lk + 4 * r;
+    if (row < p.N && col < S) {
+      const double y = p.ycol >= 0 ? p.Z[row * p.ldz + p.ycol] : 0.0;
+      double yv = y, c0 = clin;
+      if (FAM == FAM_POISSON) {
+        const int yi = (int)y;
+        const bool small_count = (double)yi == y && (unsigned)yi < (unsigned)PJT_NFACT;
+        c0 = small_count ? tab[PJT_LFACT + (small_count ? yi : 0)] : pj_lgamma1p_call(y);
+      } else if (FAM == FAM_LINREG) {
+        c0 = fma(-(y * y), parg, clin);
+        yv = 2.0 * y;
+      }
+      p.out[row * p.ldo + col] = loglik<FAM>(acc[r], yv, parg, c0, tab);
+    }
+  }
+}
+
 // colsum[s] = sum over the workgroup partials in a fixed order: one workgroup per 64 columns, four
 // partial-index segments per column combined 0..3 (8 independent loads in flight per thread).
 __global__ __launch_bounds__(256) void colsum_reduce_kernel(const double* part, int nparts, int S, double* colsum) {
@@ -1298,9 +1383,26 @@ static int project_write(void* stream, int32_t family, const void* Z_dev, int64_
     PROJ_HIP(hipGetLastError());
     return BCX_OK;
   }
-  int wgrid = 0;
-  proj_plan(PMODE_WRITE, family, N, S, proj_aligned(p), D, &wgrid, &p.team);
-  if ((rc = launch_family<PMODE_WRITE>(family, dim3(wgrid), 0, st, p))) return rc;
+  static const bool no_mid = bcx_dev_env("BCX_PROJ_NO_MID") != nullptr;        // dev: the tiled kernel beyond 32 rows
+  if (N <= PJ_MID_ROWS && !no_mid) {
+    // a few hundred rows: 32 x 32 blocks of the product straight from L2-resident operands (proj_mid_kernel)
+    const size_t tabd = family == FAM_POISSON ? PJT_DOUBLES : family == FAM_LOGISTIC ? PJT_DOUBLES_LOGISTIC : 0;
+    if (tabd && !(p.tab = proj_tables())) { g_proj_err = "bcx_project: no device memory for the likelihood tables"; return BCX_ERR_NOMEM; }
+    const bool al = ((uintptr_t)p.theta % 16 == 0) && p.ldt % 2 == 0 && ((uintptr_t)p.Z % 16 == 0) && p.ldz % 2 == 0;
+    const dim3 mgrid((unsigned)((N + 31) / 32), (unsigned)((S + 31) / 32));
+#define PJ_MID(F)                                                                                                     \
+    do {                                                                                                                \
+      if (al) hipLaunchKernelGGL((proj_mid_kernel<F, true>), mgrid, dim3(256), tabd * sizeof(double), st, p);           \
+      else hipLaunchKernelGGL((proj_mid_kernel<F, false>), mgrid, dim3(256), tabd * sizeof(double), st, p);            \
+    } while (0)
+    if (family == FAM_LOGISTIC) PJ_MID(FAM_LOGISTIC); else if (family == FAM_POISSON) PJ_MID(FAM_POISSON); else PJ_MID(FAM_LINREG);
+#undef PJ_MID
+    PROJ_HIP(hipGetLastError());
+  } else {
+    int wgrid = 0;
+    proj_plan(PMODE_WRITE, family, N, S, proj_aligned(p), D, &wgrid, &p.team);
+    if ((rc = launch_family<PMODE_WRITE>(family, dim3(wgrid), 0, st, p))) return rc;
+  }
   if (!center) return BCX_OK;
   const int g = (int)std::min<int64_t>((N + 3) / 4, 8192);
   if (S % 2 == 0 && ldo % 2 == 0 && (uintptr_t)p.out % 16 == 0)

@@ -463,6 +463,75 @@ __global__ __launch_bounds__(256) void svi_adam_kernel(const double* __restrict_
   }
 }
 
+
+// ---- more than 64 weights: the same step as two launches of one workgroup per slab of SVB_ROWS weights --------------------------
+// (the single-workgroup kernel above walks the k x S projected coreset points three times with one wave per row: 50 us at
+// k = 300.)  svi_adam_a_kernel: row means of its slab's raw rows and the slab's share of w.dot(corevecs); svi_adam_b_kernel:
+// resid from the shares (added in slab order: fixed association), the slab's gradient entries, ADAM moments, step, clamp.
+#define SVB_ROWS 8
+#define SVB_KMAX 4096
+struct SvbArgs {
+  const double* colsum; const double* core; const double* sched;
+  double* w; double* mom1; double* mom2; double* trace;
+  double* cm;          // k: row means of the raw projected points (zeros when they arrive centred)
+  double* part;        // nslab x S: sum over the slab's rows of w_j (core[j][s] - cm_j)
+  double scaling, b1, b2, eps;
+  int64_t ldc;
+  int k, S, step, raw_core;
+};
+__global__ __launch_bounds__(256) void svi_adam_a_kernel(SvbArgs a) {
+  __shared__ double scm[SVB_ROWS], sw[SVB_ROWS];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int j0 = blockIdx.x * SVB_ROWS, nj = min(SVB_ROWS, a.k - j0);
+  for (int q = wave; q < nj; q += 4) {
+    const double* row = a.core + (size_t)(j0 + q) * a.ldc;
+    double t = 0.0;
+    if (a.raw_core) {
+      for (int s = lane; s < a.S; s += 64) t += row[s];
+      t = wave_allsum(t) / (double)a.S;               // projector.py:21
+    }
+    if (lane == 0) { scm[q] = t; sw[q] = a.w[j0 + q]; a.cm[j0 + q] = t; }
+  }
+  __syncthreads();
+  for (int s = tid; s < a.S; s += 256) {
+    double t = 0.0;
+    for (int q = 0; q < nj; ++q) t += sw[q] * (a.core[(size_t)(j0 + q) * a.ldc + s] - scm[q]);
+    a.part[(size_t)blockIdx.x * a.S + s] = t;
+  }
+}
+__global__ __launch_bounds__(256) void svi_adam_b_kernel(SvbArgs a) {
+  extern __shared__ double resid[];                 // S
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int j0 = blockIdx.x * SVB_ROWS, nj = min(SVB_ROWS, a.k - j0);
+  const int nslab = (a.k + SVB_ROWS - 1) / SVB_ROWS;
+  for (int s = tid; s < a.S; s += 256) {
+    double t = 0.0;
+    for (int b = 0; b < nslab; ++b) t += a.part[(size_t)b * a.S + s];
+    resid[s] = a.scaling * a.colsum[s] - t;         // sparsevi.py:72
+  }
+  __syncthreads();
+  for (int q = wave; q < nj; q += 4) {
+    const int j = j0 + q;
+    const double* row = a.core + (size_t)j * a.ldc;
+    const double cm = a.cm[j];
+    double t = 0.0;
+    for (int s = lane; s < a.S; s += 64) t += (row[s] - cm) * resid[s];
+    t = wave_allsum(t);
+    if (lane == 0) {
+      const double g = -t / (double)a.S;            // sparsevi.py:74
+      const double m1 = a.b1 * a.mom1[j] + (1.0 - a.b1) * g;
+      const double m2 = a.b2 * a.mom2[j] + (1.0 - a.b2) * g * g;
+      a.mom1[j] = m1;
+      a.mom2[j] = m2;
+      const double* sc = a.sched + 3 * (size_t)a.step;
+      const double stp = sc[0] * m1 / sc[1] / (a.eps + sqrt(m2 / sc[2]));
+      const double x = fmax(a.w[j] - stp, 0.0);
+      a.w[j] = x;
+      if (a.trace) a.trace[(size_t)a.step * a.k + j] = x;
+    }
+  }
+}
+
 void bcx_project_set_error(const std::string& msg);   // proj.hip
 #define SVI_HIP(call)                                                             \
   do {                                                                            \
@@ -542,6 +611,38 @@ extern "C" int bcx_sparsevi_adam_step(void* stream, int32_t k, int32_t S, const 
   hipLaunchKernelGGL(svi_adam_kernel, dim3(1), dim3(256), (size_t)S * sizeof(double), (hipStream_t)stream, (const double*)colsum_dev,
                      scaling, (const double*)core_dev, ldc, (int)k, (int)S, (double*)w_dev, (double*)mom1_dev, (double*)mom2_dev,
                      (const double*)sched_dev, (int)step, b1, b2, eps, (double*)trace_dev, (int)core_is_raw);
+  SVI_HIP(hipGetLastError());
+  return BCX_OK;
+}
+
+// The same step for any number of weights up to 4096: up to 64 the single-workgroup kernel, beyond it the two-launch form,
+// which needs bcx_sparsevi_adam_scratch_bytes(k, S) bytes of scratch (row means + the slabs' shares of w.dot(corevecs)).
+extern "C" int64_t bcx_sparsevi_adam_scratch_bytes(int32_t k, int32_t S) {
+  if (k < 1 || k > SVB_KMAX || S < 1 || S > 8192) return -1;
+  if (k <= LRS_KMAX) return 0;
+  return ((int64_t)k + (int64_t)((k + SVB_ROWS - 1) / SVB_ROWS) * S) * (int64_t)sizeof(double);
+}
+extern "C" int bcx_sparsevi_adam_step_ws(void* stream, int32_t k, int32_t S, const void* colsum_dev, double scaling, const void* core_dev,
+                                         int64_t ldc, void* w_dev, void* mom1_dev, void* mom2_dev, const void* sched_dev, int32_t step,
+                                         double b1, double b2, double eps, void* trace_dev, int32_t core_is_raw, void* work_dev,
+                                         int64_t work_bytes) {
+  if (k >= 1 && k <= LRS_KMAX)
+    return bcx_sparsevi_adam_step(stream, k, S, colsum_dev, scaling, core_dev, ldc, w_dev, mom1_dev, mom2_dev, sched_dev, step, b1, b2, eps,
+                                  trace_dev, core_is_raw);
+  if (k < 1 || k > SVB_KMAX || S < 1 || S > 8192 || ldc < S || step < 0 || !colsum_dev || !core_dev || !w_dev || !mom1_dev || !mom2_dev ||
+      !sched_dev || !work_dev || work_bytes < bcx_sparsevi_adam_scratch_bytes(k, S)) {
+    bcx_project_set_error("bcx_sparsevi_adam_step_ws: bad arguments (1 <= k <= 4096 weights, S <= 8192, scratch of "
+                          "bcx_sparsevi_adam_scratch_bytes(k, S) bytes)");
+    return BCX_ERR_ARG;
+  }
+  SvbArgs a;
+  a.colsum = (const double*)colsum_dev; a.core = (const double*)core_dev; a.sched = (const double*)sched_dev;
+  a.w = (double*)w_dev; a.mom1 = (double*)mom1_dev; a.mom2 = (double*)mom2_dev; a.trace = (double*)trace_dev;
+  a.cm = (double*)work_dev; a.part = a.cm + k;
+  a.scaling = scaling; a.b1 = b1; a.b2 = b2; a.eps = eps; a.ldc = ldc; a.k = k; a.S = S; a.step = step; a.raw_core = core_is_raw;
+  const int nslab = (k + SVB_ROWS - 1) / SVB_ROWS;
+  hipLaunchKernelGGL(svi_adam_a_kernel, dim3(nslab), dim3(256), 0, (hipStream_t)stream, a);
+  hipLaunchKernelGGL(svi_adam_b_kernel, dim3(nslab), dim3(256), (size_t)S * sizeof(double), (hipStream_t)stream, a);
   SVI_HIP(hipGetLastError());
   return BCX_OK;
 }

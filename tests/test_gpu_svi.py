@@ -28,7 +28,10 @@ def _model(rs, D):
 
 
 @pytest.mark.parametrize("D,k,S", ((7, 3, 16), (30, 1, 40), (31, 12, 64), (301, 4, 320), (301, 33, 320), (100, 64, 300),
-                                   (302, 0, 310), (129, 17, 1024), (1000, 3, 1010), (2, 2, 5), (511, 16, 520), (40, 5, 3000)))
+                                   (302, 0, 310), (129, 17, 1024), (1000, 3, 1010), (2, 2, 5), (511, 16, 520), (40, 5, 3000),
+                                   # more points than the rank-k kernels take: the D x D form (csrc/lrpost.hip)
+                                   (301, 28, 320), (301, 65, 320), (301, 300, 320), (40, 130, 64), (33, 1000, 40), (7, 70, 16),
+                                   (640, 100, 650), (1024, 40, 1030)))
 def test_posterior_draw_kernel(bc, D, k, S):
     """theta = mu_w + R Uw^T with Uw Uw^T = Sigma_w: the rows of R are the unit vectors (they return Uw itself), a zero row
     (the mean) and standard-normal rows (compared with mu_w + R Uw^T for the Uw just read)."""
@@ -74,7 +77,9 @@ def test_posterior_draw_kernel(bc, D, k, S):
         plan = smp.enqueue_plan(S, p3, 2)
         assert plan is not None
         plan.set_noise(Rd[None, :, :])
-        assert plan.fast == (k <= 32)
+        ok = bool(smp._lib.bcx_linreg_posterior_apply_ok(k, ld))
+        assert plan.fast == ok and plan.factored == (not ok)
+        plan.check()
         t4, m4 = plan.draw(torch.from_numpy(w2).cuda(), 0)
         t4, m4 = t4.cpu().numpy(), m4.cpu().numpy()
         np.testing.assert_allclose(t4[D], mu3, rtol=1e-12, atol=1e-13 * np.abs(mu3).max())
@@ -87,9 +92,13 @@ def test_posterior_sampler_limits(bc):
     rs = np.random.RandomState(0)
     mu0, Sig0, sigsq = _model(rs, 6)
     smp = bc.LinregPosteriorSampler(mu0, Sig0, sigsq)
-    assert smp.enqueue_plan(16, rs.randn(65, 7), 3) is None and smp.enqueue_plan(4097, rs.randn(3, 7), 3) is None
+    assert smp.enqueue_plan(16, rs.randn(4097, 7), 3) is None and smp.enqueue_plan(4097, rs.randn(3, 7), 3) is None
+    assert smp.enqueue_plan(16, rs.randn(65, 7), 3) is not None
+    smp.NOISE_BUDGET = 1000                                  # (a loop whose normal numbers would not fit: the host loop serves it)
+    assert smp.enqueue_plan(16, rs.randn(3, 7), 3) is None
+    del smp.NOISE_BUDGET
     with pytest.raises(ValueError):
-        smp(16, np.ones(65), rs.randn(65, 7))
+        smp(16, np.ones(4097), rs.randn(4097, 7))
     with pytest.raises(ValueError):
         smp(16, np.ones(2), rs.randn(2, 9))
     assert tuple(smp(5, np.array([]), np.array([])).shape) == (5, 6)
@@ -250,3 +259,129 @@ def test_enqueue_is_declined_where_the_host_has_to_act(bc):
     alg3 = bc.SparseVICoreset(Z, bc.DeviceProjector("linreg", smp, S, sigsq=sigsq), opt_itrs=5)
     alg3.build(2)
     assert alg3._enqueue_plan() is not None
+
+
+@pytest.mark.parametrize("D,k,prior", ((7, 3, "dense"), (31, 40, "dense"), (32, 5, "iso"), (33, 64, "dense"), (64, 200, "iso"), (100, 1, "dense"),
+                                       (301, 300, "iso"), (301, 65, "dense"), (302, 0, "dense"), (511, 130, "dense"), (1000, 50, "iso"),
+                                       (1024, 1100, "dense"), (96, 4096, "iso")))
+def test_posterior_factor_kernel(bc, D, k, prior):
+    """bcx_linreg_posterior_factor (csrc/lrpost.hip) against NumPy: L^-1 of the Cholesky factor of the weighted precision and the
+    posterior mean, as examples/common/model_linreg.py:26-41 forms them (tests/models.py, pinned to reference outputs by F12)."""
+    import torch
+    from bayesiancoresets_amd import _native
+    lib = _native.load()
+    rs = np.random.RandomState(31 * D + k)
+    mu0 = rs.randn(D)
+    if prior == "dense":
+        A0 = rs.randn(D, D)
+        Sig0 = A0.dot(A0.T) / D + np.eye(D)
+    else:
+        Sig0 = 2.5 * np.eye(D)
+    sigsq = 0.4
+    S0inv = np.linalg.inv(Sig0)
+    pts = rs.randn(max(k, 1), D + 1)[:k]
+    w = np.abs(rs.randn(k)) * 20.0
+    if k > 2:
+        w[1] = 0.0
+        w[2] = -3.0                                           # (clamped at zero, as the rank-k kernels do)
+    ld = D + D % 2
+    Xp = np.zeros((k, ld))
+    Xp[:, :D] = pts[:, :-1]
+    d = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float64)).cuda()
+    need = int(lib.bcx_linreg_posterior_factor_scratch_bytes(D))
+    assert need > 0 and lib.bcx_linreg_posterior_factor_scratch_bytes(1025) == -1
+    work = torch.empty(need // 8, dtype=torch.float64, device="cuda")
+    Linv, mu = torch.zeros(D, ld, dtype=torch.float64, device="cuda"), torch.zeros(D, dtype=torch.float64, device="cuda")
+    w_d, X_d, y_d, S_d, r_d = d(w if k else np.zeros(1)), d(Xp if k else np.zeros(2)), d(pts[:, -1] if k else np.zeros(1)), d(S0inv), d(S0inv.dot(mu0))
+    st = int(torch.cuda.current_stream().cuda_stream)
+    for rep in range(2):                                      # (the second call reuses the scratch: flags, tiles)
+        rc = lib.bcx_linreg_posterior_factor(st, k, D, ld, w_d.data_ptr(), X_d.data_ptr(), y_d.data_ptr(), S_d.data_ptr(), D, r_d.data_ptr(),
+                                             sigsq, work.data_ptr(), work.numel() * 8, Linv.data_ptr(), ld, mu.data_ptr())
+        assert rc == 0, lib.bcx_project_last_error()
+        assert lib.bcx_linreg_posterior_factor_status(st, D, work.data_ptr()) == 0, lib.bcx_project_last_error()
+    wc = np.maximum(w, 0.0)
+    X, y = pts[:, :-1], pts[:, -1]
+    P = S0inv + (wc[:, None] * X).T.dot(X) / sigsq
+    L = np.linalg.cholesky(P)
+    want = np.linalg.inv(L)
+    got = Linv.cpu().numpy()
+    assert np.all(got[:, D:] == 0.0) and np.all(np.triu(got[:, :D], 1) == 0.0)
+    assert np.abs(got[:, :D] - want).max() <= 1e-13 * D * np.abs(want).max() * max(1.0, np.linalg.cond(L) * 1e-2)
+    mu_ref = np.linalg.solve(P, S0inv.dot(mu0) + (wc * y).dot(X) / sigsq)
+    np.testing.assert_allclose(mu.cpu().numpy(), mu_ref, rtol=1e-9, atol=1e-10 * np.abs(mu_ref).max())
+    # argument checks
+    assert lib.bcx_linreg_posterior_factor(st, k, D, ld, w_d.data_ptr(), X_d.data_ptr(), y_d.data_ptr(), S_d.data_ptr(), D, r_d.data_ptr(),
+                                           sigsq, work.data_ptr(), need - 8, Linv.data_ptr(), ld, mu.data_ptr()) == _native.ERR_ARG
+    assert lib.bcx_linreg_posterior_factor(st, 4097, D, ld, w_d.data_ptr(), X_d.data_ptr(), y_d.data_ptr(), S_d.data_ptr(), D, r_d.data_ptr(),
+                                           sigsq, work.data_ptr(), need, Linv.data_ptr(), ld, mu.data_ptr()) == _native.ERR_ARG
+
+
+@pytest.mark.parametrize("k,S,raw", ((65, 256, 1), (130, 100, 0), (300, 256, 1), (1000, 48, 1), (67, 1000, 0)))
+def test_adam_step_ws_kernels_against_nn_opt(bc, k, S, raw):
+    """More than 64 weights: the two-launch form of the ADAM step (csrc/svi.hip svi_adam_a / b_kernel) against ``nn_opt``."""
+    import torch
+    from bayesiancoresets_amd import _native
+    from bayesiancoresets_amd.util.opt import nn_opt
+    lib = _native.load()
+    rs = np.random.RandomState(k * 7 + S)
+    core_raw = rs.randn(k, S) + 5.0 * rs.randn(k, 1)
+    core = core_raw - core_raw.mean(axis=1)[:, None]
+    colsum = 3.0 * rs.randn(S)
+    w0 = np.abs(rs.randn(k))
+    T, scaling = 12, 1.7
+    sched_fn = lambda i: 0.3 / (1.0 + i)
+    b1, b2, eps = 0.9, 0.999, 1e-8
+
+    def grd(w):
+        return -core.dot(scaling * colsum - w.dot(core)) / S
+    want = nn_opt(w0, grd, opt_itrs=T, step_sched=sched_fn)
+    sched = np.array([(sched_fn(i), 1.0 - b1 ** (i + 1), 1.0 - b2 ** (i + 1)) for i in range(T)])
+    d = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float64)).cuda()
+    core_d, col_d, w, m1, m2, sc, tr = d(core_raw if raw else core), d(colsum), d(w0), d(np.zeros(k)), d(np.zeros(k)), d(sched), d(np.zeros((T, k)))
+    need = int(lib.bcx_sparsevi_adam_scratch_bytes(k, S))
+    assert need > 0 and lib.bcx_sparsevi_adam_scratch_bytes(64, S) == 0 and lib.bcx_sparsevi_adam_scratch_bytes(4097, S) == -1
+    work = torch.empty(need // 8, dtype=torch.float64, device="cuda")
+    stream = int(torch.cuda.current_stream().cuda_stream)
+    for i in range(T):
+        assert lib.bcx_sparsevi_adam_step_ws(stream, k, S, col_d.data_ptr(), scaling, core_d.data_ptr(), S, w.data_ptr(), m1.data_ptr(),
+                                             m2.data_ptr(), sc.data_ptr(), i, b1, b2, eps, tr.data_ptr(), raw, work.data_ptr(), need) == 0
+    got = w.cpu().numpy()
+    np.testing.assert_allclose(got, want, rtol=1e-9, atol=1e-12)
+    assert np.array_equal(tr.cpu().numpy()[-1], got) and (got >= 0).all()
+    assert lib.bcx_sparsevi_adam_step_ws(stream, k, S, col_d.data_ptr(), scaling, core_d.data_ptr(), S, w.data_ptr(), m1.data_ptr(),
+                                         m2.data_ptr(), sc.data_ptr(), 0, b1, b2, eps, None, raw, work.data_ptr(), need - 8) == _native.ERR_ARG
+
+
+@pytest.mark.parametrize("D,k,colsum", ((301, 28, "moments"), (24, 65, "mfma"), (24, 130, "moments"), (301, 300, "moments"), (12, 300, "mfma")))
+def test_enqueued_loop_against_the_oracle_at_reference_coreset_sizes(bc, D, k, colsum):
+    """The weight optimisation (sparsevi.py:69-76) of a coreset of k points -- the sizes the reference's experiment reaches
+    (examples/linear_regression/main.py:284 coreset_size_max = 300) -- enqueued on the device against oracle/sparsevi_oracle.py
+    on the same parameter draws: both sides start from the same k seeded points and weights (what k greedy steps leave)."""
+    import torch
+    from oracle.sparsevi_oracle import SparseVIOracle, linreg_loglik
+    N, S, T = 4000, 32, 12
+    rs = np.random.RandomState(100 * D + k)
+    Z = make_linreg_data(13, N, D)
+    A0 = rs.randn(D, D)
+    mu0, Sig0, sigsq = 0.2 * rs.randn(D), 1.5 * (A0.dot(A0.T) / D + np.eye(D)), 0.8
+    idcs = np.sort(rs.choice(N, size=k, replace=False)).astype(np.int64)
+    w0 = np.abs(rs.randn(k)) * (N / k)
+    w0[::7] = 0.0
+    g = torch.Generator(device="cuda")
+    g.manual_seed(29)
+    noise = torch.randn(T + 3, S, D + D % 2, dtype=torch.float64, device="cuda", generator=g)
+    ref_smp = _ReplaySampler(bc.LinregPosteriorSampler(mu0, Sig0, sigsq), noise)
+    orc = SparseVIOracle(Z, lambda n, w, p: ref_smp(n, np.asarray(w, dtype=np.float64), p).cpu().numpy().copy(),
+                         lambda z, th: linreg_loglik(z, th, sigsq), S, opt_itrs=T)
+    orc.wts, orc.idcs, orc.pts = w0.copy(), idcs.copy(), Z[idcs].copy()
+    orc.optimize()
+    smp = _ReplaySampler(bc.LinregPosteriorSampler(mu0, Sig0, sigsq), noise)
+    alg = bc.SparseVICoreset(Z, bc.DeviceProjector("linreg", smp, S, sigsq=sigsq, colsum=colsum), opt_itrs=T)
+    alg.wts, alg.idcs, alg.pts = w0.copy(), idcs.copy(), Z[idcs].copy()
+    plan = alg._enqueue_plan()
+    assert plan is not None                                   # (no host loop at these sizes)
+    smp.at -= T                                               # (the probe drew a plan's worth of normal numbers)
+    alg._optimize()
+    assert smp.at == ref_smp.at == 1 + T
+    assert (alg.wts > 0).sum() >= k // 2
+    np.testing.assert_allclose(alg.wts, orc.wts, rtol=1e-7, atol=1e-9 * np.abs(orc.wts).max())
