@@ -36,6 +36,7 @@ SYMBOLS = (
     "bcx_project_colsum_moments_at", "bcx_linreg_posterior_draw", "bcx_sparsevi_adam_step",
     "bcx_linreg_posterior_apply", "bcx_linreg_posterior_apply_ok",
     "bcx_linreg_posterior_factor", "bcx_linreg_posterior_factor_scratch_bytes", "bcx_linreg_posterior_factor_status",
+    "bcx_linreg_posterior_draw_factored",
     "bcx_sparsevi_adam_step_ws", "bcx_sparsevi_adam_scratch_bytes",
 )
 
@@ -161,6 +162,7 @@ def load():
     sigs["bcx_gram_check"] = [vp, vp]
     sigs["bcx_linreg_posterior_factor"] = [vp, i32, i32, i32, vp, vp, vp, vp, i32, vp, dbl, vp, i64, vp, i64, vp]
     sigs["bcx_linreg_posterior_factor_status"] = [vp, i32, vp]
+    sigs["bcx_linreg_posterior_draw_factored"] = [vp, i32, i32, vp, i64, vp, vp, vp, i32, vp, vp]
     sigs["bcx_sparsevi_adam_step_ws"] = [vp, i32, i32, vp, dbl, vp, i64, vp, vp, vp, vp, i32, dbl, dbl, dbl, vp, i32, vp, i64]
     lib.bcx_linreg_posterior_factor_scratch_bytes.restype = ctypes.c_int64
     lib.bcx_linreg_posterior_factor_scratch_bytes.argtypes = [i32]

@@ -74,12 +74,15 @@ class LinregPosteriorSampler(object):
         return 0 <= k <= (self.KMAX if self.D <= self.DMAX else self.KLOW) and 1 <= n <= self.SMAX
 
     def _low_rank(self, k):
-        """Which form serves k points: the rank-k correction inside one workgroup while its per-step kernel applies
-        (csrc/svi.hip lrs_apply_kernel: X and B2 in LDS), the D x D factorisation beyond (measured at D = 301: the k x k
-        Cholesky every workgroup of lrs_draw_kernel repeats costs 140 us per call at k = 32 and 350 at k = 64)."""
+        """Which form serves k points: the rank-k correction inside one workgroup (csrc/svi.hip lrs_apply_kernel: every
+        workgroup repeats the k x k Cholesky, a thread per column does the triangular solves) while that is the faster one,
+        the D x D factorisation (csrc/lrpost.hip) beyond.  Measured per ADAM step of the enqueued loop at D = 301, S = 256
+        (tools/c5_ksweep.py): rank-k 40 / 54 / 72 / 94 / 119 / 147 / 171 us at k = 4 / 8 / 12 / 16 / 20 / 24 / 27, the D x D form
+        143 - 157 us whatever k (its chain of D pivots does not depend on k: ~9 us per block of 32 columns + ~60 us)."""
         if self.D > self.DMAX:
             return True
-        return k == 0 or bool(self._lib.bcx_linreg_posterior_apply_ok(k, self.ld))
+        nt = (self.D + 31) // 32
+        return k == 0 or (k <= 4 + 2 * nt and bool(self._lib.bcx_linreg_posterior_apply_ok(k, self.ld)))
 
     def _factor_state(self):
         f = self._factor
@@ -90,7 +93,7 @@ class LinregPosteriorSampler(object):
                 "S0inv": torch.from_numpy(np.ascontiguousarray(self._S0inv_host)).to(self.device),
                 "rhs0": torch.from_numpy(self._S0inv_host.dot(self.mu0)).to(self.device),
                 "work": torch.empty((need + 7) // 8, dtype=torch.float64, device=self.device),
-                "Linv": torch.zeros(D, self.ld, dtype=torch.float64, device=self.device),     # (the upper triangle stays zero)
+                "U": torch.zeros(D, self.ld, dtype=torch.float64, device=self.device),        # U = L^-T (the lower triangle stays zero)
                 "mu": torch.zeros(D, dtype=torch.float64, device=self.device),
             }
         return f
@@ -99,9 +102,17 @@ class LinregPosteriorSampler(object):
         """Argument list of bcx_linreg_posterior_factor at the points ``st`` and the device-resident weights ``w_dev``."""
         f = self._factor_state()
         stream = int(self._torch.cuda.current_stream(self.device).cuda_stream)
-        return [stream, st["k"], self.D, self.ld, w_dev.data_ptr(), st["X"].data_ptr(), st["y"].data_ptr(), f["S0inv"].data_ptr(), self.D,
-                f["rhs0"].data_ptr(), self.sigsq, f["work"].data_ptr(), f["work"].numel() * 8, f["Linv"].data_ptr(), self.ld,
+        return [stream, st["k"], self.D, st["ldk"], w_dev.data_ptr(), st["XT"].data_ptr(), st["y"].data_ptr(), f["S0inv"].data_ptr(), self.D,
+                f["rhs0"].data_ptr(), self.sigsq, f["work"].data_ptr(), f["work"].numel() * 8, f["U"].data_ptr(), self.ld,
                 f["mu"].data_ptr()]
+
+    def _draw_factored_args(self, theta, tbar=None):
+        """Argument list of bcx_linreg_posterior_draw_factored (theta = mu_w + R U^T); slots 6 / 7 take the normal numbers and
+        their column means."""
+        f = self._factor
+        stream = int(self._torch.cuda.current_stream(self.device).cuda_stream)
+        return [stream, self.D, self.ld, f["U"].data_ptr(), self.ld, f["mu"].data_ptr(), 0, 0, theta.shape[0], theta.data_ptr(),
+                (self._tbar if tbar is None else tbar).data_ptr()]
 
     def factor_status(self):
         """Synchronises; raises if the last factorisation's workgroups lost each other or met a non-positive pivot."""
@@ -124,9 +135,13 @@ class LinregPosteriorSampler(object):
         Xp = np.zeros((k, self.ld))
         Xp[:, :self.D] = X
         if not self._low_rank(k):
-            # the D x D form needs the features and the responses only
-            d = torch.from_numpy(np.concatenate((y, np.zeros(k % 2), Xp.ravel()))).to(self.device)
-            st = {"k": k, "y": d[:k], "X": d[k + k % 2:], "blob": d, "low_rank": False}
+            # the D x D form needs the responses and the features BY points (row a: feature a of the k points; the row stride
+            # is k rounded up to 32, zero padded: csrc/lrpost.hip reads both operands of X^T diag(w) X along the points)
+            ldk = (k + 31) // 32 * 32
+            XT = np.zeros((self.D, ldk))
+            XT[:, :k] = X.T
+            d = torch.from_numpy(np.concatenate((y, np.zeros(k % 2), XT.ravel()))).to(self.device)
+            st = {"k": k, "y": d[:k], "XT": d[k + k % 2:], "ldk": ldk, "blob": d, "low_rank": False}
             self._pts_key, self._pts_state = pts.copy(), st
             return st
         XU0, XS0 = np.zeros((k, self.ld)), np.zeros((k, self.ld))
@@ -180,8 +195,12 @@ class LinregPosteriorSampler(object):
             rc = self._lib.bcx_linreg_posterior_factor(*self._factor_args(st, w_dev))
             if rc != 0:
                 raise self._nat.EngineError(rc, self._lib.bcx_project_last_error().decode())
-            f = self._factor
-            self._launch(None, self._none, R, R.mean(dim=0), theta, mu0=f["mu"], U0T=f["Linv"])
+            a = self._draw_factored_args(theta)
+            rbar = R.mean(dim=0)
+            a[6], a[7] = R.data_ptr(), rbar.data_ptr()
+            rc = self._lib.bcx_linreg_posterior_draw_factored(*a)
+            if rc != 0:
+                raise self._nat.EngineError(rc, self._lib.bcx_project_last_error().decode())
             self.factor_status()
         else:
             self._launch(st, w_dev, R, R.mean(dim=0), theta)
@@ -249,10 +268,8 @@ class _Plan(object):
             elif self.factored:
                 # the D x D form: factor at the current weights (csrc/lrpost.hip), then theta = mu_w + R L^-1
                 self._pre = (s._lib.bcx_linreg_posterior_factor, s._factor_args(st, w_dev))
-                f = s._factor
-                a = [stream, 0, s.D, s.ld, None, None, None, None, None, None, f["Linv"].data_ptr(), f["mu"].data_ptr(), s.sigsq, 0, 0,
-                     self.n, self.theta.data_ptr(), s._tbar.data_ptr()]
-                self._at, self._fn = (13, 14), s._lib.bcx_linreg_posterior_draw
+                a = s._draw_factored_args(self.theta)
+                self._at, self._fn = (6, 7), s._lib.bcx_linreg_posterior_draw_factored
                 rows, means = self.noise, self.rbar
             else:
                 a = [stream, st["k"], s.D, s.ld, w_dev.data_ptr(), st["K0"].data_ptr(), st["xmu0"].data_ptr(), st["y"].data_ptr(),

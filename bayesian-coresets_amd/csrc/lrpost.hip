@@ -53,7 +53,7 @@ typedef double lp4d __attribute__((ext_vector_type(4)));
 
 struct LpArgs {
   // inputs of the form kernel
-  const double* w; const double* X; const double* y;      // k weights, k x ldx features (padding columns zero), k responses
+  const double* w; const double* XT; const double* y;     // k weights, D x ldx features BY points (row a: feature a of the k points), k responses
   const double* S0inv; const double* rhs0;                 // D x lds0 prior precision, Sig0^-1 mu0
   double sigsq;
   int k, D, ldx, lds0;
@@ -67,7 +67,7 @@ struct LpArgs {
   double* rhs;    // 32 nt doubles: Sig0^-1 mu0 + X^T (w y) / sigsq, zero padded
   int* flags;     // F1 [nt] | C [nt] | A1 [nt] | A2 [nt] | status
   // outputs
-  double* Linv; int64_t ldl;   // D x ldl row-major, lower triangular (the upper triangle is never written: the caller zeroes it once)
+  double* U; int64_t ldu;      // D x ldu row-major: U = L^-T, upper triangular (the lower triangle is never written: the caller zeroes it once)
   double* mu;                  // D
   int nt, H;
   long long timeout_ticks;
@@ -123,48 +123,44 @@ static __device__ __forceinline__ void lp_quad_store(double* tile, int rb, int c
 
 // ---- P and the right-hand side ------------------------------------------------------------------------------------------
 // Workgroups 0 .. nt (nt + 1) / 2 - 1: tile (i, j), i >= j, of P = S0inv + X^T diag(w / sigsq) X (k-grouped, into TT); rows /
-// columns >= D are padded with the identity.  Workgroups after them, one per block of 32 columns: that block of the
-// right-hand side; the first of them clears the flags.
+// columns >= D are padded with the identity.  The features arrive BY points (XT: row a = feature a of all k points), so
+// both operands of the product are read along the contraction index: lane (i = lane % 16, g = lane / 16) takes the values
+// 8 g .. 8 g + 7 of each run of 32 points as four 16-byte loads, one value per MFMA step (any assignment of the inner index
+// to steps serves as long as both operands use the same one); three runs are in flight.  Workgroups after them, one per
+// block of 32 columns: that block of the right-hand side; the first of them clears the flags.
+typedef double lp2d __attribute__((ext_vector_type(2)));
 __global__ __launch_bounds__(256) void lrp_form_kernel(LpArgs a) {
-  __shared__ double sw[4096];                       // w_j / sigsq (the second kind of workgroup: w_j y_j / sigsq)
-  __shared__ double sred[8][32];
+  __shared__ double sw[4096 + 32];                  // w_j / sigsq (the second kind of workgroup: w_j y_j / sigsq), zero padded
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int nt = a.nt, D = a.D, k = a.k;
   const int ntop = nt * (nt + 1) / 2;
+  const int kp = (k + 31) & ~31;
   if ((int)blockIdx.x >= ntop) {
     const int j = blockIdx.x - ntop;
     if (j == 0) for (int e = tid; e < 4 * nt + 1; e += 256) a.flags[e] = 0;
-    for (int e = tid; e < k; e += 256) sw[e] = fmax(a.w[e], 0.0) / a.sigsq * a.y[e];
+    for (int e = tid; e < kp; e += 256) sw[e] = e < k ? fmax(a.w[e], 0.0) / a.sigsq * a.y[e] : 0.0;
     __syncthreads();
-    // rhs0 + X^T (w y) / sigsq for the 32 columns of block j: eight groups of points, added in group order
-    const int c = j * 32 + (tid & 31), g = tid >> 5;
-    double s = 0.0;
-    if (c < D) {
-      int jj = g;
-      for (; jj + 24 < k; jj += 32) {               // (four independent loads in flight)
-        const double x0 = a.X[(size_t)jj * a.ldx + c], x1 = a.X[(size_t)(jj + 8) * a.ldx + c];
-        const double x2 = a.X[(size_t)(jj + 16) * a.ldx + c], x3 = a.X[(size_t)(jj + 24) * a.ldx + c];
-        s += sw[jj] * x0; s += sw[jj + 8] * x1; s += sw[jj + 16] * x2; s += sw[jj + 24] * x3;
-      }
-      for (; jj < k; jj += 8) s += sw[jj] * a.X[(size_t)jj * a.ldx + c];
-    }
-    sred[g][tid & 31] = s;
-    __syncthreads();
-    if (tid < 32) {
-      double v = 0.0;
+    // rhs0 + X^T (w y) / sigsq: a wave per column, lanes along the points
+    for (int q = wave; q < 32; q += 4) {
+      const int c = j * 32 + q;
+      double s = 0.0;
       if (c < D) {
-        v = a.rhs0[c];
-#pragma unroll
-        for (int q = 0; q < 8; ++q) v += sred[q][tid];
+        const double* row = a.XT + (size_t)c * a.ldx;
+        for (int jj = 2 * lane; jj < k; jj += 128) {
+          const lp2d x = *(const lp2d*)(row + jj);
+          s = fma(sw[jj], x.x, s);
+          if (jj + 1 < k) s = fma(sw[jj + 1], x.y, s);
+        }
+        s = wave_allsum(s) + a.rhs0[c];
       }
-      a.rhs[c] = v;
+      if (lane == 0) a.rhs[c] = s;
     }
     return;
   }
   int i = 0, t = blockIdx.x;
   while (t >= i + 1) { t -= i + 1; ++i; }
   const int j = t;                                  // tile (i, j), j <= i
-  for (int e = tid; e < k; e += 256) sw[e] = fmax(a.w[e], 0.0) / a.sigsq;
+  for (int e = tid; e < kp; e += 256) sw[e] = e < k ? fmax(a.w[e], 0.0) / a.sigsq : 0.0;
   const int rb = wave >> 1, cb = wave & 1;
   const int li = lane & 15, lk = lane >> 4;
   const int ra = i * 32 + rb * 16 + li;             // the A operand's row of P (a feature), this lane
@@ -178,33 +174,35 @@ __global__ __launch_bounds__(256) void lrp_form_kernel(LpArgs a) {
       acc[r] = (row < D && col < D) ? a.S0inv[(size_t)row * a.lds0 + col] : (row == col ? 1.0 : 0.0);
     }
   }
+  const double* pa = a.XT + (size_t)(ra < D ? ra : 0) * a.ldx + 8 * lk;
+  const double* pb = a.XT + (size_t)(rbcol < D ? rbcol : 0) * a.ldx + 8 * lk;
   const bool aok = ra < D, bok = rbcol < D;
-  // 32 points per round: the next round's features are requested before this round's products (two register sets)
+  // (ldx >= kp rounded to 32 points and the padding is zero: bcx_linreg_posterior_factor checks the stride, the caller pads)
   auto fetch = [&](int j0, double (&xa)[8], double (&xb)[8]) {
 #pragma unroll
-    for (int tt = 0; tt < 8; ++tt) {
-      const int jj = j0 + 4 * tt + lk;
-      const bool ok = jj < k;
-      const size_t o = (size_t)(ok ? jj : 0) * a.ldx;
-      xa[tt] = (ok && aok) ? a.X[o + ra] : 0.0;
-      xb[tt] = (ok && bok) ? a.X[o + rbcol] : 0.0;
+    for (int q = 0; q < 4; ++q) {
+      const lp2d u = *(const lp2d*)(pa + j0 + 2 * q), v = *(const lp2d*)(pb + j0 + 2 * q);
+      xa[2 * q] = aok ? u.x : 0.0; xa[2 * q + 1] = aok ? u.y : 0.0;
+      xb[2 * q] = bok ? v.x : 0.0; xb[2 * q + 1] = bok ? v.y : 0.0;
     }
   };
   auto scale = [&](int j0, double (&xa)[8]) {
 #pragma unroll
-    for (int tt = 0; tt < 8; ++tt) { const int jj = j0 + 4 * tt + lk; xa[tt] *= jj < k ? sw[jj] : 0.0; }
+    for (int q = 0; q < 8; ++q) xa[q] *= sw[j0 + 8 * lk + q];
   };
-  double xa0[8], xb0[8], xa1[8], xb1[8];
-  if (k > 0) fetch(0, xa0, xb0);
+  double xa[3][8], xb[3][8];
+  if (kp > 0) fetch(0, xa[0], xb[0]);
+  if (kp > 32) fetch(32, xa[1], xb[1]);
   __syncthreads();                                  // (sw)
-  for (int j0 = 0; j0 < k; j0 += 64) {
-    if (j0 + 32 < k) fetch(j0 + 32, xa1, xb1);
-    scale(j0, xa0);
-    acc = lp_mma(xa0, xb0, acc);
-    if (j0 + 32 < k) {
-      if (j0 + 64 < k) fetch(j0 + 64, xa0, xb0);
-      scale(j0 + 32, xa1);
-      acc = lp_mma(xa1, xb1, acc);
+  for (int j0 = 0; j0 < kp; j0 += 96) {
+#pragma unroll
+    for (int u = 0; u < 3; ++u) {
+      const int jc = j0 + 32 * u;
+      if (jc < kp) {
+        if (jc + 64 < kp) fetch(jc + 64, xa[(u + 2) % 3], xb[(u + 2) % 3]);
+        scale(jc, xa[u]);
+        acc = lp_mma(xa[u], xb[u], acc);
+      }
     }
   }
   lp_quad_store<false>(a.TT + (size_t)(i * nt + j) * LP_TILE, rb, cb, lane, acc);
@@ -334,7 +332,6 @@ __global__ __launch_bounds__(256) void lrp_chol_kernel(LpArgs a) {
   __shared__ double s_w[LP_TILE];                   // W_pp
   __shared__ double s_a1[LP_TILE];                  // chain: sub-diagonal tile before the multiplication by W_pp^T; helpers: the same role
   __shared__ double s_l1[2][LP_TILE];               // the chain's sub-diagonal tiles L_{p+1,p}, this step's and the last's
-  __shared__ double s_red[8][32];
   __shared__ int s_ok, s_bad;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int nt = a.nt, H = a.H, D = a.D;
@@ -500,12 +497,12 @@ __global__ __launch_bounds__(256) void lrp_chol_kernel(LpArgs a) {
       else {
         lp_quad_store<true>(a.BL + (size_t)(rrow * nt + p) * LP_TILE, rb, cb, lane, c);
         if (!is_rhs) {
-          // finished tile (r, p) of L^-T: its transpose is block (p, r) of L^-1, row-major for the draw kernel
-          const int orow = p * 32 + cb * 16 + (lane & 15);
+          // finished tile (r, p) of U = L^-T, row-major for the draw kernel
+          const int ocol = p * 32 + cb * 16 + (lane & 15);
 #pragma unroll
           for (int q = 0; q < 4; ++q) {
-            const int ocol = R * 32 + rb * 16 + (lane >> 4) + 4 * q;
-            if (orow < D && ocol < D) lp_st(a.Linv + (size_t)orow * a.ldl + ocol, c[q]);
+            const int orow = R * 32 + rb * 16 + (lane >> 4) + 4 * q;
+            if (orow < D && ocol < D) lp_st(a.U + (size_t)orow * a.ldu + ocol, c[q]);
           }
         }
       }
@@ -513,25 +510,95 @@ __global__ __launch_bounds__(256) void lrp_chol_kernel(LpArgs a) {
     }
     if (done) { lp_signal(&C[p], done); if (wave == 0) LP_STAMP(2); }
   }
-  // ---- mu = L^-T u, u = L^-1 rhs (row 0 of the finished right-hand side tiles): 32 columns per workgroup ----
+  // ---- mu = U u, u = L^-1 rhs (row 0 of the finished right-hand side tiles): 32 rows of U per workgroup, a wave per row, lanes
+  // along the row.  Everything has been published: ONE acquire, then plain (pipelined) loads.
   if (!lp_wait(&C[nt - 1], lp_panel_count(nt, nt - 1), a, &s_ok)) return;
+  if (tid == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+  __syncthreads();
   for (int cbk = h; cbk < nt; cbk += H) {
-    const int c = cbk * 32 + (tid & 31), g = tid >> 5;                // eight groups of rows
-    double s = 0.0;
-    if (c < D)
-      for (int i = cbk * 32 + g; i < D; i += 8) {
-        const double u = lp_ld(a.BL + (size_t)(nt * nt + (i >> 5)) * LP_TILE + lp_kg(0, i & 31));
-        s += u * lp_ld(a.Linv + (size_t)i * a.ldl + c);
+    for (int q = wave; q < 32; q += 4) {
+      const int c = cbk * 32 + q;
+      if (c >= D) continue;                         // (wave-uniform)
+      const double* row = a.U + (size_t)c * a.ldu;
+      double s = 0.0;
+      for (int i = (c & ~63) + lane; i < D; i += 64) {
+        const double u = a.BL[(size_t)(nt * nt + (i >> 5)) * LP_TILE + lp_kg(0, i & 31)];
+        s = fma(i >= c ? row[i] : 0.0, u, s);
       }
-    s_red[g][tid & 31] = s;
-    __syncthreads();
-    if (tid < 32 && c < D) {
-      double m = 0.0;
-#pragma unroll
-      for (int q = 0; q < 8; ++q) m += s_red[q][tid];
-      a.mu[c] = m;
+      s = wave_allsum(s);
+      if (lane == 0) a.mu[c] = s;
     }
-    __syncthreads();
+  }
+}
+
+// ---- the draws: theta = mu + [R; Rbar] U^T ----------------------------------------------------------------------------------
+// (examples/linear_regression/main.py:147: muw + randn(n, D).dot(USigw.T))  32 x 32 blocks of the product, one 16 x 16 tile per
+// wave, both operands read along the contraction index as in lrp_form_kernel; U is upper triangular, so the block of columns
+// c0 .. c0 + 31 of theta starts its inner index at c0.  Row S of the left operand is Rbar, the column means of R: its "draw"
+// is the mean of the draws (what the closed-form column sums are expanded around, csrc/moments.hip).
+struct LpDrawArgs {
+  const double* U; const double* mu; const double* R; const double* Rbar;
+  double* theta; double* tbar;
+  int64_t ldu;
+  int D, S, ld;
+};
+__global__ __launch_bounds__(256) void lrp_draw_kernel(LpDrawArgs a) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 15, lk = lane >> 4, rb = wave >> 1, cb = wave & 1;
+  const int D = a.D, S = a.S;
+  const int arow = blockIdx.x * 32 + rb * 16 + li;  // row of [R; Rbar]
+  const int bcol = blockIdx.y * 32 + cb * 16 + li;  // column of theta = row of U
+  const double* rp = (arow < S ? a.R + (size_t)arow * a.ld : a.Rbar) + 8 * lk;
+  const double* up = a.U + (size_t)(bcol < D ? bcol : 0) * a.ldu + 8 * lk;
+  const bool aok = arow <= S, bok = bcol < D;
+  const int k0 = blockIdx.y * 32;                   // (U[c][i] = 0 for i < c)
+  auto fetch = [&](int kb, double (&xa)[8], double (&xb)[8]) {
+    const int kk = kb + 8 * lk;
+    if (kk + 8 <= D) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const lp2d u = *(const lp2d*)(rp + kb + 2 * q), v = *(const lp2d*)(up + kb + 2 * q);
+        xa[2 * q] = u.x; xa[2 * q + 1] = u.y; xb[2 * q] = v.x; xb[2 * q + 1] = v.y;
+      }
+    } else {
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const bool ok = kk + q < D;
+        xa[q] = ok ? rp[kb + (ok ? q : 0)] : 0.0;
+        xb[q] = ok ? up[kb + (ok ? q : 0)] : 0.0;
+      }
+    }
+    if (!aok) {
+#pragma unroll
+      for (int q = 0; q < 8; ++q) xa[q] = 0.0;
+    }
+    if (!bok) {
+#pragma unroll
+      for (int q = 0; q < 8; ++q) xb[q] = 0.0;
+    }
+  };
+  lp4d acc = (lp4d){0.0, 0.0, 0.0, 0.0};
+  double xa[3][8], xb[3][8];
+  fetch(k0, xa[0], xb[0]);
+  if (k0 + 32 < D) fetch(k0 + 32, xa[1], xb[1]);
+  for (int kb = k0; kb < D; kb += 96) {
+#pragma unroll
+    for (int u = 0; u < 3; ++u) {
+      const int kc = kb + 32 * u;
+      if (kc < D) {
+        if (kc + 64 < D) fetch(kc + 64, xa[(u + 2) % 3], xb[(u + 2) % 3]);
+        acc = lp_mma(xa[u], xb[u], acc);
+      }
+    }
+  }
+  const int col = blockIdx.y * 32 + cb * 16 + li;
+  const double mu = col < D ? a.mu[col] : 0.0;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int row = blockIdx.x * 32 + rb * 16 + lk + 4 * r;
+    const double v = col < D ? mu + acc[r] : 0.0;
+    if (row < S && col < a.ld) a.theta[(size_t)row * a.ld + col] = v;
+    else if (row == S && col < D) a.tbar[col] = v;
   }
 }
 
@@ -563,18 +630,19 @@ extern "C" int64_t bcx_linreg_posterior_factor_scratch_bytes(int32_t D) {
   return lrp_tiles(nt) * LP_TILE * 8 + (int64_t)nt * 32 * 8 + lrp_flag_bytes(nt) + LRP_DBG_BYTES(nt);
 }
 
-extern "C" int bcx_linreg_posterior_factor(void* stream, int32_t k, int32_t D, int32_t ldx, const void* w_dev, const void* X_dev,
+extern "C" int bcx_linreg_posterior_factor(void* stream, int32_t k, int32_t D, int32_t ldx, const void* w_dev, const void* XT_dev,
                                            const void* y_dev, const void* S0inv_dev, int32_t lds0, const void* rhs0_dev, double sigsq,
-                                           void* work_dev, int64_t work_bytes, void* Linv_dev, int64_t ldl, void* mu_dev) {
-  if (k < 0 || k > 4096 || D < 1 || D > LP_NB * LP_MAX_NT || ldx < D || lds0 < D || ldl < D || !(sigsq > 0.0) || !S0inv_dev || !rhs0_dev ||
-      !work_dev || !Linv_dev || !mu_dev || (k > 0 && (!w_dev || !X_dev || !y_dev)) ||
-      work_bytes < bcx_linreg_posterior_factor_scratch_bytes(D) || ((uintptr_t)work_dev & 15)) {
-    bcx_project_set_error("bcx_linreg_posterior_factor: bad arguments (k <= 4096 points, D <= 1024 features, scratch of "
+                                           void* work_dev, int64_t work_bytes, void* U_dev, int64_t ldu, void* mu_dev) {
+  if (k < 0 || k > 4096 || D < 1 || D > LP_NB * LP_MAX_NT || ldx < (k + 31) / 32 * 32 || lds0 < D || ldu < D || (ldu & 1) || !(sigsq > 0.0) ||
+      !S0inv_dev || !rhs0_dev || !work_dev || !U_dev || !mu_dev || (k > 0 && (!w_dev || !XT_dev || !y_dev)) ||
+      work_bytes < bcx_linreg_posterior_factor_scratch_bytes(D) || (((uintptr_t)work_dev | (uintptr_t)XT_dev | (uintptr_t)U_dev) & 15)) {
+    bcx_project_set_error("bcx_linreg_posterior_factor: bad arguments (k <= 4096 points, D <= 1024 features, the features by points "
+                          "with a row stride of k rounded up to 32, zero padded, 16-byte aligned; scratch of "
                           "bcx_linreg_posterior_factor_scratch_bytes(D) bytes)");
     return BCX_ERR_ARG;
   }
   LpArgs a;
-  a.w = (const double*)w_dev; a.X = (const double*)X_dev; a.y = (const double*)y_dev;
+  a.w = (const double*)w_dev; a.XT = (const double*)XT_dev; a.y = (const double*)y_dev;
   a.S0inv = (const double*)S0inv_dev; a.rhs0 = (const double*)rhs0_dev;
   a.sigsq = sigsq; a.k = k; a.D = D; a.ldx = ldx; a.lds0 = lds0;
   const int nt = (D + LP_NB - 1) / LP_NB;
@@ -589,7 +657,7 @@ extern "C" int bcx_linreg_posterior_factor(void* stream, int32_t k, int32_t D, i
   a.flags = (int*)base;
   static const bool dbg = bcx_dev_env("BCX_LRP_DBG") != nullptr;
   a.dbg = dbg ? (long long*)((char*)base + lrp_flag_bytes(nt)) : nullptr;
-  a.Linv = (double*)Linv_dev; a.ldl = ldl; a.mu = (double*)mu_dev;
+  a.U = (double*)U_dev; a.ldu = ldu; a.mu = (double*)mu_dev;
   a.nt = nt; a.H = lrp_helpers(nt);
   a.timeout_ticks = 200000000LL;                    // 2 s of the 100 MHz wall clock
   hipLaunchKernelGGL(lrp_form_kernel, dim3(nt * (nt + 1) / 2 + nt), dim3(256), 0, (hipStream_t)stream, a);
@@ -609,5 +677,22 @@ extern "C" int bcx_linreg_posterior_factor_status(void* stream, int32_t D, const
   LRP_HIP(hipStreamSynchronize((hipStream_t)stream));
   if (v == 1) { bcx_project_set_error("linreg posterior factorisation: a wait between workgroups timed out (GPU shared or preempted)"); return BCX_ERR_TIMEOUT; }
   if (v == 2) { bcx_project_set_error("linreg posterior factorisation: the precision matrix is not positive definite"); return BCX_ERR_STATE; }
+  return BCX_OK;
+}
+
+// theta_dev (S x ld) = mu + R U^T, tbar_dev (D) = mu + Rbar U^T for the factor U_dev (D x ldu, upper triangular) and mean mu_dev
+// of bcx_linreg_posterior_factor: the reference's `muw + np.random.randn(n, D).dot(USigw.T)` with R in the place of randn.
+extern "C" int bcx_linreg_posterior_draw_factored(void* stream, int32_t D, int32_t ld, const void* U_dev, int64_t ldu, const void* mu_dev,
+                                                  const void* R_dev, const void* Rbar_dev, int32_t S, void* theta_dev, void* tbar_dev) {
+  if (D < 1 || D > LP_NB * LP_MAX_NT || ld < D || (ld & 1) || ldu < D || (ldu & 1) || S < 1 || S > (1 << 22) || !U_dev || !mu_dev || !R_dev ||
+      !Rbar_dev || !theta_dev || !tbar_dev || (((uintptr_t)U_dev | (uintptr_t)R_dev | (uintptr_t)Rbar_dev) & 15)) {
+    bcx_project_set_error("bcx_linreg_posterior_draw_factored: bad arguments (even leading dimensions, 16-byte aligned rows)");
+    return BCX_ERR_ARG;
+  }
+  LpDrawArgs a;
+  a.U = (const double*)U_dev; a.mu = (const double*)mu_dev; a.R = (const double*)R_dev; a.Rbar = (const double*)Rbar_dev;
+  a.theta = (double*)theta_dev; a.tbar = (double*)tbar_dev; a.ldu = ldu; a.D = D; a.S = S; a.ld = ld;
+  hipLaunchKernelGGL(lrp_draw_kernel, dim3((S + 1 + 31) / 32, (ld + 31) / 32), dim3(256), 0, (hipStream_t)stream, a);
+  LRP_HIP(hipGetLastError());
   return BCX_OK;
 }

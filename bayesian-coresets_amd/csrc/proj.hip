@@ -997,16 +997,18 @@ __global__ __launch_bounds__(256) void proj_mid_kernel(ProjArgs p) {
       for (int q = 0; q < 8; ++q) xb[q] = 0.0;
     }
   };
-  double xa0[8], xb0[8], xa1[8], xb1[8];
-  fetch(0, xa0, xb0);
-  for (int kb = 0; kb < D; kb += 64) {
-    if (kb + 32 < D) fetch(kb + 32, xa1, xb1);
+  double xa[3][8], xb[3][8];                       // three runs of the inner dimension in flight
+  fetch(0, xa[0], xb[0]);
+  if (32 < D) fetch(32, xa[1], xb[1]);
+  for (int kb = 0; kb < D; kb += 96) {
 #pragma unroll
-    for (int t = 0; t < 8; ++t) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(xa0[t], xb0[t], acc, 0, 0, 0);
-    if (kb + 32 < D) {
-      if (kb + 64 < D) fetch(kb + 64, xa0, xb0);
+    for (int u = 0; u < 3; ++u) {
+      const int kc = kb + 32 * u;
+      if (kc < D) {
+        if (kc + 64 < D) fetch(kc + 64, xa[(u + 2) % 3], xb[(u + 2) % 3]);
 #pragma unroll
-      for (int t = 0; t < 8; ++t) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(xa1[t], xb1[t], acc, 0, 0, 0);
+        for (int t = 0; t < 8; ++t) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(xa[u][t], xb[u][t], acc, 0, 0, 0);
+      }
     }
   }
   // accumulator layout: register r holds (row 16 rb + lane / 16 + 4 r, column 16 cb + lane % 16)

@@ -468,6 +468,7 @@ __global__ __launch_bounds__(256) void svi_adam_kernel(const double* __restrict_
 // (the single-workgroup kernel above walks the k x S projected coreset points three times with one wave per row: 50 us at
 // k = 300.)  svi_adam_a_kernel: row means of its slab's raw rows and the slab's share of w.dot(corevecs); svi_adam_b_kernel:
 // resid from the shares (added in slab order: fixed association), the slab's gradient entries, ADAM moments, step, clamp.
+// Slabs of 8 weights; every loop over rows or shares keeps its loads independent and in flight together.
 #define SVB_ROWS 8
 #define SVB_KMAX 4096
 struct SvbArgs {
@@ -483,19 +484,33 @@ __global__ __launch_bounds__(256) void svi_adam_a_kernel(SvbArgs a) {
   __shared__ double scm[SVB_ROWS], sw[SVB_ROWS];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int j0 = blockIdx.x * SVB_ROWS, nj = min(SVB_ROWS, a.k - j0);
-  for (int q = wave; q < nj; q += 4) {
-    const double* row = a.core + (size_t)(j0 + q) * a.ldc;
-    double t = 0.0;
-    if (a.raw_core) {
-      for (int s = lane; s < a.S; s += 64) t += row[s];
-      t = wave_allsum(t) / (double)a.S;               // projector.py:21
+  // row means: the four rows of a wave are requested together
+  {
+    double t[SVB_ROWS / 4];
+#pragma unroll
+    for (int u = 0; u < SVB_ROWS / 4; ++u) {
+      const int q = wave + 4 * u;
+      t[u] = 0.0;
+      if (a.raw_core && q < nj) {
+        const double* row = a.core + (size_t)(j0 + q) * a.ldc;
+        for (int s = lane; s < a.S; s += 64) t[u] += row[s];
+      }
     }
-    if (lane == 0) { scm[q] = t; sw[q] = a.w[j0 + q]; a.cm[j0 + q] = t; }
+#pragma unroll
+    for (int u = 0; u < SVB_ROWS / 4; ++u) {
+      const int q = wave + 4 * u;
+      const double m = wave_allsum(t[u]) / (double)a.S;     // projector.py:21
+      if (lane == 0 && q < nj) { scm[q] = m; sw[q] = a.w[j0 + q]; a.cm[j0 + q] = m; }
+    }
   }
   __syncthreads();
   for (int s = tid; s < a.S; s += 256) {
+    double v[SVB_ROWS];
+#pragma unroll
+    for (int q = 0; q < SVB_ROWS; ++q) v[q] = q < nj ? a.core[(size_t)(j0 + q) * a.ldc + s] : 0.0;
     double t = 0.0;
-    for (int q = 0; q < nj; ++q) t += sw[q] * (a.core[(size_t)(j0 + q) * a.ldc + s] - scm[q]);
+#pragma unroll
+    for (int q = 0; q < SVB_ROWS; ++q) if (q < nj) t += sw[q] * (v[q] - scm[q]);
     a.part[(size_t)blockIdx.x * a.S + s] = t;
   }
 }
@@ -506,21 +521,37 @@ __global__ __launch_bounds__(256) void svi_adam_b_kernel(SvbArgs a) {
   const int nslab = (a.k + SVB_ROWS - 1) / SVB_ROWS;
   for (int s = tid; s < a.S; s += 256) {
     double t = 0.0;
-    for (int b = 0; b < nslab; ++b) t += a.part[(size_t)b * a.S + s];
+    int b = 0;
+    for (; b + 8 <= nslab; b += 8) {                // (eight shares in flight; added in slab order)
+      double v[8];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) v[q] = a.part[(size_t)(b + q) * a.S + s];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) t += v[q];
+    }
+    for (; b < nslab; ++b) t += a.part[(size_t)b * a.S + s];
     resid[s] = a.scaling * a.colsum[s] - t;         // sparsevi.py:72
   }
   __syncthreads();
-  for (int q = wave; q < nj; q += 4) {
-    const int j = j0 + q;
-    const double* row = a.core + (size_t)j * a.ldc;
-    const double cm = a.cm[j];
-    double t = 0.0;
-    for (int s = lane; s < a.S; s += 64) t += (row[s] - cm) * resid[s];
-    t = wave_allsum(t);
-    if (lane == 0) {
-      const double g = -t / (double)a.S;            // sparsevi.py:74
-      const double m1 = a.b1 * a.mom1[j] + (1.0 - a.b1) * g;
-      const double m2 = a.b2 * a.mom2[j] + (1.0 - a.b2) * g * g;
+  double g[SVB_ROWS / 4];
+#pragma unroll
+  for (int u = 0; u < SVB_ROWS / 4; ++u) {
+    const int q = wave + 4 * u;
+    g[u] = 0.0;
+    if (q < nj) {
+      const double* row = a.core + (size_t)(j0 + q) * a.ldc;
+      const double cm = a.cm[j0 + q];
+      for (int s = lane; s < a.S; s += 64) g[u] += (row[s] - cm) * resid[s];
+    }
+  }
+#pragma unroll
+  for (int u = 0; u < SVB_ROWS / 4; ++u) {
+    const int q = wave + 4 * u, j = j0 + q;
+    const double t = wave_allsum(g[u]);
+    if (lane == 0 && q < nj) {
+      const double gr = -t / (double)a.S;           // sparsevi.py:74
+      const double m1 = a.b1 * a.mom1[j] + (1.0 - a.b1) * gr;
+      const double m2 = a.b2 * a.mom2[j] + (1.0 - a.b2) * gr * gr;
       a.mom1[j] = m1;
       a.mom2[j] = m2;
       const double* sc = a.sched + 3 * (size_t)a.step;

@@ -82,6 +82,9 @@ def parse():
     ap.add_argument("--no-f16-leg", action="store_true", help="c4: skip the extra leg with fp16-stored rows")
     ap.add_argument("--opt-itrs", type=int, default=100, help="c5: ADAM steps per greedy step (sparsevi.py:7)")
     ap.add_argument("--no-side-legs", action="store_true", help="default line only: skip the compact c2 / c3 / c5 legs")
+    ap.add_argument("--k-curve", default=None,
+                    help="c5: comma-separated coreset sizes; every greedy step is timed on its own and the line gains "
+                         "steps/s and ADAM-step microseconds at these sizes (run enough --steps to reach them)")
     ap.add_argument("--colsum", default="mfma", choices=["mfma", "moments", "auto"],
                     help="c5: column sums of the full-data projection by the fp64-MFMA projection kernel (101 per greedy step), "
                          "or in closed form from the one-time (D+1)x(D+1) moments of the data (linear-regression family)")
@@ -698,8 +701,21 @@ def run_sparsevi(args, torch, dist, nat, world, rank, local_rank):
         alg.build(args.warmup)
     prj.profile(True)
     sync()
+    k_curve = [int(x) for x in str(args.k_curve).split(",")] if getattr(args, "k_curve", None) else None
+    per_step = None
     t0 = time.perf_counter()
-    alg.build(args.steps)
+    if k_curve:
+        # every greedy step on its own clock (the weight read-back at the end of a step synchronises anyway): wall seconds,
+        # the coreset size the step's ADAM loop ran at, milliseconds of that step's select projection kernel
+        per_step = []
+        for _ in range(args.steps):
+            km0 = prj.profile_read()[0]
+            ts = time.perf_counter()
+            alg.build(1)
+            torch.cuda.synchronize()
+            per_step.append((time.perf_counter() - ts, int(alg.wts.shape[0]), prj.profile_read()[0] - km0))
+    else:
+        alg.build(args.steps)
     sync()
     elapsed = time.perf_counter() - t0
     if world > 1:
@@ -737,7 +753,7 @@ def run_sparsevi(args, torch, dist, nat, world, rank, local_rank):
                        "weights that stay on the device)" % (D, D),
             "adam_loop": "enqueued: opt_itrs x (draws, column sums, coreset projection, ADAM step) without host synchronisation, "
                          "one read-back per greedy step (csrc/svi.hip)" if alg._enqueue_plan() is not None else "host loop (nn_opt)",
-            "coreset_size": int(alg.size()), "coreset_idcs": [int(i) for i in alg.idcs],
+            "coreset_size": int(alg.size()), "coreset_points": int(alg.wts.shape[0]), "coreset_idcs": [int(i) for i in alg.idcs],
             "projection_ms_per_step_kernels": kms / args.steps,
         },
         "roofline": {
@@ -750,6 +766,21 @@ def run_sparsevi(args, torch, dist, nat, world, rank, local_rank):
                                "profiles/r02_mfma_f64_probe.txt)",
         },
     }
+    if per_step:
+        # steps/s and microseconds per ADAM step (everything of the step that is not the select projection kernel, over
+        # opt_itrs) at the asked coreset sizes: the mean over the steps whose loop ran at k - 2 .. k + 2 points
+        curve = {}
+        for kq in k_curve:
+            win = [(t, km) for (t, kk, km) in per_step if abs(kk - kq) <= 2]
+            if not win:
+                continue
+            tm = sum(t for t, _ in win) / len(win)
+            km = sum(m for _, m in win) / len(win)
+            curve[str(kq)] = {"steps_s": 1.0 / tm, "ms_per_step": tm * 1e3, "select_kernel_ms": km,
+                              "adam_step_us": (tm * 1e3 - km) / max(args.opt_itrs, 1) * 1e3, "steps_in_window": len(win)}
+        out["k_curve"] = curve
+        out["per_step_seconds_first64"] = sum(t for t, _, _ in per_step[:64])
+        out["steps_timed"] = len(per_step)
     if not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline_sparsevi(args, Z, mu0, Sig0, sigsq, S)
         out["speedup_vs_cpu_baseline"] = out["value"] / max(out["cpu_baseline"]["value"], 1e-300)
@@ -827,25 +858,41 @@ def side_legs(args, out, torch, dist, nat):
             # everything of an OMP iteration that is not the scan: the fused resolve + Lawson-Hanson step kernel
             out["c3_omp_step_us"] = (r["ms_per_step"] - r["roofline"]["avg_launch_ms"]) * 1e3
             out["c3_final_error"] = r["config"]["final_error"]
-    for key, over in (("c5_steps_s", dict(colsum="mfma")), ("c5_steps_s_moments", dict(colsum="moments"))):
-        r = leg("c5", **over)
-        if r is None:
-            continue
-        out[key] = r["value"]
-        out[key.replace("steps_s", "ms_per_step")] = r["ms_per_step"]
-        out[key.replace("steps_s", "leg_wall_s")] = r["leg_wall_s"]
-        if over["colsum"] == "mfma":
-            out["c5_mfma_frac"] = r["roofline"]["frac"]
-            out["c5_mfma_tflops"] = r["roofline"]["achieved"]
-            out["c5_workload"] = r["config"]["workload"]
-            out["c5_coreset_idcs"] = r["config"]["coreset_idcs"]
-        else:
-            out["c5_moments_mfma_frac"] = r["roofline"]["frac"]
-            out["c5_moments_same_idcs"] = r["config"]["coreset_idcs"] == out.get("c5_coreset_idcs")
-            out["c5_moments_setup_ms"] = r["config"].get("moments_setup_ms")
-            out["c5_adam_loop"] = r["config"].get("adam_loop")
-            # everything of a closed-form greedy step that is not the select projection, per ADAM step
-            out["c5_moments_adam_step_us"] = (r["ms_per_step"] - r["config"]["projection_ms_per_step_kernels"]) / max(r["config"]["opt_itrs"], 1) * 1e3
+    # c5, MFMA form (every column sum a projection of all rows, as the reference does): 3 greedy steps after 1
+    r = leg("c5", colsum="mfma")
+    if r is not None:
+        out["c5_steps_s"] = r["value"]
+        out["c5_ms_per_step"] = r["ms_per_step"]
+        out["c5_leg_wall_s"] = r["leg_wall_s"]
+        out["c5_mfma_frac"] = r["roofline"]["frac"]
+        out["c5_mfma_tflops"] = r["roofline"]["achieved"]
+        out["c5_workload"] = r["config"]["workload"]
+        out["c5_coreset_idcs"] = r["config"]["coreset_idcs"]
+    # c5, closed-form column sums: the coreset grown from empty to the reference experiment's 300 points
+    # (examples/linear_regression/main.py:284 coreset_size_max), every greedy step timed; steps/s over the first 64 steps and
+    # at k = 8 / 32 / 64 / 128 / 300, with the microseconds of one ADAM step there
+    r = leg("c5", colsum="moments", steps=304, warmup=0, k_curve="8,32,64,128,300")
+    if r is not None:
+        n64 = min(64, r.get("steps_timed", 0))
+        out["c5_steps_s_moments"] = n64 / r["per_step_seconds_first64"] if n64 else None
+        out["c5_ms_per_step_moments"] = r["per_step_seconds_first64"] / n64 * 1e3 if n64 else None
+        out["c5_moments_steps"] = r.get("steps_timed")
+        out["c5_moments_coreset_points"] = r["config"]["coreset_points"]
+        out["c5_leg_wall_s_moments"] = r["leg_wall_s"]
+        out["c5_moments_mfma_frac"] = r["roofline"]["frac"]
+        ref_idcs = out.get("c5_coreset_idcs")
+        out["c5_moments_same_idcs"] = (r["config"]["coreset_idcs"][:len(ref_idcs)] == ref_idcs) if ref_idcs else None
+        out["c5_moments_setup_ms"] = r["config"].get("moments_setup_ms")
+        out["c5_adam_loop"] = r["config"].get("adam_loop")
+        for kq, rec in r.get("k_curve", {}).items():
+            out["c5_steps_s_at_k%s" % kq] = rec["steps_s"]
+            out["c5_adam_step_us_at_k%s" % kq] = rec["adam_step_us"]
+        out["c5_select_kernel_ms"] = (r.get("k_curve", {}).get("300") or {}).get("select_kernel_ms")
+        # which kernels an ADAM step is made of at each size: profiles/r06_c5_adam_k*.txt (rocprofv3 traces of tools/c5_ksweep.py)
+        out["c5_adam_kernels"] = ("k <= 4 + 2 ceil(D / 32) (= 24): lrs_apply_kernel (rank-k form, every workgroup repeats the k x k "
+                                  "Cholesky) dominates from k ~ 8; beyond: lrp_chol_kernel (cooperative D x D Cholesky + inverse, "
+                                  "~57 % of the step), then moments_quad_kernel, lrp_form_kernel, proj_mid_kernel, lrp_draw_kernel, "
+                                  "svi_adam_a / b_kernel")
     gram_leg(out, torch, nat)
     optimize_leg(out, torch, nat)
 

@@ -298,23 +298,27 @@ int bcx_sparsevi_adam_step_ws(void* stream, int32_t k, int32_t S, const void* co
                               double b1, double b2, double eps, void* trace_dev, int32_t core_is_raw, void* work_dev,
                               int64_t work_bytes);
 /* The weighted conjugate posterior of Gaussian linear regression for ANY number of weighted points, in the reference's own
- * arithmetic (examples/common/model_linreg.py:26-41 weighted_post; the sampler of examples/linear_regression/main.py:141-147
- * draws mu_w + randn . USigp^T with USigp = L^-T):
- *     P = S0inv + X^T diag(max(w, 0)) X / sigsq = L L^T,   Linv_dev (D x ldl doubles, row-major, lower triangular) = L^-1,
- *     mu_dev (D) = P^-1 (rhs0 + X^T (w y) / sigsq),   rhs0 = Sig0^-1 mu0,
- * from k weights w_dev that live on the device (SparseVI's ADAM loop updates them there), the points' features X_dev (k x ldx,
- * padding columns zero) and responses y_dev, the prior precision S0inv_dev (D x lds0).  The draws are then
- * bcx_linreg_posterior_draw(k = 0, U0T_dev = Linv_dev, mu0_dev = mu_dev): theta = mu_w + R L^-1.  D <= 1024, k <= 4096;
- * Linv_dev's upper triangle is never written (zero it once); work_dev: bcx_linreg_posterior_factor_scratch_bytes(D) bytes,
- * 16-byte aligned, not shared between streams.  Two launches, asynchronous on `stream`: P on the fp64 matrix cores, then ONE
- * cooperative launch of <= 64 workgroups (blocked Cholesky whose row operations also produce L^-1 and L^-1 rhs: csrc/lrpost.hip);
- * its workgroups hand tiles to each other and give up a wait after 2 s -- bcx_linreg_posterior_factor_status synchronises
- * the stream and returns BCX_ERR_TIMEOUT for that, BCX_ERR_STATE if a pivot was not positive, BCX_OK otherwise. */
+ * arithmetic (examples/common/model_linreg.py:26-41 weighted_post returns mup, USigp, LSigpInv; the sampler of
+ * examples/linear_regression/main.py:141-147 draws muw + randn . USigw^T):
+ *     P = S0inv + X^T diag(max(w, 0)) X / sigsq = L L^T,   U_dev (D x ldu doubles, row-major, UPPER triangular) = USigp = L^-T,
+ *     mu_dev (D) = mup = P^-1 (rhs0 + X^T (w y) / sigsq),   rhs0 = Sig0^-1 mu0,
+ * from k weights w_dev that live on the device (SparseVI's ADAM loop updates them there), the points' features BY points
+ * XT_dev (D x ldx: row a holds feature a of the k points; ldx >= k rounded up to 32, the padding zero, 16-byte aligned), their
+ * responses y_dev and the prior precision S0inv_dev (D x lds0).  D <= 1024, k <= 4096; U_dev's lower triangle is never
+ * written (zero it once), ldu even; work_dev: bcx_linreg_posterior_factor_scratch_bytes(D) bytes, 16-byte aligned, not
+ * shared between streams.  Two launches, asynchronous on `stream`: P on the fp64 matrix cores, then ONE cooperative launch of
+ * <= 63 workgroups (blocked Cholesky whose row operations also produce L^-T and L^-1 rhs: csrc/lrpost.hip); its workgroups
+ * hand tiles to each other and give up a wait after 2 s -- bcx_linreg_posterior_factor_status synchronises the stream and
+ * returns BCX_ERR_TIMEOUT for that, BCX_ERR_STATE if a pivot was not positive, BCX_OK otherwise.
+ * bcx_linreg_posterior_draw_factored: theta_dev (S x ld) = mu + R U^T for standard-normal R_dev (S x ld, 16-byte aligned rows),
+ * tbar_dev (D) = mu + Rbar U^T for their column means Rbar_dev (ld) -- the mean of the draws. */
 int64_t bcx_linreg_posterior_factor_scratch_bytes(int32_t D);
-int bcx_linreg_posterior_factor(void* stream, int32_t k, int32_t D, int32_t ldx, const void* w_dev, const void* X_dev,
+int bcx_linreg_posterior_factor(void* stream, int32_t k, int32_t D, int32_t ldx, const void* w_dev, const void* XT_dev,
                                 const void* y_dev, const void* S0inv_dev, int32_t lds0, const void* rhs0_dev, double sigsq,
-                                void* work_dev, int64_t work_bytes, void* Linv_dev, int64_t ldl, void* mu_dev);
+                                void* work_dev, int64_t work_bytes, void* U_dev, int64_t ldu, void* mu_dev);
 int bcx_linreg_posterior_factor_status(void* stream, int32_t D, const void* work_dev);
+int bcx_linreg_posterior_draw_factored(void* stream, int32_t D, int32_t ld, const void* U_dev, int64_t ldu, const void* mu_dev,
+                                       const void* R_dev, const void* Rbar_dev, int32_t S, void* theta_dev, void* tbar_dev);
 /* The dense re-weight's Gram matrix as an operator of its own (optimize() forms it over the active rows, snnls.py:82-97:
  * `nnls(A[:, active], b)` solves the normal equations of that k-column block): G_dev (k x ldg doubles, both triangles) =
  * V V^T for the k rows of d doubles at rows_dev (row stride ld >= d), on the fp64 matrix cores; the d products of an entry

@@ -77,8 +77,7 @@ def test_posterior_draw_kernel(bc, D, k, S):
         plan = smp.enqueue_plan(S, p3, 2)
         assert plan is not None
         plan.set_noise(Rd[None, :, :])
-        ok = bool(smp._lib.bcx_linreg_posterior_apply_ok(k, ld))
-        assert plan.fast == ok and plan.factored == (not ok)
+        assert plan.factored == (not smp._low_rank(k)) and plan.fast == (smp._low_rank(k) and bool(smp._lib.bcx_linreg_posterior_apply_ok(k, ld)))
         plan.check()
         t4, m4 = plan.draw(torch.from_numpy(w2).cuda(), 0)
         t4, m4 = t4.cpu().numpy(), m4.cpu().numpy()
@@ -285,35 +284,50 @@ def test_posterior_factor_kernel(bc, D, k, prior):
         w[1] = 0.0
         w[2] = -3.0                                           # (clamped at zero, as the rank-k kernels do)
     ld = D + D % 2
-    Xp = np.zeros((k, ld))
-    Xp[:, :D] = pts[:, :-1]
+    ldk = max((k + 31) // 32 * 32, 32)
+    XT = np.zeros((D, ldk))
+    XT[:, :k] = pts[:, :-1].T
     d = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float64)).cuda()
     need = int(lib.bcx_linreg_posterior_factor_scratch_bytes(D))
     assert need > 0 and lib.bcx_linreg_posterior_factor_scratch_bytes(1025) == -1
     work = torch.empty(need // 8, dtype=torch.float64, device="cuda")
-    Linv, mu = torch.zeros(D, ld, dtype=torch.float64, device="cuda"), torch.zeros(D, dtype=torch.float64, device="cuda")
-    w_d, X_d, y_d, S_d, r_d = d(w if k else np.zeros(1)), d(Xp if k else np.zeros(2)), d(pts[:, -1] if k else np.zeros(1)), d(S0inv), d(S0inv.dot(mu0))
+    U, mu = torch.zeros(D, ld, dtype=torch.float64, device="cuda"), torch.zeros(D, dtype=torch.float64, device="cuda")
+    w_d, X_d, y_d, S_d, r_d = d(w if k else np.zeros(1)), d(XT), d(pts[:, -1] if k else np.zeros(1)), d(S0inv), d(S0inv.dot(mu0))
     st = int(torch.cuda.current_stream().cuda_stream)
     for rep in range(2):                                      # (the second call reuses the scratch: flags, tiles)
-        rc = lib.bcx_linreg_posterior_factor(st, k, D, ld, w_d.data_ptr(), X_d.data_ptr(), y_d.data_ptr(), S_d.data_ptr(), D, r_d.data_ptr(),
-                                             sigsq, work.data_ptr(), work.numel() * 8, Linv.data_ptr(), ld, mu.data_ptr())
+        rc = lib.bcx_linreg_posterior_factor(st, k, D, ldk, w_d.data_ptr(), X_d.data_ptr(), y_d.data_ptr(), S_d.data_ptr(), D, r_d.data_ptr(),
+                                             sigsq, work.data_ptr(), work.numel() * 8, U.data_ptr(), ld, mu.data_ptr())
         assert rc == 0, lib.bcx_project_last_error()
         assert lib.bcx_linreg_posterior_factor_status(st, D, work.data_ptr()) == 0, lib.bcx_project_last_error()
     wc = np.maximum(w, 0.0)
     X, y = pts[:, :-1], pts[:, -1]
     P = S0inv + (wc[:, None] * X).T.dot(X) / sigsq
     L = np.linalg.cholesky(P)
-    want = np.linalg.inv(L)
-    got = Linv.cpu().numpy()
-    assert np.all(got[:, D:] == 0.0) and np.all(np.triu(got[:, :D], 1) == 0.0)
+    want = np.linalg.inv(L).T                                 # USigp of model_linreg.py:33
+    got = U.cpu().numpy()
+    assert np.all(got[:, D:] == 0.0) and np.all(np.tril(got[:, :D], -1) == 0.0)
     assert np.abs(got[:, :D] - want).max() <= 1e-13 * D * np.abs(want).max() * max(1.0, np.linalg.cond(L) * 1e-2)
     mu_ref = np.linalg.solve(P, S0inv.dot(mu0) + (wc * y).dot(X) / sigsq)
     np.testing.assert_allclose(mu.cpu().numpy(), mu_ref, rtol=1e-9, atol=1e-10 * np.abs(mu_ref).max())
+    # the draws from this factor: theta = mu + R U^T, the mean of the draws from the column means of R
+    S = 70
+    R = torch.from_numpy(rs.randn(S, ld)).cuda()
+    rbar = R.mean(dim=0)
+    theta, tbar = torch.zeros(S, ld, dtype=torch.float64, device="cuda"), torch.zeros(D, dtype=torch.float64, device="cuda")
+    assert lib.bcx_linreg_posterior_draw_factored(st, D, ld, U.data_ptr(), ld, mu.data_ptr(), R.data_ptr(), rbar.data_ptr(), S,
+                                                  theta.data_ptr(), tbar.data_ptr()) == 0, lib.bcx_project_last_error()
+    th_ref = mu_ref + R.cpu().numpy()[:, :D].dot(want.T)
+    th = theta.cpu().numpy()
+    assert np.abs(th[:, :D] - th_ref).max() <= 1e-11 * np.abs(th_ref).max() * max(1.0, np.linalg.cond(L) * 1e-2) and np.all(th[:, D:] == 0.0)
+    np.testing.assert_allclose(tbar.cpu().numpy(), th[:, :D].mean(axis=0), rtol=1e-10, atol=1e-12 * np.abs(th).max())
     # argument checks
-    assert lib.bcx_linreg_posterior_factor(st, k, D, ld, w_d.data_ptr(), X_d.data_ptr(), y_d.data_ptr(), S_d.data_ptr(), D, r_d.data_ptr(),
-                                           sigsq, work.data_ptr(), need - 8, Linv.data_ptr(), ld, mu.data_ptr()) == _native.ERR_ARG
-    assert lib.bcx_linreg_posterior_factor(st, 4097, D, ld, w_d.data_ptr(), X_d.data_ptr(), y_d.data_ptr(), S_d.data_ptr(), D, r_d.data_ptr(),
-                                           sigsq, work.data_ptr(), need, Linv.data_ptr(), ld, mu.data_ptr()) == _native.ERR_ARG
+    assert lib.bcx_linreg_posterior_factor(st, k, D, ldk, w_d.data_ptr(), X_d.data_ptr(), y_d.data_ptr(), S_d.data_ptr(), D, r_d.data_ptr(),
+                                           sigsq, work.data_ptr(), need - 8, U.data_ptr(), ld, mu.data_ptr()) == _native.ERR_ARG
+    assert lib.bcx_linreg_posterior_factor(st, 4097, D, ldk, w_d.data_ptr(), X_d.data_ptr(), y_d.data_ptr(), S_d.data_ptr(), D, r_d.data_ptr(),
+                                           sigsq, work.data_ptr(), need, U.data_ptr(), ld, mu.data_ptr()) == _native.ERR_ARG
+    if k > 32:
+        assert lib.bcx_linreg_posterior_factor(st, k, D, ldk - 32, w_d.data_ptr(), X_d.data_ptr(), y_d.data_ptr(), S_d.data_ptr(), D, r_d.data_ptr(),
+                                               sigsq, work.data_ptr(), need, U.data_ptr(), ld, mu.data_ptr()) == _native.ERR_ARG
 
 
 @pytest.mark.parametrize("k,S,raw", ((65, 256, 1), (130, 100, 0), (300, 256, 1), (1000, 48, 1), (67, 1000, 0)))

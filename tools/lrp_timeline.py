@@ -26,17 +26,18 @@ def main():
     D, k = a.D, a.k
     rs = np.random.RandomState(1)
     ld = D + D % 2
-    Xp = np.zeros((k, ld))
-    Xp[:, :D] = rs.rand(k, D)
+    ldk = (k + 31) // 32 * 32
+    XT = np.zeros((D, ldk))
+    XT[:, :k] = rs.rand(D, k)
     w = np.abs(rs.randn(k)) * 50
     d = lambda x: torch.from_numpy(np.ascontiguousarray(x, dtype=np.float64)).cuda()
     need = int(lib.bcx_linreg_posterior_factor_scratch_bytes(D))
     work = torch.zeros(need // 8, dtype=torch.float64, device="cuda")
-    Linv, mu = torch.zeros(D, ld, dtype=torch.float64, device="cuda"), torch.zeros(D, dtype=torch.float64, device="cuda")
-    w_d, X_d, y_d, S_d, r_d = d(w), d(Xp), d(rs.randn(k)), d(np.eye(D) * 0.03), d(np.ones(D))
+    U, mu = torch.zeros(D, ld, dtype=torch.float64, device="cuda"), torch.zeros(D, dtype=torch.float64, device="cuda")
+    w_d, X_d, y_d, S_d, r_d = d(w), d(XT), d(rs.randn(k)), d(np.eye(D) * 0.03), d(np.ones(D))
     st = int(torch.cuda.current_stream().cuda_stream)
-    call = lambda: lib.bcx_linreg_posterior_factor(st, k, D, ld, w_d.data_ptr(), X_d.data_ptr(), y_d.data_ptr(), S_d.data_ptr(), D, r_d.data_ptr(),
-                                                   0.02, work.data_ptr(), work.numel() * 8, Linv.data_ptr(), ld, mu.data_ptr())
+    call = lambda: lib.bcx_linreg_posterior_factor(st, k, D, ldk, w_d.data_ptr(), X_d.data_ptr(), y_d.data_ptr(), S_d.data_ptr(), D, r_d.data_ptr(),
+                                                   0.02, work.data_ptr(), work.numel() * 8, U.data_ptr(), ld, mu.data_ptr())
     for _ in range(3):
         assert call() == 0
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -75,6 +76,8 @@ def main():
         line += " | %10.2f %11.2f %14.2f" % (np.nanmax(h[:, 0]) - c[2], np.nanmax(h[:, 1]) - c[2], np.nanmax(h[:, 2]) - c[2])
         print(line)
     print("chain total %.2f us; last helper signal %.2f us" % (ch[nt - 1, 2], np.nanmax(hp[:, nt - 1, 2])))
+    allst = stamps[stamps > 0]
+    print("first stamp of any workgroup %.2f us, last %.2f us (relative to the chain's first diag)" % (allst.min() - t0, allst.max() - t0))
 
 
 if __name__ == "__main__":
