@@ -160,7 +160,7 @@ def load():
     sigs["bcx_sparsevi_adam_step"] = [vp, i32, i32, vp, dbl, vp, i64, vp, vp, vp, vp, i32, dbl, dbl, dbl, vp, i32]
     sigs["bcx_gram"] = [vp, vp, i32, i32, i64, vp, i64, vp, i64]
     sigs["bcx_gram_check"] = [vp, vp]
-    sigs["bcx_linreg_posterior_factor"] = [vp, i32, i32, i32, vp, vp, vp, vp, i32, vp, dbl, vp, i64, vp, i64, vp]
+    sigs["bcx_linreg_posterior_factor"] = [vp, i32, i32, i32, vp, vp, vp, vp, i32, vp, dbl, vp, i64, vp, i64, vp, vp]
     sigs["bcx_linreg_posterior_factor_status"] = [vp, i32, vp]
     sigs["bcx_linreg_posterior_draw_factored"] = [vp, i32, i32, vp, i64, vp, vp, vp, i32, vp, vp]
     sigs["bcx_sparsevi_adam_step_ws"] = [vp, i32, i32, vp, dbl, vp, i64, vp, vp, vp, vp, i32, dbl, dbl, dbl, vp, i32, vp, i64]

@@ -94,7 +94,7 @@ class LinregPosteriorSampler(object):
                 "rhs0": torch.from_numpy(self._S0inv_host.dot(self.mu0)).to(self.device),
                 "work": torch.empty((need + 7) // 8, dtype=torch.float64, device=self.device),
                 "U": torch.zeros(D, self.ld, dtype=torch.float64, device=self.device),        # U = L^-T (the lower triangle stays zero)
-                "mu": torch.zeros(D, dtype=torch.float64, device=self.device),
+                "u": torch.zeros(D, dtype=torch.float64, device=self.device),                   # L^-1 rhs: mu_w = U u
             }
         return f
 
@@ -104,14 +104,14 @@ class LinregPosteriorSampler(object):
         stream = int(self._torch.cuda.current_stream(self.device).cuda_stream)
         return [stream, st["k"], self.D, st["ldk"], w_dev.data_ptr(), st["XT"].data_ptr(), st["y"].data_ptr(), f["S0inv"].data_ptr(), self.D,
                 f["rhs0"].data_ptr(), self.sigsq, f["work"].data_ptr(), f["work"].numel() * 8, f["U"].data_ptr(), self.ld,
-                f["mu"].data_ptr()]
+                f["u"].data_ptr(), None]                    # (no mean: the draws are U (u + r))
 
     def _draw_factored_args(self, theta, tbar=None):
         """Argument list of bcx_linreg_posterior_draw_factored (theta = mu_w + R U^T); slots 6 / 7 take the normal numbers and
         their column means."""
         f = self._factor
         stream = int(self._torch.cuda.current_stream(self.device).cuda_stream)
-        return [stream, self.D, self.ld, f["U"].data_ptr(), self.ld, f["mu"].data_ptr(), 0, 0, theta.shape[0], theta.data_ptr(),
+        return [stream, self.D, self.ld, f["U"].data_ptr(), self.ld, f["u"].data_ptr(), 0, 0, theta.shape[0], theta.data_ptr(),
                 (self._tbar if tbar is None else tbar).data_ptr()]
 
     def factor_status(self):

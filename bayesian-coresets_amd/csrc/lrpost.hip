@@ -58,7 +58,8 @@ struct LpArgs {
   double sigsq;
   int k, D, ldx, lds0;
   // work
-  double* TT;     // nt * nt tiles of P (lower block triangle), [i * nt + j]: written by lrp_form_kernel, read-only afterwards
+  double* TT;     // ks * nt * nt tiles: P (lower block triangle, [i * nt + j]) as the SUM of ks slices (each from a share of the
+                  // points); written by lrp_form_kernel, read-only afterwards
   double* LT;     // finished tiles of L (strictly lower block triangle)
   double* BL;     // (nt + 1) * nt finished tiles of the bottom part: rows 0 .. nt-1 L^-T (upper block triangle), row nt the row (L^-1 rhs)^T
   double* XW;     // nt tiles: the inverses of the diagonal tiles, W_pp = L_pp^-1 (rows c, k)
@@ -68,8 +69,9 @@ struct LpArgs {
   int* flags;     // F1 [nt] | C [nt] | A1 [nt] | A2 [nt] | status
   // outputs
   double* U; int64_t ldu;      // D x ldu row-major: U = L^-T, upper triangular (the lower triangle is never written: the caller zeroes it once)
-  double* mu;                  // D
-  int nt, H;
+  double* uvec;                // D: u = L^-1 rhs  (mu_w = U u; the draws are U (u + r))
+  double* mu;                  // D, or null: the mean is then not formed (lrp_mean_kernel is not launched)
+  int nt, H, ks;
   long long timeout_ticks;
   long long* dbg;              // dev (BCX_LRP_DBG=1): wall-clock stamps [workgroup][step][8] (tools/lrp_timeline.py); else null
 };
@@ -111,6 +113,15 @@ static __device__ __forceinline__ lp4d lp_quad_load(const double* tile, int rb, 
   for (int r = 0; r < 4; ++r) c[r] = COH ? lp_ld(tile + lp_kg(row0 + 4 * r, col)) : tile[lp_kg(row0 + 4 * r, col)];
   return c;
 }
+// tile (i, j) of P: the sum of its slices, in slice order
+static __device__ __forceinline__ lp4d lp_quad_load_p(const double* TT, int nt, int ks, int tile, int rb, int cb, int lane) {
+  lp4d c = lp_quad_load<false>(TT + (size_t)tile * LP_TILE, rb, cb, lane);
+  for (int s = 1; s < ks; ++s) {
+    const lp4d d = lp_quad_load<false>(TT + ((size_t)s * nt * nt + tile) * LP_TILE, rb, cb, lane);
+    c += d;
+  }
+  return c;
+}
 template <bool COH>
 static __device__ __forceinline__ void lp_quad_store(double* tile, int rb, int cb, int lane, lp4d c) {
   const int col = cb * 16 + (lane & 15), row0 = rb * 16 + (lane >> 4);
@@ -122,8 +133,10 @@ static __device__ __forceinline__ void lp_quad_store(double* tile, int rb, int c
 }
 
 // ---- P and the right-hand side ------------------------------------------------------------------------------------------
-// Workgroups 0 .. nt (nt + 1) / 2 - 1: tile (i, j), i >= j, of P = S0inv + X^T diag(w / sigsq) X (k-grouped, into TT); rows /
-// columns >= D are padded with the identity.  The features arrive BY points (XT: row a = feature a of all k points), so
+// Workgroups 0 .. ks nt (nt + 1) / 2 - 1: slice s of tile (i, j), i >= j, of P = S0inv + X^T diag(w / sigsq) X (k-grouped, into TT):
+// the runs s, s + ks, ... of 32 points (the kernel's time is one workgroup's chain of dependent loads, so the points are
+// dealt over ks workgroups per tile and the readers add the slices in slice order); rows / columns >= D are padded with
+// the identity.  The features arrive BY points (XT: row a = feature a of all k points), so
 // both operands of the product are read along the contraction index: lane (i = lane % 16, g = lane / 16) takes the values
 // 8 g .. 8 g + 7 of each run of 32 points as four 16-byte loads, one value per MFMA step (any assignment of the inner index
 // to steps serves as long as both operands use the same one); three runs are in flight.  Workgroups after them, one per
@@ -135,8 +148,8 @@ __global__ __launch_bounds__(256) void lrp_form_kernel(LpArgs a) {
   const int nt = a.nt, D = a.D, k = a.k;
   const int ntop = nt * (nt + 1) / 2;
   const int kp = (k + 31) & ~31;
-  if ((int)blockIdx.x >= ntop) {
-    const int j = blockIdx.x - ntop;
+  if ((int)blockIdx.x >= ntop * a.ks) {
+    const int j = blockIdx.x - ntop * a.ks;
     if (j == 0) for (int e = tid; e < 4 * nt + 1; e += 256) a.flags[e] = 0;
     for (int e = tid; e < kp; e += 256) sw[e] = e < k ? fmax(a.w[e], 0.0) / a.sigsq * a.y[e] : 0.0;
     __syncthreads();
@@ -157,7 +170,8 @@ __global__ __launch_bounds__(256) void lrp_form_kernel(LpArgs a) {
     }
     return;
   }
-  int i = 0, t = blockIdx.x;
+  const int slice = blockIdx.x / ntop;              // this workgroup's share of the points: runs of 32, dealt round robin
+  int i = 0, t = blockIdx.x - slice * ntop;
   while (t >= i + 1) { t -= i + 1; ++i; }
   const int j = t;                                  // tile (i, j), j <= i
   for (int e = tid; e < kp; e += 256) sw[e] = e < k ? fmax(a.w[e], 0.0) / a.sigsq : 0.0;
@@ -171,7 +185,7 @@ __global__ __launch_bounds__(256) void lrp_form_kernel(LpArgs a) {
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int row = i * 32 + rb * 16 + lk + 4 * r;
-      acc[r] = (row < D && col < D) ? a.S0inv[(size_t)row * a.lds0 + col] : (row == col ? 1.0 : 0.0);
+      acc[r] = slice ? 0.0 : ((row < D && col < D) ? a.S0inv[(size_t)row * a.lds0 + col] : (row == col ? 1.0 : 0.0));
     }
   }
   const double* pa = a.XT + (size_t)(ra < D ? ra : 0) * a.ldx + 8 * lk;
@@ -190,22 +204,24 @@ __global__ __launch_bounds__(256) void lrp_form_kernel(LpArgs a) {
 #pragma unroll
     for (int q = 0; q < 8; ++q) xa[q] *= sw[j0 + 8 * lk + q];
   };
+  // runs slice, slice + ks, slice + 2 ks, ... of 32 points; three in flight
+  const int step = 32 * a.ks, first = 32 * slice;
   double xa[3][8], xb[3][8];
-  if (kp > 0) fetch(0, xa[0], xb[0]);
-  if (kp > 32) fetch(32, xa[1], xb[1]);
+  if (first < kp) fetch(first, xa[0], xb[0]);
+  if (first + step < kp) fetch(first + step, xa[1], xb[1]);
   __syncthreads();                                  // (sw)
-  for (int j0 = 0; j0 < kp; j0 += 96) {
+  for (int j0 = first; j0 < kp; j0 += 3 * step) {
 #pragma unroll
     for (int u = 0; u < 3; ++u) {
-      const int jc = j0 + 32 * u;
+      const int jc = j0 + step * u;
       if (jc < kp) {
-        if (jc + 64 < kp) fetch(jc + 64, xa[(u + 2) % 3], xb[(u + 2) % 3]);
+        if (jc + 2 * step < kp) fetch(jc + 2 * step, xa[(u + 2) % 3], xb[(u + 2) % 3]);
         scale(jc, xa[u]);
         acc = lp_mma(xa[u], xb[u], acc);
       }
     }
   }
-  lp_quad_store<false>(a.TT + (size_t)(i * nt + j) * LP_TILE, rb, cb, lane, acc);
+  lp_quad_store<false>(a.TT + ((size_t)slice * nt * nt + i * nt + j) * LP_TILE, rb, cb, lane, acc);
 }
 
 // ---- the factorisation ---------------------------------------------------------------------------------------------------
@@ -343,7 +359,7 @@ __global__ __launch_bounds__(256) void lrp_chol_kernel(LpArgs a) {
   if (blockIdx.x == 0) {
     // ================= the chain =================
     {
-      const lp4d c = lp_quad_load<false>(a.TT, rb, cb, lane);          // tile (0, 0), written by the kernel before
+      const lp4d c = lp_quad_load_p(a.TT, nt, a.ks, 0, rb, cb, lane);   // tile (0, 0), written by the kernel before
       const int col = cb * 16 + (lane & 15), row0 = rb * 16 + (lane >> 4);
 #pragma unroll
       for (int r = 0; r < 4; ++r) s_dg[(row0 + 4 * r) * 33 + col] = c[r];
@@ -371,8 +387,8 @@ __global__ __launch_bounds__(256) void lrp_chol_kernel(LpArgs a) {
         }
         ok = __shfl(ok ? 1 : 0, 0, 64) != 0;
         if (wave == 1) LP_STAMP(3);
-        const double* t_sub = p >= 1 ? a.AS + (size_t)p * LP_TILE : a.TT + (size_t)((p + 1) * nt + p) * LP_TILE;
-        const double* t_dg = p >= 1 ? a.AD + (size_t)p * LP_TILE : a.TT + (size_t)((p + 1) * nt + p + 1) * LP_TILE;
+        const double* t_sub = a.AS + (size_t)p * LP_TILE;
+        const double* t_dg = a.AD + (size_t)p * LP_TILE;
         const double* l_far = p >= 1 ? a.LT + (size_t)((p + 1) * nt + p - 1) * LP_TILE : nullptr;      // L_{p+1,p-1}: a helper's
         const double* l_prev = s_l1[(p + 1) & 1];                                                        // L_{p,p-1}: the chain's last
         if (ok) {
@@ -383,7 +399,8 @@ __global__ __launch_bounds__(256) void lrp_chol_kernel(LpArgs a) {
             const int job = wave - 1 + 3 * u;
             if (job < 8) {
               const int q = job & 3, qr = q >> 1, qc = q & 1;
-              c[u] = p >= 1 ? lp_quad_load<true>(job < 4 ? t_sub : t_dg, qr, qc, lane) : lp_quad_load<false>(job < 4 ? t_sub : t_dg, qr, qc, lane);
+              c[u] = p >= 1 ? lp_quad_load<true>(job < 4 ? t_sub : t_dg, qr, qc, lane)
+                            : lp_quad_load_p(a.TT, nt, a.ks, job < 4 ? nt : nt + 1, qr, qc, lane);      // (tiles (1, 0) and (1, 1) of P)
               if (p >= 1) {
                 lp_rows<true>(l_far, qr, lane, x[u]);
                 if (job < 4) lp_rows<false>(l_prev, qc, lane, y[u]);
@@ -440,7 +457,7 @@ __global__ __launch_bounds__(256) void lrp_chol_kernel(LpArgs a) {
     for (int p = 1; p + 1 < nt; ++p) {
       if (p >= 2 && !lp_wait(&C[p - 2], lp_panel_count(nt, p - 2), a, &s_ok)) return;
       if (wave == 0) LP_STAMP(0);
-      lp4d c = lp_quad_load<false>(a.TT + (size_t)((p + 1) * nt + (sub ? p : p + 1)) * LP_TILE, rb, cb, lane);
+      lp4d c = lp_quad_load_p(a.TT, nt, a.ks, (p + 1) * nt + (sub ? p : p + 1), rb, cb, lane);
       const double* ta = a.LT + (size_t)((p + 1) * nt) * LP_TILE;                     // row p + 1 of L
       const double* tb = a.LT + (size_t)((sub ? p : p + 1) * nt) * LP_TILE;           // row p (or p + 1 again)
       c = lp_accumulate(c, ta, LP_TILE, tb, LP_TILE, 0, p - 1, rb, cb, lane);
@@ -472,7 +489,7 @@ __global__ __launch_bounds__(256) void lrp_chol_kernel(LpArgs a) {
       int q0 = 0;
       const double* ta;
       if (is_top) {
-        c = lp_quad_load<false>(a.TT + (size_t)(R * nt + p) * LP_TILE, rb, cb, lane);
+        c = lp_quad_load_p(a.TT, nt, a.ks, R * nt + p, rb, cb, lane);
         ta = a.LT + (size_t)(R * nt) * LP_TILE;
       } else {
         const int col = cb * 16 + (lane & 15), row0 = rb * 16 + (lane >> 4);
@@ -496,7 +513,9 @@ __global__ __launch_bounds__(256) void lrp_chol_kernel(LpArgs a) {
       if (is_top) lp_quad_store<true>(a.LT + (size_t)(R * nt + p) * LP_TILE, rb, cb, lane, c);
       else {
         lp_quad_store<true>(a.BL + (size_t)(rrow * nt + p) * LP_TILE, rb, cb, lane, c);
-        if (!is_rhs) {
+        if (is_rhs) {
+          if (rb == 0 && (lane >> 4) == 0) { const int oc = p * 32 + cb * 16 + (lane & 15); if (oc < D) a.uvec[oc] = c[0]; }      // row 0: u
+        } else {
           // finished tile (r, p) of U = L^-T, row-major for the draw kernel
           const int ocol = p * 32 + cb * 16 + (lane & 15);
 #pragma unroll
@@ -510,40 +529,59 @@ __global__ __launch_bounds__(256) void lrp_chol_kernel(LpArgs a) {
     }
     if (done) { lp_signal(&C[p], done); if (wave == 0) LP_STAMP(2); }
   }
-  // ---- mu = U u, u = L^-1 rhs (row 0 of the finished right-hand side tiles): 32 rows of U per workgroup, a wave per row, lanes
-  // along the row.  Everything has been published: ONE acquire, then plain (pipelined) loads.
-  if (!lp_wait(&C[nt - 1], lp_panel_count(nt, nt - 1), a, &s_ok)) return;
-  if (tid == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+}
+
+// mu = U u, u = L^-1 rhs: a launch of its own, and only for a caller that asks for the mean -- the draws do not need it
+// (theta = mu + U r = U (u + r): lrp_draw_kernel adds u to the normal numbers).  32 rows of U per workgroup, a wave per row,
+// lanes along the row.
+__global__ __launch_bounds__(256) void lrp_mean_kernel(LpArgs a) {
+  __shared__ double su[LP_NB * LP_MAX_NT];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int nt = a.nt, D = a.D;
+  for (int i = tid; i < nt * 32; i += 256) su[i] = i < D ? a.uvec[i] : 0.0;
   __syncthreads();
-  for (int cbk = h; cbk < nt; cbk += H) {
-    for (int q = wave; q < 32; q += 4) {
-      const int c = cbk * 32 + q;
-      if (c >= D) continue;                         // (wave-uniform)
-      const double* row = a.U + (size_t)c * a.ldu;
-      double s = 0.0;
-      for (int i = (c & ~63) + lane; i < D; i += 64) {
-        const double u = a.BL[(size_t)(nt * nt + (i >> 5)) * LP_TILE + lp_kg(0, i & 31)];
-        s = fma(i >= c ? row[i] : 0.0, u, s);
-      }
-      s = wave_allsum(s);
-      if (lane == 0) a.mu[c] = s;
+  // eight rows per wave; every row's pieces are requested before any is used (D <= 1024: at most 16 per lane and row)
+  double s[8];
+#pragma unroll
+  for (int u = 0; u < 8; ++u) {
+    const int c = blockIdx.x * 32 + wave + 4 * u;
+    const double* row = a.U + (size_t)(c < D ? c : 0) * a.ldu;
+    const int base = (c & ~63) + lane;
+    double v[4] = {0.0, 0.0, 0.0, 0.0};
+    for (int t0 = 0; base + 64 * t0 < D; t0 += 4) {
+      double x[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) { const int i = base + 64 * (t0 + q); x[q] = (c < D && i < D && i >= c) ? row[i] : 0.0; }
+#pragma unroll
+      for (int q = 0; q < 4; ++q) { const int i = base + 64 * (t0 + q); v[q] = fma(x[q], i < D ? su[i] : 0.0, v[q]); }
     }
+    s[u] = (v[0] + v[1]) + (v[2] + v[3]);
+  }
+#pragma unroll
+  for (int u = 0; u < 8; ++u) {
+    const int c = blockIdx.x * 32 + wave + 4 * u;
+    const double m = wave_allsum(s[u]);
+    if (lane == 0 && c < D) a.mu[c] = m;
   }
 }
 
-// ---- the draws: theta = mu + [R; Rbar] U^T ----------------------------------------------------------------------------------
-// (examples/linear_regression/main.py:147: muw + randn(n, D).dot(USigw.T))  32 x 32 blocks of the product, one 16 x 16 tile per
-// wave, both operands read along the contraction index as in lrp_form_kernel; U is upper triangular, so the block of columns
-// c0 .. c0 + 31 of theta starts its inner index at c0.  Row S of the left operand is Rbar, the column means of R: its "draw"
-// is the mean of the draws (what the closed-form column sums are expanded around, csrc/moments.hip).
+// ---- the draws: theta = mu + [R; Rbar] U^T = ([R; Rbar] + 1 u^T) U^T ---------------------------------------------------------
+// (examples/linear_regression/main.py:147: muw + randn(n, D).dot(USigw.T), with muw = U u for u = L^-1 rhs: the mean needs no
+// product of its own, u is added to every row of the normal numbers as they are read.)  32 x 32 blocks of the product, one
+// 16 x 16 tile per wave, both operands read along the contraction index as in lrp_form_kernel; U is upper triangular, so the
+// block of columns c0 .. c0 + 31 of theta starts its inner index at c0.  Row S of the left operand is Rbar, the column means
+// of R: its "draw" is the mean of the draws (what the closed-form column sums are expanded around, csrc/moments.hip).
 struct LpDrawArgs {
-  const double* U; const double* mu; const double* R; const double* Rbar;
+  const double* U; const double* u; const double* R; const double* Rbar;
   double* theta; double* tbar;
   int64_t ldu;
   int D, S, ld;
 };
 __global__ __launch_bounds__(256) void lrp_draw_kernel(LpDrawArgs a) {
+  __shared__ double su[LP_NB * LP_MAX_NT + 32];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  for (int i = tid; i < ((a.D + 31) & ~31); i += 256) su[i] = i < a.D ? a.u[i] : 0.0;
+  __syncthreads();
   const int li = lane & 15, lk = lane >> 4, rb = wave >> 1, cb = wave & 1;
   const int D = a.D, S = a.S;
   const int arow = blockIdx.x * 32 + rb * 16 + li;  // row of [R; Rbar]
@@ -577,6 +615,12 @@ __global__ __launch_bounds__(256) void lrp_draw_kernel(LpDrawArgs a) {
       for (int q = 0; q < 8; ++q) xb[q] = 0.0;
     }
   };
+  auto shift = [&](int kb, double (&xa)[8]) {       // r + u (rows that exist; the pad of su is zero)
+    if (aok) {
+#pragma unroll
+      for (int q = 0; q < 8; ++q) xa[q] += su[kb + 8 * lk + q];
+    }
+  };
   lp4d acc = (lp4d){0.0, 0.0, 0.0, 0.0};
   double xa[3][8], xb[3][8];
   fetch(k0, xa[0], xb[0]);
@@ -587,16 +631,16 @@ __global__ __launch_bounds__(256) void lrp_draw_kernel(LpDrawArgs a) {
       const int kc = kb + 32 * u;
       if (kc < D) {
         if (kc + 64 < D) fetch(kc + 64, xa[(u + 2) % 3], xb[(u + 2) % 3]);
+        shift(kc, xa[u]);
         acc = lp_mma(xa[u], xb[u], acc);
       }
     }
   }
   const int col = blockIdx.y * 32 + cb * 16 + li;
-  const double mu = col < D ? a.mu[col] : 0.0;
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
     const int row = blockIdx.x * 32 + rb * 16 + lk + 4 * r;
-    const double v = col < D ? mu + acc[r] : 0.0;
+    const double v = col < D ? acc[r] : 0.0;
     if (row < S && col < a.ld) a.theta[(size_t)row * a.ld + col] = v;
     else if (row == S && col < D) a.tbar[col] = v;
   }
@@ -620,7 +664,14 @@ static int lrp_helpers(int nt) {
   if (h > LP_MAX_H) h = LP_MAX_H;
   return h;
 }
-static int64_t lrp_tiles(int nt) { return (int64_t)2 * nt * nt + (int64_t)(nt + 1) * nt + 3 * nt; }
+#define LP_MAX_KS 4
+static int lrp_slices(int k) {                      // workgroups per tile of P: about three runs of 32 points each
+  static const int forced = [] { const char* e = bcx_dev_env("BCX_LRP_KS"); return e ? atoi(e) : 0; }();      // dev
+  if (forced >= 1 && forced <= LP_MAX_KS) return forced;
+  const int runs = (k + 31) / 32;
+  return runs >= 12 ? 4 : runs >= 8 ? 3 : runs >= 4 ? 2 : 1;
+}
+static int64_t lrp_tiles(int nt) { return (int64_t)(1 + LP_MAX_KS) * nt * nt + (int64_t)(nt + 1) * nt + 3 * nt; }
 static int64_t lrp_flag_bytes(int nt) { return (int64_t)(4 * nt + 1 + 15) / 16 * 16 * 4; }
 #define LRP_DBG_BYTES(nt) ((int64_t)(LP_FIXED_WGS + LP_MAX_H) * (nt) * 8 * 8)
 
@@ -632,9 +683,9 @@ extern "C" int64_t bcx_linreg_posterior_factor_scratch_bytes(int32_t D) {
 
 extern "C" int bcx_linreg_posterior_factor(void* stream, int32_t k, int32_t D, int32_t ldx, const void* w_dev, const void* XT_dev,
                                            const void* y_dev, const void* S0inv_dev, int32_t lds0, const void* rhs0_dev, double sigsq,
-                                           void* work_dev, int64_t work_bytes, void* U_dev, int64_t ldu, void* mu_dev) {
+                                           void* work_dev, int64_t work_bytes, void* U_dev, int64_t ldu, void* u_dev, void* mu_dev) {
   if (k < 0 || k > 4096 || D < 1 || D > LP_NB * LP_MAX_NT || ldx < (k + 31) / 32 * 32 || lds0 < D || ldu < D || (ldu & 1) || !(sigsq > 0.0) ||
-      !S0inv_dev || !rhs0_dev || !work_dev || !U_dev || !mu_dev || (k > 0 && (!w_dev || !XT_dev || !y_dev)) ||
+      !S0inv_dev || !rhs0_dev || !work_dev || !U_dev || !u_dev || (k > 0 && (!w_dev || !XT_dev || !y_dev)) ||
       work_bytes < bcx_linreg_posterior_factor_scratch_bytes(D) || (((uintptr_t)work_dev | (uintptr_t)XT_dev | (uintptr_t)U_dev) & 15)) {
     bcx_project_set_error("bcx_linreg_posterior_factor: bad arguments (k <= 4096 points, D <= 1024 features, the features by points "
                           "with a row stride of k rounded up to 32, zero padded, 16-byte aligned; scratch of "
@@ -647,7 +698,7 @@ extern "C" int bcx_linreg_posterior_factor(void* stream, int32_t k, int32_t D, i
   a.sigsq = sigsq; a.k = k; a.D = D; a.ldx = ldx; a.lds0 = lds0;
   const int nt = (D + LP_NB - 1) / LP_NB;
   double* base = (double*)work_dev;
-  a.TT = base; base += (size_t)nt * nt * LP_TILE;
+  a.TT = base; base += (size_t)LP_MAX_KS * nt * nt * LP_TILE;
   a.LT = base; base += (size_t)nt * nt * LP_TILE;
   a.BL = base; base += (size_t)(nt + 1) * nt * LP_TILE;
   a.XW = base; base += (size_t)nt * LP_TILE;
@@ -657,11 +708,12 @@ extern "C" int bcx_linreg_posterior_factor(void* stream, int32_t k, int32_t D, i
   a.flags = (int*)base;
   static const bool dbg = bcx_dev_env("BCX_LRP_DBG") != nullptr;
   a.dbg = dbg ? (long long*)((char*)base + lrp_flag_bytes(nt)) : nullptr;
-  a.U = (double*)U_dev; a.ldu = ldu; a.mu = (double*)mu_dev;
-  a.nt = nt; a.H = lrp_helpers(nt);
+  a.U = (double*)U_dev; a.ldu = ldu; a.uvec = (double*)u_dev; a.mu = (double*)mu_dev;
+  a.nt = nt; a.H = lrp_helpers(nt); a.ks = lrp_slices(k);
   a.timeout_ticks = 200000000LL;                    // 2 s of the 100 MHz wall clock
-  hipLaunchKernelGGL(lrp_form_kernel, dim3(nt * (nt + 1) / 2 + nt), dim3(256), 0, (hipStream_t)stream, a);
+  hipLaunchKernelGGL(lrp_form_kernel, dim3(a.ks * nt * (nt + 1) / 2 + nt), dim3(256), 0, (hipStream_t)stream, a);
   hipLaunchKernelGGL(lrp_chol_kernel, dim3(LP_FIXED_WGS + a.H), dim3(256), 0, (hipStream_t)stream, a);
+  if (a.mu) hipLaunchKernelGGL(lrp_mean_kernel, dim3(nt), dim3(256), 0, (hipStream_t)stream, a);
   LRP_HIP(hipGetLastError());
   return BCX_OK;
 }
@@ -680,17 +732,17 @@ extern "C" int bcx_linreg_posterior_factor_status(void* stream, int32_t D, const
   return BCX_OK;
 }
 
-// theta_dev (S x ld) = mu + R U^T, tbar_dev (D) = mu + Rbar U^T for the factor U_dev (D x ldu, upper triangular) and mean mu_dev
-// of bcx_linreg_posterior_factor: the reference's `muw + np.random.randn(n, D).dot(USigw.T)` with R in the place of randn.
-extern "C" int bcx_linreg_posterior_draw_factored(void* stream, int32_t D, int32_t ld, const void* U_dev, int64_t ldu, const void* mu_dev,
+// theta_dev (S x ld) = mu + R U^T, tbar_dev (D) = mu + Rbar U^T for the factor U_dev (D x ldu, upper triangular) and the vector u_dev
+// (mu = U u) of bcx_linreg_posterior_factor: the reference's `muw + np.random.randn(n, D).dot(USigw.T)` with R in the place of randn.
+extern "C" int bcx_linreg_posterior_draw_factored(void* stream, int32_t D, int32_t ld, const void* U_dev, int64_t ldu, const void* u_dev,
                                                   const void* R_dev, const void* Rbar_dev, int32_t S, void* theta_dev, void* tbar_dev) {
-  if (D < 1 || D > LP_NB * LP_MAX_NT || ld < D || (ld & 1) || ldu < D || (ldu & 1) || S < 1 || S > (1 << 22) || !U_dev || !mu_dev || !R_dev ||
+  if (D < 1 || D > LP_NB * LP_MAX_NT || ld < D || (ld & 1) || ldu < D || (ldu & 1) || S < 1 || S > (1 << 22) || !U_dev || !u_dev || !R_dev ||
       !Rbar_dev || !theta_dev || !tbar_dev || (((uintptr_t)U_dev | (uintptr_t)R_dev | (uintptr_t)Rbar_dev) & 15)) {
     bcx_project_set_error("bcx_linreg_posterior_draw_factored: bad arguments (even leading dimensions, 16-byte aligned rows)");
     return BCX_ERR_ARG;
   }
   LpDrawArgs a;
-  a.U = (const double*)U_dev; a.mu = (const double*)mu_dev; a.R = (const double*)R_dev; a.Rbar = (const double*)Rbar_dev;
+  a.U = (const double*)U_dev; a.u = (const double*)u_dev; a.R = (const double*)R_dev; a.Rbar = (const double*)Rbar_dev;
   a.theta = (double*)theta_dev; a.tbar = (double*)tbar_dev; a.ldu = ldu; a.D = D; a.S = S; a.ld = ld;
   hipLaunchKernelGGL(lrp_draw_kernel, dim3((S + 1 + 31) / 32, (ld + 31) / 32), dim3(256), 0, (hipStream_t)stream, a);
   LRP_HIP(hipGetLastError());

@@ -289,9 +289,9 @@ int bcx_linreg_posterior_apply(void* stream, int32_t k, int32_t D, int32_t ld, c
 int bcx_sparsevi_adam_step(void* stream, int32_t k, int32_t S, const void* colsum_dev, double scaling, const void* core_dev,
                            int64_t ldc, void* w_dev, void* mom1_dev, void* mom2_dev, const void* sched_dev, int32_t step,
                            double b1, double b2, double eps, void* trace_dev, int32_t core_is_raw);
-/* The same ADAM step for up to 4096 weights: up to 64 the single-workgroup kernel above, beyond it two launches of one
+/* The same ADAM step for up to 4096 weights: up to 32 the single-workgroup kernel above, beyond it two launches of one
  * workgroup per slab of 8 weights (row means + the slabs' shares of w.dot(corevecs); resid, gradient, moments, step), which
- * need work_dev = bcx_sparsevi_adam_scratch_bytes(k, S) bytes of scratch (0 for k <= 64; -1: k or S out of range). */
+ * need work_dev = bcx_sparsevi_adam_scratch_bytes(k, S) bytes of scratch (0 for k <= 32; -1: k or S out of range). */
 int64_t bcx_sparsevi_adam_scratch_bytes(int32_t k, int32_t S);
 int bcx_sparsevi_adam_step_ws(void* stream, int32_t k, int32_t S, const void* colsum_dev, double scaling, const void* core_dev,
                               int64_t ldc, void* w_dev, void* mom1_dev, void* mom2_dev, const void* sched_dev, int32_t step,
@@ -301,23 +301,24 @@ int bcx_sparsevi_adam_step_ws(void* stream, int32_t k, int32_t S, const void* co
  * arithmetic (examples/common/model_linreg.py:26-41 weighted_post returns mup, USigp, LSigpInv; the sampler of
  * examples/linear_regression/main.py:141-147 draws muw + randn . USigw^T):
  *     P = S0inv + X^T diag(max(w, 0)) X / sigsq = L L^T,   U_dev (D x ldu doubles, row-major, UPPER triangular) = USigp = L^-T,
- *     mu_dev (D) = mup = P^-1 (rhs0 + X^T (w y) / sigsq),   rhs0 = Sig0^-1 mu0,
+ *     u_dev (D) = L^-1 (rhs0 + X^T (w y) / sigsq),  rhs0 = Sig0^-1 mu0,   mu_dev (D, may be NULL) = mup = U u,
  * from k weights w_dev that live on the device (SparseVI's ADAM loop updates them there), the points' features BY points
  * XT_dev (D x ldx: row a holds feature a of the k points; ldx >= k rounded up to 32, the padding zero, 16-byte aligned), their
  * responses y_dev and the prior precision S0inv_dev (D x lds0).  D <= 1024, k <= 4096; U_dev's lower triangle is never
  * written (zero it once), ldu even; work_dev: bcx_linreg_posterior_factor_scratch_bytes(D) bytes, 16-byte aligned, not
- * shared between streams.  Two launches, asynchronous on `stream`: P on the fp64 matrix cores, then ONE cooperative launch of
- * <= 63 workgroups (blocked Cholesky whose row operations also produce L^-T and L^-1 rhs: csrc/lrpost.hip); its workgroups
- * hand tiles to each other and give up a wait after 2 s -- bcx_linreg_posterior_factor_status synchronises the stream and
- * returns BCX_ERR_TIMEOUT for that, BCX_ERR_STATE if a pivot was not positive, BCX_OK otherwise.
- * bcx_linreg_posterior_draw_factored: theta_dev (S x ld) = mu + R U^T for standard-normal R_dev (S x ld, 16-byte aligned rows),
- * tbar_dev (D) = mu + Rbar U^T for their column means Rbar_dev (ld) -- the mean of the draws. */
+ * shared between streams.  Asynchronous on `stream`: P on the fp64 matrix cores, then ONE cooperative launch of <= 63
+ * workgroups (blocked Cholesky whose row operations also produce L^-T and L^-1 rhs: csrc/lrpost.hip), then -- only when
+ * mu_dev is given -- the product U u; the cooperative launch's workgroups hand tiles to each other and give up a wait after
+ * 2 s: bcx_linreg_posterior_factor_status synchronises the stream and returns BCX_ERR_TIMEOUT for that, BCX_ERR_STATE if a
+ * pivot was not positive, BCX_OK otherwise.
+ * bcx_linreg_posterior_draw_factored: theta_dev (S x ld) = mup + R U^T = (R + 1 u^T) U^T for standard-normal R_dev (S x ld,
+ * 16-byte aligned rows), tbar_dev (D) = mup + Rbar U^T for their column means Rbar_dev (ld) -- the mean of the draws. */
 int64_t bcx_linreg_posterior_factor_scratch_bytes(int32_t D);
 int bcx_linreg_posterior_factor(void* stream, int32_t k, int32_t D, int32_t ldx, const void* w_dev, const void* XT_dev,
                                 const void* y_dev, const void* S0inv_dev, int32_t lds0, const void* rhs0_dev, double sigsq,
-                                void* work_dev, int64_t work_bytes, void* U_dev, int64_t ldu, void* mu_dev);
+                                void* work_dev, int64_t work_bytes, void* U_dev, int64_t ldu, void* u_dev, void* mu_dev);
 int bcx_linreg_posterior_factor_status(void* stream, int32_t D, const void* work_dev);
-int bcx_linreg_posterior_draw_factored(void* stream, int32_t D, int32_t ld, const void* U_dev, int64_t ldu, const void* mu_dev,
+int bcx_linreg_posterior_draw_factored(void* stream, int32_t D, int32_t ld, const void* U_dev, int64_t ldu, const void* u_dev,
                                        const void* R_dev, const void* Rbar_dev, int32_t S, void* theta_dev, void* tbar_dev);
 /* The dense re-weight's Gram matrix as an operator of its own (optimize() forms it over the active rows, snnls.py:82-97:
  * `nnls(A[:, active], b)` solves the normal equations of that k-column block): G_dev (k x ldg doubles, both triangles) =

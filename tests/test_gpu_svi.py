@@ -291,12 +291,12 @@ def test_posterior_factor_kernel(bc, D, k, prior):
     need = int(lib.bcx_linreg_posterior_factor_scratch_bytes(D))
     assert need > 0 and lib.bcx_linreg_posterior_factor_scratch_bytes(1025) == -1
     work = torch.empty(need // 8, dtype=torch.float64, device="cuda")
-    U, mu = torch.zeros(D, ld, dtype=torch.float64, device="cuda"), torch.zeros(D, dtype=torch.float64, device="cuda")
+    U, mu, uv = torch.zeros(D, ld, dtype=torch.float64, device="cuda"), torch.zeros(D, dtype=torch.float64, device="cuda"), torch.zeros(D, dtype=torch.float64, device="cuda")
     w_d, X_d, y_d, S_d, r_d = d(w if k else np.zeros(1)), d(XT), d(pts[:, -1] if k else np.zeros(1)), d(S0inv), d(S0inv.dot(mu0))
     st = int(torch.cuda.current_stream().cuda_stream)
     for rep in range(2):                                      # (the second call reuses the scratch: flags, tiles)
         rc = lib.bcx_linreg_posterior_factor(st, k, D, ldk, w_d.data_ptr(), X_d.data_ptr(), y_d.data_ptr(), S_d.data_ptr(), D, r_d.data_ptr(),
-                                             sigsq, work.data_ptr(), work.numel() * 8, U.data_ptr(), ld, mu.data_ptr())
+                                             sigsq, work.data_ptr(), work.numel() * 8, U.data_ptr(), ld, uv.data_ptr(), mu.data_ptr())
         assert rc == 0, lib.bcx_project_last_error()
         assert lib.bcx_linreg_posterior_factor_status(st, D, work.data_ptr()) == 0, lib.bcx_project_last_error()
     wc = np.maximum(w, 0.0)
@@ -309,12 +309,13 @@ def test_posterior_factor_kernel(bc, D, k, prior):
     assert np.abs(got[:, :D] - want).max() <= 1e-13 * D * np.abs(want).max() * max(1.0, np.linalg.cond(L) * 1e-2)
     mu_ref = np.linalg.solve(P, S0inv.dot(mu0) + (wc * y).dot(X) / sigsq)
     np.testing.assert_allclose(mu.cpu().numpy(), mu_ref, rtol=1e-9, atol=1e-10 * np.abs(mu_ref).max())
-    # the draws from this factor: theta = mu + R U^T, the mean of the draws from the column means of R
+    np.testing.assert_allclose(uv.cpu().numpy(), np.linalg.solve(L, S0inv.dot(mu0) + (wc * y).dot(X) / sigsq), rtol=1e-9, atol=1e-10 * np.abs(mu_ref).max() * np.abs(L).max())
+    # the draws from this factor: theta = mu + R U^T = (R + 1 u^T) U^T, the mean of the draws from the column means of R
     S = 70
     R = torch.from_numpy(rs.randn(S, ld)).cuda()
     rbar = R.mean(dim=0)
     theta, tbar = torch.zeros(S, ld, dtype=torch.float64, device="cuda"), torch.zeros(D, dtype=torch.float64, device="cuda")
-    assert lib.bcx_linreg_posterior_draw_factored(st, D, ld, U.data_ptr(), ld, mu.data_ptr(), R.data_ptr(), rbar.data_ptr(), S,
+    assert lib.bcx_linreg_posterior_draw_factored(st, D, ld, U.data_ptr(), ld, uv.data_ptr(), R.data_ptr(), rbar.data_ptr(), S,
                                                   theta.data_ptr(), tbar.data_ptr()) == 0, lib.bcx_project_last_error()
     th_ref = mu_ref + R.cpu().numpy()[:, :D].dot(want.T)
     th = theta.cpu().numpy()
@@ -322,17 +323,17 @@ def test_posterior_factor_kernel(bc, D, k, prior):
     np.testing.assert_allclose(tbar.cpu().numpy(), th[:, :D].mean(axis=0), rtol=1e-10, atol=1e-12 * np.abs(th).max())
     # argument checks
     assert lib.bcx_linreg_posterior_factor(st, k, D, ldk, w_d.data_ptr(), X_d.data_ptr(), y_d.data_ptr(), S_d.data_ptr(), D, r_d.data_ptr(),
-                                           sigsq, work.data_ptr(), need - 8, U.data_ptr(), ld, mu.data_ptr()) == _native.ERR_ARG
+                                           sigsq, work.data_ptr(), need - 8, U.data_ptr(), ld, uv.data_ptr(), mu.data_ptr()) == _native.ERR_ARG
     assert lib.bcx_linreg_posterior_factor(st, 4097, D, ldk, w_d.data_ptr(), X_d.data_ptr(), y_d.data_ptr(), S_d.data_ptr(), D, r_d.data_ptr(),
-                                           sigsq, work.data_ptr(), need, U.data_ptr(), ld, mu.data_ptr()) == _native.ERR_ARG
+                                           sigsq, work.data_ptr(), need, U.data_ptr(), ld, uv.data_ptr(), mu.data_ptr()) == _native.ERR_ARG
     if k > 32:
         assert lib.bcx_linreg_posterior_factor(st, k, D, ldk - 32, w_d.data_ptr(), X_d.data_ptr(), y_d.data_ptr(), S_d.data_ptr(), D, r_d.data_ptr(),
-                                               sigsq, work.data_ptr(), need, U.data_ptr(), ld, mu.data_ptr()) == _native.ERR_ARG
+                                               sigsq, work.data_ptr(), need, U.data_ptr(), ld, uv.data_ptr(), mu.data_ptr()) == _native.ERR_ARG
 
 
-@pytest.mark.parametrize("k,S,raw", ((65, 256, 1), (130, 100, 0), (300, 256, 1), (1000, 48, 1), (67, 1000, 0)))
+@pytest.mark.parametrize("k,S,raw", ((33, 64, 1), (65, 256, 1), (130, 100, 0), (300, 256, 1), (1000, 48, 1), (67, 1000, 0)))
 def test_adam_step_ws_kernels_against_nn_opt(bc, k, S, raw):
-    """More than 64 weights: the two-launch form of the ADAM step (csrc/svi.hip svi_adam_a / b_kernel) against ``nn_opt``."""
+    """More than 32 weights: the two-launch form of the ADAM step (csrc/svi.hip svi_adam_a / b_kernel) against ``nn_opt``."""
     import torch
     from bayesiancoresets_amd import _native
     from bayesiancoresets_amd.util.opt import nn_opt
@@ -353,7 +354,7 @@ def test_adam_step_ws_kernels_against_nn_opt(bc, k, S, raw):
     d = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float64)).cuda()
     core_d, col_d, w, m1, m2, sc, tr = d(core_raw if raw else core), d(colsum), d(w0), d(np.zeros(k)), d(np.zeros(k)), d(sched), d(np.zeros((T, k)))
     need = int(lib.bcx_sparsevi_adam_scratch_bytes(k, S))
-    assert need > 0 and lib.bcx_sparsevi_adam_scratch_bytes(64, S) == 0 and lib.bcx_sparsevi_adam_scratch_bytes(4097, S) == -1
+    assert need > 0 and lib.bcx_sparsevi_adam_scratch_bytes(32, S) == 0 and lib.bcx_sparsevi_adam_scratch_bytes(4097, S) == -1
     work = torch.empty(need // 8, dtype=torch.float64, device="cuda")
     stream = int(torch.cuda.current_stream().cuda_stream)
     for i in range(T):

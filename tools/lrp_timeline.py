@@ -37,7 +37,7 @@ def main():
     w_d, X_d, y_d, S_d, r_d = d(w), d(XT), d(rs.randn(k)), d(np.eye(D) * 0.03), d(np.ones(D))
     st = int(torch.cuda.current_stream().cuda_stream)
     call = lambda: lib.bcx_linreg_posterior_factor(st, k, D, ldk, w_d.data_ptr(), X_d.data_ptr(), y_d.data_ptr(), S_d.data_ptr(), D, r_d.data_ptr(),
-                                                   0.02, work.data_ptr(), work.numel() * 8, U.data_ptr(), ld, mu.data_ptr())
+                                                   0.02, work.data_ptr(), work.numel() * 8, U.data_ptr(), ld, mu.data_ptr(), None)
     for _ in range(3):
         assert call() == 0
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -49,7 +49,7 @@ def main():
     assert lib.bcx_linreg_posterior_factor_status(st, D, work.data_ptr()) == 0
     print("form + chol: %.1f us per call (events, %d calls back to back)" % (e0.elapsed_time(e1) * 1e3 / a.reps, a.reps))
     nt = (D + 31) // 32
-    ntiles = 2 * nt * nt + (nt + 1) * nt + 3 * nt
+    ntiles = 5 * nt * nt + (nt + 1) * nt + 3 * nt
     flag_bytes = (4 * nt + 1 + 15) // 16 * 16 * 4
     off = ntiles * 1024 + nt * 32 + flag_bytes // 8
     nwg = 63
