@@ -37,7 +37,8 @@ SYMBOLS = (
     "bcx_linreg_posterior_apply", "bcx_linreg_posterior_apply_ok",
     "bcx_linreg_posterior_factor", "bcx_linreg_posterior_factor_scratch_bytes", "bcx_linreg_posterior_factor_status",
     "bcx_linreg_posterior_draw_factored",
-    "bcx_sparsevi_adam_step_ws", "bcx_sparsevi_adam_scratch_bytes",
+    "bcx_sparsevi_adam_step_ws", "bcx_sparsevi_adam_scratch_bytes", "bcx_standard_normal", "bcx_column_means",
+    "bcx_center_rows", "bcx_row_sumsq", "bcx_project_write_points",
 )
 
 
@@ -146,6 +147,7 @@ def load():
     proj_common = [vp, i32, vp, i64, i64, i32, i32, vp, i32, i32, dbl]
     sigs["bcx_project_write"] = proj_common + [vp, i64, vp]
     sigs["bcx_project_write_raw"] = proj_common + [vp, i64]
+    sigs["bcx_project_write_points"] = proj_common + [vp, i64, i32]
     sigs["bcx_project_colsum"] = proj_common + [vp, vp]
     sigs["bcx_project_select"] = proj_common + [vp, dbl, vp, vp]
     sigs["bcx_project_select_ws"] = proj_common + [vp, dbl, vp, vp, i64]
@@ -155,13 +157,17 @@ def load():
     sigs["bcx_project_colsum_moments"] = [vp, vp, i64, i32, i32, vp, i32, i32, dbl, vp, vp]
     sigs["bcx_project_colsum_moments_at"] = [vp, vp, i64, i32, i32, vp, i32, i32, dbl, vp, vp, vp]
     sigs["bcx_linreg_posterior_draw"] = [vp, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, dbl, vp, vp, i32, vp, vp]
-    sigs["bcx_linreg_posterior_apply"] = [vp, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, dbl, vp, vp, i32, vp, vp]
+    sigs["bcx_linreg_posterior_apply"] = [vp, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, dbl, vp, vp, i32, vp, vp, vp]
     sigs["bcx_linreg_posterior_apply_ok"] = [i32, i32]
     sigs["bcx_sparsevi_adam_step"] = [vp, i32, i32, vp, dbl, vp, i64, vp, vp, vp, vp, i32, dbl, dbl, dbl, vp, i32]
     sigs["bcx_gram"] = [vp, vp, i32, i32, i64, vp, i64, vp, i64]
     sigs["bcx_gram_check"] = [vp, vp]
     sigs["bcx_linreg_posterior_factor"] = [vp, i32, i32, i32, vp, vp, vp, vp, i32, vp, dbl, vp, i64, vp, i64, vp, vp]
     sigs["bcx_linreg_posterior_factor_status"] = [vp, i32, vp]
+    sigs["bcx_standard_normal"] = [vp, ctypes.c_uint64, ctypes.c_uint64, i64, vp]
+    sigs["bcx_column_means"] = [vp, vp, i32, i32, i32, i64, vp, i64]
+    sigs["bcx_center_rows"] = [vp, vp, i64, i32, i64]
+    sigs["bcx_row_sumsq"] = [vp, vp, i64, i32, i64, vp]
     sigs["bcx_linreg_posterior_draw_factored"] = [vp, i32, i32, vp, i64, vp, vp, vp, i32, vp, vp]
     sigs["bcx_sparsevi_adam_step_ws"] = [vp, i32, i32, vp, dbl, vp, i64, vp, vp, vp, vp, i32, dbl, dbl, dbl, vp, i32, vp, i64]
     lib.bcx_linreg_posterior_factor_scratch_bytes.restype = ctypes.c_int64
@@ -465,3 +471,32 @@ class Engine(object):
         ms, n = ctypes.c_double(), ctypes.c_int64()
         self._check(self.lib.bcx_profile_read(self.h, ctypes.byref(ms), ctypes.byref(n)))
         return ms.value, n.value
+
+
+def device_row_sumsq(rows):
+    """Sum of squares of every row of a device tensor (N x S fp64, unit column stride) as an ndarray: csrc/proj.hip
+    row_sumsq_kernel (hilbert.py:19-22 drops the rows where it is zero)."""
+    import torch
+    lib = load()
+    if rows.dtype != torch.float64 or rows.stride(1) != 1:
+        rows = rows.to(torch.float64).contiguous()
+    out = torch.empty(rows.shape[0], dtype=torch.float64, device=rows.device)
+    with torch.cuda.device(rows.device):
+        rc = lib.bcx_row_sumsq(int(torch.cuda.current_stream(rows.device).cuda_stream), rows.data_ptr(), rows.shape[0], rows.shape[1],
+                               rows.stride(0), out.data_ptr())
+    if rc != 0:
+        raise EngineError(rc, lib.bcx_project_last_error().decode())
+    return out.cpu().numpy()
+
+
+def device_centred_copy(rows):
+    """rows - rows.mean(axis=1)[:, None] for a device tensor (N x S fp64) as a NEW tensor: a device copy, then csrc/proj.hip
+    center_kernel in place (projector.py:21)."""
+    import torch
+    lib = load()
+    out = rows.to(torch.float64).contiguous().clone()
+    with torch.cuda.device(out.device):
+        rc = lib.bcx_center_rows(int(torch.cuda.current_stream(out.device).cuda_stream), out.data_ptr(), out.shape[0], out.shape[1], out.stride(0))
+    if rc != 0:
+        raise EngineError(rc, lib.bcx_project_last_error().decode())
+    return out

@@ -61,8 +61,11 @@ class HilbertCoreset(Coreset):
 
     @staticmethod
     def _nonzero_rows(vecs):
+        if _is_torch(vecs) and vecs.is_cuda:
+            from .. import _native as nat
+            return nat.device_row_sumsq(vecs) > 0.0         # (a device projector's output stays on the device: one row pass)
         if _is_torch(vecs):
-            return ((vecs ** 2).sum(dim=1).sqrt() > 0.0).cpu().numpy()
+            vecs = vecs.detach().numpy()
         return np.sqrt((vecs ** 2).sum(axis=1)) > 0.0
 
     @staticmethod

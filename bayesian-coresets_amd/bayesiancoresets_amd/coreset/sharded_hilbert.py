@@ -100,8 +100,11 @@ class ShardedHilbertCoreset(Coreset):
         v = vecs if is_t else torch.from_numpy(np.ascontiguousarray(vecs, dtype=np.float64))
         if world > 1 and v.device.type == "cpu" and dist.get_backend(self.group) == "nccl":
             v = v.to(torch.device("cuda", torch.cuda.current_device()))     # RCCL moves device tensors only
-        keep = (v * v).sum(dim=1) > 0.0
-        v, mine = v[keep], mine[keep.cpu().numpy()]
+        if v.is_cuda:
+            keep = nat.device_row_sumsq(v) > 0.0            # (one row pass of csrc/proj.hip)
+        else:
+            keep = (v.numpy() ** 2).sum(axis=1) > 0.0
+        v, mine = v[torch.as_tensor(keep, device=v.device)], mine[keep]
         if world == 1:
             return (v if is_t else v.numpy()), mine
         everyone = [None] * world

@@ -51,8 +51,7 @@ class LinregPosteriorSampler(object):
             dg[:D] = np.diag(self.U0)
             self._U0_diag = torch.from_numpy(dg).to(self.device)
         self._mu0 = torch.from_numpy(self.mu0).to(self.device)
-        self.gen = torch.Generator(device=self.device)
-        self.gen.manual_seed(0 if seed is None else int(seed))
+        self._seed, self._offset = (0 if seed is None else int(seed)) & 0xFFFFFFFFFFFFFFFF, 0
         self._pts_key, self._pts_state = None, None
         self._theta, self._tbar = {}, torch.empty(D, dtype=torch.float64, device=self.device)
         self._none = torch.zeros(1, dtype=torch.float64, device=self.device)
@@ -63,11 +62,38 @@ class LinregPosteriorSampler(object):
         self._factor = None
 
     # -- noise: separate hooks so that a test can feed both entry points the same numbers --------------------------------
+    # Standard normal doubles from the library's own counter-based generator (csrc/svi.hip svi_normal_kernel: Philox-4x32-10 +
+    # Box-Muller, key = the sampler's seed): one reproducible stream, the pair counter advances by what each call consumed.
+    def _normal(self, *shape):
+        torch = self._torch
+        out = torch.empty(*shape, dtype=torch.float64, device=self.device)
+        count = out.numel()
+        rc = self._lib.bcx_standard_normal(int(torch.cuda.current_stream(self.device).cuda_stream), self._seed, self._offset, count,
+                                           out.data_ptr())
+        if rc != 0:
+            raise self._nat.EngineError(rc, self._lib.bcx_project_last_error().decode())
+        self._offset += (count + 1) // 2
+        return out
+
     def _noise(self, n):
-        return self._torch.randn(n, self.ld, dtype=self._torch.float64, device=self.device, generator=self.gen)
+        return self._normal(n, self.ld)
 
     def _noise_block(self, steps, n):
-        return self._torch.randn(steps, n, self.ld, dtype=self._torch.float64, device=self.device, generator=self.gen)
+        return self._normal(steps, n, self.ld)
+
+    def _column_means(self, blocks):
+        """Column means of every n x ld block of ``blocks`` (steps x n x ld, or n x ld): steps x ld (or ld), one launch."""
+        torch = self._torch
+        three = blocks.dim() == 3
+        nb, n = (blocks.shape[0], blocks.shape[1]) if three else (1, blocks.shape[0])
+        if blocks.stride(-1) != 1 or blocks.stride(-2) != self.ld or (three and nb > 1 and blocks.stride(0) < n * self.ld):
+            blocks = blocks.contiguous()
+        out = torch.empty((nb, self.ld) if three else (self.ld,), dtype=torch.float64, device=self.device)
+        rc = self._lib.bcx_column_means(int(torch.cuda.current_stream(self.device).cuda_stream), blocks.data_ptr(), nb, n, self.ld,
+                                        blocks.stride(0) if three else 0, out.data_ptr(), self.ld)
+        if rc != 0:
+            raise self._nat.EngineError(rc, self._lib.bcx_project_last_error().decode())
+        return out
 
     # -- per-point state ------------------------------------------------------------------------------------------------------
     def supports(self, n, k):
@@ -196,14 +222,14 @@ class LinregPosteriorSampler(object):
             if rc != 0:
                 raise self._nat.EngineError(rc, self._lib.bcx_project_last_error().decode())
             a = self._draw_factored_args(theta)
-            rbar = R.mean(dim=0)
+            rbar = self._column_means(R)
             a[6], a[7] = R.data_ptr(), rbar.data_ptr()
             rc = self._lib.bcx_linreg_posterior_draw_factored(*a)
             if rc != 0:
                 raise self._nat.EngineError(rc, self._lib.bcx_project_last_error().decode())
             self.factor_status()
         else:
-            self._launch(st, w_dev, R, R.mean(dim=0), theta)
+            self._launch(st, w_dev, R, self._column_means(R), theta)
         self.mean = self._tbar
         return theta[:, :self.D]
 
@@ -237,15 +263,19 @@ class _Plan(object):
         s, torch, n = self.s, self.s._torch, self.n
         steps = noise.shape[0]
         self.noise, self._args = noise, None
-        self.rbar = noise.mean(dim=1)                       # steps x ld: the column means of every step's normal draws
+        self.rbar = s._column_means(noise)                  # steps x ld: the column means of every step's normal draws
+        self.gscale = None
         if self.fast:
             if s._U0_diag is not None:
-                self.G, self.Gbar = noise * s._U0_diag, self.rbar * s._U0_diag
+                # an isotropic / diagonal prior: G = R U0^T is a column scaling, applied by the kernel as it reads the rows
+                self.G, self.Gbar, self.gscale = noise, self.rbar, s._U0_diag
             else:
-                ext = torch.cat((noise.reshape(steps * n, s.ld), self.rbar))
-                G = torch.empty_like(ext)
-                s._launch(None, s._none, ext, ext, G, mu0=s._zero_mu, tbar=s._scratch_mean)     # k = 0, zero prior mean: R U0^T
-                self.G, self.Gbar = G[:steps * n].view(steps, n, s.ld), G[steps * n:]
+                # G = R U0^T for the rows of every step and for their means (lrs_draw_kernel with k = 0 and a zero prior mean)
+                rows = noise if noise.is_contiguous() else noise.contiguous()
+                G, Gbar = torch.empty_like(rows), torch.empty_like(self.rbar)
+                s._launch(None, s._none, rows.view(steps * n, s.ld), self.rbar[0], G.view(steps * n, s.ld), mu0=s._zero_mu, tbar=s._scratch_mean)
+                s._launch(None, s._none, self.rbar, self.rbar[0], Gbar, mu0=s._zero_mu, tbar=s._scratch_mean)
+                self.G, self.Gbar = G, Gbar
 
     def buffers(self):
         """(draws S x D, their mean): the same two device buffers at every step, rewritten in stream order."""
@@ -262,7 +292,7 @@ class _Plan(object):
             if self.fast:
                 a = [stream, st["k"], s.D, s.ld, w_dev.data_ptr(), st["K0"].data_ptr(), st["xmu0"].data_ptr(), st["y"].data_ptr(),
                      st["X"].data_ptr(), st["XS0"].data_ptr(), s._mu0.data_ptr(), s.sigsq, 0, 0, self.n, self.theta.data_ptr(),
-                     s._tbar.data_ptr()]
+                     s._tbar.data_ptr(), None if self.gscale is None else self.gscale.data_ptr()]
                 self._at, self._fn = (12, 13), s._lib.bcx_linreg_posterior_apply
                 rows, means = self.G, self.Gbar
             elif self.factored:

@@ -393,7 +393,8 @@ class DeviceProjector(Projector):
         else:
             self._colsum_projected(Z, out=col)      # (a shard without rows: zeros, and still the all-reduce its peers join)
         if k:
-            self._launch(self._lib.bcx_project_write, self._common(C) + [buf[S:].data_ptr(), S, None], C)
+            # (the coreset points: every shard projects them alike -- the kernel may be chosen by their number)
+            self._launch(self._lib.bcx_project_write_points, self._common(C) + [buf[S:].data_ptr(), S, 1], C)
         return buf, k
 
     def enqueue_step_plan(self, pts, core, persistent, draws, mean):
@@ -414,7 +415,7 @@ class DeviceProjector(Projector):
             self._cc_buf = torch.empty(S * (max(k, 7) + 1), dtype=torch.float64, device=self.device)
         buf = self._cc_buf[:S * (k + 1)]
         col = buf[:S]
-        core_args = self._common(C) + [buf[S:].data_ptr(), S]
+        core_args = self._common(C) + [buf[S:].data_ptr(), S, 0]
         state = {"mom": None}
 
         def run():
@@ -431,7 +432,7 @@ class DeviceProjector(Projector):
                 self._check(lib.bcx_project_colsum_moments_at(*a))
             else:
                 self._colsum_projected(Z, out=col)
-            self._check(lib.bcx_project_write_raw(*core_args))
+            self._check(lib.bcx_project_write_points(*core_args))
         return run, buf, k
 
     def project_select(self, pts, resid, row_ids=None):

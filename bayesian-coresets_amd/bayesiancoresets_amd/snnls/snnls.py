@@ -206,7 +206,14 @@ class DeviceSparseNNLS(SparseNNLS):
             return self._A_arg
         if self._A_centred is None:
             A = self._A_arg
-            self._A_centred = A - (A.mean(dim=0, keepdim=True) if hasattr(A, "dim") else A.mean(axis=0, keepdims=True))
+            if hasattr(A, "dim") and A.is_cuda:
+                # the N x S rows on the device: a device copy, then the library's centring pass in place (csrc/proj.hip)
+                self._A_centred = nat.device_centred_copy(A.t()).t()
+            elif hasattr(A, "dim"):
+                An = A.detach().numpy()
+                self._A_centred = A.new_tensor(An - An.mean(axis=0, keepdims=True))       # (a host tensor: NumPy)
+            else:
+                self._A_centred = A - A.mean(axis=0, keepdims=True)
         return self._A_centred
 
     @property

@@ -875,6 +875,19 @@ __global__ __launch_bounds__(256) void center_kernel(double* out, int64_t ldo, i
   }
 }
 
+// out[n] = sum_c rows[n][c]^2: a wave per row (the zero-vector filter of the subsample branch, hilbert.py:19-22).
+__global__ __launch_bounds__(256) void row_sumsq_kernel(const double* rows, int64_t ld, int64_t N, int S, double* out) {
+  const int lane = threadIdx.x & 63;
+  const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = (int64_t)gridDim.x * 4;
+  for (int64_t n = wave; n < N; n += nwaves) {
+    const double* row = rows + n * ld;
+    double acc = 0.0;
+    for (int c = lane; c < S; c += 64) acc = fma(row[c], row[c], acc);
+    acc = wave_allsum(acc);
+    if (lane == 0) out[n] = acc;
+  }
+}
+
 // A handful of rows (the coreset points SparseVI projects at every ADAM step, sparsevi.py:38-39): one workgroup of sixteen
 // waves per row, x_row in LDS.  A WAVE takes a sample at a time (four in flight): its lanes read the sample's parameter row
 // as consecutive 16-byte pieces (D = 301: three loads per lane, 1 KiB contiguous per instruction -- a thread per sample walked
@@ -953,7 +966,11 @@ __global__ __launch_bounds__(1024) void proj_small_kernel(ProjArgs p, int center
 // Z Theta^T -- one 16 x 16 tile per wave on v_mfma_f64_16x16x4_f64 -- with both operands straight from global memory (they are
 // L2-resident: k x D and S x D doubles): lane (i = lane % 16, g = lane / 16) feeds row i's values 8 g .. 8 g + 7 of each run
 // of 32 of the inner dimension, one per MFMA step (any assignment of the inner index to steps serves, as long as both
-// operands use the same one), i.e. four 16-byte loads per operand and run.  Raw log-likelihoods (the caller centres).
+// operands use the same one), i.e. four 16-byte loads per operand and run; three runs in flight.  9 us for 300 x 301 x 256.
+// The inner index is summed in ANOTHER order than in the tiled kernel (last bits differ: with the tiled kernel's order and
+// 8-byte loads it ran 14 us and still did not reproduce it), so only the *_points entries use it: for rows that every shard
+// projects alike -- the coreset points -- while data rows keep the tiled kernel whatever their shard's size, and a row-sharded
+// build reproduces the single-shard one bit for bit (tests/test_gpu_sharded.py).  Raw log-likelihoods (the caller centres).
 #define PJ_MID_ROWS 4096
 typedef double pjm4d __attribute__((ext_vector_type(4)));
 template <int FAM, bool AL>
@@ -1357,7 +1374,7 @@ static int fill(ProjArgs& p, int family, const void* Z, int64_t N, int64_t ldz, 
 // vecs (N x S) into out_dev, centred by a second pass over the rows (center != 0) or left as the raw log-likelihoods
 static int project_write(void* stream, int32_t family, const void* Z_dev, int64_t N, int64_t ldz, int32_t D,
                          int32_t ycol, const void* theta_dev, int32_t S, int32_t ldt, double param,
-                         void* out_dev, int64_t ldo, void* rowsum_dev, bool center) {
+                         void* out_dev, int64_t ldo, void* rowsum_dev, bool center, bool points = false) {
   ProjArgs p;
   int rc = fill(p, family, Z_dev, N, ldz, D, ycol, theta_dev, S, ldt, param);
   if (rc) return rc;
@@ -1386,8 +1403,9 @@ static int project_write(void* stream, int32_t family, const void* Z_dev, int64_
     return BCX_OK;
   }
   static const bool no_mid = bcx_dev_env("BCX_PROJ_NO_MID") != nullptr;        // dev: the tiled kernel beyond 32 rows
-  if (N <= PJ_MID_ROWS && !no_mid) {
-    // a few hundred rows: 32 x 32 blocks of the product straight from L2-resident operands (proj_mid_kernel)
+  if (points && N <= PJ_MID_ROWS && !no_mid) {
+    // a few hundred rows that every shard projects alike (the coreset points): 32 x 32 blocks of the product straight from
+    // L2-resident operands (proj_mid_kernel)
     const size_t tabd = family == FAM_POISSON ? PJT_DOUBLES : family == FAM_LOGISTIC ? PJT_DOUBLES_LOGISTIC : 0;
     if (tabd && !(p.tab = proj_tables())) { g_proj_err = "bcx_project: no device memory for the likelihood tables"; return BCX_ERR_NOMEM; }
     const bool al = ((uintptr_t)p.theta % 16 == 0) && p.ldt % 2 == 0 && ((uintptr_t)p.Z % 16 == 0) && p.ldz % 2 == 0;
@@ -1427,6 +1445,14 @@ extern "C" int bcx_project_write_raw(void* stream, int32_t family, const void* Z
                                      int32_t ycol, const void* theta_dev, int32_t S, int32_t ldt, double param,
                                      void* out_dev, int64_t ldo) {
   return project_write(stream, family, Z_dev, N, ldz, D, ycol, theta_dev, S, ldt, param, out_dev, ldo, nullptr, false);
+}
+
+// The same two for the POINTS of a coreset (sparsevi.py:38-39): rows that every shard holds and projects alike, so the kernel
+// may be chosen by their number -- up to 4096 of them take proj_mid_kernel (9 us where the tiled kernel takes 56 at 300 rows).
+extern "C" int bcx_project_write_points(void* stream, int32_t family, const void* Z_dev, int64_t N, int64_t ldz, int32_t D,
+                                        int32_t ycol, const void* theta_dev, int32_t S, int32_t ldt, double param,
+                                        void* out_dev, int64_t ldo, int32_t center) {
+  return project_write(stream, family, Z_dev, N, ldz, D, ycol, theta_dev, S, ldt, param, out_dev, ldo, nullptr, center != 0, true);
 }
 
 // colsum_dev[s] = sum_n vecs[n][s] without materialising vecs.  work_dev: 2048 * S doubles.
@@ -1514,4 +1540,28 @@ extern "C" int bcx_project_select_ws(void* stream, int32_t family, const void* Z
   if (work_bytes < bcx_project_select_scratch_bytes(family, N, S)) { g_proj_err = "bcx_project_select_ws: scratch too small"; return BCX_ERR_ARG; }
   return project_select(stream, family, Z_dev, N, ldz, D, ycol, theta_dev, S, ldt, param, resid_dev, resid_sum, result_dev, work_dev,
                         work_dev ? (char*)work_dev + 4096 * sizeof(double) : nullptr);
+}
+
+// rows_dev (N x ld doubles, S used per row) -= its row means, in place: projector.py:21 for rows that were written raw
+// (the same kernel bcx_project_write centres with).
+extern "C" int bcx_center_rows(void* stream, void* rows_dev, int64_t N, int32_t S, int64_t ld) {
+  if (!rows_dev || N < 0 || S < 1 || ld < S) { g_proj_err = "bcx_center_rows: bad arguments"; return BCX_ERR_ARG; }
+  if (N == 0) return BCX_OK;
+  hipStream_t st = (hipStream_t)stream;
+  const int g = (int)std::min<int64_t>((N + 3) / 4, 8192);
+  if (S % 2 == 0 && ld % 2 == 0 && (uintptr_t)rows_dev % 16 == 0)
+    hipLaunchKernelGGL(center_kernel<true>, dim3(g), dim3(256), 0, st, (double*)rows_dev, ld, N, (int)S);
+  else
+    hipLaunchKernelGGL(center_kernel<false>, dim3(g), dim3(256), 0, st, (double*)rows_dev, ld, N, (int)S);
+  PROJ_HIP(hipGetLastError());
+  return BCX_OK;
+}
+// out_dev[n] = sum of squares of row n of rows_dev (N x ld doubles, S used per row): hilbert.py:19-22 drops the rows where it is 0.
+extern "C" int bcx_row_sumsq(void* stream, const void* rows_dev, int64_t N, int32_t S, int64_t ld, void* out_dev) {
+  if (!rows_dev || !out_dev || N < 0 || S < 1 || ld < S) { g_proj_err = "bcx_row_sumsq: bad arguments"; return BCX_ERR_ARG; }
+  if (N == 0) return BCX_OK;
+  const int g = (int)std::min<int64_t>((N + 3) / 4, 8192);
+  hipLaunchKernelGGL(row_sumsq_kernel, dim3(g), dim3(256), 0, (hipStream_t)stream, (const double*)rows_dev, ld, N, (int)S, (double*)out_dev);
+  PROJ_HIP(hipGetLastError());
+  return BCX_OK;
 }

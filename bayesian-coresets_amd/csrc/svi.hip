@@ -274,6 +274,7 @@ struct LraArgs {
   const double* mu0;    // D
   const double* G;      // S x ld: R U0^T
   const double* Gbar;   // ld: column means of G
+  const double* gscale; // ld, or null: G and Gbar are R and Rbar, the prior's factor is diag(gscale) (an isotropic / diagonal prior)
   double* theta; double* tbar;
   double sigsq;
   int k, D, S, ld;
@@ -296,6 +297,7 @@ __global__ __launch_bounds__(256) void lrs_apply_kernel(LraArgs a) {
     const int c = 2 * lane + 128 * i;
     const bool ok = c < ld && row_ok;
     g[i] = ok ? *(const double2*)(gp + c) : make_double2(0.0, 0.0);
+    if (a.gscale && ok) { const double2 sc = *(const double2*)(a.gscale + c); g[i].x *= sc.x; g[i].y *= sc.y; }
     m0[i].x = (ok && c < D) ? a.mu0[c] : 0.0;
     m0[i].y = (ok && c + 1 < D) ? a.mu0[c + 1] : 0.0;
   }
@@ -564,6 +566,56 @@ __global__ __launch_bounds__(256) void svi_adam_b_kernel(SvbArgs a) {
   }
 }
 
+
+// ---- the sampler's normal numbers and their column means, without the framework ------------------------------------------------
+// svi_normal_kernel: standard normal doubles from the counter-based generator Philox-4x32-10 (Salmon et al., SC'11: the round
+// and key constants below are the published ones) + Box-Muller: counter (index / 2 + offset, 0), key = seed; two 53-bit
+// uniforms in (0, 1) per counter give two normals.  The same (seed, offset) gives the same numbers whatever the launch shape.
+static __device__ __forceinline__ void philox_round(unsigned (&c)[4], unsigned k0, unsigned k1) {
+  const unsigned long long p0 = (unsigned long long)0xD2511F53u * c[0], p1 = (unsigned long long)0xCD9E8D57u * c[2];
+  const unsigned n0 = (unsigned)(p1 >> 32) ^ c[1] ^ k0, n1 = (unsigned)p1, n2 = (unsigned)(p0 >> 32) ^ c[3] ^ k1, n3 = (unsigned)p0;
+  c[0] = n0; c[1] = n1; c[2] = n2; c[3] = n3;
+}
+__global__ __launch_bounds__(256) void svi_normal_kernel(double* __restrict__ out, int64_t count, unsigned long long seed,
+                                                         unsigned long long offset) {
+  const int64_t pair = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (2 * pair >= count) return;
+  const unsigned long long ctr = (unsigned long long)pair + offset;
+  unsigned c[4] = {(unsigned)ctr, (unsigned)(ctr >> 32), 0u, 0u};
+  unsigned k0 = (unsigned)seed, k1 = (unsigned)(seed >> 32);
+#pragma unroll
+  for (int r = 0; r < 10; ++r) { philox_round(c, k0, k1); k0 += 0x9E3779B9u; k1 += 0xBB67AE85u; }
+  // 53 bits of each pair of words, centred in its cell: never 0 or 1
+  const double u1 = ((double)((((unsigned long long)c[0] << 32) | c[1]) >> 11) + 0.5) * 0x1.0p-53;
+  const double u2 = ((double)((((unsigned long long)c[2] << 32) | c[3]) >> 11) + 0.5) * 0x1.0p-53;
+  const double rad = sqrt(-2.0 * log(u1));
+  double sn, cs;
+  sincospi(2.0 * u2, &sn, &cs);
+  out[2 * pair] = rad * cs;
+  if (2 * pair + 1 < count) out[2 * pair + 1] = rad * sn;
+}
+// svi_colmean_kernel: out[b][c] = mean over the n rows of block b of rows (nblocks x n x ld): one workgroup per block and 64
+// columns, four row groups added in group order.
+__global__ __launch_bounds__(256) void svi_colmean_kernel(const double* __restrict__ rows, int n, int ld, int64_t block_stride,
+                                                          double* __restrict__ out, int64_t out_stride) {
+  __shared__ double sp[4][64];
+  const int c = blockIdx.y * 64 + (threadIdx.x & 63), g = threadIdx.x >> 6;
+  const double* base = rows + (size_t)blockIdx.x * block_stride;
+  double t = 0.0;
+  if (c < ld) {
+    int r = g;
+    for (; r + 12 < n; r += 16) {                   // (four rows in flight)
+      const double x0 = base[(size_t)r * ld + c], x1 = base[(size_t)(r + 4) * ld + c];
+      const double x2 = base[(size_t)(r + 8) * ld + c], x3 = base[(size_t)(r + 12) * ld + c];
+      t += x0; t += x1; t += x2; t += x3;
+    }
+    for (; r < n; r += 4) t += base[(size_t)r * ld + c];
+  }
+  sp[g][threadIdx.x & 63] = t;
+  __syncthreads();
+  if (g == 0 && c < ld) out[(size_t)blockIdx.x * out_stride + c] = (((sp[0][c & 63] + sp[1][c & 63]) + sp[2][c & 63]) + sp[3][c & 63]) / (double)n;
+}
+
 void bcx_project_set_error(const std::string& msg);   // proj.hip
 #define SVI_HIP(call)                                                             \
   do {                                                                            \
@@ -604,17 +656,17 @@ extern "C" int bcx_linreg_posterior_apply_ok(int32_t k, int32_t ld) {
 extern "C" int bcx_linreg_posterior_apply(void* stream, int32_t k, int32_t D, int32_t ld, const void* w_dev, const void* K0_dev,
                                           const void* xmu0_dev, const void* y_dev, const void* X_dev, const void* XS0_dev,
                                           const void* mu0_dev, double sigsq, const void* G_dev, const void* Gbar_dev, int32_t S,
-                                          void* theta_dev, void* tbar_dev) {
+                                          void* theta_dev, void* tbar_dev, const void* gscale_dev) {
   if (!bcx_linreg_posterior_apply_ok(k, ld) || D < 1 || ld < D || (ld & 1) || S < 1 || !(sigsq > 0.0) || !w_dev || !K0_dev || !xmu0_dev ||
       !y_dev || !X_dev || !XS0_dev || !mu0_dev || !G_dev || !Gbar_dev || !theta_dev || !tbar_dev ||
-      (((uintptr_t)G_dev | (uintptr_t)Gbar_dev | (uintptr_t)XS0_dev | (uintptr_t)theta_dev) & 15)) {
+      (((uintptr_t)G_dev | (uintptr_t)Gbar_dev | (uintptr_t)XS0_dev | (uintptr_t)theta_dev | (uintptr_t)gscale_dev) & 15)) {
     bcx_project_set_error("bcx_linreg_posterior_apply: bad arguments (see bcx_linreg_posterior_apply_ok; 16-byte aligned rows)");
     return BCX_ERR_ARG;
   }
   LraArgs a;
   a.w = (const double*)w_dev; a.K0 = (const double*)K0_dev; a.xmu0 = (const double*)xmu0_dev; a.y = (const double*)y_dev;
   a.X = (const double*)X_dev; a.XS0 = (const double*)XS0_dev; a.mu0 = (const double*)mu0_dev; a.G = (const double*)G_dev;
-  a.Gbar = (const double*)Gbar_dev; a.theta = (double*)theta_dev; a.tbar = (double*)tbar_dev;
+  a.Gbar = (const double*)Gbar_dev; a.gscale = (const double*)gscale_dev; a.theta = (double*)theta_dev; a.tbar = (double*)tbar_dev;
   a.sigsq = sigsq; a.k = k; a.D = D; a.S = S; a.ld = ld;
   const size_t lds = (size_t)2 * k * ld * sizeof(double);
   if (lds > 32 * 1024) {
@@ -675,6 +727,32 @@ extern "C" int bcx_sparsevi_adam_step_ws(void* stream, int32_t k, int32_t S, con
   const int nslab = (k + SVB_ROWS - 1) / SVB_ROWS;
   hipLaunchKernelGGL(svi_adam_a_kernel, dim3(nslab), dim3(256), 0, (hipStream_t)stream, a);
   hipLaunchKernelGGL(svi_adam_b_kernel, dim3(nslab), dim3(256), (size_t)S * sizeof(double), (hipStream_t)stream, a);
+  SVI_HIP(hipGetLastError());
+  return BCX_OK;
+}
+
+// count standard normal doubles into out_dev (Philox-4x32-10 + Box-Muller; csrc/svi.hip svi_normal_kernel): the numbers of the
+// pair counters offset .. offset + ceil(count / 2) - 1 under the key `seed` -- a caller that advances `offset` by
+// ceil(count / 2) per call draws one reproducible stream.
+extern "C" int bcx_standard_normal(void* stream, uint64_t seed, uint64_t offset, int64_t count, void* out_dev) {
+  if (count < 0 || (count > 0 && !out_dev)) { bcx_project_set_error("bcx_standard_normal: bad arguments"); return BCX_ERR_ARG; }
+  if (count == 0) return BCX_OK;
+  const int64_t pairs = (count + 1) / 2;
+  hipLaunchKernelGGL(svi_normal_kernel, dim3((unsigned)((pairs + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (double*)out_dev, count,
+                     (unsigned long long)seed, (unsigned long long)offset);
+  SVI_HIP(hipGetLastError());
+  return BCX_OK;
+}
+// out_dev[b * out_stride + c] = mean over the n rows of block b of rows_dev (nblocks blocks of n x ld doubles, block_stride doubles
+// apart): the column means of every ADAM step's normal numbers in one launch.
+extern "C" int bcx_column_means(void* stream, const void* rows_dev, int32_t nblocks, int32_t n, int32_t ld, int64_t block_stride,
+                                void* out_dev, int64_t out_stride) {
+  if (nblocks < 1 || n < 1 || ld < 1 || block_stride < 0 || out_stride < ld || !rows_dev || !out_dev) {
+    bcx_project_set_error("bcx_column_means: bad arguments");
+    return BCX_ERR_ARG;
+  }
+  hipLaunchKernelGGL(svi_colmean_kernel, dim3(nblocks, (ld + 63) / 64), dim3(256), 0, (hipStream_t)stream, (const double*)rows_dev, (int)n,
+                     (int)ld, block_stride, (double*)out_dev, out_stride);
   SVI_HIP(hipGetLastError());
   return BCX_OK;
 }

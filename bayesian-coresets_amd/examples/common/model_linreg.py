@@ -5,8 +5,8 @@ examples/common/model_linreg.py).  Rows are z = [x, y]; prior theta ~ N(mu0, Sig
     Sigma_w^-1 = Sig0^-1 + X^T diag(w) X / sigsq,    mu_w = Sigma_w (Sig0^-1 mu0 + X^T diag(w) y / sigsq)
 
 ``posterior_sampler(..., device=None)`` is the host (NumPy) sampler; with ``device=`` a torch device the same
-posterior is formed on the GPU (for up to 64 weighted points as a low-rank update of the prior's factor by
-``bc.LinregPosteriorSampler``, otherwise by a Cholesky of the D x D system) and the draws come back as a device tensor,
+posterior is formed on the GPU (by ``bc.LinregPosteriorSampler``: a low-rank update of the prior's factor for a few weighted
+points, the reference's own Cholesky of the D x D system beyond) and the draws come back as a device tensor,
 which ``bc.DeviceProjector`` uses in place.
 SparseVI calls the sampler once per ADAM step (sparsevi.py:25 via projector.update); at D = 301 the host
 version costs ~29 ms per call on a 128-thread box (SciPy triangular solve + Cholesky of a 301 x 301 matrix)
@@ -142,15 +142,15 @@ def posterior_sampler(mu0, Sig0, sigsq, device=None, seed=None):
         U = torch.linalg.solve_triangular(L, eye, upper=False).T
         return U @ (U.T @ rhs), U
 
-    # On a GPU the draws for up to 64 weighted points come from the library's own kernel (bc.LinregPosteriorSampler,
-    # csrc/svi.hip: the same rank-k correction through a k x k Cholesky instead of the eigenproblem, one launch, and -- through
-    # `enqueue_plan` -- from weights that never leave the device: SparseVI then enqueues its whole ADAM loop).  The torch
-    # forms below remain for torch's CPU device, for more points and for more than 1024 draws per call.
+    # On a GPU the draws come from the library's own kernels (bc.LinregPosteriorSampler: a rank-k correction of the prior's factor
+    # inside one workgroup for a few points, csrc/svi.hip; the reference's own D x D Cholesky form beyond, csrc/lrpost.hip -- up to
+    # 4096 points and D = 1024, its normal numbers from the library's counter-based generator) and -- through `enqueue_plan` -- from
+    # weights that never leave the device: SparseVI then enqueues its whole ADAM loop.  The torch forms below remain for
+    # torch's CPU device and for sizes beyond those limits.
     fast = None
     if dev.type == "cuda":
         import bayesiancoresets_amd as bc
-        fast = bc.LinregPosteriorSampler(mu0, Sig0, sigsq, device=dev)
-        fast.gen = gen                                              # one random stream whichever form serves a call
+        fast = bc.LinregPosteriorSampler(mu0, Sig0, sigsq, device=dev, seed=seed)
 
     def sampler(n, wts, pts):
         k = 0 if wts is None else len(wts)

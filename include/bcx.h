@@ -217,6 +217,13 @@ int bcx_project_write(void* stream, int32_t family, const void* Z_dev, int64_t N
 int bcx_project_write_raw(void* stream, int32_t family, const void* Z_dev, int64_t N, int64_t ldz, int32_t D,
                           int32_t ycol, const void* theta_dev, int32_t S, int32_t ldt, double param,
                           void* out_dev, int64_t ldo);
+/* The same for the POINTS of a coreset (sparsevi.py:38-39): rows that every shard holds and projects alike, so the kernel may
+ * be chosen by their number (up to 4096 rows: 32 x 32 blocks straight from L2; the data rows of bcx_project_write keep one
+ * kernel whatever their shard's size, so that row-sharded builds reproduce the single-shard one bit for bit).  center != 0:
+ * centred rows as bcx_project_write, 0: raw as bcx_project_write_raw. */
+int bcx_project_write_points(void* stream, int32_t family, const void* Z_dev, int64_t N, int64_t ldz, int32_t D,
+                             int32_t ycol, const void* theta_dev, int32_t S, int32_t ldt, double param,
+                             void* out_dev, int64_t ldo, int32_t center);
 int bcx_project_colsum(void* stream, int32_t family, const void* Z_dev, int64_t N, int64_t ldz, int32_t D,
                        int32_t ycol, const void* theta_dev, int32_t S, int32_t ldt, double param,
                        void* colsum_dev, void* work_dev);
@@ -279,16 +286,28 @@ int bcx_linreg_posterior_draw(void* stream, int32_t k, int32_t D, int32_t ld, co
 /*   bcx_linreg_posterior_apply the same draws for a loop of calls at the same points: G_dev (S x ld) = R U0^T and Gbar_dev (ld, its
  *                              column means) are formed once for all steps (bcx_linreg_posterior_draw with k = 0 and a zero
  *                              prior mean returns R U0^T), a step is then the rank-k correction theta = mu_w + G - (G X^T) B2
- *                              of rows read once.  X_dev: the points' features (k x ld, padding 0).  Serves the (k, ld) for which
- *                              bcx_linreg_posterior_apply_ok is non-zero (k <= 32 and 16 k ld <= 128 KiB of LDS). */
+ *                              of rows read once.  X_dev: the points' features (k x ld, padding 0).  gscale_dev (ld doubles,
+ *                              or NULL): the prior's factor is diag(gscale) (an isotropic / diagonal prior) and G_dev / Gbar_dev
+ *                              hold R and its column means themselves -- the scaling is applied as the rows are read, R U0^T
+ *                              is never stored.  Serves the (k, ld) for which bcx_linreg_posterior_apply_ok is non-zero
+ *                              (k <= 32 and 16 k ld <= 128 KiB of LDS). */
 int bcx_linreg_posterior_apply_ok(int32_t k, int32_t ld);
 int bcx_linreg_posterior_apply(void* stream, int32_t k, int32_t D, int32_t ld, const void* w_dev, const void* K0_dev,
                                const void* xmu0_dev, const void* y_dev, const void* X_dev, const void* XS0_dev,
                                const void* mu0_dev, double sigsq, const void* G_dev, const void* Gbar_dev, int32_t S,
-                               void* theta_dev, void* tbar_dev);
+                               void* theta_dev, void* tbar_dev, const void* gscale_dev);
 int bcx_sparsevi_adam_step(void* stream, int32_t k, int32_t S, const void* colsum_dev, double scaling, const void* core_dev,
                            int64_t ldc, void* w_dev, void* mom1_dev, void* mom2_dev, const void* sched_dev, int32_t step,
                            double b1, double b2, double eps, void* trace_dev, int32_t core_is_raw);
+/* The sampler's raw material without the framework: bcx_standard_normal fills out_dev with `count` standard normal doubles
+ * (counter-based Philox-4x32-10 + Box-Muller: the numbers of pair counters offset .. offset + ceil(count / 2) - 1 under the key
+ * `seed`, the same whatever the launch shape; a caller that advances `offset` by ceil(count / 2) per call draws one
+ * reproducible stream -- the role of np.random.randn in examples/linear_regression/main.py:147); bcx_column_means writes the
+ * column means of `nblocks` blocks of n x ld doubles (block_stride doubles apart) to out_dev[b * out_stride + c] -- the means
+ * of every ADAM step's normal numbers in one launch (their image under the posterior's factor is the mean of the draws). */
+int bcx_standard_normal(void* stream, uint64_t seed, uint64_t offset, int64_t count, void* out_dev);
+int bcx_column_means(void* stream, const void* rows_dev, int32_t nblocks, int32_t n, int32_t ld, int64_t block_stride,
+                     void* out_dev, int64_t out_stride);
 /* The same ADAM step for up to 4096 weights: up to 32 the single-workgroup kernel above, beyond it two launches of one
  * workgroup per slab of 8 weights (row means + the slabs' shares of w.dot(corevecs); resid, gradient, moments, step), which
  * need work_dev = bcx_sparsevi_adam_scratch_bytes(k, S) bytes of scratch (0 for k <= 32; -1: k or S out of range). */
@@ -338,6 +357,11 @@ int bcx_gram(void* stream, const void* rows_dev, int32_t k, int32_t d, int64_t l
  * not valid (zero the first 8 bytes of the scratch to re-arm); BCX_OK otherwise.  optimize() (bcx_optimize) makes the same
  * check on its own Gram launches and returns BCX_ERR_TIMEOUT. */
 int bcx_gram_check(void* stream, const void* work_dev);
+/* Two row passes of the constructor path behind a device projector (reference: projector.py:21, hilbert.py:19-22):
+ * bcx_center_rows subtracts every row's mean in place (rows_dev: N x ld doubles, S used per row); bcx_row_sumsq writes every
+ * row's sum of squares to out_dev (N doubles) -- the subsample branch drops the rows where it is zero. */
+int bcx_center_rows(void* stream, void* rows_dev, int64_t N, int32_t S, int64_t ld);
+int bcx_row_sumsq(void* stream, const void* rows_dev, int64_t N, int32_t S, int64_t ld, void* out_dev);
 const char* bcx_project_last_error(void);
 /* Measurement: hipEvents around the projection kernel alone, recorded on the stream the kernel is launched on.
  * bcx_project_profile(1) starts timing every later projection launch of the calling host thread, (0) stops;

@@ -50,6 +50,32 @@ def test_project_matches_numpy(bc, family):
     np.testing.assert_allclose(prj.project(Z[:3]).cpu().numpy(), ref.project(Z[:3]), rtol=1e-11, atol=1e-12 * scale)
 
 
+@pytest.mark.parametrize("family", ("logistic", "poisson", "linreg"))
+def test_a_rows_projection_does_not_depend_on_how_many_rows_its_shard_holds(bc, family):
+    """Data rows go through ONE kernel whatever their number (beyond the 32-row form): a row's values are the same to the last
+    bit in every slice of the data -- what lets row shards of any size reproduce the single-shard build.  The
+    32 x 32 kernel for a few hundred rows (csrc/proj.hip proj_mid_kernel) sums the inner index in another order and serves
+    the coreset points only (bcx_project_write_points): checked here against NumPy and against the data-row kernel to rounding."""
+    import torch
+    Z, theta, ll, sigsq = _cases()[family]
+    prj = bc.DeviceProjector(family, lambda n, w, p: theta, theta.shape[0], sigsq=sigsq)
+    full_raw = prj.project_uncentred(Z).cpu().numpy()
+    full = prj.project(Z).cpu().numpy()
+    for lo, hi in ((0, 33), (100, 400), (1000, 5096), (17, 4000), (4000, Z.shape[0])):
+        assert np.array_equal(prj.project_uncentred(Z[lo:hi]).cpu().numpy(), full_raw[lo:hi]), (lo, hi)
+        assert np.array_equal(prj.project(Z[lo:hi]).cpu().numpy(), full[lo:hi]), (lo, hi)
+    S = theta.shape[0]
+    scale = np.abs(full_raw).max()
+    for lo, hi in ((0, 33), (100, 400), (7, 2008)):
+        C = prj._dev(Z[lo:hi])
+        for center, want in ((0, full_raw), (1, full)):
+            out = torch.full((hi - lo, S + 1), -7.0, dtype=torch.float64, device="cuda")
+            prj._launch(prj._lib.bcx_project_write_points, prj._common(C) + [out.data_ptr(), S + 1, center], C)
+            got = out.cpu().numpy()
+            np.testing.assert_allclose(got[:, :S], want[lo:hi], rtol=1e-12, atol=1e-13 * scale)
+            assert np.all(got[:, S] == -7.0)
+
+
 def test_hilbert_coreset_with_device_projector(bc):
     """Config-3 end to end on the device: logistic projection -> normalised rows -> OMP / GIGA, vs the
     same pipeline with the host BlackBoxProjector (identical selections, weights to 1e-5)."""

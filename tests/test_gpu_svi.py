@@ -400,3 +400,36 @@ def test_enqueued_loop_against_the_oracle_at_reference_coreset_sizes(bc, D, k, c
     assert smp.at == ref_smp.at == 1 + T
     assert (alg.wts > 0).sum() >= k // 2
     np.testing.assert_allclose(alg.wts, orc.wts, rtol=1e-7, atol=1e-9 * np.abs(orc.wts).max())
+
+
+def test_standard_normal_generator_and_column_means(bc):
+    """bcx_standard_normal (Philox-4x32-10 + Box-Muller): reproducible, the same numbers whatever the split into calls, first
+    four moments and a Kolmogorov-Smirnov distance of a standard normal; bcx_column_means against NumPy."""
+    import torch
+    from scipy import stats
+    from bayesiancoresets_amd import _native
+    lib = _native.load()
+    st = int(torch.cuda.current_stream().cuda_stream)
+    n = 1_000_001                                             # (odd: the last pair is half used)
+    a, b = torch.empty(n, dtype=torch.float64, device="cuda"), torch.empty(n, dtype=torch.float64, device="cuda")
+    assert lib.bcx_standard_normal(st, 12345, 0, n, a.data_ptr()) == 0
+    assert lib.bcx_standard_normal(st, 12345, 0, 400, b.data_ptr()) == 0
+    assert lib.bcx_standard_normal(st, 12345, 200, n - 400, b[400:].data_ptr()) == 0      # (400 numbers = 200 pair counters)
+    x = a.cpu().numpy()
+    assert np.array_equal(x, b.cpu().numpy()) and np.isfinite(x).all()
+    assert lib.bcx_standard_normal(st, 12346, 0, n, b.data_ptr()) == 0
+    assert not np.array_equal(x[:100], b.cpu().numpy()[:100])
+    assert abs(x.mean()) < 5e-3 and abs(x.var() - 1.0) < 5e-3 and abs(stats.skew(x)) < 1e-2 and abs(stats.kurtosis(x)) < 2e-2
+    assert stats.kstest(x, "norm").statistic < 2.5e-3
+    assert abs(np.corrcoef(x[:-1:2], x[1::2])[0, 1]) < 5e-3   # (the two numbers of a pair are independent)
+    # column means of blocks
+    rs = np.random.RandomState(0)
+    for (nb, rows, ld) in ((1, 7, 5), (3, 256, 302), (5, 33, 64), (2, 1000, 130)):
+        R = rs.randn(nb, rows, ld)
+        Rd = torch.from_numpy(R).cuda()
+        out = torch.zeros(nb, ld + 3, dtype=torch.float64, device="cuda")
+        assert lib.bcx_column_means(st, Rd.data_ptr(), nb, rows, ld, rows * ld, out.data_ptr(), ld + 3) == 0
+        got = out.cpu().numpy()
+        np.testing.assert_allclose(got[:, :ld], R.mean(axis=1), rtol=1e-13, atol=1e-15)
+        assert np.all(got[:, ld:] == 0.0)
+    assert lib.bcx_column_means(st, Rd.data_ptr(), 0, 1, 1, 0, out.data_ptr(), 1) == _native.ERR_ARG

@@ -65,7 +65,7 @@ def test_sparsevi_host_loop_matches_reference():
 
 def test_enqueue_plan_is_offered_only_where_the_loop_needs_no_host():
     """``SparseVICoreset._enqueue_plan`` (the switch between the device-resident ADAM loop and the host loop, csrc/svi.hip):
-    asked of the sampler only with a device projector, the full data set at every step, a non-empty coreset of at most 64
+    asked of the sampler only with a device projector, the full data set at every step, a non-empty coreset of at most 4096
     points and opt_itrs > 0; a sampler without ``enqueue_plan`` or one that declines (None) keeps the host loop."""
     Z = make_linreg_data(3, 500, 4)
     calls = []
@@ -89,11 +89,12 @@ def test_enqueue_plan_is_offered_only_where_the_loop_needs_no_host():
     assert alg_for(Sampler("plan"), opt_itrs=5)._enqueue_plan() == "plan" and calls == [(8, (2, 5), 5)]
     assert alg_for(Sampler(None), opt_itrs=5)._enqueue_plan() is None                       # the sampler declines
     assert alg_for(lambda n, w, p: np.zeros((n, 4)), opt_itrs=5)._enqueue_plan() is None    # no device form
+    assert alg_for(Sampler("plan"), k=65, opt_itrs=5)._enqueue_plan() == "plan"             # (the reference grows coresets to 300 points)
     n = len(calls)
     assert alg_for(Sampler("plan"), opt_itrs=5, n_subsample_opt=100)._enqueue_plan() is None     # sub-sample drawn on the host
     assert alg_for(Sampler("plan"), opt_itrs=0)._enqueue_plan() is None
     assert alg_for(Sampler("plan"), k=0, opt_itrs=5)._enqueue_plan() is None
-    assert alg_for(Sampler("plan"), k=65, opt_itrs=5)._enqueue_plan() is None
+    assert alg_for(Sampler("plan"), k=4097, opt_itrs=5)._enqueue_plan() is None
     off = alg_for(Sampler("plan"), opt_itrs=5)
     off.ENQUEUE = False
     assert off._enqueue_plan() is None and len(calls) == n                                  # none of these asked the sampler
