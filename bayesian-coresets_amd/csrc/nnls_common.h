@@ -60,6 +60,8 @@ struct GridSync {
   unsigned long long* counter;
   unsigned long long base;
   long long timeout_ticks;
+  int fences;       // 1 (default): agent-scope release before every arrival and acquire after every wait; 0 (dev switch of
+                    // omp_lh.hip): none -- valid where all cross-workgroup data is written write-through and read with sc1 loads
 };
 
 // write-through (sc1) store / sc1 load of one double: the pair that is coherent across XCDs without relying on
@@ -83,8 +85,10 @@ static __device__ __forceinline__ void grid_publish() {
   __syncthreads();
 }
 static __device__ __forceinline__ void grid_signal(const GridSync& g, unsigned long long times) {   // lane 0 only
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  if (g.fences) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
   __hip_atomic_fetch_add(g.counter, times, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 // arrive `times` times without waiting (paths that skip barriers).  All threads.
@@ -104,7 +108,7 @@ static __device__ bool grid_barrier(const GridSync& g, int index, int* s_flag) {
       __builtin_amdgcn_s_sleep(1);
       if (wall_clock64() - t0 > g.timeout_ticks) { ok = 0; break; }
     }
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    if (g.fences) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     *s_flag = ok;
   }
   __syncthreads();

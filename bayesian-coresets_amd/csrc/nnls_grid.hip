@@ -239,6 +239,7 @@ int bcx_launch_optimize_grid(bcx_solver* s, double tol, int k) {
   gs.counter = s->grid_counter;
   gs.base = 0;
   gs.timeout_ticks = 1000000000LL;   // 10 s
+  gs.fences = 1;
   hipLaunchKernelGGL(optimize_grid_kernel, dim3(OPT_WGS), dim3(NN_THREADS), lds, s->stream, n, gs, tol, kcap, dpad);
   BCX_HIP(hipGetLastError());
   s->grid_dirty = true;   // counter[0] now holds this launch's arrivals; an OMP step that follows without a build_begin re-zeroes

@@ -1025,6 +1025,12 @@ int bcx_launch_optimize_lh(bcx_solver* s, double tol, int k, const int32_t* warm
   gs.counter = s->grid_counter;
   gs.base = 0;
   gs.timeout_ticks = 1000000000LL;     // 10 s
+  // dev: BCX_GRID_NOFENCE=1 drops the barriers' release / acquire fences (every cross-workgroup datum of this file is an
+  // exchange vector written write-through and read with sc1 loads, so they order nothing that is read).  Measured round 6:
+  // optimize() k = 1497, d = 1024 34.5 ms without against 36.3 with, the OMP step of configs[2] 35.9 us either way -- the
+  // fences are not what bounds these kernels (unlike csrc/lrpost.hip, where they sat on a 5 us critical path), so they stay.
+  static const bool nofence = bcx_dev_env("BCX_GRID_NOFENCE") != nullptr;
+  gs.fences = nofence ? 0 : 1;
   static const int forced_wgs = bcx_dev_env("BCX_OPT_WGS") ? atoi(bcx_dev_env("BCX_OPT_WGS")) : 0;     // dev
   const int wgs = forced_wgs > 0 ? forced_wgs : (k <= 256 ? 16 : (k <= 1024 ? 32 : OPTL_MAX_WGS));
   const int threads = k <= 192 ? 256 : (k <= 768 ? 512 : 1024);
@@ -1061,6 +1067,12 @@ int bcx_launch_omp_lh(bcx_solver* s, NnlsArgs& n, const ResolveArgs* fused) {
   gs.counter = s->grid_counter;
   gs.base = 0;                         // (read from device memory by the kernel: s->grid_counter[1])
   gs.timeout_ticks = 1000000000LL;     // 10 s
+  // dev: BCX_GRID_NOFENCE=1 drops the barriers' release / acquire fences (every cross-workgroup datum of this file is an
+  // exchange vector written write-through and read with sc1 loads, so they order nothing that is read).  Measured round 6:
+  // optimize() k = 1497, d = 1024 34.5 ms without against 36.3 with, the OMP step of configs[2] 35.9 us either way -- the
+  // fences are not what bounds these kernels (unlike csrc/lrpost.hip, where they sat on a 5 us critical path), so they stay.
+  static const bool nofence = bcx_dev_env("BCX_GRID_NOFENCE") != nullptr;
+  gs.fences = nofence ? 0 : 1;
   s->grid_epoch += 1;
   const int fr = (force > 0 && (s->grid_epoch % force) == 0) ? 1 : 0;
   // Workgroup width.  The step is a chain of short latency-bound phases separated by workgroup barriers and block
