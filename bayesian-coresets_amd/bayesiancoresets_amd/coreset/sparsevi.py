@@ -209,7 +209,7 @@ class SparseVICoreset(Coreset):
         w, m1, m2, sched_d = state[:k], state[k:2 * k], state[2 * k:3 * k], state[3 * k:]
         theta, mean = plan.buffers()
         run, buf, _ = prj.enqueue_step_plan(self.data, self._core_points_device(), True, theta, mean)    # sparsevi.py:35-41
-        # (more than 32 weights: the ADAM step is two launches over slabs of weights and needs scratch, csrc/svi.hip)
+        # (more than 16 weights: the ADAM step is two launches over slabs of weights and needs scratch, csrc/svi.hip)
         need = int(prj._lib.bcx_sparsevi_adam_scratch_bytes(k, S))
         work = torch.empty(max(need // 8, 1), dtype=torch.float64, device=prj.device)
         adam, args = prj._lib.bcx_sparsevi_adam_step_ws, [prj._stream(), k, S, buf.data_ptr(), 1.0, buf[S:].data_ptr(), S, w.data_ptr(),

@@ -78,6 +78,7 @@ class ShardedSolver(object):
         self.last_trace = None
         self._flat_gather = True
         self.exchange = "collective"
+        self._xt = None
         # how the exchange mode was decided (reported by bench.py as config.exchange_probe)
         self.probe_info = {"attempted": False, "result": None, "reason": "single shard" if self.world == 1 else
                            ("BCX_EXCHANGE=%s" % os.environ.get("BCX_EXCHANGE") if os.environ.get("BCX_EXCHANGE", "mailbox") != "mailbox"
@@ -197,7 +198,17 @@ class ShardedSolver(object):
                     err = e
                     self.send.zero_()          # flags 0: "no candidate from this shard"
             if self.world > 1:
-                self._all_gather(self.recv, self.send)
+                xt = self._xt
+                if xt is not None:
+                    # the exchange step on the stream's clock (collective mode has no device-side stamps: the all-gather is a
+                    # library call): from the record being ready to the gathered records being usable
+                    e0, e1 = self.torch.cuda.Event(enable_timing=True), self.torch.cuda.Event(enable_timing=True)
+                    e0.record()
+                    self._all_gather(self.recv, self.send)
+                    e1.record()
+                    xt.append((e0, e1))
+                else:
+                    self._all_gather(self.recv, self.send)
             if err is None:
                 try:
                     self.engine.step_apply_tensor(self.recv if self.world > 1 else self.send)
@@ -205,6 +216,18 @@ class ShardedSolver(object):
                     err = e
                     self.send.zero_()
         return err
+
+    def time_exchange(self, on=True):
+        """Collective mode: bracket every all-gather of the records with events (``exchange_times_us`` reads them)."""
+        self._xt = [] if on else None
+
+    def exchange_times_us(self):
+        """Microseconds of every all-gather since ``time_exchange(True)`` (synchronises); the list is emptied."""
+        xt, self._xt = (self._xt or []), ([] if self._xt is not None else None)
+        if not xt:
+            return []
+        self.torch.cuda.synchronize()
+        return [e0.elapsed_time(e1) * 1e3 for e0, e1 in xt]
 
     def _settle(self, err):
         """Collective: None if no rank failed; otherwise EVERY rank raises -- the failing ones their own error, the others

@@ -466,14 +466,14 @@ __global__ __launch_bounds__(256) void svi_adam_kernel(const double* __restrict_
 }
 
 
-// ---- more than 32 weights: the same step as two launches of one workgroup per slab of SVB_ROWS weights --------------------------
+// ---- more than 16 weights: the same step as two launches of one workgroup per slab of SVB_ROWS weights --------------------------
 // (the single-workgroup kernel above walks the k x S projected coreset points three times with one wave per row: 50 us at
 // k = 300.)  svi_adam_a_kernel: row means of its slab's raw rows and the slab's share of w.dot(corevecs); svi_adam_b_kernel:
 // resid from the shares (added in slab order: fixed association), the slab's gradient entries, ADAM moments, step, clamp.
 // Slabs of 8 weights; every loop over rows or shares keeps its loads independent and in flight together.
 #define SVB_ROWS 8
 #define SVB_KMAX 4096
-#define SVB_SINGLE_MAX 32    // weights up to which the single-workgroup kernel is the faster form (22 us at k = 64 against 13 for the two launches)
+#define SVB_SINGLE_MAX 16    // weights up to which the single-workgroup kernel is the faster form (8 us at 16, 20 at 32, 36 at 64; the two launches: 10-13)
 struct SvbArgs {
   const double* colsum; const double* core; const double* sched;
   double* w; double* mom1; double* mom2; double* trace;
@@ -699,7 +699,7 @@ extern "C" int bcx_sparsevi_adam_step(void* stream, int32_t k, int32_t S, const 
   return BCX_OK;
 }
 
-// The same step for any number of weights up to 4096: up to 32 the single-workgroup kernel, beyond it the two-launch form,
+// The same step for any number of weights up to 4096: up to 16 the single-workgroup kernel, beyond it the two-launch form,
 // which needs bcx_sparsevi_adam_scratch_bytes(k, S) bytes of scratch (row means + the slabs' shares of w.dot(corevecs)).
 extern "C" int64_t bcx_sparsevi_adam_scratch_bytes(int32_t k, int32_t S) {
   if (k < 1 || k > SVB_KMAX || S < 1 || S > 8192) return -1;

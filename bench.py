@@ -417,6 +417,8 @@ def run_snnls(args, torch, dist, nat, world, rank, local_rank):
             s.engine.profile(every)
         if s.exchange == "mailbox":
             s.engine.exchange_stats(reset=True)       # device-side wait stamps of the timed region only
+        elif world > 1 and not solo and hasattr(s, "time_exchange"):
+            s.time_exchange(True)                     # collective mode: events around every all-gather of the records
         sync()
         t0 = time.perf_counter()
         tr = build(s, steps)
@@ -436,6 +438,16 @@ def run_snnls(args, torch, dist, nat, world, rank, local_rank):
     out = None
     # device-stamped exchange step of the timed region (mailbox mode): every rank's own view, worst rank reported
     xstat = None
+    if world > 1 and solver.exchange == "collective":
+        # no device-side stamps in this mode: the all-gather of the records on the stream's clock, worst / best rank
+        us = solver.exchange_times_us()
+        solver.time_exchange(False)
+        mean, mx = (sum(us) / len(us), max(us)) if us else (0.0, 0.0)
+        t = torch.tensor([mean, mx, mean, mx], dtype=torch.float64, device="cuda")
+        lo_t = t.clone()
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dist.all_reduce(lo_t, op=dist.ReduceOp.MIN)
+        xstat = {"n": len(us), "max": [float(v) for v in t.tolist()], "min": [float(v) for v in lo_t.tolist()]}
     if world > 1 and solver.exchange == "mailbox":
         xs = solver.engine.exchange_stats()
         t = torch.tensor([xs["wait_us_mean"], xs["wait_us_max"], xs["total_us_mean"], xs["total_us_max"]],
@@ -480,7 +492,8 @@ def run_snnls(args, torch, dist, nat, world, rank, local_rank):
                 "alg": args.alg, "rows": args.rows, "dim": args.dim, "rows_per_gpu": solver.n_local,
                 "exchange": solver.exchange if world > 1 else None,   # mailbox = device-side P2P stores; collective = all-gather
                 "exchange_probe": solver.probe_info,
-                # wall_clock64 stamps inside the tail kernel (csrc/resolve.hip mailbox_exchange), timed region only:
+                # mailbox: wall_clock64 stamps inside the tail kernel (csrc/resolve.hip mailbox_exchange), timed region only;
+                # collective: events around every all-gather of the records (wait == exchange there):
                 # wait = from this shard's record being posted to the slowest peer's record arriving (load imbalance +
                 # xGMI latency); exchange = wait + this shard's own G record stores.  Worst / best rank.
                 "exchange_wait_us": xstat["max"][0] if xstat else None,
@@ -515,6 +528,10 @@ def run_snnls(args, torch, dist, nat, world, rank, local_rank):
         solver.fallback_to_collective()
         solver.engine.reset()
         el_c, tr_c, _, _, _ = timed(solver, min(args.warmup, 5), n_c)
+        us_c = solver.exchange_times_us()
+        solver.time_exchange(False)
+        tc = torch.tensor([sum(us_c) / max(len(us_c), 1), max(us_c) if us_c else 0.0], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tc, op=dist.ReduceOp.MAX)
         if rank == 0:
             out["mailbox_ms_per_step"] = out["ms_per_step"]
             out["collective_ms_per_step"] = el_c / max(len(tr_c[0]), 1) * 1e3
@@ -522,6 +539,8 @@ def run_snnls(args, torch, dist, nat, world, rank, local_rank):
                 "what": "same shards, records exchanged by one RCCL all-gather per iteration (host-driven scan / apply launches) "
                         "instead of the device-side peer mailbox; %d iterations after a reset" % len(tr_c[0]),
                 "ms_per_step": out["collective_ms_per_step"], "iterations_per_s": len(tr_c[0]) / el_c,
+                # the all-gather itself on the stream's clock (events around the call), worst rank: mean / max microseconds
+                "exchange_us": float(tc[0].item()), "exchange_us_max": float(tc[1].item()), "exchanges_timed": len(us_c),
                 "final_error": float(tr_c[1][-1]) if len(tr_c[1]) else None}
     # ---- row shards: the same workload as ONE shard on rank 0's GPU, in the same run (the other ranks wait off the CPU, see
     # the end of this function): the line then carries its own 1-GPU figure and the scaling efficiency against it ----------
@@ -858,6 +877,16 @@ def side_legs(args, out, torch, dist, nat):
             # everything of an OMP iteration that is not the scan: the fused resolve + Lawson-Hanson step kernel
             out["c3_omp_step_us"] = (r["ms_per_step"] - r["roofline"]["avg_launch_ms"]) * 1e3
             out["c3_final_error"] = r["config"]["final_error"]
+    # configs[1] at its stated M = 1000 from a fresh solver (no warm-up): GIGA reaches its numeric limit on the way (the latch
+    # of snnls.py:63-74) -- the whole run, latch included, on the driver's clock
+    r = leg("c2", steps=1000, warmup=0)
+    if r is not None:
+        out["c2_m1000_its"] = r["value"]
+        out["c2_m1000_iterations_run"] = r["config"]["iterations_run"]
+        out["c2_m1000_reached_numeric_limit"] = r["config"]["reached_numeric_limit"]
+        out["c2_m1000_steps_accepted"] = r["config"]["steps_accepted"]
+        out["c2_m1000_final_error"] = r["config"]["final_error"]
+        out["c2_m1000_leg_wall_s"] = r["leg_wall_s"]
     # c5, MFMA form (every column sum a projection of all rows, as the reference does): 3 greedy steps after 1
     r = leg("c5", colsum="mfma")
     if r is not None:

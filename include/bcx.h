@@ -308,9 +308,9 @@ int bcx_sparsevi_adam_step(void* stream, int32_t k, int32_t S, const void* colsu
 int bcx_standard_normal(void* stream, uint64_t seed, uint64_t offset, int64_t count, void* out_dev);
 int bcx_column_means(void* stream, const void* rows_dev, int32_t nblocks, int32_t n, int32_t ld, int64_t block_stride,
                      void* out_dev, int64_t out_stride);
-/* The same ADAM step for up to 4096 weights: up to 32 the single-workgroup kernel above, beyond it two launches of one
+/* The same ADAM step for up to 4096 weights: up to 16 the single-workgroup kernel above, beyond it two launches of one
  * workgroup per slab of 8 weights (row means + the slabs' shares of w.dot(corevecs); resid, gradient, moments, step), which
- * need work_dev = bcx_sparsevi_adam_scratch_bytes(k, S) bytes of scratch (0 for k <= 32; -1: k or S out of range). */
+ * need work_dev = bcx_sparsevi_adam_scratch_bytes(k, S) bytes of scratch (0 for k <= 16; -1: k or S out of range). */
 int64_t bcx_sparsevi_adam_scratch_bytes(int32_t k, int32_t S);
 int bcx_sparsevi_adam_step_ws(void* stream, int32_t k, int32_t S, const void* colsum_dev, double scaling, const void* core_dev,
                               int64_t ldc, void* w_dev, void* mom1_dev, void* mom2_dev, const void* sched_dev, int32_t step,

@@ -580,6 +580,16 @@ def test_bench_contract_eight_ranks():
     assert 0.0 < eight["config"]["exchange_wait_us"] <= eight["config"]["exchange_wait_us_max"]
     assert eight["config"]["exchange_us"] >= eight["config"]["exchange_wait_us_best_rank"]
     assert eight["config"]["exchange_probe"]["result"] == 1
+    # the same line carries the OTHER exchange mode on the same shards (one all-gather of the records per iteration) with its
+    # exchange step timed, so that the first 8-GPU box yields mailbox and collective numbers in one run ...
+    leg = eight["config"]["collective_leg"]
+    assert leg["exchanges_timed"] >= 40 and 0.0 < leg["exchange_us"] <= leg["exchange_us_max"]
+    assert leg["final_error"] == one["config"]["final_error"]
+    # ... and a run that is FORCED onto the collective (what a failed mailbox probe does) reports the same fields
+    forced, _ = _run_bench({"BENCH_SHARE_GPU": "1", "BCX_EXCHANGE": "collective"}, 8, args)
+    assert forced["config"]["exchange"] == "collective" and forced["config"]["exchanges_timed"] == 40
+    assert 0.0 < forced["config"]["exchange_us"] <= forced["config"]["exchange_us_max"]
+    assert forced["config"]["final_error"] == one["config"]["final_error"]
 
 
 def test_multi_rank_line_carries_cpu_baseline_and_both_rooflines():

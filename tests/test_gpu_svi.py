@@ -331,9 +331,9 @@ def test_posterior_factor_kernel(bc, D, k, prior):
                                                sigsq, work.data_ptr(), need, U.data_ptr(), ld, uv.data_ptr(), mu.data_ptr()) == _native.ERR_ARG
 
 
-@pytest.mark.parametrize("k,S,raw", ((33, 64, 1), (65, 256, 1), (130, 100, 0), (300, 256, 1), (1000, 48, 1), (67, 1000, 0)))
+@pytest.mark.parametrize("k,S,raw", ((17, 64, 1), (33, 64, 0), (65, 256, 1), (130, 100, 0), (300, 256, 1), (1000, 48, 1), (67, 1000, 0)))
 def test_adam_step_ws_kernels_against_nn_opt(bc, k, S, raw):
-    """More than 32 weights: the two-launch form of the ADAM step (csrc/svi.hip svi_adam_a / b_kernel) against ``nn_opt``."""
+    """More than 16 weights: the two-launch form of the ADAM step (csrc/svi.hip svi_adam_a / b_kernel) against ``nn_opt``."""
     import torch
     from bayesiancoresets_amd import _native
     from bayesiancoresets_amd.util.opt import nn_opt
@@ -354,7 +354,7 @@ def test_adam_step_ws_kernels_against_nn_opt(bc, k, S, raw):
     d = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float64)).cuda()
     core_d, col_d, w, m1, m2, sc, tr = d(core_raw if raw else core), d(colsum), d(w0), d(np.zeros(k)), d(np.zeros(k)), d(sched), d(np.zeros((T, k)))
     need = int(lib.bcx_sparsevi_adam_scratch_bytes(k, S))
-    assert need > 0 and lib.bcx_sparsevi_adam_scratch_bytes(32, S) == 0 and lib.bcx_sparsevi_adam_scratch_bytes(4097, S) == -1
+    assert need > 0 and lib.bcx_sparsevi_adam_scratch_bytes(16, S) == 0 and lib.bcx_sparsevi_adam_scratch_bytes(4097, S) == -1
     work = torch.empty(need // 8, dtype=torch.float64, device="cuda")
     stream = int(torch.cuda.current_stream().cuda_stream)
     for i in range(T):
