@@ -95,9 +95,15 @@ class HilbertCoreset(Coreset):
         super().reset()
 
     def _read_solver(self):
-        w = self.snnls.weights()
-        support = w > 0
-        self.wts, self.idcs = w[support], self.sub_idcs[support]
+        sup = getattr(self.snnls, "support", None)
+        if sup is not None:
+            # a device solver: its sparse list (k entries), in index order -- the same triple as the dense form below
+            idx, self.wts = sup()
+            self.idcs = self.sub_idcs[idx]
+        else:
+            w = self.snnls.weights()                        # hilbert.py:36-38
+            support = w > 0
+            self.wts, self.idcs = w[support], self.sub_idcs[support]
         self.pts = self.data[self.idcs]
 
     def _build(self, itrs):

@@ -255,6 +255,15 @@ class DeviceSparseNNLS(SparseNNLS):
         idx, wv = self._eng.sparse_weights()
         return int((wv > 0).sum())
 
+    def support(self):
+        """(indices ascending, weights) of the columns with a positive weight -- what ``weights()`` holds, without the dense
+        length-N vector (HilbertCoreset reads the solver through this: k values instead of N after every build call)."""
+        idx, wv = self._eng.sparse_weights()
+        keep = wv > 0
+        idx, wv = idx[keep], wv[keep]
+        order = np.argsort(idx, kind="stable")
+        return idx[order], wv[order]
+
     def weights(self):
         return self.w.copy()
 
