@@ -9,6 +9,7 @@ Namespace mirrors bayesiancoresets/__init__.py:1-2 for the classes on the greedy
 from .coreset import Coreset, HilbertCoreset, UniformSamplingCoreset, SparseVICoreset, BatchPSVICoreset, ShardedHilbertCoreset
 from .projector import BlackBoxProjector, Projector, DeviceProjector
 from .linreg_sampler import LinregPosteriorSampler
+from .laplace_sampler import LaplacePosteriorSampler
 from . import snnls
 from . import util
 

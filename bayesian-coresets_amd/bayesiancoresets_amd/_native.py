@@ -39,6 +39,7 @@ SYMBOLS = (
     "bcx_linreg_posterior_draw_factored",
     "bcx_sparsevi_adam_step_ws", "bcx_sparsevi_adam_scratch_bytes", "bcx_standard_normal", "bcx_column_means",
     "bcx_center_rows", "bcx_row_sumsq", "bcx_project_write_points",
+    "bcx_laplace_sampler", "bcx_laplace_sampler_ok", "bcx_laplace_sampler_lds_bytes",
 )
 
 
@@ -167,6 +168,10 @@ def load():
     sigs["bcx_standard_normal"] = [vp, ctypes.c_uint64, ctypes.c_uint64, i64, vp]
     sigs["bcx_column_means"] = [vp, vp, i32, i32, i32, i64, vp, i64]
     sigs["bcx_center_rows"] = [vp, vp, i64, i32, i64]
+    sigs["bcx_laplace_sampler"] = [vp, i32, i32, i32, vp, vp, i64, vp, i32, dbl, i32, vp, vp, i32, i32, vp, vp, vp]
+    sigs["bcx_laplace_sampler_ok"] = [i32, i32]
+    lib.bcx_laplace_sampler_lds_bytes.restype = ctypes.c_int64
+    lib.bcx_laplace_sampler_lds_bytes.argtypes = [i32, i32]
     sigs["bcx_row_sumsq"] = [vp, vp, i64, i32, i64, vp]
     sigs["bcx_linreg_posterior_draw_factored"] = [vp, i32, i32, vp, i64, vp, vp, vp, i32, vp, vp]
     sigs["bcx_sparsevi_adam_step_ws"] = [vp, i32, i32, vp, dbl, vp, i64, vp, vp, vp, vp, i32, dbl, dbl, dbl, vp, i32, vp, i64]

@@ -20,7 +20,46 @@ points change (once per greedy step) and uploaded in one piece.  There is no CPU
 import numpy as np
 
 
-class LinregPosteriorSampler(object):
+class _DeviceNormals(object):
+    """The samplers' raw material: normal numbers and their column means by the library's own kernels (csrc/svi.hip).  Needs
+    ``_torch``, ``_lib``, ``_nat``, ``device``, ``ld``, ``_seed``, ``_offset``."""
+
+    # -- noise: separate hooks so that a test can feed both entry points the same numbers --------------------------------
+    # Standard normal doubles from the library's own counter-based generator (csrc/svi.hip svi_normal_kernel: Philox-4x32-10 +
+    # Box-Muller, key = the sampler's seed): one reproducible stream, the pair counter advances by what each call consumed.
+    def _normal(self, *shape):
+        torch = self._torch
+        out = torch.empty(*shape, dtype=torch.float64, device=self.device)
+        count = out.numel()
+        rc = self._lib.bcx_standard_normal(int(torch.cuda.current_stream(self.device).cuda_stream), self._seed, self._offset, count,
+                                           out.data_ptr())
+        if rc != 0:
+            raise self._nat.EngineError(rc, self._lib.bcx_project_last_error().decode())
+        self._offset += (count + 1) // 2
+        return out
+
+    def _noise(self, n):
+        return self._normal(n, self.ld)
+
+    def _noise_block(self, steps, n):
+        return self._normal(steps, n, self.ld)
+
+    def _column_means(self, blocks):
+        """Column means of every n x ld block of ``blocks`` (steps x n x ld, or n x ld): steps x ld (or ld), one launch."""
+        torch = self._torch
+        three = blocks.dim() == 3
+        nb, n = (blocks.shape[0], blocks.shape[1]) if three else (1, blocks.shape[0])
+        if blocks.stride(-1) != 1 or blocks.stride(-2) != self.ld or (three and nb > 1 and blocks.stride(0) < n * self.ld):
+            blocks = blocks.contiguous()
+        out = torch.empty((nb, self.ld) if three else (self.ld,), dtype=torch.float64, device=self.device)
+        rc = self._lib.bcx_column_means(int(torch.cuda.current_stream(self.device).cuda_stream), blocks.data_ptr(), nb, n, self.ld,
+                                        blocks.stride(0) if three else 0, out.data_ptr(), self.ld)
+        if rc != 0:
+            raise self._nat.EngineError(rc, self._lib.bcx_project_last_error().decode())
+        return out
+
+
+class LinregPosteriorSampler(_DeviceNormals):
     KMAX = 4096    # weighted points (csrc/lrpost.hip)
     KLOW = 64      # ... that the rank-k form of csrc/svi.hip takes (LRS_KMAX)
     DMAX = 1024    # features the D x D form takes (csrc/lrpost.hip LP_NB * LP_MAX_NT)
@@ -60,40 +99,6 @@ class LinregPosteriorSampler(object):
         # the D x D form (csrc/lrpost.hip): prior precision and Sig0^-1 mu0 once; scratch, L^-1 and mu_w on first use
         self._S0inv_host = np.linalg.inv(self.Sig0)
         self._factor = None
-
-    # -- noise: separate hooks so that a test can feed both entry points the same numbers --------------------------------
-    # Standard normal doubles from the library's own counter-based generator (csrc/svi.hip svi_normal_kernel: Philox-4x32-10 +
-    # Box-Muller, key = the sampler's seed): one reproducible stream, the pair counter advances by what each call consumed.
-    def _normal(self, *shape):
-        torch = self._torch
-        out = torch.empty(*shape, dtype=torch.float64, device=self.device)
-        count = out.numel()
-        rc = self._lib.bcx_standard_normal(int(torch.cuda.current_stream(self.device).cuda_stream), self._seed, self._offset, count,
-                                           out.data_ptr())
-        if rc != 0:
-            raise self._nat.EngineError(rc, self._lib.bcx_project_last_error().decode())
-        self._offset += (count + 1) // 2
-        return out
-
-    def _noise(self, n):
-        return self._normal(n, self.ld)
-
-    def _noise_block(self, steps, n):
-        return self._normal(steps, n, self.ld)
-
-    def _column_means(self, blocks):
-        """Column means of every n x ld block of ``blocks`` (steps x n x ld, or n x ld): steps x ld (or ld), one launch."""
-        torch = self._torch
-        three = blocks.dim() == 3
-        nb, n = (blocks.shape[0], blocks.shape[1]) if three else (1, blocks.shape[0])
-        if blocks.stride(-1) != 1 or blocks.stride(-2) != self.ld or (three and nb > 1 and blocks.stride(0) < n * self.ld):
-            blocks = blocks.contiguous()
-        out = torch.empty((nb, self.ld) if three else (self.ld,), dtype=torch.float64, device=self.device)
-        rc = self._lib.bcx_column_means(int(torch.cuda.current_stream(self.device).cuda_stream), blocks.data_ptr(), nb, n, self.ld,
-                                        blocks.stride(0) if three else 0, out.data_ptr(), self.ld)
-        if rc != 0:
-            raise self._nat.EngineError(rc, self._lib.bcx_project_last_error().decode())
-        return out
 
     # -- per-point state ------------------------------------------------------------------------------------------------------
     def supports(self, n, k):

@@ -42,6 +42,7 @@
 #include <string>
 #include "bcx_internal.h"
 #include "dev_util.h"
+#include "chol32.h"
 
 typedef double lp4d __attribute__((ext_vector_type(4)));
 
@@ -253,60 +254,17 @@ static __device__ __forceinline__ int lp_panel_count(int nt, int p) {     // til
   return (nt - p - 2 > 0 ? nt - p - 2 : 0) + (p + 1 < nt ? 1 : 0) + (p + 1) + 1;
 }
 
-static __device__ __forceinline__ double lp_readlane(double v, int l) {
-  const unsigned long long b = (unsigned long long)__double_as_longlong(v);
-  const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)b, l), hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(b >> 32), l);
-  return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
-}
-
-// One wave: Cholesky of the 32 x 32 tile in sdg (row-major, stride 33) and the inverse of its factor.  Lane l < 32 holds row l
-// of the tile, lane 32 + l row l of the identity; the column operations that produce L in the first turn the second into
-// X = L^-T.  Per column c the multipliers l_jc (j > c) reach all lanes by v_readlane; they are fetched EIGHT at a time into
-// distinct scalar registers before their multiply-adds, and the 30 - c updates of columns j >= c + 2 are issued beside the next
-// column's dependent chain (update of column c + 1 -> pivot -> rsqrt with two Newton steps -> scale).  Measured on this chip
-// (tools/probe/f64_chain_probe.hip, cycles per wave instruction): independent v_fma_f64 5, dependent 6.5, v_rsq_f64 18, a
-// v_readlane pair + fma 11 when the scalar pair is not reused back to back (29 when it is: the compiler's own schedule of the
-// plain loop, 6 us per tile), a readlane -> fma hop 25, a BROADCAST ds_read_b128 36 per wave (so multipliers through LDS are
-// slower than through v_readlane: 8 us per tile), a dependent v_mfma_f64_16x16x4 64.  The loop body is software-pipelined by
-// hand and pinned with scheduling barriers.  Writes W = L^-1 = X^T k-grouped into sw (LDS) and gw (global, write-through).
-// bad: a pivot was not positive.
-static __device__ __forceinline__ double lp_rsqrt(double d) {
-  double r = __builtin_amdgcn_rsq(d);
-  double e = fma(-d * r, r, 1.0);                   // two Newton steps for 1 / sqrt(d)
-  r = fma(0.5 * r, e, r);
-  e = fma(-d * r, r, 1.0);
-  return fma(0.5 * r, e, r);
-}
+// One wave: Cholesky of the 32 x 32 tile in sdg (row-major, stride 33) and the inverse of its factor (csrc/chol32.h: how, and
+// what it cost to get there).  Writes W = L^-1 = X^T k-grouped into sw (LDS) and gw (global, write-through).  bad: a pivot was
+// not positive.
 static __device__ __forceinline__ void lp_diag(const double* sdg, double* sw, double* gw, int lane, int* bad) {
   double a[32];
   const int row = lane & 31;
   const bool top = lane < 32;
 #pragma unroll
   for (int c = 0; c < 32; ++c) a[c] = top ? (c <= row ? sdg[row * 33 + c] : 0.0) : (c == row ? 1.0 : 0.0);
-  double d = lp_readlane(a[0], 0);
-  double dmin = d;
-  double r = lp_rsqrt(d);
-#pragma unroll
-  for (int c = 0; c < 32; ++c) {
-    a[c] *= r;
-    if (c + 1 < 32) {
-      const double l1 = lp_readlane(a[c], c + 1);
-      a[c + 1] = fma(-a[c], l1, a[c + 1]);
-      __builtin_amdgcn_sched_barrier(0);
-      d = lp_readlane(a[c + 1], c + 1);
-      dmin = fmin(dmin, d);                         // (a non-positive pivot leaves NaNs behind; reported once, after the loop)
-      r = lp_rsqrt(d);
-#pragma unroll
-      for (int j0 = c + 2; j0 < 32; j0 += 8) {
-        double m[8];
-#pragma unroll
-        for (int b = 0; b < 8; ++b) if (j0 + b < 32) m[b] = lp_readlane(a[c], j0 + b);
-#pragma unroll
-        for (int b = 0; b < 8; ++b) if (j0 + b < 32) a[j0 + b] = fma(-a[c], m[b], a[j0 + b]);
-      }
-      __builtin_amdgcn_sched_barrier(0);
-    }
-  }
+  double dmin;
+  chol32_factor(a, dmin);
   if (!(dmin > 0.0)) *bad = 1;
   if (!top) {
     // lane 32 + kk holds X[kk][c] = W[c][kk]

@@ -87,6 +87,14 @@ def run(a):
         mu, Sig = laplace(np.atleast_2d(pts)[keep], np.asarray(wts)[keep])
         return np.atleast_2d(np.random.multivariate_normal(mu, Sig, n))
 
+    # the same sampler on the device (csrc/laplace.hip: one launch per call, and -- through enqueue_plan -- from weights that
+    # never leave the device, so SparseVI enqueues its whole ADAM loop) where the model fits it: D <= 32 parameters
+    sampler_host = sampler_w
+    if D <= 32 and not getattr(a, "host_sampler", False):
+        try:
+            sampler_w = bc.LaplacePosteriorSampler(family, D, seed=a.trial)
+        except RuntimeError:
+            sampler_w = sampler_host
     dev = lambda sampler: bc.DeviceProjector(family, sampler, a.proj_dim)
     build = {
         "SVI": lambda: bc.SparseVICoreset(Z, dev(sampler_w), opt_itrs=a.opt_itrs, step_sched=eval(a.step_sched)),
@@ -140,6 +148,7 @@ def parser():
     ap.add_argument("--trial", type=int, default=1)
     ap.add_argument("--results_folder", type=str, default="results/")
     ap.add_argument("--verbosity", type=str, default="error", choices=["error", "warning", "critical", "info", "debug"])
+    ap.add_argument("--host_sampler", action="store_true", help="SVI: the Laplace fit of every sampler call on the host (NumPy) instead of csrc/laplace.hip")
     return ap
 
 

@@ -339,6 +339,21 @@ int bcx_linreg_posterior_factor(void* stream, int32_t k, int32_t D, int32_t ldx,
 int bcx_linreg_posterior_factor_status(void* stream, int32_t D, const void* work_dev);
 int bcx_linreg_posterior_draw_factored(void* stream, int32_t D, int32_t ld, const void* U_dev, int64_t ldu, const void* u_dev,
                                        const void* R_dev, const void* Rbar_dev, int32_t S, void* theta_dev, void* tbar_dev);
+/* The sampler of the reference's logistic / Poisson regression experiment (examples/logistic_poisson_regression/main.py:15-41
+ * get_laplace, :155-162 sampler_w) from k weights that live on the device: the Laplace approximation of the weighted posterior
+ * of the points pts_dev (k x ldp; logistic: rows y x of D values; Poisson: rows [x, y]) under a standard-normal prior --
+ * mu_dev (D) = the mode (damped Newton to |step| < tol, at most max_iter steps; warm != 0: started from the contents of mu_dev,
+ * e.g. the previous ADAM step's mode), and the draws theta_dev (S x ld) = mu + R W, tbar_dev (D) = mu + Rbar W with W = L^-1 for
+ * the Cholesky factor L of the negative Hessian at the mode (Sigma = W^T W), R_dev (S x ld) standard normal numbers and Rbar_dev
+ * their column means.  family 0: logistic, 1: Poisson (softplus rate).  ONE launch of one workgroup (csrc/laplace.hip), the
+ * points resident in LDS: serves the (k, D) for which bcx_laplace_sampler_ok is non-zero (D <= 32, the points + four doubles
+ * each within 96 KiB).  status_dev (2 int32): [0] 0 converged / 1 iteration limit / 2 no positive definite Newton matrix,
+ * [1] Newton steps taken.  Asynchronous on `stream`. */
+int bcx_laplace_sampler_ok(int32_t k, int32_t D);
+int64_t bcx_laplace_sampler_lds_bytes(int32_t k, int32_t D);
+int bcx_laplace_sampler(void* stream, int32_t family, int32_t k, int32_t D, const void* w_dev, const void* pts_dev, int64_t ldp,
+                        void* mu_dev, int32_t warm, double tol, int32_t max_iter, const void* R_dev, const void* Rbar_dev,
+                        int32_t S, int32_t ld, void* theta_dev, void* tbar_dev, void* status_dev);
 /* The dense re-weight's Gram matrix as an operator of its own (optimize() forms it over the active rows, snnls.py:82-97:
  * `nnls(A[:, active], b)` solves the normal equations of that k-column block): G_dev (k x ldg doubles, both triangles) =
  * V V^T for the k rows of d doubles at rows_dev (row stride ld >= d), on the fp64 matrix cores; the d products of an entry

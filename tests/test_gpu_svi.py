@@ -433,3 +433,104 @@ def test_standard_normal_generator_and_column_means(bc):
         np.testing.assert_allclose(got[:, :ld], R.mean(axis=1), rtol=1e-13, atol=1e-15)
         assert np.all(got[:, ld:] == 0.0)
     assert lib.bcx_column_means(st, Rd.data_ptr(), 0, 1, 1, 0, out.data_ptr(), 1) == _native.ERR_ARG
+
+
+# ---- the Laplace sampler of the logistic / Poisson experiment on the device (csrc/laplace.hip) ---------------------------------
+def _laplace_case(family, D, k, seed):
+    sys_path_examples()
+    import model_lr
+    import model_poiss
+    rs = np.random.RandomState(seed)
+    if family == "logistic":
+        pts = model_lr.synthetic_rows(max(k, 1), D, rs)[:k]
+        fit = model_lr.laplace_fit
+    else:
+        pts = model_poiss.synthetic_rows(max(k, 1), D, rs)[:k]
+        fit = model_poiss.laplace_fit
+    wts = np.abs(rs.randn(k)) * 3.0
+    if k > 3:
+        wts[1] = 0.0
+    return pts, wts, fit
+
+
+def sys_path_examples():
+    import os
+    import sys
+    p = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bayesian-coresets_amd", "examples", "common")
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+
+@pytest.mark.parametrize("family,D,k", (("logistic", 10, 40), ("logistic", 3, 1), ("logistic", 32, 300), ("logistic", 7, 0),
+                                        ("poisson", 10, 60), ("poisson", 5, 2), ("poisson", 31, 250), ("poisson", 4, 900)))
+def test_laplace_sampler_against_the_host_fit(bc, family, D, k):
+    """bc.LaplacePosteriorSampler (one launch: damped Newton + in-register Cholesky + draws) against the package's host
+    ``laplace_fit`` (examples/common/model_lr.py / model_poiss.py: the same objective, pinned to the reference's get_laplace
+    outputs by tests/test_host_golden.py): mode, covariance, and the draws as mu + R W for the W just read."""
+    import torch
+    pts, wts, fit = _laplace_case(family, D, k, 50 * D + k)
+    smp = bc.LaplacePosteriorSampler(family, D, seed=4)
+    mu, W = smp.posterior(wts if k else None, pts if k else None)
+    if k and (wts > 0).any():
+        mu_ref, cov_ref = fit(pts[wts > 0], wts[wts > 0])
+    else:
+        mu_ref, cov_ref = np.zeros(D), np.eye(D)
+    np.testing.assert_allclose(mu, mu_ref, rtol=1e-7, atol=1e-9)
+    np.testing.assert_allclose(W.T.dot(W), cov_ref, rtol=1e-6, atol=1e-9 * np.abs(cov_ref).max())
+    assert np.all(np.triu(W, 1) == 0.0) and smp.newton_steps <= 60
+    # the draws at the sampler's own normal numbers: right shape / alignment, the posterior's first two moments
+    n = 2000
+    th = smp(n, wts if k else None, pts if k else None)
+    assert tuple(th.shape) == (n, D) and th.stride(0) == D + D % 2 and th.data_ptr() % 16 == 0
+    t = th.cpu().numpy()
+    sd = np.sqrt(np.diag(cov_ref))
+    assert np.all(np.abs(t.mean(axis=0) - mu_ref) < 6 * sd / np.sqrt(n))
+    np.testing.assert_allclose(smp.mean.cpu().numpy(), t.mean(axis=0), rtol=1e-10, atol=1e-12)
+    assert np.abs(np.cov(t.T).reshape(D, D) - cov_ref).max() < 0.25 * (sd.max() ** 2)
+
+
+def test_laplace_sampler_limits(bc):
+    rs = np.random.RandomState(1)
+    with pytest.raises(ValueError):
+        bc.LaplacePosteriorSampler("gamma", 3)
+    smp = bc.LaplacePosteriorSampler("logistic", 33)
+    assert not smp.supports(8, 4) and smp.enqueue_plan(8, rs.randn(4, 33), 3) is None
+    with pytest.raises(ValueError):
+        smp(8, np.ones(4), rs.randn(4, 33))
+    smp = bc.LaplacePosteriorSampler("poisson", 6)
+    assert smp.enqueue_plan(8, rs.randn(3000, 7), 3) is None              # (the points would not fit the workgroup's LDS)
+    with pytest.raises(ValueError):
+        smp(8, np.ones(2), rs.randn(2, 6))                                 # Poisson rows carry the response: 7 columns
+    assert tuple(smp(5, np.array([]), np.array([])).shape) == (5, 6)       # no points: the prior
+
+
+@pytest.mark.parametrize("family", ("logistic", "poisson"))
+def test_laplace_enqueued_loop_matches_the_host_loop(bc, family):
+    """SparseVI on the logistic / Poisson model with bc.LaplacePosteriorSampler: the ADAM loop enqueued on the device-resident
+    weights (one Laplace fit per step where they are, csrc/laplace.hip) against the host loop (nn_opt around projector.update
+    + two projections, the reference's sequence) on the same normal numbers."""
+    import torch
+    sys_path_examples()
+    import model_lr
+    import model_poiss
+    D, N, S, T, steps = 6, 6000, 64, 12, 3
+    rs = np.random.RandomState(3)
+    Z = model_lr.synthetic_rows(N, D, rs) if family == "logistic" else model_poiss.synthetic_rows(N, D, rs)
+    g = torch.Generator(device="cuda")
+    g.manual_seed(31)
+    noise = torch.randn(steps * (T + 1) + 4, S, D + D % 2, dtype=torch.float64, device="cuda", generator=g)
+    out = {}
+    for mode in (True, False):
+        smp = _ReplaySampler(bc.LaplacePosteriorSampler(family, D), noise)
+        prj = bc.DeviceProjector(family, smp, S)
+        alg = bc.SparseVICoreset(Z, prj, opt_itrs=T)
+        alg.ENQUEUE = mode
+        alg.build(steps)
+        if mode:
+            assert alg._enqueue_plan() is not None
+            smp.at -= T
+        out[mode] = (alg.wts.copy(), alg.idcs.copy(), smp.at)
+    assert out[True][2] == out[False][2] == 1 + steps * (T + 1)
+    assert np.array_equal(out[True][1], out[False][1]) and out[True][1].shape[0] >= 2
+    np.testing.assert_allclose(out[True][0], out[False][0], rtol=1e-6, atol=1e-10)
+    assert (out[True][0] > 0).any()
