@@ -65,6 +65,7 @@ class LinregPosteriorSampler(_DeviceNormals):
     DMAX = 1024    # features the D x D form takes (csrc/lrpost.hip LP_NB * LP_MAX_NT)
     SMAX = 4096    # draws per call (DeviceProjector's own limit on the projection dimension)
     NOISE_BUDGET = 2 << 30      # bytes of pre-drawn normal numbers (+ their images) an enqueue plan may hold
+    ROWS_MAX = 1 << 22          # ... and rows of them one launch of the draw kernel takes (csrc/svi.hip LRS_SMAX)
 
     def __init__(self, mu0, Sig0, sigsq, device="cuda", seed=None):
         import torch
@@ -244,7 +245,7 @@ class LinregPosteriorSampler(_DeviceNormals):
         pts = np.atleast_2d(np.asarray(pts, dtype=np.float64))
         if pts.shape[0] < 1 or not self.supports(n, pts.shape[0]):
             return None
-        if 3 * steps * (n + 1) * self.ld * 8 > self.NOISE_BUDGET:
+        if 3 * steps * (n + 1) * self.ld * 8 > self.NOISE_BUDGET or steps * (n + 1) > self.ROWS_MAX:
             return None                                     # (the caller's host loop draws step by step)
         return _Plan(self, n, self._points(pts), self._noise_block(steps, n))
 
