@@ -236,6 +236,18 @@ static __device__ __forceinline__ bool lp_poll(const int* p, int target, const L
   }
   return true;
 }
+// one lane: three of them at once (each round trip costs ~0.5 us when taken one after the other)
+static __device__ __forceinline__ bool lp_poll3(const int* c, int target, const int* f1, const int* f2, const LpArgs& a) {
+  const long long t0 = wall_clock64();
+  for (;;) {
+    const int v0 = __hip_atomic_load(c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const int v1 = __hip_atomic_load(f1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const int v2 = __hip_atomic_load(f2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (v0 >= target && v1 >= 1 && v2 >= 1) return true;
+    __builtin_amdgcn_s_sleep(1);
+    if (wall_clock64() - t0 > a.timeout_ticks) { atomicExch(a.flags + 4 * a.nt, 1); return false; }
+  }
+}
 // all threads of the workgroup
 static __device__ __forceinline__ bool lp_wait(const int* p, int target, const LpArgs& a, int* s_ok) {
   if (threadIdx.x == 0) *s_ok = lp_poll(p, target, a) ? 1 : 0;
@@ -250,8 +262,8 @@ static __device__ __forceinline__ void lp_signal(int* p, int add) {
   __syncthreads();
   if (threadIdx.x == 0) __hip_atomic_fetch_add(p, add, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
-static __device__ __forceinline__ int lp_panel_count(int nt, int p) {     // tiles of panel p: helpers' top, the chain's, bottom, rhs
-  return (nt - p - 2 > 0 ? nt - p - 2 : 0) + (p + 1 < nt ? 1 : 0) + (p + 1) + 1;
+static __device__ __forceinline__ int lp_panel_count(int nt, int p) {     // counts of panel p: helpers' top tiles, the chain's three storing waves, bottom tiles, rhs
+  return (nt - p - 2 > 0 ? nt - p - 2 : 0) + (p + 1 < nt ? 3 : 0) + (p + 1) + 1;
 }
 
 // One wave: Cholesky of the 32 x 32 tile in sdg (row-major, stride 33) and the inverse of its factor (csrc/chol32.h: how, and
@@ -327,69 +339,81 @@ __global__ __launch_bounds__(256) void lrp_chol_kernel(LpArgs a) {
       const bool more = p + 1 < nt;
       if (wave == 0) {
         LP_STAMP(0);
-        lp_diag(s_dg, s_w, a.XW + (size_t)p * LP_TILE, lane, &s_bad);
+        lp_diag(s_dg, s_w, a.XW + (size_t)p * LP_TILE, lane, &s_bad);      // (W_pp is on its way to memory; published below)
         LP_STAMP(1);
-        // the inverse of the diagonal tile is what every helper waits for: out at once (this wave wrote all of it)
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        if (lane == 0) __hip_atomic_store(&F1[p], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        LP_STAMP(2);
-      } else if (more) {
-        // meanwhile: what does not depend on this diagonal tile -- tiles (p+1, p) and (p+1, p+1) up to and including the term
-        // of column p - 1.  Eight quadrant jobs over three waves (<= 3 each, their operands requested together); each wave
-        // waits for the assistants and for column p - 1 on its own.
-        bool ok = true;
-        if (lane == 0 && p >= 1) {
-          ok = lp_poll(&C[p - 1], lp_panel_count(nt, p - 1), a);
-          if (ok) ok = lp_poll(&A1[p], 1, a);
-          if (ok) ok = lp_poll(&A2[p], 1, a);
+      } else {
+        // last step's sub-diagonal tile has had a step's time to reach memory: publish it (one count per storing wave)
+        if (p >= 1) {
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          if (lane == 0) __hip_atomic_fetch_add(&C[p - 1], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
-        ok = __shfl(ok ? 1 : 0, 0, 64) != 0;
-        if (wave == 1) LP_STAMP(3);
-        const double* t_sub = a.AS + (size_t)p * LP_TILE;
-        const double* t_dg = a.AD + (size_t)p * LP_TILE;
-        const double* l_far = p >= 1 ? a.LT + (size_t)((p + 1) * nt + p - 1) * LP_TILE : nullptr;      // L_{p+1,p-1}: a helper's
-        const double* l_prev = s_l1[(p + 1) & 1];                                                        // L_{p,p-1}: the chain's last
-        if (ok) {
-          lp4d c[3];
-          double x[3][8], y[3][8];
+        if (more) {
+          // meanwhile: what does not depend on this diagonal tile -- tiles (p+1, p) and (p+1, p+1) up to and including the term
+          // of column p - 1.  Eight quadrant jobs over three waves (<= 3 each, their operands requested together); each wave
+          // waits for the assistants and for column p - 1 on its own (the three flags polled together).
+          bool ok = true;
+          if (lane == 0 && p >= 1) ok = lp_poll3(&C[p - 1], lp_panel_count(nt, p - 1), &A1[p], &A2[p], a);
+          ok = __shfl(ok ? 1 : 0, 0, 64) != 0;
+          if (wave == 1) LP_STAMP(3);
+          const double* t_sub = a.AS + (size_t)p * LP_TILE;
+          const double* t_dg = a.AD + (size_t)p * LP_TILE;
+          const double* l_far = p >= 1 ? a.LT + (size_t)((p + 1) * nt + p - 1) * LP_TILE : nullptr;      // L_{p+1,p-1}: a helper's
+          const double* l_prev = s_l1[(p + 1) & 1];                                                        // L_{p,p-1}: the chain's last
+          if (ok) {
+            lp4d c[3];
+            double x[3][8], y[3][8];
 #pragma unroll
-          for (int u = 0; u < 3; ++u) {
-            const int job = wave - 1 + 3 * u;
-            if (job < 8) {
-              const int q = job & 3, qr = q >> 1, qc = q & 1;
-              c[u] = p >= 1 ? lp_quad_load<true>(job < 4 ? t_sub : t_dg, qr, qc, lane)
-                            : lp_quad_load_p(a.TT, nt, a.ks, job < 4 ? nt : nt + 1, qr, qc, lane);      // (tiles (1, 0) and (1, 1) of P)
-              if (p >= 1) {
-                lp_rows<true>(l_far, qr, lane, x[u]);
-                if (job < 4) lp_rows<false>(l_prev, qc, lane, y[u]);
-                else lp_rows<true>(l_far, qc, lane, y[u]);
+            for (int u = 0; u < 3; ++u) {
+              const int job = wave - 1 + 3 * u;
+              if (job < 8) {
+                const int q = job & 3, qr = q >> 1, qc = q & 1;
+                c[u] = p >= 1 ? lp_quad_load<true>(job < 4 ? t_sub : t_dg, qr, qc, lane)
+                              : lp_quad_load_p(a.TT, nt, a.ks, job < 4 ? nt : nt + 1, qr, qc, lane);      // (tiles (1, 0) and (1, 1) of P)
+                if (p >= 1) {
+                  lp_rows<true>(l_far, qr, lane, x[u]);
+                  if (job < 4) lp_rows<false>(l_prev, qc, lane, y[u]);
+                  else lp_rows<true>(l_far, qc, lane, y[u]);
+                }
+              }
+            }
+#pragma unroll
+            for (int u = 0; u < 3; ++u) {
+              const int job = wave - 1 + 3 * u;
+              if (job < 8) {
+                const int q = job & 3, qr = q >> 1, qc = q & 1;
+                if (p >= 1) c[u] = lp_mma_neg(x[u], y[u], c[u]);
+                lp_quad_store<false>(job < 4 ? s_a1 : s_dgp, qr, qc, lane, c[u]);
               }
             }
           }
-#pragma unroll
-          for (int u = 0; u < 3; ++u) {
-            const int job = wave - 1 + 3 * u;
-            if (job < 8) {
-              const int q = job & 3, qr = q >> 1, qc = q & 1;
-              if (p >= 1) c[u] = lp_mma_neg(x[u], y[u], c[u]);
-              lp_quad_store<false>(job < 4 ? s_a1 : s_dgp, qr, qc, lane, c[u]);
-            }
-          }
+          if (!ok && lane == 0) s_ok = 0;
+          if (wave == 1) LP_STAMP(4);
         }
-        if (!ok && lane == 0) s_ok = 0;
-        if (wave == 1) LP_STAMP(4);
       }
       __syncthreads();
-      if (!more || !s_ok) break;
-      // L_{p+1,p} = (tile) W_pp^T
+      if (!more || !s_ok) {
+        if (wave == 0) {                            // the last inverse (or, after a time-out, whatever unblocks a helper)
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          if (lane == 0) __hip_atomic_store(&F1[p], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        break;
+      }
+      // L_{p+1,p} = (tile) W_pp^T.  Wave 0 keeps its quadrant in LDS only (wave 1 sends it to memory below): the one thing it
+      // has in flight is W_pp, which every helper waits for -- out as soon as this product is issued.
       double* l1 = s_l1[p & 1];
+      double* l1g = a.LT + (size_t)((p + 1) * nt + p) * LP_TILE;
       {
         double x[8], y[8];
         lp_rows<false>(s_a1, rb, lane, x);
         lp_rows<false>(s_w, cb, lane, y);
         const lp4d c = lp_mma(x, y, (lp4d){0.0, 0.0, 0.0, 0.0});
         lp_quad_store<false>(l1, rb, cb, lane, c);
-        lp_quad_store<true>(a.LT + (size_t)((p + 1) * nt + p) * LP_TILE, rb, cb, lane, c);
+        if (wave != 0) lp_quad_store<true>(l1g, rb, cb, lane, c);
+        else {
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          if (lane == 0) __hip_atomic_store(&F1[p], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          LP_STAMP(2);
+        }
       }
       __syncthreads();
       // the next diagonal tile: its last update
@@ -402,7 +426,14 @@ __global__ __launch_bounds__(256) void lrp_chol_kernel(LpArgs a) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) s_dg[(row0 + 4 * r) * 33 + col] = c[r];
       }
-      lp_signal(&C[p], 1);                          // (its barrier also hands s_dg to wave 0)
+      if (wave == 1) {                              // quadrant (0, 0) of L_{p+1,p}: four runs of 64 doubles in the k-grouped tile
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          const int o = (lane >> 4) * 128 + (lane & 15) * 4 + t;
+          lp_st(l1g + o, l1[o]);
+        }
+      }
+      __syncthreads();                              // (hands s_dg to wave 0; the tile's count follows at the top of the next step)
       if (wave == 0) LP_STAMP(5);
     }
     if (tid == 0 && s_bad) atomicExch(a.flags + 4 * nt, 2);
