@@ -53,3 +53,84 @@ static __device__ __forceinline__ void chol32_factor(double (&a)[32], double& dm
     }
   }
 }
+
+// ---- the same through a 16 + 16 split ---------------------------------------------------------------------------------------
+// Columns 0 .. 15 as above (updates kept inside the block), then the update of columns 16 .. 31 of ALL 64 rows by the first
+// sixteen in one go on the matrix cores,  A[:, 16:32] -= Y L21^T  (Y = the finished columns 0 .. 15, L21 = its rows 16 .. 31),
+// then columns 16 .. 31.  That replaces 256 of the 496 readlane-pair updates (11 cycles each) by 16 v_mfma_f64_16x16x4 and two
+// trips through LDS (row-per-lane -> operand layout, accumulator layout -> row-per-lane): ~1100 cycles for ~2800.
+// sc: 1088 doubles of LDS private to the wave.
+typedef double c32_4d __attribute__((ext_vector_type(4)));
+typedef double c32_2d __attribute__((ext_vector_type(2)));
+template <int C0, int C1>
+static __device__ __forceinline__ void chol32_block(double (&a)[32], double& r, double& dmin) {
+#pragma unroll
+  for (int c = C0; c < C1; ++c) {
+    a[c] *= r;
+    if (c + 1 < C1) {
+      const double l1 = lp_readlane(a[c], c + 1);
+      a[c + 1] = fma(-a[c], l1, a[c + 1]);
+      __builtin_amdgcn_sched_barrier(0);
+      const double d = lp_readlane(a[c + 1], c + 1);
+      dmin = fmin(dmin, d);
+      r = lp_rsqrt(d);
+#pragma unroll
+      for (int j0 = c + 2; j0 < C1; j0 += 8) {
+        double m[8];
+#pragma unroll
+        for (int b = 0; b < 8; ++b) if (j0 + b < C1) m[b] = lp_readlane(a[c], j0 + b);
+#pragma unroll
+        for (int b = 0; b < 8; ++b) if (j0 + b < C1) a[j0 + b] = fma(-a[c], m[b], a[j0 + b]);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+}
+static __device__ __forceinline__ void chol32_factor_split(double (&a)[32], double& dmin, double* sc) {
+  const int lane = threadIdx.x & 63;
+  double d = lp_readlane(a[0], 0);
+  dmin = d;
+  double r = lp_rsqrt(d);
+  chol32_block<0, 16>(a, r, dmin);
+  // Y, element (row, c) at (c / 4) * 256 + row * 4 + c % 4: the operand slices (row l % 16 of a block of 16 rows, c = 4 t + l / 16)
+  // are 64 consecutive doubles
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    *(c32_2d*)(sc + g * 256 + lane * 4) = (c32_2d){a[4 * g], a[4 * g + 1]};
+    *(c32_2d*)(sc + g * 256 + lane * 4 + 2) = (c32_2d){a[4 * g + 2], a[4 * g + 3]};
+  }
+  __builtin_amdgcn_sched_barrier(0);
+  double y[4][4];
+#pragma unroll
+  for (int b = 0; b < 4; ++b)
+#pragma unroll
+    for (int t = 0; t < 4; ++t) y[b][t] = sc[t * 256 + (16 * b + (lane & 15)) * 4 + (lane >> 4)];
+  __builtin_amdgcn_sched_barrier(0);
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_sched_barrier(0);
+  c32_4d acc[4];
+#pragma unroll
+  for (int b = 0; b < 4; ++b) acc[b] = (c32_4d){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+  for (int t = 0; t < 4; ++t)
+#pragma unroll
+    for (int b = 0; b < 4; ++b) acc[b] = __builtin_amdgcn_mfma_f64_16x16x4f64(y[b][t], y[1][t], acc[b], 0, 0, 0);
+  // accumulator register q of block b: row 16 b + lane / 16 + 4 q, column lane % 16 -> row-major, stride 17
+#pragma unroll
+  for (int b = 0; b < 4; ++b)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) sc[(16 * b + (lane >> 4) + 4 * q) * 17 + (lane & 15)] = acc[b][q];
+  __builtin_amdgcn_sched_barrier(0);
+  double pr[16];
+#pragma unroll
+  for (int c = 0; c < 16; ++c) pr[c] = sc[lane * 17 + c];
+  __builtin_amdgcn_sched_barrier(0);
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int c = 0; c < 16; ++c) a[16 + c] -= pr[c];
+  d = lp_readlane(a[16], 16);
+  dmin = fmin(dmin, d);
+  r = lp_rsqrt(d);
+  chol32_block<16, 32>(a, r, dmin);
+}

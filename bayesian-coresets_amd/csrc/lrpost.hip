@@ -51,6 +51,7 @@ typedef double lp4d __attribute__((ext_vector_type(4)));
 #define LP_MAX_NT 32                 // D <= 1024
 #define LP_MAX_H 60
 #define LP_FIXED_WGS 3               // the chain and its two assistants
+#define LP_SENT 0xFFF7A5A5A5A5A5A5ull  // "not written yet" (see lrp_chol_kernel)
 
 struct LpArgs {
   // inputs of the form kernel
@@ -143,6 +144,10 @@ static __device__ __forceinline__ void lp_quad_store(double* tile, int rb, int c
 // to steps serves as long as both operands use the same one); three runs are in flight.  Workgroups after them, one per
 // block of 32 columns: that block of the right-hand side; the first of them clears the flags.
 typedef double lp2d __attribute__((ext_vector_type(2)));
+static __device__ __forceinline__ void lp_fill_sent(double* tile, int tid) {
+#pragma unroll
+  for (int e = 0; e < 4; ++e) ((unsigned long long*)tile)[tid + 256 * e] = LP_SENT;
+}
 __global__ __launch_bounds__(256) void lrp_form_kernel(LpArgs a) {
   __shared__ double sw[4096 + 32];                  // w_j / sigsq (the second kind of workgroup: w_j y_j / sigsq), zero padded
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -152,6 +157,10 @@ __global__ __launch_bounds__(256) void lrp_form_kernel(LpArgs a) {
   if ((int)blockIdx.x >= ntop * a.ks) {
     const int j = blockIdx.x - ntop * a.ks;
     if (j == 0) for (int e = tid; e < 4 * nt + 1; e += 256) a.flags[e] = 0;
+    lp_fill_sent(a.BL + ((size_t)nt * nt + j) * LP_TILE, tid);
+    lp_fill_sent(a.XW + (size_t)j * LP_TILE, tid);
+    lp_fill_sent(a.AS + (size_t)j * LP_TILE, tid);
+    lp_fill_sent(a.AD + (size_t)j * LP_TILE, tid);
     for (int e = tid; e < kp; e += 256) sw[e] = e < k ? fmax(a.w[e], 0.0) / a.sigsq * a.y[e] : 0.0;
     __syncthreads();
     // rhs0 + X^T (w y) / sigsq: a wave per column, lanes along the points
@@ -175,6 +184,10 @@ __global__ __launch_bounds__(256) void lrp_form_kernel(LpArgs a) {
   int i = 0, t = blockIdx.x - slice * ntop;
   while (t >= i + 1) { t -= i + 1; ++i; }
   const int j = t;                                  // tile (i, j), j <= i
+  if (slice == 0) {                                 // the tiles the next kernel's workgroups hand to each other: "not written yet"
+    if (i > j) lp_fill_sent(a.LT + (size_t)(i * nt + j) * LP_TILE, tid);
+    lp_fill_sent(a.BL + (size_t)(j * nt + i) * LP_TILE, tid);
+  }
   for (int e = tid; e < kp; e += 256) sw[e] = e < k ? fmax(a.w[e], 0.0) / a.sigsq : 0.0;
   const int rb = wave >> 1, cb = wave & 1;
   const int li = lane & 15, lk = lane >> 4;
@@ -227,56 +240,65 @@ __global__ __launch_bounds__(256) void lrp_form_kernel(LpArgs a) {
 
 // ---- the factorisation ---------------------------------------------------------------------------------------------------
 #define LP_STAMP(slot) do { if (a.dbg && (threadIdx.x & 63) == 0) a.dbg[((size_t)blockIdx.x * a.nt + p) * 8 + (slot)] = wall_clock64(); } while (0)
-// one lane: relaxed polls until *p >= target (the payload behind it was stored write-through: no acquire fence)
-static __device__ __forceinline__ bool lp_poll(const int* p, int target, const LpArgs& a) {
-  const long long t0 = wall_clock64();
-  while (__hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
-    __builtin_amdgcn_s_sleep(1);
-    if (wall_clock64() - t0 > a.timeout_ticks) { atomicExch(a.flags + 4 * a.nt, 1); return false; }
-  }
-  return true;
-}
-// one lane: three of them at once (each round trip costs ~0.5 us when taken one after the other)
-static __device__ __forceinline__ bool lp_poll3(const int* c, int target, const int* f1, const int* f2, const LpArgs& a) {
-  const long long t0 = wall_clock64();
-  for (;;) {
-    const int v0 = __hip_atomic_load(c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const int v1 = __hip_atomic_load(f1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const int v2 = __hip_atomic_load(f2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (v0 >= target && v1 >= 1 && v2 >= 1) return true;
-    __builtin_amdgcn_s_sleep(1);
-    if (wall_clock64() - t0 > a.timeout_ticks) { atomicExch(a.flags + 4 * a.nt, 1); return false; }
-  }
-}
-// all threads of the workgroup
-static __device__ __forceinline__ bool lp_wait(const int* p, int target, const LpArgs& a, int* s_ok) {
-  if (threadIdx.x == 0) *s_ok = lp_poll(p, target, a) ? 1 : 0;
-  __syncthreads();
-  const bool ok = *s_ok != 0;
-  __syncthreads();
+
+// A tile that crosses workgroups carries its own "ready": lrp_form_kernel fills every such tile with LP_SENT, a signalling NaN
+// that no arithmetic produces (results are quiet NaNs), the producer overwrites it with 8-byte write-through stores in any
+// order, and a consumer simply loads its operands (sc1) until none of them is the sentinel -- one trip through memory per
+// hand-off instead of three (drain the stores, raise a flag, see the flag, load), and no flag or counter at all.
+static __device__ __forceinline__ int lp_set(double v) { return (unsigned long long)__double_as_longlong(v) != LP_SENT ? 1 : 0; }
+static __device__ __forceinline__ int lp_set8(const double (&v)[8]) {
+  int ok = 1;
+#pragma unroll
+  for (int t = 0; t < 8; ++t) ok &= lp_set(v[t]);
   return ok;
 }
-// all threads: every wave's write-through stores have left, then the counter moves
-static __device__ __forceinline__ void lp_signal(int* p, int add) {
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-  if (threadIdx.x == 0) __hip_atomic_fetch_add(p, add, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+static __device__ __forceinline__ int lp_set4(lp4d c) { return lp_set(c[0]) & lp_set(c[1]) & lp_set(c[2]) & lp_set(c[3]); }
+// A wave's waiting state (wave-uniform).  dead: a wait expired here or anywhere else -- no more waiting, the launch runs out
+// with whatever it reads and the status word tells the host.
+#ifndef LP_SLEEP
+#define LP_SLEEP 1
+#endif
+struct LpSpin { long long t0; int n; bool dead; };
+static __device__ __forceinline__ bool lp_again(LpSpin& sp, const LpArgs& a) {     // after a failed check; false: give up
+  if (sp.t0 < 0) sp.t0 = wall_clock64();
+  __builtin_amdgcn_s_sleep(LP_SLEEP);
+  int* status = a.flags + 4 * a.nt;
+  if (wall_clock64() - sp.t0 > a.timeout_ticks) {
+    if ((threadIdx.x & 63) == 0) atomicCAS(status, 0, 1);
+    sp.dead = true;
+  } else if (((++sp.n) & 255) == 0 && __hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 1) sp.dead = true;
+  return !sp.dead;
 }
-static __device__ __forceinline__ int lp_panel_count(int nt, int p) {     // counts of panel p: helpers' top tiles, the chain's three storing waves, bottom tiles, rhs
-  return (nt - p - 2 > 0 ? nt - p - 2 : 0) + (p + 1 < nt ? 3 : 0) + (p + 1) + 1;
-}
+// The statements after PEEK_OK (re)load the wave's operands and clear the lane's `ok` where a value is missing; until every
+// lane has everything the wave spins LIGHTLY -- on PEEK_OK, one or two values at the end of the newest tile(s), not on all of
+// its operands (three waves re-requesting 60 values each beside the wave that factors the diagonal tile slowed that wave by 10 %).
+#define LP_LAST 1023                                // element (31, 31) of a k-grouped tile: the last one every producer here stores
+#define LP_PEEK(tile) lp_set(lp_ld((tile) + LP_LAST))
+#define LP_WAIT(sp, PEEK_OK, ...)                   \
+  for (;;) {                                        \
+    int ok = 1;                                     \
+    __VA_ARGS__;                                    \
+    if ((sp).dead || __all(ok)) break;              \
+    do { if (!lp_again(sp, a)) break; } while (!(PEEK_OK)); \
+  }
 
 // One wave: Cholesky of the 32 x 32 tile in sdg (row-major, stride 33) and the inverse of its factor (csrc/chol32.h: how, and
 // what it cost to get there).  Writes W = L^-1 = X^T k-grouped into sw (LDS) and gw (global, write-through).  bad: a pivot was
 // not positive.
-static __device__ __forceinline__ void lp_diag(const double* sdg, double* sw, double* gw, int lane, int* bad) {
+static __device__ __forceinline__ void lp_diag(const double* sdg, double* sw, double* gw, double* sc, int lane, int* bad) {
   double a[32];
   const int row = lane & 31;
   const bool top = lane < 32;
 #pragma unroll
-  for (int c = 0; c < 32; ++c) a[c] = top ? (c <= row ? sdg[row * 33 + c] : 0.0) : (c == row ? 1.0 : 0.0);
+  for (int c = 0; c < 32; ++c) a[c] = sdg[row * 33 + c];
+  // (all 32 reads in flight, ONE wait: left to itself the compiler waits between groups of them -- 0.4 us per tile)
+  __builtin_amdgcn_sched_barrier(0);
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int c = 0; c < 32; ++c) a[c] = top ? (c <= row ? a[c] : 0.0) : (c == row ? 1.0 : 0.0);
   double dmin;
-  chol32_factor(a, dmin);
+  chol32_factor_split(a, dmin, sc);
   if (!(dmin > 0.0)) *bad = 1;
   if (!top) {
     // lane 32 + kk holds X[kk][c] = W[c][kk]
@@ -289,24 +311,28 @@ static __device__ __forceinline__ void lp_diag(const double* sdg, double* sw, do
   }
 }
 
-// acc (quadrant rb, cb) -= sum_{q = q0}^{q1 - 1} tileA(q) tileB(q)^T, tiles stepping by strideA / strideB doubles; two terms'
-// operands in flight
+// acc (quadrant rb, cb) -= sum_{q = q0}^{q1 - 1} tileA(q) tileB(q)^T, tiles stepping by strideA / strideB doubles, each waited
+// for as its turn comes; two terms' operands in flight
 static __device__ __forceinline__ lp4d lp_accumulate(lp4d acc, const double* ta, size_t strideA, const double* tb, size_t strideB,
-                                                     int q0, int q1, int rb, int cb, int lane) {
+                                                     int q0, int q1, int rb, int cb, int lane, LpSpin& sp, const LpArgs& a) {
   int q = q0;
   for (; q + 1 < q1; q += 2) {
     double x0[8], y0[8], x1[8], y1[8];
-    lp_rows<true>(ta + (size_t)q * strideA, rb, lane, x0);
-    lp_rows<true>(tb + (size_t)q * strideB, cb, lane, y0);
-    lp_rows<true>(ta + (size_t)(q + 1) * strideA, rb, lane, x1);
-    lp_rows<true>(tb + (size_t)(q + 1) * strideB, cb, lane, y1);
+    LP_WAIT(sp, LP_PEEK(ta + (size_t)(q + 1) * strideA) && LP_PEEK(tb + (size_t)(q + 1) * strideB),
+      lp_rows<true>(ta + (size_t)q * strideA, rb, lane, x0);
+      lp_rows<true>(tb + (size_t)q * strideB, cb, lane, y0);
+      lp_rows<true>(ta + (size_t)(q + 1) * strideA, rb, lane, x1);
+      lp_rows<true>(tb + (size_t)(q + 1) * strideB, cb, lane, y1);
+      ok = lp_set8(x0) & lp_set8(y0) & lp_set8(x1) & lp_set8(y1));
     acc = lp_mma_neg(x0, y0, acc);
     acc = lp_mma_neg(x1, y1, acc);
   }
   if (q < q1) {
     double x0[8], y0[8];
-    lp_rows<true>(ta + (size_t)q * strideA, rb, lane, x0);
-    lp_rows<true>(tb + (size_t)q * strideB, cb, lane, y0);
+    LP_WAIT(sp, LP_PEEK(ta + (size_t)q * strideA) && LP_PEEK(tb + (size_t)q * strideB),
+      lp_rows<true>(ta + (size_t)q * strideA, rb, lane, x0);
+      lp_rows<true>(tb + (size_t)q * strideB, cb, lane, y0);
+      ok = lp_set8(x0) & lp_set8(y0));
     acc = lp_mma_neg(x0, y0, acc);
   }
   return acc;
@@ -316,13 +342,14 @@ __global__ __launch_bounds__(256) void lrp_chol_kernel(LpArgs a) {
   __shared__ double s_dg[32 * 33];                  // the diagonal tile the chain factors next (row-major)
   __shared__ double s_dgp[LP_TILE];                 // ... its value before the last update (k-grouped)
   __shared__ double s_w[LP_TILE];                   // W_pp
+  __shared__ double s_k2[1088];                     // the factoring wave's scratch (csrc/chol32.h)
   __shared__ double s_a1[LP_TILE];                  // chain: sub-diagonal tile before the multiplication by W_pp^T; helpers: the same role
   __shared__ double s_l1[2][LP_TILE];               // the chain's sub-diagonal tiles L_{p+1,p}, this step's and the last's
   __shared__ int s_ok, s_bad;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int nt = a.nt, H = a.H, D = a.D;
   const int rb = wave >> 1, cb = wave & 1;
-  int* F1 = a.flags; int* C = a.flags + nt; int* A1 = a.flags + 2 * nt; int* A2 = a.flags + 3 * nt;
+  LpSpin sp = {-1, 0, false};
   if (tid == 0) { s_ok = 1; s_bad = 0; }
   __syncthreads();
 
@@ -339,82 +366,64 @@ __global__ __launch_bounds__(256) void lrp_chol_kernel(LpArgs a) {
       const bool more = p + 1 < nt;
       if (wave == 0) {
         LP_STAMP(0);
-        lp_diag(s_dg, s_w, a.XW + (size_t)p * LP_TILE, lane, &s_bad);      // (W_pp is on its way to memory; published below)
+        lp_diag(s_dg, s_w, a.XW + (size_t)p * LP_TILE, s_k2, lane, &s_bad);      // (W_pp is on its way to the helpers: nothing to wait for)
         LP_STAMP(1);
-      } else {
-        // last step's sub-diagonal tile has had a step's time to reach memory: publish it (one count per storing wave)
-        if (p >= 1) {
-          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-          if (lane == 0) __hip_atomic_fetch_add(&C[p - 1], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-        if (more) {
-          // meanwhile: what does not depend on this diagonal tile -- tiles (p+1, p) and (p+1, p+1) up to and including the term
-          // of column p - 1.  Eight quadrant jobs over three waves (<= 3 each, their operands requested together); each wave
-          // waits for the assistants and for column p - 1 on its own (the three flags polled together).
-          bool ok = true;
-          if (lane == 0 && p >= 1) ok = lp_poll3(&C[p - 1], lp_panel_count(nt, p - 1), &A1[p], &A2[p], a);
-          ok = __shfl(ok ? 1 : 0, 0, 64) != 0;
-          if (wave == 1) LP_STAMP(3);
-          const double* t_sub = a.AS + (size_t)p * LP_TILE;
-          const double* t_dg = a.AD + (size_t)p * LP_TILE;
-          const double* l_far = p >= 1 ? a.LT + (size_t)((p + 1) * nt + p - 1) * LP_TILE : nullptr;      // L_{p+1,p-1}: a helper's
-          const double* l_prev = s_l1[(p + 1) & 1];                                                        // L_{p,p-1}: the chain's last
-          if (ok) {
-            lp4d c[3];
-            double x[3][8], y[3][8];
+      } else if (more) {
+        // meanwhile: what does not depend on this diagonal tile -- tiles (p+1, p) and (p+1, p+1) up to and including the term
+        // of column p - 1.  Eight quadrant jobs over three waves (<= 3 each, their operands requested together).
+        const double* t_sub = a.AS + (size_t)p * LP_TILE;
+        const double* t_dg = a.AD + (size_t)p * LP_TILE;
+        const double* l_far = p >= 1 ? a.LT + (size_t)((p + 1) * nt + p - 1) * LP_TILE : nullptr;      // L_{p+1,p-1}: a helper's
+        const double* l_prev = s_l1[(p + 1) & 1];                                                        // L_{p,p-1}: the chain's last
+        lp4d c[3];
+        double x[3][8], y[3][8];
+        if (p == 0) {
 #pragma unroll
-            for (int u = 0; u < 3; ++u) {
-              const int job = wave - 1 + 3 * u;
-              if (job < 8) {
-                const int q = job & 3, qr = q >> 1, qc = q & 1;
-                c[u] = p >= 1 ? lp_quad_load<true>(job < 4 ? t_sub : t_dg, qr, qc, lane)
-                              : lp_quad_load_p(a.TT, nt, a.ks, job < 4 ? nt : nt + 1, qr, qc, lane);      // (tiles (1, 0) and (1, 1) of P)
-                if (p >= 1) {
-                  lp_rows<true>(l_far, qr, lane, x[u]);
-                  if (job < 4) lp_rows<false>(l_prev, qc, lane, y[u]);
-                  else lp_rows<true>(l_far, qc, lane, y[u]);
-                }
-              }
-            }
-#pragma unroll
-            for (int u = 0; u < 3; ++u) {
-              const int job = wave - 1 + 3 * u;
-              if (job < 8) {
-                const int q = job & 3, qr = q >> 1, qc = q & 1;
-                if (p >= 1) c[u] = lp_mma_neg(x[u], y[u], c[u]);
-                lp_quad_store<false>(job < 4 ? s_a1 : s_dgp, qr, qc, lane, c[u]);
-              }
-            }
+          for (int u = 0; u < 3; ++u) {
+            const int job = wave - 1 + 3 * u;
+            if (job < 8) c[u] = lp_quad_load_p(a.TT, nt, a.ks, job < 4 ? nt : nt + 1, (job & 3) >> 1, job & 1, lane);      // (tiles (1, 0) and (1, 1) of P)
           }
-          if (!ok && lane == 0) s_ok = 0;
-          if (wave == 1) LP_STAMP(4);
+        } else {
+          LP_WAIT(sp, LP_PEEK(l_far) && LP_PEEK(t_sub) && LP_PEEK(t_dg),
+            _Pragma("unroll")
+            for (int u = 0; u < 3; ++u) {
+              const int job = wave - 1 + 3 * u;
+              if (job < 8) {
+                const int q = job & 3, qr = q >> 1, qc = q & 1;
+                c[u] = lp_quad_load<true>(job < 4 ? t_sub : t_dg, qr, qc, lane);
+                lp_rows<true>(l_far, qr, lane, x[u]);
+                ok &= lp_set4(c[u]) & lp_set8(x[u]);
+                if (job < 4) lp_rows<false>(l_prev, qc, lane, y[u]);
+                else { lp_rows<true>(l_far, qc, lane, y[u]); ok &= lp_set8(y[u]); }
+              }
+            });
         }
+        if (wave == 1) LP_STAMP(3);
+#pragma unroll
+        for (int u = 0; u < 3; ++u) {
+          const int job = wave - 1 + 3 * u;
+          if (job < 8) {
+            const int q = job & 3, qr = q >> 1, qc = q & 1;
+            if (p >= 1) c[u] = lp_mma_neg(x[u], y[u], c[u]);
+            lp_quad_store<false>(job < 4 ? s_a1 : s_dgp, qr, qc, lane, c[u]);
+          }
+        }
+        if (sp.dead && lane == 0) s_ok = 0;
+        if (wave == 1) LP_STAMP(4);
       }
       __syncthreads();
-      if (!more || !s_ok) {
-        if (wave == 0) {                            // the last inverse (or, after a time-out, whatever unblocks a helper)
-          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-          if (lane == 0) __hip_atomic_store(&F1[p], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-        break;
-      }
-      // L_{p+1,p} = (tile) W_pp^T.  Wave 0 keeps its quadrant in LDS only (wave 1 sends it to memory below): the one thing it
-      // has in flight is W_pp, which every helper waits for -- out as soon as this product is issued.
+      if (!more || !s_ok) break;
+      // L_{p+1,p} = (tile) W_pp^T
       double* l1 = s_l1[p & 1];
-      double* l1g = a.LT + (size_t)((p + 1) * nt + p) * LP_TILE;
       {
         double x[8], y[8];
         lp_rows<false>(s_a1, rb, lane, x);
         lp_rows<false>(s_w, cb, lane, y);
         const lp4d c = lp_mma(x, y, (lp4d){0.0, 0.0, 0.0, 0.0});
         lp_quad_store<false>(l1, rb, cb, lane, c);
-        if (wave != 0) lp_quad_store<true>(l1g, rb, cb, lane, c);
-        else {
-          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-          if (lane == 0) __hip_atomic_store(&F1[p], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          LP_STAMP(2);
-        }
+        lp_quad_store<true>(a.LT + (size_t)((p + 1) * nt + p) * LP_TILE, rb, cb, lane, c);
       }
+      if (wave == 0) LP_STAMP(2);
       __syncthreads();
       // the next diagonal tile: its last update
       {
@@ -426,14 +435,7 @@ __global__ __launch_bounds__(256) void lrp_chol_kernel(LpArgs a) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) s_dg[(row0 + 4 * r) * 33 + col] = c[r];
       }
-      if (wave == 1) {                              // quadrant (0, 0) of L_{p+1,p}: four runs of 64 doubles in the k-grouped tile
-#pragma unroll
-        for (int t = 0; t < 4; ++t) {
-          const int o = (lane >> 4) * 128 + (lane & 15) * 4 + t;
-          lp_st(l1g + o, l1[o]);
-        }
-      }
-      __syncthreads();                              // (hands s_dg to wave 0; the tile's count follows at the top of the next step)
+      __syncthreads();                              // (hands s_dg to wave 0)
       if (wave == 0) LP_STAMP(5);
     }
     if (tid == 0 && s_bad) atomicExch(a.flags + 4 * nt, 2);
@@ -444,14 +446,12 @@ __global__ __launch_bounds__(256) void lrp_chol_kernel(LpArgs a) {
     // ================= an assistant: the chain's tile of step p, all terms of the columns q <= p - 2 =================
     const bool sub = blockIdx.x == 1;               // 1: tile (p+1, p); 2: tile (p+1, p+1)
     for (int p = 1; p + 1 < nt; ++p) {
-      if (p >= 2 && !lp_wait(&C[p - 2], lp_panel_count(nt, p - 2), a, &s_ok)) return;
       if (wave == 0) LP_STAMP(0);
       lp4d c = lp_quad_load_p(a.TT, nt, a.ks, (p + 1) * nt + (sub ? p : p + 1), rb, cb, lane);
       const double* ta = a.LT + (size_t)((p + 1) * nt) * LP_TILE;                     // row p + 1 of L
       const double* tb = a.LT + (size_t)((sub ? p : p + 1) * nt) * LP_TILE;           // row p (or p + 1 again)
-      c = lp_accumulate(c, ta, LP_TILE, tb, LP_TILE, 0, p - 1, rb, cb, lane);
+      c = lp_accumulate(c, ta, LP_TILE, tb, LP_TILE, 0, p - 1, rb, cb, lane, sp, a);
       lp_quad_store<true>((sub ? a.AS : a.AD) + (size_t)p * LP_TILE, rb, cb, lane, c);
-      lp_signal(sub ? &A1[p] : &A2[p], 1);
       if (wave == 0) LP_STAMP(1);
     }
     return;
@@ -464,10 +464,8 @@ __global__ __launch_bounds__(256) void lrp_chol_kernel(LpArgs a) {
     // job n goes to helper (n + 3 p) mod H
     const int ntopj = nt - p - 2 > 0 ? nt - p - 2 : 0;
     const int njobs = ntopj + p + 2;
-    bool waited_c = p == 0, waited_f = false;
     int done = 0;
     for (int n = (h + H - (3 * p) % H) % H; n < njobs; n += H) {
-      if (!waited_c) { if (!lp_wait(&C[p - 1], lp_panel_count(nt, p - 1), a, &s_ok)) return; waited_c = true; }
       if (wave == 0 && done == 0) LP_STAMP(0);
       const bool is_top = n < ntopj;
       const int R = is_top ? p + 2 + n : n - ntopj;                     // top row i, or bottom row r (r == p + 1 here means: the rhs row)
@@ -490,14 +488,14 @@ __global__ __launch_bounds__(256) void lrp_chol_kernel(LpArgs a) {
         ta = a.BL + (size_t)(rrow * nt) * LP_TILE;
         q0 = is_rhs ? 0 : R;                        // (row r of L^-T starts at column r)
       }
-      c = lp_accumulate(c, ta, LP_TILE, a.LT + (size_t)(p * nt) * LP_TILE, LP_TILE, q0, p, rb, cb, lane);
+      c = lp_accumulate(c, ta, LP_TILE, a.LT + (size_t)(p * nt) * LP_TILE, LP_TILE, q0, p, rb, cb, lane, sp, a);
       __syncthreads();                              // (the previous job's reads of s_a1)
       lp_quad_store<false>(s_a1, rb, cb, lane, c);
-      if (!waited_f) { if (!lp_wait(&F1[p], 1, a, &s_ok)) return; waited_f = true; } else __syncthreads();
-      if (wave == 0 && done == 0) LP_STAMP(1);
+      __syncthreads();
       double x[8], wq[8];
-      lp_rows<true>(a.XW + (size_t)p * LP_TILE, cb, lane, wq);
       lp_rows<false>(s_a1, rb, lane, x);
+      LP_WAIT(sp, LP_PEEK(a.XW + (size_t)p * LP_TILE), lp_rows<true>(a.XW + (size_t)p * LP_TILE, cb, lane, wq); ok = lp_set8(wq));
+      if (wave == 0 && done == 0) LP_STAMP(1);
       c = lp_mma(x, wq, (lp4d){0.0, 0.0, 0.0, 0.0});
       if (is_top) lp_quad_store<true>(a.LT + (size_t)(R * nt + p) * LP_TILE, rb, cb, lane, c);
       else {
@@ -516,7 +514,7 @@ __global__ __launch_bounds__(256) void lrp_chol_kernel(LpArgs a) {
       }
       ++done;
     }
-    if (done) { lp_signal(&C[p], done); if (wave == 0) LP_STAMP(2); }
+    if (done && wave == 0) LP_STAMP(2);
   }
 }
 
