@@ -90,12 +90,15 @@ static __device__ __forceinline__ void lp_st(double* p, double v) {
 }
 // operand slice of a k-grouped tile: rows 16 half .. 16 half + 15, all 32 values of the contraction index.  COH: the tile is
 // (or may have been) written by another workgroup of this launch.
-template <bool COH>
+template <bool COH, int GS = 128>
 static __device__ __forceinline__ void lp_rows(const double* tile, int half, int lane, double (&v)[8]) {
   const int o = (half * 16 + (lane & 15)) * 4 + (lane >> 4);
 #pragma unroll
-  for (int t = 0; t < 8; ++t) v[t] = COH ? lp_ld(tile + t * 128 + o) : tile[t * 128 + o];
+  for (int t = 0; t < 8; ++t) v[t] = COH ? lp_ld(tile + t * GS + o) : tile[t * GS + o];
 }
+// W_pp in LDS: groups of four columns 132 doubles apart, not 128 -- the factoring wave writes a COLUMN per lane, eight groups
+// at once, which at 128 land in the same banks (8-way conflict on each of its 32 writes: 0.4 us per tile)
+#define LP_WGS 132
 static __device__ __forceinline__ lp4d lp_mma(const double (&a)[8], const double (&b)[8], lp4d acc) {
 #pragma unroll
   for (int t = 0; t < 8; ++t) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[t], b[t], acc, 0, 0, 0);
@@ -124,12 +127,18 @@ static __device__ __forceinline__ lp4d lp_quad_load_p(const double* TT, int nt, 
   }
   return c;
 }
-template <bool COH>
+// a store another workgroup of the launch will read.  ONE: every workgroup of the launch sits on the same XCD -- one L2, which
+// an ordinary store reaches by itself (the L1 is write-through) and the readers' sc1 loads read; otherwise write-through (sc1)
+template <bool ONE>
+static __device__ __forceinline__ void lp_gst(double* p, double v) {
+  if (ONE) *p = v; else lp_st(p, v);
+}
+template <bool COH, bool ONE = false>
 static __device__ __forceinline__ void lp_quad_store(double* tile, int rb, int cb, int lane, lp4d c) {
   const int col = cb * 16 + (lane & 15), row0 = rb * 16 + (lane >> 4);
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
-    if (COH) lp_st(tile + lp_kg(row0 + 4 * r, col), c[r]);
+    if (COH) lp_gst<ONE>(tile + lp_kg(row0 + 4 * r, col), c[r]);
     else tile[lp_kg(row0 + 4 * r, col)] = c[r];
   }
 }
@@ -239,7 +248,7 @@ __global__ __launch_bounds__(256) void lrp_form_kernel(LpArgs a) {
 }
 
 // ---- the factorisation ---------------------------------------------------------------------------------------------------
-#define LP_STAMP(slot) do { if (a.dbg && (threadIdx.x & 63) == 0) a.dbg[((size_t)blockIdx.x * a.nt + p) * 8 + (slot)] = wall_clock64(); } while (0)
+#define LP_STAMP(slot) do { if (a.dbg && (threadIdx.x & 63) == 0) a.dbg[((size_t)bid * a.nt + p) * 8 + (slot)] = wall_clock64(); } while (0)
 
 // A tile that crosses workgroups carries its own "ready": lrp_form_kernel fills every such tile with LP_SENT, a signalling NaN
 // that no arithmetic produces (results are quiet NaNs), the producer overwrites it with 8-byte write-through stores in any
@@ -285,6 +294,7 @@ static __device__ __forceinline__ bool lp_again(LpSpin& sp, const LpArgs& a) {  
 // One wave: Cholesky of the 32 x 32 tile in sdg (row-major, stride 33) and the inverse of its factor (csrc/chol32.h: how, and
 // what it cost to get there).  Writes W = L^-1 = X^T k-grouped into sw (LDS) and gw (global, write-through).  bad: a pivot was
 // not positive.
+template <bool ONE>
 static __device__ __forceinline__ void lp_diag(const double* sdg, double* sw, double* gw, double* sc, int lane, int* bad) {
   double a[32];
   const int row = lane & 31;
@@ -305,8 +315,8 @@ static __device__ __forceinline__ void lp_diag(const double* sdg, double* sw, do
 #pragma unroll
     for (int c = 0; c < 32; ++c) {
       const int o = lp_kg(c, row);
-      sw[o] = a[c];
-      lp_st(gw + o, a[c]);
+      sw[(row >> 2) * LP_WGS + c * 4 + (row & 3)] = a[c];
+      lp_gst<ONE>(gw + o, a[c]);
     }
   }
 }
@@ -338,10 +348,11 @@ static __device__ __forceinline__ lp4d lp_accumulate(lp4d acc, const double* ta,
   return acc;
 }
 
+template <bool ONE>
 __global__ __launch_bounds__(256) void lrp_chol_kernel(LpArgs a) {
   __shared__ double s_dg[32 * 33];                  // the diagonal tile the chain factors next (row-major)
   __shared__ double s_dgp[LP_TILE];                 // ... its value before the last update (k-grouped)
-  __shared__ double s_w[LP_TILE];                   // W_pp
+  __shared__ double s_w[8 * LP_WGS];                // W_pp
   __shared__ double s_k2[1088];                     // the factoring wave's scratch (csrc/chol32.h)
   __shared__ double s_a1[LP_TILE];                  // chain: sub-diagonal tile before the multiplication by W_pp^T; helpers: the same role
   __shared__ double s_l1[2][LP_TILE];               // the chain's sub-diagonal tiles L_{p+1,p}, this step's and the last's
@@ -349,11 +360,15 @@ __global__ __launch_bounds__(256) void lrp_chol_kernel(LpArgs a) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int nt = a.nt, H = a.H, D = a.D;
   const int rb = wave >> 1, cb = wave & 1;
+  // ONE: the launch has 8 workgroups per participant and only those that land on XCD 0 take part (workgroup i of a launch goes
+  // to XCD i % 8: checked once per device by lrp_one_xcd)
+  if (ONE && (blockIdx.x & 7)) return;
+  const int bid = ONE ? blockIdx.x >> 3 : blockIdx.x;
   LpSpin sp = {-1, 0, false};
   if (tid == 0) { s_ok = 1; s_bad = 0; }
   __syncthreads();
 
-  if (blockIdx.x == 0) {
+  if (bid == 0) {
     // ================= the chain =================
     {
       const lp4d c = lp_quad_load_p(a.TT, nt, a.ks, 0, rb, cb, lane);   // tile (0, 0), written by the kernel before
@@ -362,70 +377,20 @@ __global__ __launch_bounds__(256) void lrp_chol_kernel(LpArgs a) {
       for (int r = 0; r < 4; ++r) s_dg[(row0 + 4 * r) * 33 + col] = c[r];
     }
     __syncthreads();
-    for (int p = 0; p < nt; ++p) {
-      const bool more = p + 1 < nt;
-      if (wave == 0) {
-        LP_STAMP(0);
-        lp_diag(s_dg, s_w, a.XW + (size_t)p * LP_TILE, s_k2, lane, &s_bad);      // (W_pp is on its way to the helpers: nothing to wait for)
-        LP_STAMP(1);
-      } else if (more) {
-        // meanwhile: what does not depend on this diagonal tile -- tiles (p+1, p) and (p+1, p+1) up to and including the term
-        // of column p - 1.  Eight quadrant jobs over three waves (<= 3 each, their operands requested together).
-        const double* t_sub = a.AS + (size_t)p * LP_TILE;
-        const double* t_dg = a.AD + (size_t)p * LP_TILE;
-        const double* l_far = p >= 1 ? a.LT + (size_t)((p + 1) * nt + p - 1) * LP_TILE : nullptr;      // L_{p+1,p-1}: a helper's
-        const double* l_prev = s_l1[(p + 1) & 1];                                                        // L_{p,p-1}: the chain's last
-        lp4d c[3];
-        double x[3][8], y[3][8];
-        if (p == 0) {
-#pragma unroll
-          for (int u = 0; u < 3; ++u) {
-            const int job = wave - 1 + 3 * u;
-            if (job < 8) c[u] = lp_quad_load_p(a.TT, nt, a.ks, job < 4 ? nt : nt + 1, (job & 3) >> 1, job & 1, lane);      // (tiles (1, 0) and (1, 1) of P)
-          }
-        } else {
-          LP_WAIT(sp, LP_PEEK(l_far) && LP_PEEK(t_sub) && LP_PEEK(t_dg),
-            _Pragma("unroll")
-            for (int u = 0; u < 3; ++u) {
-              const int job = wave - 1 + 3 * u;
-              if (job < 8) {
-                const int q = job & 3, qr = q >> 1, qc = q & 1;
-                c[u] = lp_quad_load<true>(job < 4 ? t_sub : t_dg, qr, qc, lane);
-                lp_rows<true>(l_far, qr, lane, x[u]);
-                ok &= lp_set4(c[u]) & lp_set8(x[u]);
-                if (job < 4) lp_rows<false>(l_prev, qc, lane, y[u]);
-                else { lp_rows<true>(l_far, qc, lane, y[u]); ok &= lp_set8(y[u]); }
-              }
-            });
-        }
-        if (wave == 1) LP_STAMP(3);
-#pragma unroll
-        for (int u = 0; u < 3; ++u) {
-          const int job = wave - 1 + 3 * u;
-          if (job < 8) {
-            const int q = job & 3, qr = q >> 1, qc = q & 1;
-            if (p >= 1) c[u] = lp_mma_neg(x[u], y[u], c[u]);
-            lp_quad_store<false>(job < 4 ? s_a1 : s_dgp, qr, qc, lane, c[u]);
-          }
-        }
-        if (sp.dead && lane == 0) s_ok = 0;
-        if (wave == 1) LP_STAMP(4);
-      }
-      __syncthreads();
-      if (!more || !s_ok) break;
-      // L_{p+1,p} = (tile) W_pp^T
+    // after the diagonal tile and the side work of step p (barrier): L_{p+1,p} = (tile) W_pp^T, barrier, the next diagonal
+    // tile's last update, barrier (hands s_dg to wave 0)
+    auto finish_step = [&](int p) {
       double* l1 = s_l1[p & 1];
       {
         double x[8], y[8];
         lp_rows<false>(s_a1, rb, lane, x);
-        lp_rows<false>(s_w, cb, lane, y);
+        lp_rows<false, LP_WGS>(s_w, cb, lane, y);
         const lp4d c = lp_mma(x, y, (lp4d){0.0, 0.0, 0.0, 0.0});
         lp_quad_store<false>(l1, rb, cb, lane, c);
-        lp_quad_store<true>(a.LT + (size_t)((p + 1) * nt + p) * LP_TILE, rb, cb, lane, c);
+        lp_quad_store<true, ONE>(a.LT + (size_t)((p + 1) * nt + p) * LP_TILE, rb, cb, lane, c);
       }
       if (wave == 0) LP_STAMP(2);
       __syncthreads();
-      // the next diagonal tile: its last update
       {
         double x[8], y[8];
         lp_rows<false>(l1, rb, lane, x);
@@ -435,30 +400,94 @@ __global__ __launch_bounds__(256) void lrp_chol_kernel(LpArgs a) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) s_dg[(row0 + 4 * r) * 33 + col] = c[r];
       }
-      __syncthreads();                              // (hands s_dg to wave 0)
-      if (wave == 0) LP_STAMP(5);
+      __syncthreads();
+    };
+    // Two loops with the same barriers, one per role, so that the factoring wave's carries nothing of the other role's state
+    // (in one loop the register allocator parked ~100 values of the side work in AGPRs around the factorisation and copied
+    // them back at the join, on the critical path of every step)
+    if (wave == 0) {
+      for (int p = 0; p < nt; ++p) {
+        LP_STAMP(0);
+        lp_diag<ONE>(s_dg, s_w, a.XW + (size_t)p * LP_TILE, s_k2, lane, &s_bad);      // (W_pp is on its way to the helpers: nothing to wait for)
+        LP_STAMP(1);
+        __syncthreads();
+        if (p + 1 >= nt || !s_ok) break;
+        finish_step(p);
+        LP_STAMP(5);
+      }
+    } else {
+      for (int p = 0; p < nt; ++p) {
+        const bool more = p + 1 < nt;
+        if (more) {
+          // while wave 0 factors: what does not depend on this diagonal tile -- tiles (p+1, p) and (p+1, p+1) up to and
+          // including the term of column p - 1.  Eight quadrant jobs over three waves (<= 3 each, their operands requested together).
+          const double* t_sub = a.AS + (size_t)p * LP_TILE;
+          const double* t_dg = a.AD + (size_t)p * LP_TILE;
+          const double* l_far = p >= 1 ? a.LT + (size_t)((p + 1) * nt + p - 1) * LP_TILE : nullptr;      // L_{p+1,p-1}: a helper's
+          const double* l_prev = s_l1[(p + 1) & 1];                                                        // L_{p,p-1}: the chain's last
+          lp4d c[3];
+          double x[3][8], y[3][8];
+          if (p == 0) {
+#pragma unroll
+            for (int u = 0; u < 3; ++u) {
+              const int job = wave - 1 + 3 * u;
+              if (job < 8) c[u] = lp_quad_load_p(a.TT, nt, a.ks, job < 4 ? nt : nt + 1, (job & 3) >> 1, job & 1, lane);      // (tiles (1, 0) and (1, 1) of P)
+            }
+          } else {
+            LP_WAIT(sp, LP_PEEK(l_far) && LP_PEEK(t_sub) && LP_PEEK(t_dg),
+              _Pragma("unroll")
+              for (int u = 0; u < 3; ++u) {
+                const int job = wave - 1 + 3 * u;
+                if (job < 8) {
+                  const int q = job & 3, qr = q >> 1, qc = q & 1;
+                  c[u] = lp_quad_load<true>(job < 4 ? t_sub : t_dg, qr, qc, lane);
+                  lp_rows<true>(l_far, qr, lane, x[u]);
+                  ok &= lp_set4(c[u]) & lp_set8(x[u]);
+                  if (job < 4) lp_rows<false>(l_prev, qc, lane, y[u]);
+                  else { lp_rows<true>(l_far, qc, lane, y[u]); ok &= lp_set8(y[u]); }
+                }
+              });
+          }
+          if (wave == 1) LP_STAMP(3);
+#pragma unroll
+          for (int u = 0; u < 3; ++u) {
+            const int job = wave - 1 + 3 * u;
+            if (job < 8) {
+              const int q = job & 3, qr = q >> 1, qc = q & 1;
+              if (p >= 1) c[u] = lp_mma_neg(x[u], y[u], c[u]);
+              lp_quad_store<false>(job < 4 ? s_a1 : s_dgp, qr, qc, lane, c[u]);
+            }
+          }
+          if (sp.dead && lane == 0) s_ok = 0;
+          if (wave == 1) LP_STAMP(4);
+        }
+        __syncthreads();
+        if (!more || !s_ok) break;
+        finish_step(p);
+      }
     }
+    __syncthreads();
     if (tid == 0 && s_bad) atomicExch(a.flags + 4 * nt, 2);
     return;
   }
 
-  if (blockIdx.x < LP_FIXED_WGS) {
+  if (bid < LP_FIXED_WGS) {
     // ================= an assistant: the chain's tile of step p, all terms of the columns q <= p - 2 =================
-    const bool sub = blockIdx.x == 1;               // 1: tile (p+1, p); 2: tile (p+1, p+1)
+    const bool sub = bid == 1;                      // 1: tile (p+1, p); 2: tile (p+1, p+1)
     for (int p = 1; p + 1 < nt; ++p) {
       if (wave == 0) LP_STAMP(0);
       lp4d c = lp_quad_load_p(a.TT, nt, a.ks, (p + 1) * nt + (sub ? p : p + 1), rb, cb, lane);
       const double* ta = a.LT + (size_t)((p + 1) * nt) * LP_TILE;                     // row p + 1 of L
       const double* tb = a.LT + (size_t)((sub ? p : p + 1) * nt) * LP_TILE;           // row p (or p + 1 again)
       c = lp_accumulate(c, ta, LP_TILE, tb, LP_TILE, 0, p - 1, rb, cb, lane, sp, a);
-      lp_quad_store<true>((sub ? a.AS : a.AD) + (size_t)p * LP_TILE, rb, cb, lane, c);
+      lp_quad_store<true, ONE>((sub ? a.AS : a.AD) + (size_t)p * LP_TILE, rb, cb, lane, c);
       if (wave == 0) LP_STAMP(1);
     }
     return;
   }
 
   // ================= a helper =================
-  const int h = blockIdx.x - LP_FIXED_WGS;
+  const int h = bid - LP_FIXED_WGS;
   for (int p = 0; p < nt; ++p) {
     // the jobs of block column p, in a fixed order: top rows p + 2 .. nt - 1, bottom rows 0 .. p, the right-hand side row;
     // job n goes to helper (n + 3 p) mod H
@@ -497,9 +526,9 @@ __global__ __launch_bounds__(256) void lrp_chol_kernel(LpArgs a) {
       LP_WAIT(sp, LP_PEEK(a.XW + (size_t)p * LP_TILE), lp_rows<true>(a.XW + (size_t)p * LP_TILE, cb, lane, wq); ok = lp_set8(wq));
       if (wave == 0 && done == 0) LP_STAMP(1);
       c = lp_mma(x, wq, (lp4d){0.0, 0.0, 0.0, 0.0});
-      if (is_top) lp_quad_store<true>(a.LT + (size_t)(R * nt + p) * LP_TILE, rb, cb, lane, c);
+      if (is_top) lp_quad_store<true, ONE>(a.LT + (size_t)(R * nt + p) * LP_TILE, rb, cb, lane, c);
       else {
-        lp_quad_store<true>(a.BL + (size_t)(rrow * nt + p) * LP_TILE, rb, cb, lane, c);
+        lp_quad_store<true, ONE>(a.BL + (size_t)(rrow * nt + p) * LP_TILE, rb, cb, lane, c);
         if (is_rhs) {
           if (rb == 0 && (lane >> 4) == 0) { const int oc = p * 32 + cb * 16 + (lane & 15); if (oc < D) a.uvec[oc] = c[0]; }      // row 0: u
         } else {
@@ -508,7 +537,7 @@ __global__ __launch_bounds__(256) void lrp_chol_kernel(LpArgs a) {
 #pragma unroll
           for (int q = 0; q < 4; ++q) {
             const int orow = R * 32 + rb * 16 + (lane >> 4) + 4 * q;
-            if (orow < D && ocol < D) lp_st(a.U + (size_t)orow * a.ldu + ocol, c[q]);
+            if (orow < D && ocol < D) a.U[(size_t)orow * a.ldu + ocol] = c[q];
           }
         }
       }
@@ -651,6 +680,34 @@ static int lrp_helpers(int nt) {
   if (h > LP_MAX_H) h = LP_MAX_H;
   return h;
 }
+// Does workgroup i of a launch run on XCD i % 8 on this device?  (Then lrp_chol_kernel keeps all of its workgroups on one XCD
+// and hands tiles over with ordinary stores.)  Checked once per device with a launch that records every workgroup's XCC_ID.
+__global__ void lrp_xcc_probe_kernel(int* out) {
+  if (threadIdx.x == 0) { int id; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(id)); out[blockIdx.x] = id & 0xf; }
+}
+static bool lrp_one_xcd(hipStream_t st) {
+  static std::atomic<int> known[64];                // 0 unknown, 1 yes, 2 no
+  static const bool off = [] { const char* e = bcx_dev_env("BCX_LRP_ONE_XCD"); return e && atoi(e) == 0; }();      // dev
+  if (off) return false;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return false;
+  int k = known[dev].load();
+  if (k == 0) {
+    const int n = 8 * 40;
+    int* d = nullptr;
+    int h[8 * 40];
+    bool ok = hipMalloc(&d, n * sizeof(int)) == hipSuccess;
+    if (ok) {
+      hipLaunchKernelGGL(lrp_xcc_probe_kernel, dim3(n), dim3(64), 0, st, d);
+      ok = hipMemcpyAsync(h, d, n * sizeof(int), hipMemcpyDeviceToHost, st) == hipSuccess && hipStreamSynchronize(st) == hipSuccess;
+      for (int i = 0; ok && i < n; ++i) ok = (i % 8 == 0) == (h[i] == h[0]);
+      (void)hipFree(d);
+    }
+    k = ok ? 1 : 2;
+    known[dev].store(k);
+  }
+  return k == 1;
+}
 #define LP_MAX_KS 4
 static int lrp_slices(int k) {                      // workgroups per tile of P: about three runs of 32 points each
   static const int forced = [] { const char* e = bcx_dev_env("BCX_LRP_KS"); return e ? atoi(e) : 0; }();      // dev
@@ -699,7 +756,9 @@ extern "C" int bcx_linreg_posterior_factor(void* stream, int32_t k, int32_t D, i
   a.nt = nt; a.H = lrp_helpers(nt); a.ks = lrp_slices(k);
   a.timeout_ticks = 200000000LL;                    // 2 s of the 100 MHz wall clock
   hipLaunchKernelGGL(lrp_form_kernel, dim3(a.ks * nt * (nt + 1) / 2 + nt), dim3(256), 0, (hipStream_t)stream, a);
-  hipLaunchKernelGGL(lrp_chol_kernel, dim3(LP_FIXED_WGS + a.H), dim3(256), 0, (hipStream_t)stream, a);
+  // (one XCD has 32 CUs and the kernel's registers allow one workgroup per CU: beyond 28 participants the launch spreads out)
+  if (LP_FIXED_WGS + a.H <= 28 && lrp_one_xcd((hipStream_t)stream)) hipLaunchKernelGGL(lrp_chol_kernel<true>, dim3(8 * (LP_FIXED_WGS + a.H)), dim3(256), 0, (hipStream_t)stream, a);
+  else hipLaunchKernelGGL(lrp_chol_kernel<false>, dim3(LP_FIXED_WGS + a.H), dim3(256), 0, (hipStream_t)stream, a);
   if (a.mu) hipLaunchKernelGGL(lrp_mean_kernel, dim3(nt), dim3(256), 0, (hipStream_t)stream, a);
   LRP_HIP(hipGetLastError());
   return BCX_OK;
