@@ -57,7 +57,7 @@ static __device__ __forceinline__ void chol32_factor(double (&a)[32], double& dm
 // ---- the same through a 16 + 16 split ---------------------------------------------------------------------------------------
 // Columns 0 .. 15 as above (updates kept inside the block), then the update of columns 16 .. 31 of ALL 64 rows by the first
 // sixteen in one go on the matrix cores,  A[:, 16:32] -= Y L21^T  (Y = the finished columns 0 .. 15, L21 = its rows 16 .. 31),
-// then columns 16 .. 31.  That replaces 256 of the 496 readlane-pair updates (11 cycles each) by 16 v_mfma_f64_16x16x4 and two
+// then columns 16 .. 31.  That replaces 256 of the 496 readlane-pair updates (11 cycles each) by 8 v_mfma_f64_16x16x4 and two
 // trips through LDS (row-per-lane -> operand layout, accumulator layout -> row-per-lane): ~1100 cycles for ~2800.
 // sc: 1088 doubles of LDS private to the wave.
 typedef double c32_4d __attribute__((ext_vector_type(4)));
@@ -100,26 +100,29 @@ static __device__ __forceinline__ void chol32_factor_split(double (&a)[32], doub
     *(c32_2d*)(sc + g * 256 + lane * 4 + 2) = (c32_2d){a[4 * g + 2], a[4 * g + 3]};
   }
   __builtin_amdgcn_sched_barrier(0);
-  double y[4][4];
+  // Only two of the four blocks of 16 rows need the update: rows 16 .. 31 of the tile (lanes 16 .. 31) and rows 0 .. 15 of
+  // X = L^-T (lanes 32 .. 47).  Lanes 0 .. 15 hold finished rows of L (their entries right of the diagonal are not read by
+  // anyone), lanes 48 .. 63 rows of X that are still zero in columns 0 .. 15.
+  double y[2][4];
 #pragma unroll
-  for (int b = 0; b < 4; ++b)
+  for (int b = 0; b < 2; ++b)
 #pragma unroll
-    for (int t = 0; t < 4; ++t) y[b][t] = sc[t * 256 + (16 * b + (lane & 15)) * 4 + (lane >> 4)];
+    for (int t = 0; t < 4; ++t) y[b][t] = sc[t * 256 + (16 * (b + 1) + (lane & 15)) * 4 + (lane >> 4)];
   __builtin_amdgcn_sched_barrier(0);
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_sched_barrier(0);
-  c32_4d acc[4];
+  c32_4d acc[2];
 #pragma unroll
-  for (int b = 0; b < 4; ++b) acc[b] = (c32_4d){0.0, 0.0, 0.0, 0.0};
+  for (int b = 0; b < 2; ++b) acc[b] = (c32_4d){0.0, 0.0, 0.0, 0.0};
 #pragma unroll
   for (int t = 0; t < 4; ++t)
 #pragma unroll
-    for (int b = 0; b < 4; ++b) acc[b] = __builtin_amdgcn_mfma_f64_16x16x4f64(y[b][t], y[1][t], acc[b], 0, 0, 0);
-  // accumulator register q of block b: row 16 b + lane / 16 + 4 q, column lane % 16 -> row-major, stride 17
+    for (int b = 0; b < 2; ++b) acc[b] = __builtin_amdgcn_mfma_f64_16x16x4f64(y[b][t], y[0][t], acc[b], 0, 0, 0);
+  // accumulator register q of block b: row 16 (b + 1) + lane / 16 + 4 q, column lane % 16 -> row-major, stride 17
 #pragma unroll
-  for (int b = 0; b < 4; ++b)
+  for (int b = 0; b < 2; ++b)
 #pragma unroll
-    for (int q = 0; q < 4; ++q) sc[(16 * b + (lane >> 4) + 4 * q) * 17 + (lane & 15)] = acc[b][q];
+    for (int q = 0; q < 4; ++q) sc[(16 * (b + 1) + (lane >> 4) + 4 * q) * 17 + (lane & 15)] = acc[b][q];
   __builtin_amdgcn_sched_barrier(0);
   double pr[16];
 #pragma unroll
@@ -127,8 +130,9 @@ static __device__ __forceinline__ void chol32_factor_split(double (&a)[32], doub
   __builtin_amdgcn_sched_barrier(0);
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_sched_barrier(0);
+  const bool upd = lane >= 16 && lane < 48;
 #pragma unroll
-  for (int c = 0; c < 16; ++c) a[16 + c] -= pr[c];
+  for (int c = 0; c < 16; ++c) a[16 + c] -= upd ? pr[c] : 0.0;
   d = lp_readlane(a[16], 16);
   dmin = fmin(dmin, d);
   r = lp_rsqrt(d);

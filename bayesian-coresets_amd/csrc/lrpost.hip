@@ -11,27 +11,29 @@
 // greedy step, each depending on the last (sparsevi.py:69-76), so what counts is the LATENCY of one D x D Cholesky +
 // inverse -- 19 MFLOP behind a chain of D dependent pivots -- not its throughput:
 //
-//   lrp_form_kernel   P (lower triangle, 32 x 32 tiles) on the fp64 matrix cores and the right-hand side; clears the flags of
-//                     the next kernel.  One workgroup per tile of P.
+//   lrp_form_kernel   P (lower triangle, 32 x 32 tiles) on the fp64 matrix cores and the right-hand side; marks every tile the
+//                     next kernel's workgroups will hand to each other "not written yet".  One workgroup per tile of P.
 //   lrp_chol_kernel   ONE launch of 3 + H co-resident workgroups: blocked Cholesky of the augmented matrix [P; I; rhs^T] --
 //                     the row operations that turn P into L turn I into L^-T and rhs^T into (L^-1 rhs)^T, a forward
 //                     substitution that rides along (no sweep after the factorisation).  LEFT-looking: tile (R, p) of block
 //                     column p is  (init - sum_{q<p} tile(R, q) L_{p,q}^T) W_pp^T,  W_pp = L_pp^-1, formed in one go when
 //                     column p's turn comes -- nothing is ever read-modified-written across steps.
-//                       * workgroup 0, the CHAIN, factors every diagonal tile (one wave, a row per lane; the identity rows
-//                         in the other 32 lanes give W_pp for free) and forms the sub-diagonal tile L_{p+1,p} and the next
-//                         diagonal tile itself, so the critical path diag(p) -> diag(p+1) never leaves the workgroup;
+//                       * workgroup 0, the CHAIN: wave 0 factors every diagonal tile (a row per lane; the identity rows in
+//                         the other 32 lanes give W_pp for free; csrc/chol32.h), all four waves then form the sub-diagonal
+//                         tile L_{p+1,p} and the next diagonal tile, so the critical path diag(p) -> diag(p+1) never leaves
+//                         the workgroup;
 //                       * workgroups 1 and 2, the ASSISTANTS, pre-accumulate for the chain the two sums over columns q <= p - 2
 //                         of those tiles (they are ready a step early); while wave 0 factors, the chain's waves 1-3 add the
 //                         one term of column p - 1;
-//                       * H helpers share the other tiles of column p: accumulate as soon as column p - 1 is complete
-//                         (counter C[p-1]) -- that overlaps diag(p) -- then wait for W_pp (flag F1[p]), multiply, publish
-//                         (C[p]); finished tiles of L^-T leave transposed, as L^-1 row-major for the draw kernel.
-//                     Every tile that crosses workgroups is stored WRITE-THROUGH (sc1) and read with sc1 loads: a hand-off is
-//                     "every storing wave drains its stores, workgroup barrier, one relaxed agent-scope flag / counter", no
-//                     release / acquire fence (a release fence behind 16 KB of fresh tiles costs ~6.5 us and sat twice per
-//                     step on the critical path of the first version: 146 us for D = 301).
-//                     At the end mu_w = L^-T (L^-1 rhs) from the finished tiles.
+//                       * H helpers share the other tiles of column p: they accumulate as the tiles of column p - 1 appear
+//                         -- that overlaps diag(p) -- then multiply by W_pp as soon as it appears; finished tiles of L^-T
+//                         leave transposed, as L^-1 row-major for the draw kernel.
+//                     A tile that crosses workgroups carries its own readiness (a sentinel no arithmetic produces until its
+//                     producer has stored it: no flags, counters or fences; see LP_WAIT), and when the launch fits one XCD
+//                     (D <= 736) all of its workgroups are placed on XCD 0, where ordinary stores reach the one L2 the
+//                     readers' sc1 loads read; otherwise the stores are write-through (sc1).  (First version: release /
+//                     acquire fences at every hand-off -- a release fence behind 16 KB of fresh tiles costs ~6.5 us and sat
+//                     twice per step on the critical path: 146 us for D = 301; now 62.)
 //   the draws         theta = mu_w + [R; Rbar] L^-1: csrc/svi.hip's lrs_draw_kernel with L^-1 in the place of the prior's
 //                     factor (k = 0).
 //
@@ -68,7 +70,7 @@ struct LpArgs {
   double* AS;     // nt tiles: P_{p+1,p} - sum_{q <= p-2} L_{p+1,q} L_{p,q}^T        (assistant 1 -> chain)
   double* AD;     // nt tiles: P_{p+1,p+1} - sum_{q <= p-2} L_{p+1,q} L_{p+1,q}^T    (assistant 2 -> chain)
   double* rhs;    // 32 nt doubles: Sig0^-1 mu0 + X^T (w y) / sigsq, zero padded
-  int* flags;     // F1 [nt] | C [nt] | A1 [nt] | A2 [nt] | status
+  int* flags;     // [4 nt]: the status word (0 ok, 1 a wait expired, 2 a pivot was not positive); the words before it are not used
   // outputs
   double* U; int64_t ldu;      // D x ldu row-major: U = L^-T, upper triangular (the lower triangle is never written: the caller zeroes it once)
   double* uvec;                // D: u = L^-1 rhs  (mu_w = U u; the draws are U (u + r))
@@ -151,7 +153,7 @@ static __device__ __forceinline__ void lp_quad_store(double* tile, int rb, int c
 // both operands of the product are read along the contraction index: lane (i = lane % 16, g = lane / 16) takes the values
 // 8 g .. 8 g + 7 of each run of 32 points as four 16-byte loads, one value per MFMA step (any assignment of the inner index
 // to steps serves as long as both operands use the same one); three runs are in flight.  Workgroups after them, one per
-// block of 32 columns: that block of the right-hand side; the first of them clears the flags.
+// block of 32 columns: that block of the right-hand side; the first of them clears the status word.
 typedef double lp2d __attribute__((ext_vector_type(2)));
 static __device__ __forceinline__ void lp_fill_sent(double* tile, int tid) {
 #pragma unroll

@@ -42,6 +42,7 @@ c3) kt bench_c3 python $R/bench.py --config c3
     python $R/tools/scan_traffic.py $O/scan_traffic.json omp_n1000000_d512_float32=$(find $O/raw_scan_c3_fetch -name "*.db" | head -1) ;;
 c5) kt bench_c5 python $R/bench.py --config c5 --steps 1 --warmup 1 --no-cpu-baseline --no-side-legs
     kt bench_c5_moments python $R/bench.py --config c5 --colsum moments --steps 3 --warmup 1 --no-cpu-baseline
+    python $R/tools/kernels_after.py $(find $O/raw_bench_c5_moments -name "*.db" | head -1) moments_kernel > $O/bench_c5_moments_kernels_after_setup.txt 2>&1
     pmc proj_c5_fetch "FETCH_SIZE" python $R/tools/proj_shape.py --mode colsum --rows 5000000 --reps 4
     python $R/tools/scan_traffic.py $O/scan_traffic.json proj_colsum_linreg_n5000000_d301_s256=$(find $O/raw_proj_c5_fetch -name "*.db" | head -1) ;;
 c5pmc) pmc proj_c5shard_mfma "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS" python $R/tools/proj_shape.py --mode colsum --reps 8

@@ -14,7 +14,6 @@ for k in 8 32 64 128 300; do tools/prof_ksweep.sh r06 $k > /dev/null 2>&1; cp gp
 BCX_LRP_DBG=1 python tools/lrp_timeline.py 2>&1 | grep -v amdgpu.ids > $P/lrp_chol_timeline.txt
 tools/probe/f64_chain_probe 2>&1 | grep -v amdgpu.ids > $P/f64_chain_probe.txt
 tools/probe/xcd_handoff_probe 4000 2>&1 | grep -v amdgpu.ids > $P/xcd_handoff_probe.txt
-python tools/kernels_after.py $(find $P/raw_bench_c5_moments -name "*.db" | head -1) moments_kernel > $P/bench_c5_moments_kernels_after_setup.txt 2>&1
 python tools/c5_ksweep.py --ks 4,8,16,24,25,32,64,128,300 --select 2>/dev/null | tail -1 > $P/c5_ksweep.json
 python tools/svi_laplace_bench.py 2>/dev/null | tail -1 > $P/svi_laplace_bench.txt
 python tools/svi_laplace_bench.py --family poisson --steps 4 2>/dev/null | tail -1 >> $P/svi_laplace_bench.txt
