@@ -887,6 +887,15 @@ def side_legs(args, out, torch, dist, nat):
         out["c2_m1000_steps_accepted"] = r["config"]["steps_accepted"]
         out["c2_m1000_final_error"] = r["config"]["final_error"]
         out["c2_m1000_leg_wall_s"] = r["leg_wall_s"]
+    # configs[3] (the headline's workload) at ITS stated M = 1000 as well, from a fresh solver: Frank-Wolfe's whole error
+    # trajectory on the driver's clock (the headline times 20 iterations; the rate per iteration is flat)
+    r = leg("c4", steps=1000, warmup=0, no_f16_leg=True)
+    if r is not None:
+        out["c4_m1000_its"] = r["value"]
+        out["c4_m1000_iterations_run"] = r["config"]["iterations_run"]
+        out["c4_m1000_scan_frac"] = r["roofline"]["frac"]
+        out["c4_m1000_final_error"] = r["config"]["final_error"]
+        out["c4_m1000_leg_wall_s"] = r["leg_wall_s"]
     # c5, MFMA form (every column sum a projection of all rows, as the reference does): 3 greedy steps after 1
     r = leg("c5", colsum="mfma")
     if r is not None:
