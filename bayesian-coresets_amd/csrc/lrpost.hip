@@ -41,6 +41,7 @@
 // 16 x 4 operand slices of v_mfma_f64_16x16x4_f64 -- lane l: row l % 16, k = l / 16 -- are 512 contiguous bytes per wave load;
 // every product here has the form C (+)= A B^T with both operands read that way.
 #include <atomic>
+#include <cstdlib>
 #include <string>
 #include "bcx_internal.h"
 #include "dev_util.h"
@@ -689,7 +690,11 @@ __global__ void lrp_xcc_probe_kernel(int* out) {
 }
 static bool lrp_one_xcd(hipStream_t st) {
   static std::atomic<int> known[64];                // 0 unknown, 1 yes, 2 no
-  static const bool off = [] { const char* e = bcx_dev_env("BCX_LRP_ONE_XCD"); return e && atoi(e) == 0; }();      // dev
+  // BCX_LRP_SPREAD=1 (a runtime option, not a dev switch): keep the workgroups spread over the chip.  One XCD has room for
+  // two such launches at a time; more than two PROCESSES factoring on one GPU at once could each hold part of the XCD and wait
+  // for the rest until the time-out (status BCX_ERR_TIMEOUT, never a wrong result).  One process per GPU -- the deployment
+  // this library is for -- cannot get there: a stream's launches run one after the other.
+  static const bool off = [] { const char* e = getenv("BCX_LRP_SPREAD"); return e && e[0] == '1'; }();
   if (off) return false;
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return false;
