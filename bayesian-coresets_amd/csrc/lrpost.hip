@@ -255,8 +255,9 @@ __global__ __launch_bounds__(256) void lrp_form_kernel(LpArgs a) {
 
 // A tile that crosses workgroups carries its own "ready": lrp_form_kernel fills every such tile with LP_SENT, a signalling NaN
 // that no arithmetic produces (results are quiet NaNs), the producer overwrites it with 8-byte write-through stores in any
-// order, and a consumer simply loads its operands (sc1) until none of them is the sentinel -- one trip through memory per
-// hand-off instead of three (drain the stores, raise a flag, see the flag, load), and no flag or counter at all.
+// order, and a consumer simply loads its operands (sc1) until none of them is the sentinel -- one trip through the L2 (or, with
+// the workgroups spread over the XCDs, through memory) per hand-off instead of three (drain the stores, raise a flag, see the
+// flag, load), and no flag or counter at all.
 static __device__ __forceinline__ int lp_set(double v) { return (unsigned long long)__double_as_longlong(v) != LP_SENT ? 1 : 0; }
 static __device__ __forceinline__ int lp_set8(const double (&v)[8]) {
   int ok = 1;
@@ -283,7 +284,7 @@ static __device__ __forceinline__ bool lp_again(LpSpin& sp, const LpArgs& a) {  
 }
 // The statements after PEEK_OK (re)load the wave's operands and clear the lane's `ok` where a value is missing; until every
 // lane has everything the wave spins LIGHTLY -- on PEEK_OK, one or two values at the end of the newest tile(s), not on all of
-// its operands (three waves re-requesting 60 values each beside the wave that factors the diagonal tile slowed that wave by 10 %).
+// its operands (up to 60 loads per lane and round).
 #define LP_LAST 1023                                // element (31, 31) of a k-grouped tile: the last one every producer here stores
 #define LP_PEEK(tile) lp_set(lp_ld((tile) + LP_LAST))
 #define LP_WAIT(sp, PEEK_OK, ...)                   \
@@ -295,8 +296,8 @@ static __device__ __forceinline__ bool lp_again(LpSpin& sp, const LpArgs& a) {  
   }
 
 // One wave: Cholesky of the 32 x 32 tile in sdg (row-major, stride 33) and the inverse of its factor (csrc/chol32.h: how, and
-// what it cost to get there).  Writes W = L^-1 = X^T k-grouped into sw (LDS) and gw (global, write-through).  bad: a pivot was
-// not positive.
+// what it cost to get there).  Writes W = L^-1 = X^T k-grouped into sw (LDS, column groups LP_WGS apart) and gw (global: the
+// helpers read it from there as soon as it lands).  bad: a pivot was not positive.
 template <bool ONE>
 static __device__ __forceinline__ void lp_diag(const double* sdg, double* sw, double* gw, double* sc, int lane, int* bad) {
   double a[32];
