@@ -33,7 +33,7 @@ SYMBOLS = (
     "bcx_set_check_monotone", "bcx_project_profile", "bcx_project_profile_read", "bcx_exchange_stats", "bcx_load_rows_flags", "bcx_project_write_raw", "bcx_omp_stats", "bcx_project_select_ws", "bcx_project_select_scratch_bytes",
     "bcx_project_moments", "bcx_project_colsum_moments", "bcx_project_moments_scratch_bytes",
     "bcx_project_colsum_moments_scratch_bytes", "bcx_gram", "bcx_gram_scratch_bytes", "bcx_gram_check",
-    "bcx_project_colsum_moments_at", "bcx_linreg_posterior_draw", "bcx_sparsevi_adam_step",
+    "bcx_project_colsum_moments_at", "bcx_project_points_colsum_moments", "bcx_linreg_posterior_draw", "bcx_sparsevi_adam_step",
     "bcx_linreg_posterior_apply", "bcx_linreg_posterior_apply_ok",
     "bcx_linreg_posterior_factor", "bcx_linreg_posterior_factor_scratch_bytes", "bcx_linreg_posterior_factor_status",
     "bcx_linreg_posterior_draw_factored",
@@ -157,6 +157,7 @@ def load():
     sigs["bcx_project_moments"] = [vp, vp, i64, i64, i32, vp, i64, vp, i64]
     sigs["bcx_project_colsum_moments"] = [vp, vp, i64, i32, i32, vp, i32, i32, dbl, vp, vp]
     sigs["bcx_project_colsum_moments_at"] = [vp, vp, i64, i32, i32, vp, i32, i32, dbl, vp, vp, vp]
+    sigs["bcx_project_points_colsum_moments"] = [vp, vp, i64, i64, i32, i32, vp, i32, i32, dbl, vp, i64, vp, i64, i32, vp, vp, vp]
     sigs["bcx_linreg_posterior_draw"] = [vp, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, dbl, vp, vp, i32, vp, vp]
     sigs["bcx_linreg_posterior_apply"] = [vp, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, dbl, vp, vp, i32, vp, vp, vp]
     sigs["bcx_linreg_posterior_apply_ok"] = [i32, i32]

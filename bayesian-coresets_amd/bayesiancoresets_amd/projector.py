@@ -416,7 +416,7 @@ class DeviceProjector(Projector):
         buf = self._cc_buf[:S * (k + 1)]
         col = buf[:S]
         core_args = self._common(C) + [buf[S:].data_ptr(), S, 0]
-        state = {"mom": None}
+        state = {"mom": None, "both": None}
 
         def run():
             if self._moments_for(pts, Z, persistent) is not None:
@@ -429,6 +429,13 @@ class DeviceProjector(Projector):
                     a = state["mom"] = [core_args[0], self._mom.data_ptr(), self._mom.stride(0), D, D, self.theta.data_ptr(), S,
                                         self.theta.stride(0), self.sigsq, col.data_ptr(), self._mom_work.data_ptr(),
                                         None if mean is None else mean.data_ptr()]
+                    # both projections only read the draws: one launch (csrc/proj.hip proj_mid_quad_kernel) where they fit it
+                    c = core_args          # stream, family, Z, N, ldz, D, ycol, theta, S, ldt, param, out, ldo, center
+                    state["both"] = None if mean is None else [c[0], c[2], c[3], c[4], c[5], c[6], c[7], c[8], c[9], c[10], c[11],
+                                                               c[12], a[1], a[2], a[4], a[9], a[10], a[11]]
+                if state["both"] is not None:
+                    self._check(lib.bcx_project_points_colsum_moments(*state["both"]))
+                    return
                 self._check(lib.bcx_project_colsum_moments_at(*a))
             else:
                 self._colsum_projected(Z, out=col)

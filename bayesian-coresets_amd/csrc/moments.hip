@@ -23,15 +23,7 @@
 #include "bcx_internal.h"
 #include "dev_util.h"
 
-typedef double mv4d __attribute__((ext_vector_type(4)));
-
-// write-through (sc1) store / sc1 load: coherent across the XCDs' L2s whatever the reader's L2 holds (csrc/nnls_common.h)
-static __device__ __forceinline__ double mom_ld(const double* p) {
-  return __longlong_as_double((long long)__hip_atomic_load((const unsigned long long*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-}
-static __device__ __forceinline__ void mom_st(double* p, double v) {
-  __hip_atomic_store((unsigned long long*)p, (unsigned long long)__double_as_longlong(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
+#include "moments_quad.h"
 
 #define MOM_BLK 64          // columns per block
 #define MOM_ROWS 32         // rows staged per chunk (4 waves x 2 k-steps x 4 rows)
@@ -169,147 +161,8 @@ __global__ __launch_bounds__(256) void moments_mean_kernel(const double* __restr
   if (q == 0 && c < D) tbar[c] = (((part[0][threadIdx.x] + part[1][threadIdx.x]) + part[2][threadIdx.x]) + part[3][threadIdx.x]) / (double)S;
 }
 
-// T_s = sum_i (Delta G)[s][i] (delta_si + 2 tbar_i) - 2 delta_si g_i   (= delta_s^T G delta_s + 2 delta_s^T (G tbar - g)),
-// Delta G on the fp64 matrix cores: one WORKGROUP per 16 samples x 16 columns tile of Delta G, its four waves take the
-// k steps 4 t + wave of the D rows of G (v_mfma_f64_16x16x4_f64; lane group lk feeds k = 8 t + 2 lk (+1) to steps 2 t (2 t + 1):
-// one 16-byte load of theta per two steps) and meet in LDS in wave order -- the chain of dependent load batches is a
-// quarter as long as with one wave per tile (this kernel is all latency: 46 MFLOP).
-// Partials [column tile][sample] go to `work`; the last workgroup to arrive sums them in tile order, centres and scales.
-// work: nct * Spad partials, then one arrival counter (self-resetting).
-#define MQ_U 12
-// sc1 load without a wait of its own: the caller issues a batch, waits once (s_waitcnt vmcnt(0)) and ties the values
-// (atomic loads are issued and awaited one by one: nct round trips in the closing sum)
-static __device__ __forceinline__ double mom_ld_nowait(const double* p) {
-  double v;
-  asm volatile("global_load_dwordx2 %0, %1, off sc1" : "=v"(v) : "v"(p) : "memory");
-  return v;
-}
 template <bool AL>
-__global__ __launch_bounds__(256) void moments_quad_kernel(const double* __restrict__ M, int64_t ldm, int D, int ycol,
-                                                           const double* __restrict__ theta, int S, int ldt,
-                                                           const double* __restrict__ tbar, double sigsq,
-                                                           double* __restrict__ colsum, double* __restrict__ work, int nct, int Spad, int dbg) {
-  __shared__ double scratch[BCX_SCRATCH];
-  __shared__ double red[4][4][64];
-  __shared__ int last;
-  long long stamp[8];
-#define MQ_STAMP(i) do { if (dbg) { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); stamp[i] = wall_clock64(); } } while (0)
-  MQ_STAMP(0);
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int li = lane & 15, lk = lane >> 4;
-  const int st = blockIdx.x / nct, ct = blockIdx.x - st * nct;
-  {
-    const int sa = st * 16 + li, cb = ct * 16 + li;
-    const bool va = sa < S, vb = cb < D;
-    const double* th = theta + (size_t)(va ? sa : 0) * ldt;
-    const double* gc = M + (vb ? cb : 0);
-    mv4d acc = (mv4d){0.0, 0.0, 0.0, 0.0};
-    // what wave 0 needs after the products, requested now (f64 C/D layout: col = lane & 15, row = (lane >> 4) + 4 * reg)
-    double e_tb = 0.0, e_gy = 0.0, e_th[4] = {0.0, 0.0, 0.0, 0.0};
-    if (wave == 0 && vb) {
-      e_tb = tbar[cb];
-      e_gy = M[(size_t)ycol * ldm + cb];
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int sr = st * 16 + lk + 4 * r;
-        e_th[r] = theta[(size_t)(sr < S ? sr : 0) * ldt + cb];
-      }
-    }
-    const int ksteps = (D + 7) / 8;
-    for (int t0 = wave; t0 < ksteps; t0 += 4 * MQ_U) {
-      // MQ_U double-steps per trip (t0, t0 + 4, ...): all their loads are issued before the first MFMA (addresses clamped,
-      // values masked); D <= 384 is one trip -- one round of load latency instead of three
-      double a0[MQ_U], a1[MQ_U], b0[MQ_U], b1[MQ_U];
-#pragma unroll
-      for (int u = 0; u < MQ_U; ++u) {
-        const int k = 8 * (t0 + 4 * u) + 2 * lk;
-        const bool k0 = k < D, k1 = k + 1 < D;
-        const int kc = k0 ? k : 0, kd = k1 ? k + 1 : 0;
-        double x0, x1;
-        if (AL) { const double2 v = *(const double2*)(th + kc); x0 = v.x; x1 = v.y; }   // (kc + 1 <= ldt - 1: ldt is even)
-        else { x0 = th[kc]; x1 = th[kd]; }
-        const double t0v = tbar[kc], t1v = tbar[kd];
-        const double g0 = gc[(size_t)kc * ldm], g1 = gc[(size_t)kd * ldm];
-        a0[u] = (va && k0) ? x0 - t0v : 0.0;
-        a1[u] = (va && k1) ? x1 - t1v : 0.0;
-        b0[u] = (vb && k0) ? g0 : 0.0;
-        b1[u] = (vb && k1) ? g1 : 0.0;
-      }
-#pragma unroll
-      for (int u = 0; u < MQ_U; ++u) {
-        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[u], b0[u], acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[u], b1[u], acc, 0, 0, 0);
-      }
-    }
-    MQ_STAMP(1);
-#pragma unroll
-    for (int r = 0; r < 4; ++r) red[wave][r][lane] = acc[r];
-    __syncthreads();
-    if (wave == 0) {
-      // f64 C/D layout: col = lane & 15, row = (lane >> 4) + 4 * reg
-      const double tb = e_tb, gy = e_gy;
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const double y4 = ((red[0][r][lane] + red[1][r][lane]) + red[2][r][lane]) + red[3][r][lane];
-        const int sr = st * 16 + lk + 4 * r;
-        double v = 0.0;
-        if (vb && sr < S) {
-          const double dl = e_th[r] - tb;
-          v = y4 * (dl + 2.0 * tb) - 2.0 * dl * gy;
-        }
-        v += bcx_dpp_f64<0xB1>(v);     // sum over the 16 lanes (columns) of the row group
-        v += bcx_dpp_f64<0x4E>(v);
-        v += bcx_dpp_f64<0x141>(v);
-        v += bcx_dpp_f64<0x140>(v);
-        if (li == 0) mom_st(&work[(size_t)ct * Spad + sr], v);
-      }
-    }
-  }
-  unsigned* counter = (unsigned*)(work + (size_t)nct * Spad);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-  MQ_STAMP(2);
-  if (tid == 0) {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    last = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1;
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-  }
-  __syncthreads();
-  MQ_STAMP(3);
-  if (!last) return;
-  // the last workgroup to arrive: every partial is in memory; tile order, then sample order -- the same bits whichever it is
-  double m[1] = {0.0};
-  for (int u = tid; u < S; u += 256) {
-    double t = 0.0;
-    for (int c0 = 0; c0 < nct; c0 += 16) {
-      double v[16];
-#pragma unroll
-      for (int q = 0; q < 16; ++q) v[q] = mom_ld_nowait(work + (size_t)(c0 + q < nct ? c0 + q : c0) * Spad + u);
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#pragma unroll
-      for (int q = 0; q < 16; ++q) {
-        asm volatile("" : "+v"(v[q]));
-        if (c0 + q < nct) t += v[q];
-      }
-    }
-    mom_st(&work[u], t);
-    m[0] += t;
-  }
-  __syncthreads();
-  MQ_STAMP(4);
-  block_allsum<1>(m, scratch);
-  const double mean = m[0] / (double)S, f = -1.0 / (2.0 * sigsq);
-  for (int u = tid; u < S; u += 256) colsum[u] = f * (mom_ld(work + u) - mean);
-  if (tid == 0) __hip_atomic_store(counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  if (dbg) {
-    MQ_STAMP(5);
-    if (tid == 0) {
-      double* o = work + (size_t)nct * Spad + 1;      // (the space of the library's own thetabar: dev runs pass one)
-      for (int i = 0; i < 6; ++i) o[i] = (double)(stamp[i] - (i ? stamp[0] : 0)) * 0.01;
-    }
-  }
-}
+__global__ __launch_bounds__(256) void moments_quad_kernel(MqArgs q) { moments_quad_body<AL>(q, blockIdx.x, gridDim.x); }
 
 void bcx_project_set_error(const std::string& msg);   // proj.hip: the message bcx_project_last_error() returns
 #define MOM_HIP(call)                                                             \
@@ -560,11 +413,10 @@ extern "C" int bcx_gram_check(void* stream, const void* work_dev) {
 }
 
 // Doubles of scratch bcx_project_colsum_moments needs: the (column tile, sample) partials, thetabar, the arrival counter.
-static void colsum_plan(int D, int S, int* nct, int* Spad) { *nct = (D + 15) / 16; *Spad = (S + 15) / 16 * 16; }
 extern "C" int64_t bcx_project_colsum_moments_scratch_bytes(int32_t D, int32_t S) {
   if (D < 1 || D >= MOM_MAX_COLS || S < 1) return -1;
   int nct, Spad;
-  colsum_plan(D, S, &nct, &Spad);
+  mq_plan(D, S, &nct, &Spad);
   return ((int64_t)nct * Spad + 1 + (D + 1) / 2 * 2) * (int64_t)sizeof(double);
 }
 
@@ -582,7 +434,7 @@ extern "C" int bcx_project_colsum_moments_at(void* stream, const void* M_dev, in
     return BCX_ERR_ARG;
   }
   int nct, Spad;
-  colsum_plan(D, S, &nct, &Spad);
+  mq_plan(D, S, &nct, &Spad);
   double* work = (double*)work_dev;
   const double* tbar = (const double*)tbar_dev;
   hipStream_t st = (hipStream_t)stream;
@@ -594,12 +446,11 @@ extern "C" int bcx_project_colsum_moments_at(void* stream, const void* M_dev, in
   const int tiles = nct * (Spad / 16);
   const bool al = ((uintptr_t)theta_dev % 16 == 0) && ldt % 2 == 0;
   static const int mqdbg = bcx_dev_env("BCX_MQ_DBG") != nullptr;     // dev: time stamps of the last workgroup (needs tbar_dev)
-  if (al)
-    hipLaunchKernelGGL(moments_quad_kernel<true>, dim3(tiles), dim3(256), 0, st, (const double*)M_dev, ldm, (int)D, (int)ycol,
-                       (const double*)theta_dev, (int)S, (int)ldt, (const double*)tbar, sigsq, (double*)colsum_dev, work, nct, Spad, mqdbg);
-  else
-    hipLaunchKernelGGL(moments_quad_kernel<false>, dim3(tiles), dim3(256), 0, st, (const double*)M_dev, ldm, (int)D, (int)ycol,
-                       (const double*)theta_dev, (int)S, (int)ldt, (const double*)tbar, sigsq, (double*)colsum_dev, work, nct, Spad, mqdbg);
+  MqArgs q;
+  q.M = (const double*)M_dev; q.ldm = ldm; q.D = D; q.ycol = ycol; q.theta = (const double*)theta_dev; q.S = S; q.ldt = ldt;
+  q.tbar = tbar; q.sigsq = sigsq; q.colsum = (double*)colsum_dev; q.work = work; q.nct = nct; q.Spad = Spad; q.dbg = mqdbg;
+  if (al) hipLaunchKernelGGL(moments_quad_kernel<true>, dim3(tiles), dim3(256), 0, st, q);
+  else hipLaunchKernelGGL(moments_quad_kernel<false>, dim3(tiles), dim3(256), 0, st, q);
   MOM_HIP(hipGetLastError());
   return BCX_OK;
 }

@@ -21,6 +21,7 @@
 #include "bcx_internal.h"
 #include "dev_util.h"
 #include "proj_math.h"
+#include "moments_quad.h"
 
 enum { FAM_LOGISTIC = 0, FAM_POISSON = 1, FAM_LINREG = 2 };
 enum { PMODE_WRITE = 0, PMODE_COLSUM = 1, PMODE_SELECT = 2 };
@@ -974,7 +975,7 @@ __global__ __launch_bounds__(1024) void proj_small_kernel(ProjArgs p, int center
 #define PJ_MID_ROWS 4096
 typedef double pjm4d __attribute__((ext_vector_type(4)));
 template <int FAM, bool AL>
-__global__ __launch_bounds__(256) void proj_mid_kernel(ProjArgs p) {
+static __device__ __forceinline__ void proj_mid_body(const ProjArgs& p, const int bx, const int by) {
   extern __shared__ __attribute__((aligned(16))) unsigned char pj_lds[];
   constexpr int NTAB = FAM == FAM_POISSON ? PJT_DOUBLES : FAM == FAM_LOGISTIC ? PJT_DOUBLES_LOGISTIC : 0;
   double* tabw = (double*)pj_lds;
@@ -983,8 +984,8 @@ __global__ __launch_bounds__(256) void proj_mid_kernel(ProjArgs p) {
   const int li = lane & 15, lk = lane >> 4, rb = wave >> 1, cb = wave & 1;
   const int D = p.D, S = p.S;
   if (NTAB) { for (int k = tid; k < NTAB; k += 256) tabw[k] = p.tab[k]; __syncthreads(); }
-  const int64_t arow = (int64_t)blockIdx.x * 32 + rb * 16 + li;
-  const int bcol = blockIdx.y * 32 + cb * 16 + li;
+  const int64_t arow = (int64_t)bx * 32 + rb * 16 + li;
+  const int bcol = by * 32 + cb * 16 + li;
   const double* zp = p.Z + (arow < p.N ? arow : 0) * p.ldz;
   const double* tp = p.theta + (size_t)(bcol < S ? bcol : 0) * p.ldt;
   const bool aok = arow < p.N, bok = bcol < S;
@@ -1031,10 +1032,10 @@ __global__ __launch_bounds__(256) void proj_mid_kernel(ProjArgs p) {
   // accumulator layout: register r holds (row 16 rb + lane / 16 + 4 r, column 16 cb + lane % 16)
   const double clin = (FAM == FAM_LINREG) ? -0.5 * log(2.0 * 3.14159265358979323846 * p.param) : 0.0;
   const double parg = (FAM == FAM_LINREG) ? 1.0 / (2.0 * p.param) : p.param;
-  const int col = blockIdx.y * 32 + cb * 16 + li;
+  const int col = by * 32 + cb * 16 + li;
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
-    const int64_t row = (int64_t)blockIdx.x * 32 + rb * 16 + lk + 4 * r;
+    const int64_t row = (int64_t)bx * 32 + rb * 16 + lk + 4 * r;
     if (row < p.N && col < S) {
       const double y = p.ycol >= 0 ? p.Z[row * p.ldz + p.ycol] : 0.0;
       double yv = y, c0 = clin;
@@ -1049,6 +1050,20 @@ __global__ __launch_bounds__(256) void proj_mid_kernel(ProjArgs p) {
       p.out[row * p.ldo + col] = loglik<FAM>(acc[r], yv, parg, c0, tab);
     }
   }
+}
+
+template <int FAM, bool AL>
+__global__ __launch_bounds__(256) void proj_mid_kernel(ProjArgs p) { proj_mid_body<FAM, AL>(p, blockIdx.x, blockIdx.y); }
+
+// SparseVI's ADAM step needs, at fresh draws, the column sums of the whole data set -- in closed form for the linear-regression
+// family (csrc/moments_quad.h) -- AND the projection of the coreset points.  Both only read the draws, and each is a chain of
+// dependent round trips to memory on a fraction of the chip: ONE launch, the first nq workgroups the closed form, the rest
+// the 32 x 32 blocks of the points' projection (16 + 9 us one after the other).  The same arithmetic as the separate launches.
+template <bool ALP, bool ALQ>
+__global__ __launch_bounds__(256) void proj_mid_quad_kernel(ProjArgs p, MqArgs q, int nq, int gx) {
+  if ((int)blockIdx.x < nq) { moments_quad_body<ALQ>(q, blockIdx.x, nq); return; }
+  const int b = blockIdx.x - nq;
+  proj_mid_body<FAM_LINREG, ALP>(p, b % gx, b / gx);
 }
 
 // colsum[s] = sum over the workgroup partials in a fixed order: one workgroup per 64 columns, four
@@ -1453,6 +1468,47 @@ extern "C" int bcx_project_write_points(void* stream, int32_t family, const void
                                         int32_t ycol, const void* theta_dev, int32_t S, int32_t ldt, double param,
                                         void* out_dev, int64_t ldo, int32_t center) {
   return project_write(stream, family, Z_dev, N, ldz, D, ycol, theta_dev, S, ldt, param, out_dev, ldo, nullptr, center != 0, true);
+}
+
+// bcx_project_colsum_moments_at and bcx_project_write_points (raw rows) at the same draws, as ONE launch when the points take
+// the 32 x 32-block kernel (more than PJ_SMALL_ROWS and at most 4096 of them, linear-regression family); otherwise the two
+// calls one after the other.  The results are those of the two calls, bit for bit.
+extern "C" int bcx_project_points_colsum_moments(void* stream, const void* Zc_dev, int64_t Nc, int64_t ldzc, int32_t D, int32_t ycol,
+                                                 const void* theta_dev, int32_t S, int32_t ldt, double sigsq, void* out_dev, int64_t ldo,
+                                                 const void* M_dev, int64_t ldm, int32_t ycol_m, void* colsum_dev, void* work_dev,
+                                                 const void* tbar_dev) {
+  static const bool apart = bcx_dev_env("BCX_PROJ_NO_MERGE") != nullptr;      // dev: always the two launches
+  const bool one = !apart && tbar_dev && Nc > PJ_SMALL_ROWS && Nc <= PJ_MID_ROWS && bcx_dev_env("BCX_PROJ_NO_MID") == nullptr &&
+                   bcx_dev_env("BCX_PROJ_NO_SMALL") == nullptr;
+  if (!one) {
+    const int rc = bcx_project_colsum_moments_at(stream, M_dev, ldm, D, ycol_m, theta_dev, S, ldt, sigsq, colsum_dev, work_dev, tbar_dev);
+    if (rc) return rc;
+    return bcx_project_write_points(stream, FAM_LINREG, Zc_dev, Nc, ldzc, D, ycol, theta_dev, S, ldt, sigsq, out_dev, ldo, 0);
+  }
+  ProjArgs p;
+  int rc = fill(p, FAM_LINREG, Zc_dev, Nc, ldzc, D, ycol, theta_dev, S, ldt, sigsq);
+  if (rc) return rc;
+  if (!out_dev || ldo < S) { g_proj_err = "bcx_project_points_colsum_moments: bad output"; return BCX_ERR_ARG; }
+  if (!M_dev || !colsum_dev || !work_dev || D >= 1024 || ycol_m < 0 || ycol_m >= ldm || ldm < D) {
+    g_proj_err = "bcx_project_points_colsum_moments: bad arguments (the moments of bcx_project_moments, D < 1024)";
+    return BCX_ERR_ARG;
+  }
+  p.out = (double*)out_dev; p.ldo = ldo; p.rowsum = nullptr;
+  MqArgs q;
+  mq_plan(D, S, &q.nct, &q.Spad);
+  q.M = (const double*)M_dev; q.ldm = ldm; q.D = D; q.ycol = ycol_m; q.theta = (const double*)theta_dev; q.S = S; q.ldt = ldt;
+  q.tbar = (const double*)tbar_dev; q.sigsq = sigsq; q.colsum = (double*)colsum_dev; q.work = (double*)work_dev; q.dbg = 0;
+  const int nq = q.nct * (q.Spad / 16);
+  const int gx = (int)((Nc + 31) / 32), gy = (S + 31) / 32;
+  const bool alq = ((uintptr_t)theta_dev % 16 == 0) && ldt % 2 == 0;
+  const bool alp = alq && ((uintptr_t)p.Z % 16 == 0) && p.ldz % 2 == 0;
+  hipStream_t st = (hipStream_t)stream;
+  const dim3 grid((unsigned)(nq + gx * gy));
+  if (alp) hipLaunchKernelGGL((proj_mid_quad_kernel<true, true>), grid, dim3(256), 0, st, p, q, nq, gx);
+  else if (alq) hipLaunchKernelGGL((proj_mid_quad_kernel<false, true>), grid, dim3(256), 0, st, p, q, nq, gx);
+  else hipLaunchKernelGGL((proj_mid_quad_kernel<false, false>), grid, dim3(256), 0, st, p, q, nq, gx);
+  PROJ_HIP(hipGetLastError());
+  return BCX_OK;
 }
 
 // colsum_dev[s] = sum_n vecs[n][s] without materialising vecs.  work_dev: 2048 * S doubles.

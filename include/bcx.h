@@ -259,6 +259,15 @@ int bcx_project_colsum_moments(void* stream, const void* M_dev, int64_t ldm, int
 int bcx_project_colsum_moments_at(void* stream, const void* M_dev, int64_t ldm, int32_t D, int32_t ycol,
                                   const void* theta_dev, int32_t S, int32_t ldt, double sigsq, void* colsum_dev, void* work_dev,
                                   const void* tbar_dev);
+/* The two projections SparseVI's weight optimisation needs at every ADAM step (sparsevi.py:35-41 at fresh draws), for the
+ * linear-regression family with the data's column sums in closed form: bcx_project_colsum_moments_at (M_dev, ldm, ycol_m,
+ * colsum_dev, work_dev, tbar_dev: as there, tbar_dev given) and bcx_project_write_points of the Nc coreset points Zc_dev with
+ * center = 0 (out_dev: Nc x ldo raw log-likelihoods) -- as ONE launch when the points take the 32 x 32-block kernel (both
+ * only read the draws), else as the two calls.  Same results bit for bit either way. */
+int bcx_project_points_colsum_moments(void* stream, const void* Zc_dev, int64_t Nc, int64_t ldzc, int32_t D, int32_t ycol,
+                                      const void* theta_dev, int32_t S, int32_t ldt, double sigsq, void* out_dev, int64_t ldo,
+                                      const void* M_dev, int64_t ldm, int32_t ycol_m, void* colsum_dev, void* work_dev,
+                                      const void* tbar_dev);
 /* SparseVI's weight optimisation with the weights resident on the device (sparsevi.py:69-76 -> util/opt.py:4-28): the
  * reference's loop body is projector.update(w, pts) [sampler call, sparsevi.py:25], two projections [sparsevi.py:35-41],
  * the gradient [sparsevi.py:72-74] and one projected-ADAM update [opt.py:19-25]; with these two entry points and the

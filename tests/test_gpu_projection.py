@@ -495,6 +495,57 @@ def test_colsum_from_moments_equals_projected_colsum(bc, D, S):
     assert b.moments_info["rows"] == 9000
 
 
+@pytest.mark.parametrize("D,S,k", ((301, 256, 300), (30, 130, 65), (24, 64, 33), (301, 256, 20), (64, 37, 700)))
+def test_points_and_closed_form_column_sums_in_one_launch(bc, D, S, k):
+    """bcx_project_points_colsum_moments (csrc/proj.hip proj_mid_quad_kernel: the two projections of a SparseVI ADAM step, which
+    both only read the draws, as ONE launch) against the two calls it stands for, bit for bit -- for point counts on both
+    sides of the 32 x 32-block kernel's range (k = 20: the two calls inside) -- and against NumPy."""
+    import torch
+    from bayesiancoresets_amd import _native
+    lib = _native.load()
+    rs = np.random.RandomState(D * 7 + S + k)
+    N = 20_000
+    Z = make_linreg_data(3, N, D)
+    theta = 0.4 + 0.9 * rs.randn(S, D)
+    sigsq = 0.8
+    dev = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float64)).cuda()
+    ld = D + D % 2
+    th = torch.zeros(S, ld, dtype=torch.float64, device="cuda")
+    th[:, :D] = dev(theta)
+    Zd, Cd = dev(Z), dev(Z[rs.choice(N, k, replace=False)])
+    tbar = th[:, :D].mean(dim=0).contiguous()
+    st = int(torch.cuda.current_stream().cuda_stream)
+    C = D + 1
+    M = torch.empty(C, C, dtype=torch.float64, device="cuda")
+    need = int(lib.bcx_project_moments_scratch_bytes(N, C))
+    w0 = torch.empty(max(need // 8, 1), dtype=torch.float64, device="cuda")
+    assert lib.bcx_project_moments(st, Zd.data_ptr(), N, C, C, M.data_ptr(), C, w0.data_ptr(), need) == 0
+    qn = int(lib.bcx_project_colsum_moments_scratch_bytes(D, S)) // 8
+    outs = []
+    for merged in (False, True):
+        work = torch.zeros(qn, dtype=torch.float64, device="cuda")
+        col = torch.full((S,), np.nan, dtype=torch.float64, device="cuda")
+        out = torch.full((k, S), np.nan, dtype=torch.float64, device="cuda")
+        for _ in range(2):                          # (twice: the closing workgroup's counter must be left at zero)
+            if merged:
+                assert lib.bcx_project_points_colsum_moments(st, Cd.data_ptr(), k, C, D, D, th.data_ptr(), S, ld, sigsq, out.data_ptr(), S,
+                                                             M.data_ptr(), C, D, col.data_ptr(), work.data_ptr(), tbar.data_ptr()) == 0
+            else:
+                assert lib.bcx_project_colsum_moments_at(st, M.data_ptr(), C, D, D, th.data_ptr(), S, ld, sigsq, col.data_ptr(),
+                                                         work.data_ptr(), tbar.data_ptr()) == 0
+                assert lib.bcx_project_write_points(st, 2, Cd.data_ptr(), k, C, D, D, th.data_ptr(), S, ld, sigsq, out.data_ptr(), S, 0) == 0
+        outs.append((col.cpu().numpy(), out.cpu().numpy()))
+    assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1])
+    want = linreg_log_likelihood(Z, theta, sigsq)
+    want -= want.mean(axis=1)[:, None]
+    scale = np.abs(want.sum(axis=0)).max()
+    np.testing.assert_allclose(outs[1][0], want.sum(axis=0), rtol=1e-9, atol=1e-10 * scale)
+    np.testing.assert_allclose(outs[1][1], linreg_log_likelihood(Cd.cpu().numpy(), theta, sigsq), rtol=1e-10, atol=1e-9)
+    # bad arguments come back as codes
+    assert lib.bcx_project_points_colsum_moments(st, Cd.data_ptr(), 300, C, D, D, th.data_ptr(), S, ld, sigsq, None, S,
+                                                 M.data_ptr(), C, D, col.data_ptr(), work.data_ptr(), tbar.data_ptr()) != 0
+
+
 def test_rbf_shard_size_select_and_colsum(bc):
     """BASELINE configs[4] per-GPU shard (N = 625k, D = 301, S = 256) on the RBF design: project_select / project_colsum
     against a torch fp64 centre-then-norm restatement of sparsevi.py:47-56 over all rows (chunked), at a prior state
