@@ -598,18 +598,20 @@ struct LpDrawArgs {
   int D, S, ld;
 };
 __global__ __launch_bounds__(256) void lrp_draw_kernel(LpDrawArgs a) {
+  // A 16 x 16 tile of theta per workgroup, its four waves sharing the inner index: wave w takes the runs of 32 numbered
+  // w, w + 4, w + 8 (for D <= 384 that is ALL of a wave's loads in flight at once -- one round trip to memory, not four: the
+  // kernel is nothing but that latency), the partial tiles meet in LDS in wave order.
   __shared__ double su[LP_NB * LP_MAX_NT + 32];
+  __shared__ double red[4][4][64];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  for (int i = tid; i < ((a.D + 31) & ~31); i += 256) su[i] = i < a.D ? a.u[i] : 0.0;
-  __syncthreads();
-  const int li = lane & 15, lk = lane >> 4, rb = wave >> 1, cb = wave & 1;
+  const int li = lane & 15, lk = lane >> 4;
   const int D = a.D, S = a.S;
-  const int arow = blockIdx.x * 32 + rb * 16 + li;  // row of [R; Rbar]
-  const int bcol = blockIdx.y * 32 + cb * 16 + li;  // column of theta = row of U
+  const int arow = blockIdx.x * 16 + li;            // row of [R; Rbar]
+  const int bcol = blockIdx.y * 16 + li;            // column of theta = row of U
   const double* rp = (arow < S ? a.R + (size_t)arow * a.ld : a.Rbar) + 8 * lk;
   const double* up = a.U + (size_t)(bcol < D ? bcol : 0) * a.ldu + 8 * lk;
   const bool aok = arow <= S, bok = bcol < D;
-  const int k0 = blockIdx.y * 32;                   // (U[c][i] = 0 for i < c)
+  const int k0 = (blockIdx.y * 16) & ~31;           // (U[c][i] = 0 for i < c)
   auto fetch = [&](int kb, double (&xa)[8], double (&xb)[8]) {
     const int kk = kb + 8 * lk;
     if (kk + 8 <= D) {
@@ -635,34 +637,44 @@ __global__ __launch_bounds__(256) void lrp_draw_kernel(LpDrawArgs a) {
       for (int q = 0; q < 8; ++q) xb[q] = 0.0;
     }
   };
-  auto shift = [&](int kb, double (&xa)[8]) {       // r + u (rows that exist; the pad of su is zero)
-    if (aok) {
-#pragma unroll
-      for (int q = 0; q < 8; ++q) xa[q] += su[kb + 8 * lk + q];
-    }
-  };
   lp4d acc = (lp4d){0.0, 0.0, 0.0, 0.0};
   double xa[3][8], xb[3][8];
-  fetch(k0, xa[0], xb[0]);
-  if (k0 + 32 < D) fetch(k0 + 32, xa[1], xb[1]);
-  for (int kb = k0; kb < D; kb += 96) {
+  const int first = k0 + 32 * wave;
+  // (the loads do not need u: they go out before the copy of u into LDS is waited for)
+#pragma unroll
+  for (int u = 0; u < 3; ++u) if (first + 128 * u < D) fetch(first + 128 * u, xa[u], xb[u]);
+  for (int i = tid; i < ((D + 31) & ~31); i += 256) su[i] = i < D ? a.u[i] : 0.0;
+  __syncthreads();
+  for (int kb = first; kb < D; kb += 384) {
+    if (kb != first) {
+#pragma unroll
+      for (int u = 0; u < 3; ++u) if (kb + 128 * u < D) fetch(kb + 128 * u, xa[u], xb[u]);
+    }
 #pragma unroll
     for (int u = 0; u < 3; ++u) {
-      const int kc = kb + 32 * u;
+      const int kc = kb + 128 * u;
       if (kc < D) {
-        if (kc + 64 < D) fetch(kc + 64, xa[(u + 2) % 3], xb[(u + 2) % 3]);
-        shift(kc, xa[u]);
+        if (aok) {                                  // r + u (rows that exist; the pad of su is zero)
+#pragma unroll
+          for (int q = 0; q < 8; ++q) xa[u][q] += su[kc + 8 * lk + q];
+        }
         acc = lp_mma(xa[u], xb[u], acc);
       }
     }
   }
-  const int col = blockIdx.y * 32 + cb * 16 + li;
 #pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    const int row = blockIdx.x * 32 + rb * 16 + lk + 4 * r;
-    const double v = col < D ? acc[r] : 0.0;
-    if (row < S && col < a.ld) a.theta[(size_t)row * a.ld + col] = v;
-    else if (row == S && col < D) a.tbar[col] = v;
+  for (int r = 0; r < 4; ++r) red[wave][r][lane] = acc[r];
+  __syncthreads();
+  if (wave == 0) {
+    const int col = blockIdx.y * 16 + li;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int row = blockIdx.x * 16 + lk + 4 * r;
+      const double t = ((red[0][r][lane] + red[1][r][lane]) + red[2][r][lane]) + red[3][r][lane];
+      const double v = col < D ? t : 0.0;
+      if (row < S && col < a.ld) a.theta[(size_t)row * a.ld + col] = v;
+      else if (row == S && col < D) a.tbar[col] = v;
+    }
   }
 }
 
@@ -798,7 +810,7 @@ extern "C" int bcx_linreg_posterior_draw_factored(void* stream, int32_t D, int32
   LpDrawArgs a;
   a.U = (const double*)U_dev; a.u = (const double*)u_dev; a.R = (const double*)R_dev; a.Rbar = (const double*)Rbar_dev;
   a.theta = (double*)theta_dev; a.tbar = (double*)tbar_dev; a.ldu = ldu; a.D = D; a.S = S; a.ld = ld;
-  hipLaunchKernelGGL(lrp_draw_kernel, dim3((S + 1 + 31) / 32, (ld + 31) / 32), dim3(256), 0, (hipStream_t)stream, a);
+  hipLaunchKernelGGL(lrp_draw_kernel, dim3((S + 1 + 15) / 16, (ld + 15) / 16), dim3(256), 0, (hipStream_t)stream, a);
   LRP_HIP(hipGetLastError());
   return BCX_OK;
 }
