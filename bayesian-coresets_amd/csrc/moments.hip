@@ -16,8 +16,8 @@
 //                          upper triangle, slice of rows); operands staged through LDS, next chunk prefetched in registers
 //   moments_reduce_kernel  partials summed in slice order (fixed association: reproducible), both triangles written
 //   moments_mean_kernel    thetabar
-//   moments_quad_kernel    T_s: Delta G on the fp64 matrix cores (one wave per 16 x 16 tile), the last workgroup to finish
-//                          sums the tile partials, centres and scales
+//   moments_quad_kernel    T_s: Delta G on the fp64 matrix cores (a workgroup per 16 x 16 tile, its waves sharing the inner index),
+//                          workgroup 0 sums the tile partials as they appear, centres and scales
 #include <algorithm>
 #include <string>
 #include "bcx_internal.h"
@@ -422,7 +422,8 @@ extern "C" int64_t bcx_project_colsum_moments_scratch_bytes(int32_t D, int32_t S
 
 // colsum_dev[s] = sum_n vecs[n][s] of the linear-regression projection of the data whose moments are M_dev (features in
 // rows/columns [0, D), response in row/column ycol), for the S parameter rows of theta_dev.  work_dev:
-// bcx_project_colsum_moments_scratch_bytes(D, S) bytes, ZERO before the first call (the kernel leaves its counter zero).
+// bcx_project_colsum_moments_scratch_bytes(D, S) bytes, ZERO before the first call (the kernel leaves them zero: a zero word
+// is a partial sum not written yet, csrc/moments_quad.h).
 // tbar_dev: the point the quadratic is expanded around, D doubles (any point near the draws serves -- the expansion is exact;
 // csrc/svi.hip leaves the mean of the draws it makes), or NULL: their mean is formed here.
 extern "C" int bcx_project_colsum_moments_at(void* stream, const void* M_dev, int64_t ldm, int32_t D, int32_t ycol,

@@ -21,8 +21,8 @@ static __device__ __forceinline__ void mom_st(double* p, double v) {
 // k steps 4 t + wave of the D rows of G (v_mfma_f64_16x16x4_f64; lane group lk feeds k = 8 t + 2 lk (+1) to steps 2 t (2 t + 1):
 // one 16-byte load of theta per two steps) and meet in LDS in wave order -- the chain of dependent load batches is a
 // quarter as long as with one wave per tile (this kernel is all latency: 46 MFLOP).
-// Partials [column tile][sample] go to `work`; the last workgroup to arrive sums them in tile order, centres and scales.
-// work: nct * Spad partials, then one arrival counter (self-resetting).
+// Partials [column tile][sample] go to `work`; workgroup 0 sums them in tile order as they appear, centres and scales.
+// work: nct * Spad partials (zero between calls: a zero is "not written yet"), then one word that is no longer used.
 #define MQ_U 12
 // sc1 load without a wait of its own: the caller issues a batch, waits once (s_waitcnt vmcnt(0)) and ties the values
 // (atomic loads are issued and awaited one by one: nct round trips in the closing sum)
@@ -47,7 +47,6 @@ static __device__ __forceinline__ void moments_quad_body(const MqArgs& q, const 
   double* __restrict__ colsum = q.colsum; double* __restrict__ work = q.work; const int nct = q.nct, Spad = q.Spad, dbg = q.dbg;
   __shared__ double scratch[BCX_SCRATCH];
   __shared__ double red[4][4][64];
-  __shared__ int last;
   long long stamp[8];
 #define MQ_STAMP(i) do { if (dbg) { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); stamp[i] = wall_clock64(); } } while (0)
   MQ_STAMP(0);
@@ -117,47 +116,54 @@ static __device__ __forceinline__ void moments_quad_body(const MqArgs& q, const 
         v += bcx_dpp_f64<0x4E>(v);
         v += bcx_dpp_f64<0x141>(v);
         v += bcx_dpp_f64<0x140>(v);
-        if (li == 0) mom_st(&work[(size_t)ct * Spad + sr], v);
+        // a partial is its own "ready": the scratch is zero between calls and a partial never is (+0.0 leaves as -0.0,
+        // which adds the same)
+        if (li == 0) mom_st(&work[(size_t)ct * Spad + sr], __double_as_longlong(v) == 0 ? -0.0 : v);
       }
     }
   }
-  unsigned* counter = (unsigned*)(work + (size_t)nct * Spad);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
   MQ_STAMP(2);
-  if (tid == 0) {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    last = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)nblk - 1u;
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-  }
-  __syncthreads();
+  if (bx != 0) return;
+  // Workgroup 0 closes: it loads every sample's partials (sc1) until none of them is the zero the scratch held -- no arrival
+  // counter, no drained stores, no fences, and the loads that wait are the loads that sum (tile order: the same bits
+  // whoever finishes last) -- then centres, scales, and leaves the scratch zero for the next call.
   MQ_STAMP(3);
-  if (!last) return;
-  // the last workgroup to arrive: every partial is in memory; tile order, then sample order -- the same bits whichever it is
+  __shared__ int late;
+  if (tid == 0) late = 0;
+  __syncthreads();
   double m[1] = {0.0};
+  const long long t0 = wall_clock64();
   for (int u = tid; u < S; u += 256) {
     double t = 0.0;
     for (int c0 = 0; c0 < nct; c0 += 16) {
       double v[16];
+      for (;;) {
 #pragma unroll
-      for (int q = 0; q < 16; ++q) v[q] = mom_ld_nowait(work + (size_t)(c0 + q < nct ? c0 + q : c0) * Spad + u);
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        for (int q = 0; q < 16; ++q) v[q] = mom_ld_nowait(work + (size_t)(c0 + q < nct ? c0 + q : c0) * Spad + u);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        bool ok = true;
 #pragma unroll
-      for (int q = 0; q < 16; ++q) {
-        asm volatile("" : "+v"(v[q]));
-        if (c0 + q < nct) t += v[q];
+        for (int q = 0; q < 16; ++q) {
+          asm volatile("" : "+v"(v[q]));
+          ok &= __double_as_longlong(v[q]) != 0;
+        }
+        if (ok) break;
+        __builtin_amdgcn_s_sleep(1);
+        if (wall_clock64() - t0 > 200000000LL) { late = 1; break; }      // 2 s: a producer never ran -- NaN out, loudly
       }
+#pragma unroll
+      for (int q = 0; q < 16; ++q) if (c0 + q < nct) t += v[q];
     }
-    mom_st(&work[u], t);
+    work[u] = t;                                    // (this thread's own slot of tile 0: read back below by the same thread)
     m[0] += t;
   }
   __syncthreads();
   MQ_STAMP(4);
   block_allsum<1>(m, scratch);
-  const double mean = m[0] / (double)S, f = -1.0 / (2.0 * sigsq);
-  for (int u = tid; u < S; u += 256) colsum[u] = f * (mom_ld(work + u) - mean);
-  if (tid == 0) __hip_atomic_store(counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  const double mean = late ? __longlong_as_double(0x7ff8000000000000LL) : m[0] / (double)S, f = -1.0 / (2.0 * sigsq);
+  for (int u = tid; u < S; u += 256) colsum[u] = f * (work[u] - mean);
+  __syncthreads();
+  for (int e = tid; e < nct * Spad; e += 256) work[e] = 0.0;
   if (dbg) {
     MQ_STAMP(5);
     if (tid == 0) {

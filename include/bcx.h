@@ -247,7 +247,8 @@ int bcx_project_select_ws(void* stream, int32_t family, const void* Z_dev, int64
  *   bcx_project_colsum_moments colsum_dev[s] = sum_n vecs[n][s] (centred over s, as bcx_project_colsum returns it) for the
  *                              data whose moments are M_dev (features in [0, D), response at ycol): thetabar, then
  *                              Delta G on the fp64 matrix cores; work_dev: bcx_project_colsum_moments_scratch_bytes(D, S)
- *                              bytes, zero before the first call (the call leaves its arrival counter zero). */
+ *                              bytes, ZERO before the first call (every call leaves them zero: a zero word is a partial
+ *                              sum that has not been written yet). */
 int64_t bcx_project_moments_scratch_bytes(int64_t N, int32_t C);
 int64_t bcx_project_colsum_moments_scratch_bytes(int32_t D, int32_t S);
 int bcx_project_moments(void* stream, const void* Z_dev, int64_t N, int64_t ldz, int32_t C, void* M_dev, int64_t ldm,
