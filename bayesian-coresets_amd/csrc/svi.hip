@@ -525,7 +525,14 @@ __global__ __launch_bounds__(256) void svi_adam_b_kernel(SvbArgs a) {
   for (int s = tid; s < a.S; s += 256) {
     double t = 0.0;
     int b = 0;
-    for (; b + 8 <= nslab; b += 8) {                // (eight shares in flight; added in slab order)
+    for (; b + 32 <= nslab; b += 32) {              // (thirty-two shares in flight -- 300 weights: ONE round trip; added in slab order)
+      double v[32];
+#pragma unroll
+      for (int q = 0; q < 32; ++q) v[q] = a.part[(size_t)(b + q) * a.S + s];
+#pragma unroll
+      for (int q = 0; q < 32; ++q) t += v[q];
+    }
+    for (; b + 8 <= nslab; b += 8) {
       double v[8];
 #pragma unroll
       for (int q = 0; q < 8; ++q) v[q] = a.part[(size_t)(b + q) * a.S + s];
