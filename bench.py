@@ -928,9 +928,9 @@ def side_legs(args, out, torch, dist, nat):
         out["c5_select_kernel_ms"] = (r.get("k_curve", {}).get("300") or {}).get("select_kernel_ms")
         # which kernels an ADAM step is made of at each size: profiles/r06_c5_adam_k*.txt (rocprofv3 traces of tools/c5_ksweep.py)
         out["c5_adam_kernels"] = ("k <= 4 + 2 ceil(D / 32) (= 24): lrs_apply_kernel (rank-k form, every workgroup repeats the k x k "
-                                  "Cholesky) dominates from k ~ 8; beyond: lrp_chol_kernel (cooperative D x D Cholesky + inverse, "
-                                  "~57 % of the step), then moments_quad_kernel, lrp_form_kernel, proj_mid_kernel, lrp_draw_kernel, "
-                                  "svi_adam_a / b_kernel")
+                                  "Cholesky) dominates from k ~ 8; beyond: lrp_chol_kernel (cooperative D x D Cholesky + inverse on one XCD, "
+                                  "~56 % of the step), then proj_mid_quad_kernel (closed-form column sums and the coreset points' "
+                                  "projection in one launch), lrp_form_kernel, svi_adam_a / b_kernel, lrp_draw_kernel")
     gram_leg(out, torch, nat)
     optimize_leg(out, torch, nat)
 
