@@ -133,7 +133,9 @@ static __device__ __forceinline__ void moments_quad_body(const MqArgs& q, const 
   __syncthreads();
   double m[1] = {0.0};
   const long long t0 = wall_clock64();
-  for (int u = tid; u < S; u += 256) {
+  // (the padded samples S .. Spad - 1 are waited for too: their producers' stores must have landed before the scratch is
+  // zeroed again below)
+  for (int u = tid; u < Spad; u += 256) {
     double t = 0.0;
     for (int c0 = 0; c0 < nct; c0 += 16) {
       double v[16];
@@ -154,8 +156,10 @@ static __device__ __forceinline__ void moments_quad_body(const MqArgs& q, const 
 #pragma unroll
       for (int q = 0; q < 16; ++q) if (c0 + q < nct) t += v[q];
     }
-    work[u] = t;                                    // (this thread's own slot of tile 0: read back below by the same thread)
-    m[0] += t;
+    if (u < S) {
+      work[u] = t;                                  // (this thread's own slot of tile 0: read back below by the same thread)
+      m[0] += t;
+    }
   }
   __syncthreads();
   MQ_STAMP(4);
