@@ -35,7 +35,7 @@ static void free_all(bcx_solver* s) {
     if (p) (void)hipFree(p);
   for (size_t w = 0; w < s->peer_mbox.size(); ++w)
     if (s->peer_mbox[w] && s->peer_mbox[w] != s->mbox) (void)hipIpcCloseMemHandle(s->peer_mbox[w]);
-  void* xptrs[] = {s->mbox, s->peer_tab, s->xseq, s->xprobe, s->rec_gather, s->grid_counter, s->fin_part, s->gram_work, s->warm_buf};
+  void* xptrs[] = {s->mbox, s->peer_tab, s->xseq, s->xprobe, s->rec_gather, s->grid_counter, s->fin_part, s->gram_work, s->warm_buf, s->pflags, s->pdbg};
   for (void* p : xptrs)
     if (p) (void)hipFree(p);
   for (auto& ev : s->prof_events) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
@@ -424,25 +424,31 @@ extern "C" int bcx_build_begin(bcx_solver* s, int64_t itrs, double tol, int32_t*
 
 // Event pairs around the scan launch, on every prof_every-th launch: a pair costs 7-12 us of stream time
 // (measured: GIGA N=1M d=256 171 -> 159 us per iteration without them), so the bench samples.
-static int prof_begin(bcx_solver* s) {
+// (weight: greedy iterations the bracketed launch covers -- 1, or a whole batch of them for persist.hip, which times EVERY
+// launch: a pair per ~100 iterations costs nothing)
+int bcx_prof_begin(bcx_solver* s, int weight, bool every_launch) {
   if (!s->profile) return BCX_OK;
-  s->prof_now = (s->prof_tick++ % s->prof_every) == 0;
+  s->prof_now = every_launch || (s->prof_tick++ % s->prof_every) == 0;
   if (!s->prof_now) return BCX_OK;
   if (s->prof_used == s->prof_events.size()) {
     hipEvent_t a, b;
     BCX_HIP(hipEventCreate(&a));
     BCX_HIP(hipEventCreate(&b));
     s->prof_events.emplace_back(a, b);
+    s->prof_weight.push_back(1);
   }
+  s->prof_weight[s->prof_used] = weight;
   BCX_HIP(hipEventRecord(s->prof_events[s->prof_used].first, s->stream));
   return BCX_OK;
 }
-static int prof_end(bcx_solver* s) {
+int bcx_prof_end(bcx_solver* s) {
   if (!s->profile || !s->prof_now) return BCX_OK;
   BCX_HIP(hipEventRecord(s->prof_events[s->prof_used].second, s->stream));
   s->prof_used++;
   return BCX_OK;
 }
+static int prof_begin(bcx_solver* s) { return bcx_prof_begin(s, 1, false); }
+static int prof_end(bcx_solver* s) { return bcx_prof_end(s); }
 
 static int step_scan(bcx_solver* s, void* send_dev, int exact, bool with_tail) {
   if (!s->finalized) { s->err = "solver not finalized"; return BCX_ERR_STATE; }
@@ -496,9 +502,21 @@ static int enqueue_one(bcx_solver* s, int exact) {
 extern "C" int bcx_build_enqueue(bcx_solver* s, int64_t itrs) {
   if (!s) return BCX_ERR_ARG;
   if (!s->finalized) { s->err = "solver not finalized"; return BCX_ERR_STATE; }
-  for (int64_t i = 0; i < itrs; ++i) {
-    int rc = enqueue_one(s, 0);
+  int64_t i = 0;
+  // single shard, GIGA / FW, a few GB of rows: batches of iterations per launch with the tail's workgroup resident beside
+  // the scan's (persist.hip); everything else, and what that form declines: one launch per kernel
+  bool batches = s->cfg.world_size == 1 && s->cfg.alg != BCX_ALG_OMP;
+  while (i < itrs) {
+    if (batches) {
+      int64_t covered = 0;
+      const int rc = bcx_launch_persist(s, itrs - i, &covered);
+      if (rc == BCX_OK) { i += covered; continue; }
+      if (rc != 1) return rc;
+      batches = false;
+    }
+    const int rc = enqueue_one(s, 0);
     if (rc != BCX_OK) return rc;
+    ++i;
   }
   return BCX_OK;
 }
@@ -657,7 +675,11 @@ extern "C" int bcx_build_poll(bcx_solver* s, int64_t* n_done, int32_t* need_exac
     for (size_t i = 0; i < s->prof_used; ++i) {
       float ms = 0.f;
       if (hipEventElapsedTime(&ms, s->prof_events[i].first, s->prof_events[i].second) != hipSuccess) continue;
-      if ((double)ms >= min_ms) { s->prof_ms += ms; s->prof_launches++; }
+      const int w = s->prof_weight[i];
+      // (a launch of several iterations counts only when the call ran all of its iterations: one that stopped on the way
+      //  -- latch, exact redo -- covered fewer than w)
+      if (w > 1 && h.it != h.itrs) continue;
+      if ((double)ms >= min_ms * w) { s->prof_ms += ms; s->prof_launches += w; }
     }
     s->prof_used = 0;
   }

@@ -173,6 +173,10 @@ struct bcx_solver {
   int32_t* tr_status = nullptr;
   bool finalized = false;
   int64_t rows_loaded = 0;
+  // persist.hip: several iterations per launch
+  unsigned* pflags = nullptr;    // [0] GO (tail -> scan workgroups), [1 + b] stamp of scan workgroup b; sequence numbers
+  uint64_t pseq = 0;             // iterations enqueued that way so far (they never restart)
+  long long* pdbg = nullptr;     // dev: time stamps of the last launch (BCX_PERSIST_DBG)
   // measurement
   bool profile = false;
   bool prof_now = false;
@@ -181,6 +185,7 @@ struct bcx_solver {
   double prof_ms = 0.0;
   int64_t prof_launches = 0;
   std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_events;
+  std::vector<int> prof_weight;  // greedy iterations each pair brackets (1; a batch for persist.hip)
   size_t prof_used = 0;
 };
 
@@ -193,6 +198,9 @@ int bcx_launch_resolve(bcx_solver* s, double* send_dev, int exact);
 int bcx_launch_begin(bcx_solver* s, int64_t itrs, double tol);
 int bcx_launch_apply(bcx_solver* s, const double* recv_dev);
 int bcx_launch_tail(bcx_solver* s, int exact);
+int bcx_launch_persist(bcx_solver* s, int64_t iters, int64_t* covered);   // persist.hip: one launch of up to `iters` iterations; 1 = not applicable
+int bcx_prof_begin(bcx_solver* s, int weight, bool every_launch);          // api.hip: event pair around a scan launch (bcx_profile_scan)
+int bcx_prof_end(bcx_solver* s);
 int bcx_launch_omp_fused(bcx_solver* s, int exact);   // nnls.hip: scan partials -> OMP step in one launch; 1 = not applicable
 int bcx_launch_tail_exchange(bcx_solver* s, int exact);   // resolve + mailbox exchange + apply (world_size > 1)
 int bcx_launch_exchange_probe(bcx_solver* s);

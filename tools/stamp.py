@@ -29,7 +29,7 @@ def kernel_digest(kind):
     file, the headers it includes and the compiler flags -- so that an edit elsewhere in csrc/ does not void it.
     kind: "scan" (csrc/scan.hip) or "proj" (csrc/proj.hip)."""
     pkg = os.path.join(ROOT, "bayesian-coresets_amd")
-    names = {"scan": ["scan.hip", "dev_util.h", "bcx_internal.h"],
+    names = {"scan": ["scan.hip", "scan_core.h", "dev_util.h", "bcx_internal.h"],
              "proj": ["proj.hip", "proj_math.h", "moments_quad.h", "dev_util.h", "bcx_internal.h"]}[kind]
     return _digest([os.path.join(pkg, "csrc", n) for n in names] + [os.path.join(ROOT, "include", "bcx.h"), os.path.join(pkg, "Makefile")])
 
