@@ -101,6 +101,17 @@ static __device__ __forceinline__ dd dd_wave_allsum(dd v) {
   return v;
 }
 
+// dev builds (-DBCX_OPT_PROFILE, tools/optimize_ab.sh): wall-clock ticks of optimize_lh_kernel by phase, accumulated in
+// registers of workgroup 0 (prof[0..9]; prof[10] = the previous stamp) and left in DevState::dbg_t[0..7], [19], [31]
+static __device__ __forceinline__ void optp(long long* prof, int i) {
+  if (prof) { const long long now = wall_clock64(); prof[i] += now - prof[10]; prof[10] = now; }
+}
+
+// Elements of a row of H a lane keeps in flight in the owner-computes passes (hi and lo words: 2 * OMPL_NB loads per round
+// trip).  Written one element at a time (load, arithmetic, store) the compiler keeps the order -- the hi and lo rows may alias
+// as far as it knows -- and a pass over a row of 1024 entries was 16 dependent round trips.  8 with up to 512 threads per
+// workgroup, 2 with 1024 (128 VGPRs per lane: 3 and more spill).
+#define OMPL_NB_FOR(threads) ((threads) >= 1024 ? 2 : 8)
 struct OmpLds {
   double *g, *gl, *u, *ul, *x, *z, *xs;   // g / u (hi, lo) / z / xs by position, x by slot
   double *xfs, *qs, *bs;                  // winner's row, residual query (later: refinement scratch), b
@@ -108,19 +119,19 @@ struct OmpLds {
 };
 
 // (u, mon)[rr] = (H[rr] . v in double-double, H_hi[rr] . m in double) for the rows this wave owns; m may be null
-static __device__ __forceinline__ void ompl_mv_rows(const NnlsArgs& n, int p, const double* v, const double* m, double* Uh, double* Ul, double* M) {
+template <int OMPL_NB> static __device__ __forceinline__ void ompl_mv_rows(const NnlsArgs& n, int p, const double* v, const double* m, double* Uh, double* Ul, double* M) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
   for (int rr = blockIdx.x * nw + wave; rr < p; rr += gridDim.x * nw) {
     const double* hh = n.hinv + (size_t)rr * n.ldg;
     const double* hl = n.hlo + (size_t)rr * n.ldg;
     dd acc = dd_make(0.0, 0.0);
     double mon = 0.0;
-    for (int c0 = 0; c0 < p; c0 += 256) {
-      double a[4], b[4];
+    for (int c0 = 0; c0 < p; c0 += 64 * OMPL_NB) {
+      double a[OMPL_NB], b[OMPL_NB];
 #pragma unroll
-      for (int t = 0; t < 4; ++t) { const int c = c0 + t * 64 + lane; a[t] = c < p ? hh[c] : 0.0; b[t] = c < p ? hl[c] : 0.0; }
+      for (int t = 0; t < OMPL_NB; ++t) { const int c = c0 + t * 64 + lane; a[t] = c < p ? hh[c] : 0.0; b[t] = c < p ? hl[c] : 0.0; }
 #pragma unroll
-      for (int t = 0; t < 4; ++t) {
+      for (int t = 0; t < OMPL_NB; ++t) {
         const int c = c0 + t * 64 + lane;
         if (c < p) {
           acc = dd_add(acc, dd_mul_d(dd_make(a[t], b[t]), v[c]));
@@ -136,16 +147,26 @@ static __device__ __forceinline__ void ompl_mv_rows(const NnlsArgs& n, int p, co
 
 // H <- [[H + u u^T / s, -u/s], [-u^T/s, 1/s]] for the column entering at position p (inv = 1/s): every wave updates the rows
 // it owns, in double-double
-static __device__ __forceinline__ void ompl_border_apply(const NnlsArgs& n, const OmpLds& L, int p, dd inv) {
+template <int OMPL_NB> static __device__ __forceinline__ void ompl_border_apply(const NnlsArgs& n, const OmpLds& L, int p, dd inv) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
   const int64_t ld = n.ldg;
   for (int rr = blockIdx.x * nw + wave; rr < p; rr += gridDim.x * nw) {
     const dd wr = dd_mul(dd_make(L.u[rr], L.ul[rr]), inv);
     double* hh = n.hinv + (size_t)rr * ld;
     double* hl = n.hlo + (size_t)rr * ld;
-    for (int cc = lane; cc < p; cc += 64) {
-      const dd v = dd_add(dd_make(hh[cc], hl[cc]), dd_mul(wr, dd_make(L.u[cc], L.ul[cc])));
-      hh[cc] = v.h; hl[cc] = v.l;
+    for (int c0 = 0; c0 < p; c0 += 64 * OMPL_NB) {
+      // three phases without a branch in the first two: loads (index clamped into the row), arithmetic, then the stores
+      double a[OMPL_NB], b[OMPL_NB];
+#pragma unroll
+      for (int t = 0; t < OMPL_NB; ++t) { const int cc = min(c0 + t * 64 + lane, p - 1); a[t] = hh[cc]; b[t] = hl[cc]; }
+#pragma unroll
+      for (int t = 0; t < OMPL_NB; ++t) {
+        const int cc = min(c0 + t * 64 + lane, p - 1);
+        const dd v = dd_add(dd_make(a[t], b[t]), dd_mul(wr, dd_make(L.u[cc], L.ul[cc])));
+        a[t] = v.h; b[t] = v.l;
+      }
+#pragma unroll
+      for (int t = 0; t < OMPL_NB; ++t) { const int cc = c0 + t * 64 + lane; if (cc < p) { hh[cc] = a[t]; hl[cc] = b[t]; } }
     }
     if (lane == 0) { hh[p] = -wr.h; hl[p] = -wr.l; }
   }
@@ -160,10 +181,33 @@ static __device__ __forceinline__ void ompl_border_apply(const NnlsArgs& n, cons
   }
 }
 
+// the whole workgroup: an exchange vector pair (hi, lo) into LDS, four sc1 loads of each in flight per thread
+static __device__ __forceinline__ void ompl_fetch_pair(const double* Xh, const double* Xl, double* dh, double* dl, int p) {
+  for (int a0 = 0; a0 < p; a0 += 4 * (int)blockDim.x) {
+    double h[4], l[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) { const int a = min(a0 + t * (int)blockDim.x + (int)threadIdx.x, p - 1); h[t] = xld(&Xh[a]); l[t] = xld(&Xl[a]); }
+#pragma unroll
+    for (int t = 0; t < 4; ++t) { const int a = a0 + t * (int)blockDim.x + (int)threadIdx.x; if (a < p) { dh[a] = h[t]; dl[a] = l[t]; } }
+  }
+}
+
+// one wave: a row of H (hi, lo) into an exchange buffer pair, all loads of a batch before its write-through stores
+template <int OMPL_NB> static __device__ __forceinline__ void ompl_publish_row(const double* hh, const double* hl, double* Xh, double* Xl, int p) {
+  const int lane = threadIdx.x & 63;
+  for (int c0 = 0; c0 < p; c0 += 64 * OMPL_NB) {
+    double a[OMPL_NB], b[OMPL_NB];
+#pragma unroll
+    for (int t = 0; t < OMPL_NB; ++t) { const int cc = min(c0 + t * 64 + lane, p - 1); a[t] = hh[cc]; b[t] = hl[cc]; }
+#pragma unroll
+    for (int t = 0; t < OMPL_NB; ++t) { const int cc = c0 + t * 64 + lane; if (cc < p) { xst(&Xh[cc], a[t]); xst(&Xl[cc], b[t]); } }
+  }
+}
+
 // Position q leaves the passive set: closed-form update of the carried solution z, rank-1 downdate of H (double-double),
 // the last position moves into the hole (z, the feasible point xs and the lists move with it).  ONE barrier: the owners
 // publish row q and the not yet downdated row `last` together, every workgroup downdates its copy of the latter itself.
-static __device__ __forceinline__ void ompl_remove(const NnlsArgs& n, const OmpLds& L, int& p, int q, Grid& G) {
+template <int OMPL_NB> static __device__ __forceinline__ void ompl_remove(const NnlsArgs& n, const OmpLds& L, int& p, int q, Grid& G, long long* prof = nullptr) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = blockDim.x >> 6;
   const int64_t ld = n.ldg;
   const int last = p - 1;
@@ -174,15 +218,17 @@ static __device__ __forceinline__ void ompl_remove(const NnlsArgs& n, const OmpL
   if (owns_row(q)) {                                // row q == column q (symmetric): its owner publishes it
     const double* hh = n.hinv + (size_t)q * ld;
     const double* hl = n.hlo + (size_t)q * ld;
-    for (int cc = lane; cc < p; cc += 64) { xst(&Xh[cc], hh[cc]); xst(&Xl[cc], hl[cc]); }
+    ompl_publish_row<OMPL_NB>(hh, hl, Xh, Xl, p);
   }
   if (q != last && owns_row(last)) {
     const double* hh = n.hinv + (size_t)last * ld;
     const double* hl = n.hlo + (size_t)last * ld;
-    for (int cc = lane; cc < p; cc += 64) { xst(&Yh[cc], hh[cc]); xst(&Yl[cc], hl[cc]); }
+    ompl_publish_row<OMPL_NB>(hh, hl, Yh, Yl, p);
   }
+  optp(prof, 6);
   gsync(G);
-  for (int a = tid; a < p; a += blockDim.x) { L.g[a] = xld(&Xh[a]); L.gl[a] = xld(&Xl[a]); }   // h = H[:, q] (g is free by now)
+  optp(prof, 7);
+  ompl_fetch_pair(Xh, Xl, L.g, L.gl, p);                                                        // h = H[:, q] (g is free by now)
   __syncthreads();
   const dd hqq = dd_make(L.g[q], L.gl[q]);
   const dd iq = dd_recip(hqq);
@@ -190,14 +236,24 @@ static __device__ __forceinline__ void ompl_remove(const NnlsArgs& n, const OmpL
   if (q != last) {
     // the downdated row `last` (what moves into the hole), formed by everybody from the two published rows
     const dd fl = dd_mul(dd_make(L.g[last], L.gl[last]), iq);
-    for (int a = tid; a < p; a += blockDim.x) {
-      const dd v = dd_add(dd_make(xld(&Yh[a]), xld(&Yl[a])), dd_neg(dd_mul(fl, dd_make(L.g[a], L.gl[a]))));
-      L.u[a] = v.h; L.ul[a] = v.l;
+    for (int a0 = 0; a0 < p; a0 += 4 * (int)blockDim.x) {
+      double yh[4], yl[4];
+#pragma unroll
+      for (int t = 0; t < 4; ++t) { const int a = min(a0 + t * (int)blockDim.x + tid, p - 1); yh[t] = xld(&Yh[a]); yl[t] = xld(&Yl[a]); }
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const int a = a0 + t * (int)blockDim.x + tid;
+        if (a < p) {
+          const dd v = dd_add(dd_make(yh[t], yl[t]), dd_neg(dd_mul(fl, dd_make(L.g[a], L.gl[a]))));
+          L.u[a] = v.h; L.ul[a] = v.l;
+        }
+      }
     }
   }
   __syncthreads();                                                   // every thread has read z[q] (f) before z[q] is rewritten
   for (int a = tid; a < p; a += blockDim.x) L.z[a] -= f * L.g[a];    // least-squares solution on P \ {q}
   __syncthreads();
+  optp(prof, 8);
   for (int rr = blockIdx.x * nw + wave; rr < last; rr += gridDim.x * nw) {
     // rows that stay: downdate; row q takes the downdated row `last`, column q of every row its entry of it
     double* hh = n.hinv + (size_t)rr * ld;
@@ -209,10 +265,20 @@ static __device__ __forceinline__ void ompl_remove(const NnlsArgs& n, const OmpL
       }
     } else {
       const dd fr = dd_mul(dd_make(L.g[rr], L.gl[rr]), iq);
-      for (int cc = lane; cc < last; cc += 64) {
-        if (cc == q && q != last) { hh[cc] = L.u[rr]; hl[cc] = L.ul[rr]; continue; }
-        const dd v = dd_add(dd_make(hh[cc], hl[cc]), dd_neg(dd_mul(fr, dd_make(L.g[cc], L.gl[cc]))));
-        hh[cc] = v.h; hl[cc] = v.l;
+      for (int c0 = 0; c0 < last; c0 += 64 * OMPL_NB) {
+        double a[OMPL_NB], b[OMPL_NB];
+#pragma unroll
+        for (int t = 0; t < OMPL_NB; ++t) { const int cc = min(c0 + t * 64 + lane, last - 1); a[t] = hh[cc]; b[t] = hl[cc]; }
+        const double mvh = L.u[rr], mvl = L.ul[rr];                   // (read only where q != last: column q takes the moved row's entry)
+#pragma unroll
+        for (int t = 0; t < OMPL_NB; ++t) {
+          const int cc = min(c0 + t * 64 + lane, last - 1);
+          const dd v = dd_add(dd_make(a[t], b[t]), dd_neg(dd_mul(fr, dd_make(L.g[cc], L.gl[cc]))));
+          const bool hole = cc == q && q != last;
+          a[t] = hole ? mvh : v.h; b[t] = hole ? mvl : v.l;
+        }
+#pragma unroll
+        for (int t = 0; t < OMPL_NB; ++t) { const int cc = c0 + t * 64 + lane; if (cc < last) { hh[cc] = a[t]; hl[cc] = b[t]; } }
       }
     }
   }
@@ -228,13 +294,14 @@ static __device__ __forceinline__ void ompl_remove(const NnlsArgs& n, const OmpL
   }
   p = last;
   __syncthreads();
+  optp(prof, 9);
 }
 
 // Lawson-Hanson inner loop on the carried data: z = least-squares solution on the passive set, xs = a feasible point.
 // Columns leave until z > 0; then x <- z.  `entered`: the slot that just entered (left again at once => never re-picked).
 // n_out: members of the call's active set that are outside P and may still be picked (kept by every workgroup alike).
-static __device__ __forceinline__ int ompl_inner(const NnlsArgs& n, const OmpLds& L, int& p, int entered, int max_it, int& n_out, Grid& G,
-                                 double* scratch) {
+template <int OMPL_NB> static __device__ __forceinline__ int ompl_inner(const NnlsArgs& n, const OmpLds& L, int& p, int entered, int max_it, int& n_out, Grid& G,
+                                 double* scratch, long long* prof = nullptr) {
   const int tid = threadIdx.x;
   int removed = 0;
   for (int inner = 0; inner < max_it && G.ok && p > 0; ++inner) {
@@ -273,13 +340,15 @@ static __device__ __forceinline__ int ompl_inner(const NnlsArgs& n, const OmpLds
       }
       if (!rej) ++n_out;
       __syncthreads();
-      ompl_remove(n, L, p, top.i, G);
+      optp(prof, 5);
+      ompl_remove<OMPL_NB>(n, L, p, top.i, G, prof);
       ++removed;
       if (!G.ok) break;
     }
   }
   for (int a = tid; a < p; a += blockDim.x) L.x[L.cs[a]] = L.z[a];
   __syncthreads();
+  optp(prof, 5);
   return removed;
 }
 
@@ -290,6 +359,7 @@ static __device__ __forceinline__ int ompl_inner(const NnlsArgs& n, const OmpLds
 template <int THREADS>
 __global__ __launch_bounds__(THREADS) void omp_lh_kernel(NnlsArgs n, GridSync gs, unsigned long long* base_ptr, int kcap, int dpad,
                                                             int force_resolve, int fused, ResolveArgs rsv) {
+  constexpr int OMPL_NB = OMPL_NB_FOR(THREADS);
   const ApplyArgs& a = n.a;
   DevState* st = a.st;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = blockDim.x >> 6, d = a.d;
@@ -501,7 +571,7 @@ __global__ __launch_bounds__(THREADS) void omp_lh_kernel(NnlsArgs n, GridSync gs
     double* Uh = xbuf(n, G);
     double* Ul = xbuf(n, G);
     double* DZ = xbuf(n, G);
-    ompl_mv_rows(n, p, L.g, L.xs, Uh, Ul, DZ);
+    ompl_mv_rows<OMPL_NB>(n, p, L.g, L.xs, Uh, Ul, DZ);
     OMPL_STAMP(st, 4);
     gsync(G);                                                                                 // ---- B2
     OMPL_STAMP(st, 5);
@@ -524,7 +594,7 @@ __global__ __launch_bounds__(THREADS) void omp_lh_kernel(NnlsArgs n, GridSync gs
       // columns leave if that asks for it; then f enters from the re-solved state
       did_resolve = 1;
       g_passive_solve(n, R, p, 1, G, seg, scratch);       // (uses g / u / qs as scratch; H's high words)
-      n_removed += ompl_inner(n, L, p, -1, 3 * k1 + 16, n_out, G, scratch);
+      n_removed += ompl_inner<OMPL_NB>(n, L, p, -1, 3 * k1 + 16, n_out, G, scratch);
       for (int q = tid; q < p; q += blockDim.x) { L.xs[q] = L.x[L.cs[q]]; L.z[q] = L.xs[q]; }
       __syncthreads();
       have_u = false;
@@ -540,9 +610,9 @@ __global__ __launch_bounds__(THREADS) void omp_lh_kernel(NnlsArgs n, GridSync gs
         __syncthreads();
         double* U2h = xbuf(n, G);
         double* U2l = xbuf(n, G);
-        ompl_mv_rows(n, p, L.g, nullptr, U2h, U2l, nullptr);
+        ompl_mv_rows<OMPL_NB>(n, p, L.g, nullptr, U2h, U2l, nullptr);
         gsync(G);
-        for (int q = tid; q < p; q += blockDim.x) { L.u[q] = xld(&U2h[q]); L.ul[q] = xld(&U2l[q]); }
+        ompl_fetch_pair(U2h, U2l, L.u, L.ul, p);
         __syncthreads();
       }
       have_u = false;
@@ -577,7 +647,7 @@ __global__ __launch_bounds__(THREADS) void omp_lh_kernel(NnlsArgs n, GridSync gs
         const double t = wv / sc.h;
         const dd inv = dd_recip(sc);
         for (int q = tid; q < p; q += blockDim.x) L.z[q] -= t * L.u[q];
-        ompl_border_apply(n, L, p, inv);
+        ompl_border_apply<OMPL_NB>(n, L, p, inv);
         if (tid == 0) { L.z[p] = t; L.xs[p] = 0.0; L.cs[p] = cand; L.pos[cand] = p; }
         p += 1;
         ++n_entered;
@@ -586,7 +656,7 @@ __global__ __launch_bounds__(THREADS) void omp_lh_kernel(NnlsArgs n, GridSync gs
         __syncthreads();
       }
       if (cand < 0) break;                                // nothing entered, nothing can leave: x stays as it is, bit for bit
-      n_removed += ompl_inner(n, L, p, entered ? cand : -1, 3 * k1 + 16, n_out, G, scratch);
+      n_removed += ompl_inner<OMPL_NB>(n, L, p, entered ? cand : -1, 3 * k1 + 16, n_out, G, scratch);
       for (int q = tid; q < p; q += blockDim.x) { L.xs[q] = L.x[L.cs[q]]; L.z[q] = L.xs[q]; }
       __syncthreads();
       // next candidate: the member of S without weight that has the largest positive dual (only columns that left in this
@@ -738,7 +808,7 @@ __global__ __launch_bounds__(THREADS) void omp_lh_kernel(NnlsArgs n, GridSync gs
 // measures what the Gram-space recurrences lost -- it is applied when it is a correction (<= 1e-3 of the weights and every
 // weight stays positive); otherwise the launch restores the weights and reports OMP_OPT_FALLBACK, and the host runs the
 // refined solve of nnls_grid.hip instead.
-#define OPTL_MAX_WGS 64
+#define OPTL_MAX_WGS 128
 #define OPTL_BATCH 8
 // warm_p != null (csrc/warm.hip ran on the stream before this launch): the passive set does not start empty -- n.plist holds
 // *warm_p slots in order, n.hinv the (plain-double) inverse of their Gram block, low words zero.  The feasible point is the
@@ -746,6 +816,13 @@ __global__ __launch_bounds__(THREADS) void omp_lh_kernel(NnlsArgs n, GridSync gs
 // through the same inner loop as after any entering column, and the iteration goes on from there.
 template <int THREADS>
 __global__ __launch_bounds__(THREADS) void optimize_lh_kernel(NnlsArgs n, GridSync gs, double tol, int kcap, const int32_t* warm_p) {
+  constexpr int OMPL_NB = OMPL_NB_FOR(THREADS);
+#ifdef BCX_OPT_PROFILE
+  long long prof_[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  long long* const prof = prof_;
+#else
+  long long* const prof = nullptr;
+#endif
   const ApplyArgs& a = n.a;
   DevState* st = a.st;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = blockDim.x >> 6, d = a.d;
@@ -805,20 +882,24 @@ __global__ __launch_bounds__(THREADS) void optimize_lh_kernel(NnlsArgs n, GridSy
     if (p > 0) {
       double* Zh = xbuf(n, G);
       double* Zl = xbuf(n, G);
-      ompl_mv_rows(n, p, L.g, nullptr, Zh, Zl, nullptr);     // z = H c
+      ompl_mv_rows<OMPL_NB>(n, p, L.g, nullptr, Zh, Zl, nullptr);     // z = H c
       gsync(G);
       for (int q = tid; q < p; q += blockDim.x) L.z[q] = xld(&Zh[q]);
       __syncthreads();
       dg_p0 = p;
-      dg_out += ompl_inner(n, L, p, -1, max_outer, n_out, G, scratch);
+      optp(prof, 11);
+      dg_out += ompl_inner<OMPL_NB>(n, L, p, -1, max_outer, n_out, G, scratch, prof);
       dg_p1 = p;
       for (int q = tid; q < p; q += blockDim.x) { L.xs[q] = L.x[L.cs[q]]; L.z[q] = L.xs[q]; }
       __syncthreads();
+      optp(prof, 5);
     }
   }
+  optp(prof, 11);
   bool more = true;
   for (int outer = 0; outer < max_outer && G.ok && n_out > 0 && more; ++outer) {
     ++dg_outer;
+    optp(prof, 11);
     // duals w_j = c_j - G[j, P] x of the members without weight: one wave per candidate, dealt over all workgroups
     double* D = xbuf(n, G);
     for (int j = wg * nw + wave; j < k; j += nwg * nw) {
@@ -840,35 +921,43 @@ __global__ __launch_bounds__(THREADS) void optimize_lh_kernel(NnlsArgs n, GridSy
     for (int j = tid; j < k; j += blockDim.x) {
       const int fl = L.fl[j];
       const bool cnd = (fl & FLAG_INS) && !(fl & FLAG_REJ) && L.pos[j] < 0;
-      Ld[j] = cnd ? xld(&D[j]) : -INFINITY;
+      const double dj = cnd ? xld(&D[j]) : -INFINITY;
+      Ld[j] = (cnd && dj > tolscale * a.act_norm[j]) ? dj : -INFINITY;     // (the threshold here: the picks below stay in LDS)
     }
     __syncthreads();
     // Up to OPTL_BATCH columns enter per dual pass, in the order of these duals.  Lawson-Hanson asks for A column with a
     // positive dual (the largest is its heuristic): from the second of a batch on the list is stale, so the candidate's
     // exact dual at the current solution is formed first -- replicated, O(p), no barrier -- and a candidate whose dual
     // is no longer positive waits for the next pass.  One grid barrier less per entering column.
+    optp(prof, 0);                                             // the dual pass
     for (int bth = 0; bth < OPTL_BATCH && G.ok; ++bth) {
+      optp(prof, 11);
       double dbv = -INFINITY; int dbi = -1;
       for (int j = tid; j < k; j += blockDim.x) {
         const double wvj = Ld[j];
-        if (wvj > tolscale * a.act_norm[j] && (dbi < 0 || wvj > dbv)) { dbv = wvj; dbi = j; }
+        if (wvj > -INFINITY && (dbi < 0 || wvj > dbv)) { dbv = wvj; dbi = j; }
       }
       const ArgBest pick = block_argbest(dbv, dbi, scratch);
       const int cand = pick.i;
       if (cand < 0) { if (bth == 0) more = false; break; }
       if (tid == 0) Ld[cand] = -INFINITY;
+      // (the candidate's scalars travel with the gather below: one round trip to memory instead of four dependent ones)
+      const double ncand = a.act_norm[cand], ccand = xld(&n.cvec[cand]), gcc = n.gram[(size_t)cand * n.ldg + cand];
       // g = G[cand, P], exact dual c_cand - g . z
       double r1[1] = {0.0};
       for (int q = tid; q < p; q += blockDim.x) { const double gq = n.gram[(size_t)cand * n.ldg + L.cs[q]]; L.g[q] = gq; r1[0] += gq * L.z[q]; }
       block_allsum<1>(r1, scratch);
-      const double wv = xld(&n.cvec[cand]) - r1[0];
-      if (!(wv > tolscale * a.act_norm[cand])) continue;
+      const double wv = ccand - r1[0];
+      if (!(wv > tolscale * ncand)) continue;
+      optp(prof, 1);                                           // pick + gather g + exact dual
       if (p > 0) {
         double* Uh = xbuf(n, G);
         double* Ul = xbuf(n, G);
-        ompl_mv_rows(n, p, L.g, nullptr, Uh, Ul, nullptr);
+        ompl_mv_rows<OMPL_NB>(n, p, L.g, nullptr, Uh, Ul, nullptr);
+        optp(prof, 2);
         gsync(G);
-        for (int q = tid; q < p; q += blockDim.x) { L.u[q] = xld(&Uh[q]); L.ul[q] = xld(&Ul[q]); }
+        optp(prof, 3);
+        ompl_fetch_pair(Uh, Ul, L.u, L.ul, p);
         __syncthreads();
       }
       dd gu = dd_make(0.0, 0.0);
@@ -879,7 +968,6 @@ __global__ __launch_bounds__(THREADS) void optimize_lh_kernel(NnlsArgs n, GridSy
       gu = dd_make(seg[0][0], seg[1][0]);
       for (int w = 1; w < nw; ++w) gu = dd_add(gu, dd_make(seg[0][w], seg[1][w]));
       __syncthreads();
-      const double gcc = n.gram[(size_t)cand * n.ldg + cand];
       const dd sc = dd_add(dd_make(gcc, 0.0), dd_neg(gu));
       if (!(sc.h > 1e-12 * gcc)) {                            // numerically dependent on P: never enters
         if (tid == 0) L.fl[cand] |= FLAG_REJ;
@@ -890,13 +978,14 @@ __global__ __launch_bounds__(THREADS) void optimize_lh_kernel(NnlsArgs n, GridSy
       const double t = wv / sc.h;
       const dd inv = dd_recip(sc);
       for (int q = tid; q < p; q += blockDim.x) L.z[q] -= t * L.u[q];      // (z == xs == x on P at this point)
-      ompl_border_apply(n, L, p, inv);
+      ompl_border_apply<OMPL_NB>(n, L, p, inv);
       if (tid == 0) { L.z[p] = t; L.xs[p] = 0.0; L.cs[p] = cand; L.pos[cand] = p; }
       p += 1;
       --n_out;
       ++dg_in;
       __syncthreads();
-      dg_out += ompl_inner(n, L, p, cand, max_outer, n_out, G, scratch);
+      optp(prof, 4);
+      dg_out += ompl_inner<OMPL_NB>(n, L, p, cand, max_outer, n_out, G, scratch, prof);
       for (int q = tid; q < p; q += blockDim.x) { L.xs[q] = L.x[L.cs[q]]; L.z[q] = L.xs[q]; }
       __syncthreads();
     }
@@ -947,7 +1036,7 @@ __global__ __launch_bounds__(THREADS) void optimize_lh_kernel(NnlsArgs n, GridSy
     __syncthreads();
     double* Zh = xbuf(n, G);
     double* Zl = xbuf(n, G);
-    ompl_mv_rows(n, p, L.g, nullptr, Zh, Zl, nullptr);
+    ompl_mv_rows<OMPL_NB>(n, p, L.g, nullptr, Zh, Zl, nullptr);
     gsync(G);
     double dm1 = 0.0, xm1 = 0.0;
     int neg = 0;
@@ -974,6 +1063,10 @@ __global__ __launch_bounds__(THREADS) void optimize_lh_kernel(NnlsArgs n, GridSy
     st->dbg_t[20] = warm_p ? 1 : 0; st->dbg_t[21] = dg_p0; st->dbg_t[22] = dg_p1; st->dbg_t[23] = dg_in; st->dbg_t[24] = dg_out;
     st->dbg_t[25] = p; st->dbg_t[26] = fallback; st->dbg_t[27] = (long long)(1e15 * (xm > 0.0 ? dm / xm : 0.0)); st->dbg_t[28] = (long long)negs;
     st->dbg_t[29] = dg_outer; st->dbg_t[30] = n_out;
+#ifdef BCX_OPT_PROFILE
+    for (int i = 0; i < 8; ++i) st->dbg_t[i] = prof_[i];
+    st->dbg_t[19] = prof_[8]; st->dbg_t[31] = prof_[9];
+#endif
     if (warm_p) for (int i = 0; i < 11; ++i) st->dbg_t[8 + i] = st->dbg_t[20 + i];       // (kept when a cold run follows)
   }
   if (!G.ok) { if (tid == 0) { st->hvalid = 0; st->halt = HALT_GRID_TIMEOUT; } return; }
@@ -1032,8 +1125,13 @@ int bcx_launch_optimize_lh(bcx_solver* s, double tol, int k, const int32_t* warm
   static const bool nofence = bcx_dev_env("BCX_GRID_NOFENCE") != nullptr;
   gs.fences = nofence ? 0 : 1;
   static const int forced_wgs = bcx_dev_env("BCX_OPT_WGS") ? atoi(bcx_dev_env("BCX_OPT_WGS")) : 0;     // dev
-  const int wgs = forced_wgs > 0 ? forced_wgs : (k <= 256 ? 16 : (k <= 1024 ? 32 : OPTL_MAX_WGS));
-  const int threads = k <= 192 ? 256 : (k <= 768 ? 512 : 1024);
+  // Workgroup shape (round 6, tools/optimize_ab.sh, k = 1497, d = 1024, 311 columns enter and 311 leave): what bounds a pivot is
+  // the number of dependent round trips of its passes over H, and the batches that cut them (OMPL_NB) need registers --
+  // 1024 threads x 64 workgroups 35.6 ms, 512 x 64 31.0, 512 x 96 31.2, 512 x 128 26.7, 256 x 128 30.3, 256 x 256 30.7;
+  // k = 999, d = 512: 1024 x 32 4.0 ms, 512 x 64 3.6, 512 x 32 3.8, 256 x 64 3.8.
+  const int wgs = forced_wgs > 0 ? forced_wgs : (k <= 256 ? 16 : (k <= 768 ? 32 : (k <= 1024 ? 64 : OPTL_MAX_WGS)));
+  static const int forced_thr = bcx_dev_env("BCX_OPT_THREADS") ? atoi(bcx_dev_env("BCX_OPT_THREADS")) : 0;   // dev: 256 / 512 / 1024
+  const int threads = forced_thr > 0 ? forced_thr : (k <= 192 ? 256 : 512);
 #define OPTL_LAUNCH(T)                                                                                                          \
   do {                                                                                                                          \
     if (lds > 48 * 1024) BCX_HIP(hipFuncSetAttribute((const void*)optimize_lh_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \

@@ -26,6 +26,11 @@ def run(alg, N, d, its):
     eng.lib.bcx_debug_stamps(eng.h, st)
     print("   last optimize_lh launch: warm %d p0 %d after-inner %d entered %d left %d p %d fallback %d newton-step/weights %.2e nonpositive %d dual passes %d candidates left %d"
           % (st[20], st[21], st[22], st[23], st[24], st[25], st[26], st[27] / 1e15, st[28], st[29], st[30]))
+    if os.environ.get("OPT_PROFILE"):     # library built with EXTRA=-DBCX_OPT_PROFILE: ticks of 10 ns by phase, workgroup 0
+        names = ["dual pass", "pick + gather g", "u = H g", "barrier (u)", "fetch u, Schur, border update", "inner loop search / copies",
+                 "publish rows", "barrier (leave)", "fetch rows, moved row, z", "downdate"]
+        vals = [st[i] for i in range(8)] + [st[19], st[31]]
+        print("   phases, ms: " + "; ".join("%s %.2f" % (nm, v * 1e-5) for nm, v in zip(names, vals)) + "; sum %.2f" % (sum(vals) * 1e-5))
     if not st[20]:
         print("   the warm launch before it:  p0 %d after-inner %d entered %d left %d p %d fallback %d newton-step/weights %.2e nonpositive %d dual passes %d candidates left %d"
               % (st[9], st[10], st[11], st[12], st[13], st[14], st[15] / 1e15, st[16], st[17], st[18]))
