@@ -1056,6 +1056,15 @@ __global__ __launch_bounds__(THREADS) void optimize_lh_kernel(NnlsArgs n, GridSy
     __syncthreads();
   }
   combine(a.tmp);                                            // V_P^T x of the weights that are committed
+#ifdef BCX_OPT_PROFILE
+  // every workgroup's own wait at the barrier after u = H g and its time in the phases between the barriers (ticks), into the
+  // weight back-up buffer behind the k weights' slots that a revert would read (profile builds only; bcx_debug_wbak)
+  if (tid == 0 && wg != 0 && wg < 256 && k >= 1024) {
+    n.wbak[wg] = (double)prof_[3];
+    n.wbak[256 + wg] = (double)(prof_[1] + prof_[2] + prof_[4] + prof_[5] + prof_[6] + prof_[8] + prof_[9]);
+    n.wbak[512 + wg] = (double)prof_[7];
+  }
+#endif
   if (wg != 0) { if (G.ok) grid_arrive(G.gs, 1); return; }
   gsync(G);
   // ---- workgroup 0: publish the passive data, new weights, accept / revert (snnls.py:88-97) ------------------------------

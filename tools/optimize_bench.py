@@ -31,6 +31,18 @@ def run(alg, N, d, its):
                  "publish rows", "barrier (leave)", "fetch rows, moved row, z", "downdate"]
         vals = [st[i] for i in range(8)] + [st[19], st[31]]
         print("   phases, ms: " + "; ".join("%s %.2f" % (nm, v * 1e-5) for nm, v in zip(names, vals)) + "; sum %.2f" % (sum(vals) * 1e-5))
+    if os.environ.get("OPT_PROFILE") and k >= 1024:     # per workgroup: wait at the barrier after u = H g, own phases, wait at the leave's barrier
+        buf = (ctypes.c_double * 768)()
+        eng.lib.bcx_debug_wbak.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int32]
+        if eng.lib.bcx_debug_wbak(eng.h, buf, 768) == 0:
+            nwg = int(os.environ.get("BCX_OPT_WGS", "128"))
+            w = np.array(buf[1:nwg]) * 1e-5; c = np.array(buf[257:256 + nwg]) * 1e-5; l = np.array(buf[513:512 + nwg]) * 1e-5
+            print("   per workgroup 1..%d, ms: wait(u) min %.2f median %.2f max %.2f | own phases min %.2f median %.2f max %.2f | wait(leave) min %.2f median %.2f max %.2f"
+                  % (nwg - 1, w.min(), np.median(w), w.max(), c.min(), np.median(c), c.max(), l.min(), np.median(l), l.max()))
+            by_xcd = [("%.2f/%.2f" % (np.mean(w[np.arange(1, nwg)[:len(w)] % 8 == x]), np.mean(c[np.arange(1, nwg)[:len(c)] % 8 == x]))) for x in range(8)]
+            print("   by workgroup index mod 8 (XCD), mean wait(u) / own phases: " + " ".join(by_xcd))
+            order = np.argsort(w)
+            print("   shortest waits (the stragglers): workgroups " + " ".join("%d:%.2f" % (order[i] + 1, w[order[i]]) for i in range(8)))
     if not st[20]:
         print("   the warm launch before it:  p0 %d after-inner %d entered %d left %d p %d fallback %d newton-step/weights %.2e nonpositive %d dual passes %d candidates left %d"
               % (st[9], st[10], st[11], st[12], st[13], st[14], st[15] / 1e15, st[16], st[17], st[18]))
