@@ -1127,12 +1127,17 @@ int bcx_launch_optimize_lh(bcx_solver* s, double tol, int k, const int32_t* warm
   gs.counter = s->grid_counter;
   gs.base = 0;
   gs.timeout_ticks = 1000000000LL;     // 10 s
-  // dev: BCX_GRID_NOFENCE=1 drops the barriers' release / acquire fences (every cross-workgroup datum of this file is an
-  // exchange vector written write-through and read with sc1 loads, so they order nothing that is read).  Measured round 6:
-  // optimize() k = 1497, d = 1024 34.5 ms without against 36.3 with, the OMP step of configs[2] 35.9 us either way -- the
-  // fences are not what bounds these kernels (unlike csrc/lrpost.hip, where they sat on a 5 us critical path), so they stay.
-  static const bool nofence = bcx_dev_env("BCX_GRID_NOFENCE") != nullptr;
-  gs.fences = nofence ? 0 : 1;
+  // The barriers of this kernel carry NO release / acquire fences (dev: BCX_GRID_FENCE=1 puts them back).  Everything that
+  // crosses workgroups here is an exchange vector written write-through (sc1 stores, drained by every wave before its
+  // workgroup arrives: grid_publish) and read with sc1 loads after the wait -- the hand-off form csrc/lrpost.hip and
+  // csrc/persist.hip use -- and H is touched by its rows' owner waves only, so the fences order nothing that is read.  What
+  // they cost is H: the release writes the XCD's dirty rows back (16 MB per pass over the inverse at k = 1024), the acquire
+  // drops them from the L2 before the owner reads them again.  Measured (k = 1497, d = 1024, tools/optimize_ab.sh):
+  // 64 workgroups x 1024 threads 36.3 ms with, 34.5 without; 128 x 512 26.7 with, 22.4 without (the phase clock: the barrier
+  // after u = H g 16 -> 10 us for EVERY workgroup alike -- it is the barrier's own cost, not a straggler).  Repeated calls
+  // give one outcome in both forms (tests/race_hunt.py, tests/race_hunt_warm.py).
+  static const bool fence = bcx_dev_env("BCX_GRID_FENCE") != nullptr;
+  gs.fences = fence ? 1 : 0;
   static const int forced_wgs = bcx_dev_env("BCX_OPT_WGS") ? atoi(bcx_dev_env("BCX_OPT_WGS")) : 0;     // dev
   // Workgroup shape (round 6, tools/optimize_ab.sh, k = 1497, d = 1024, 311 columns enter and 311 leave): what bounds a pivot is
   // the number of dependent round trips of its passes over H, and the batches that cut them (OMPL_NB) need registers --
