@@ -60,6 +60,9 @@ struct GridSync {
   unsigned long long* counter;
   unsigned long long base;
   long long timeout_ticks;
+  unsigned long long* gen;   // null: every workgroup polls the arrival counter itself.  Else (optimize_lh_kernel): the word the
+                    // LAST arriver of a barrier writes the barrier's index into and everybody else polls -- 128 pollers on the
+                    // word the arrivals' atomics go to keep that word saturated (one word serves ~90 operations per us)
   int fences;       // 1 (default): agent-scope release before every arrival and acquire after every wait; 0 (dev switch of
                     // omp_lh.hip): none -- valid where all cross-workgroup data is written write-through and read with sc1 loads
 };
@@ -96,17 +99,45 @@ static __device__ __forceinline__ void grid_arrive(const GridSync& g, int times)
   grid_publish();
   if (threadIdx.x == 0) grid_signal(g, (unsigned long long)times);
 }
+// the arrival that completes barrier `index` publishes the index (split form, g.gen != null).  Lane 0 only.
+static __device__ __forceinline__ bool grid_signal_split(const GridSync& g, int index) {
+  if (g.fences) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
+  const unsigned long long target = g.base + (unsigned long long)index * gridDim.x;
+  const unsigned long long old = __hip_atomic_fetch_add(g.counter, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  const bool last = old + 1ull == target;
+  if (last) __hip_atomic_store(g.gen, (unsigned long long)index, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  return last;
+}
+// arrive at barrier `index` without waiting (a workgroup that leaves the kernel before the others' last barrier).  All threads.
+static __device__ __forceinline__ void grid_arrive_at(const GridSync& g, int index) {
+  grid_publish();
+  if (threadIdx.x == 0) {
+    if (g.gen) grid_signal_split(g, index); else grid_signal(g, 1ull);
+  }
+}
 // all threads; false after a timeout (the build is then stopped instead of hanging the GPU)
 static __device__ bool grid_barrier(const GridSync& g, int index, int* s_flag) {
   grid_publish();
   if (threadIdx.x == 0) {
-    grid_signal(g, 1ull);
-    const unsigned long long target = g.base + (unsigned long long)index * gridDim.x;
     const long long t0 = wall_clock64();
     int ok = 1;
-    while (__hip_atomic_load(g.counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
-      __builtin_amdgcn_s_sleep(1);
-      if (wall_clock64() - t0 > g.timeout_ticks) { ok = 0; break; }
+    if (g.gen) {
+      if (!grid_signal_split(g, index)) {
+        while (__hip_atomic_load(g.gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned long long)index) {
+          __builtin_amdgcn_s_sleep(1);
+          if (wall_clock64() - t0 > g.timeout_ticks) { ok = 0; break; }
+        }
+      }
+    } else {
+      grid_signal(g, 1ull);
+      const unsigned long long target = g.base + (unsigned long long)index * gridDim.x;
+      while (__hip_atomic_load(g.counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+        __builtin_amdgcn_s_sleep(1);
+        if (wall_clock64() - t0 > g.timeout_ticks) { ok = 0; break; }
+      }
     }
     if (g.fences) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     *s_flag = ok;

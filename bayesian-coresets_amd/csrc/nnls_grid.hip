@@ -223,7 +223,7 @@ __global__ __launch_bounds__(NN_THREADS) void optimize_grid_kernel(NnlsArgs n, G
 int bcx_launch_optimize_grid(bcx_solver* s, double tol, int k) {
   if (k >= OPT_MAX_K || bcx_dev_env("BCX_OPT_SINGLE")) return 1;   // caller uses the single-workgroup kernel
   if (!s->grid_counter) {
-    BCX_HIP(hipMalloc((void**)&s->grid_counter, 2 * sizeof(unsigned long long)));
+    BCX_HIP(hipMalloc((void**)&s->grid_counter, BCX_GRID_WORDS * sizeof(unsigned long long)));
   }
   BCX_HIP(hipMemsetAsync(s->grid_counter, 0, 2 * sizeof(unsigned long long), s->stream));   // [0] arrivals, [1] the OMP step's barrier base
   s->grid_epoch = 0;
@@ -240,6 +240,7 @@ int bcx_launch_optimize_grid(bcx_solver* s, double tol, int k) {
   gs.base = 0;
   gs.timeout_ticks = 1000000000LL;   // 10 s
   gs.fences = 1;
+  gs.gen = nullptr;
   hipLaunchKernelGGL(optimize_grid_kernel, dim3(OPT_WGS), dim3(NN_THREADS), lds, s->stream, n, gs, tol, kcap, dpad);
   BCX_HIP(hipGetLastError());
   s->grid_dirty = true;   // counter[0] now holds this launch's arrivals; an OMP step that follows without a build_begin re-zeroes

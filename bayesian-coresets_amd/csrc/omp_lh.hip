@@ -1065,7 +1065,7 @@ __global__ __launch_bounds__(THREADS) void optimize_lh_kernel(NnlsArgs n, GridSy
     n.wbak[512 + wg] = (double)prof_[7];
   }
 #endif
-  if (wg != 0) { if (G.ok) grid_arrive(G.gs, 1); return; }
+  if (wg != 0) { if (G.ok) grid_arrive_at(G.gs, G.bi + 1); return; }
   gsync(G);
   // ---- workgroup 0: publish the passive data, new weights, accept / revert (snnls.py:88-97) ------------------------------
   if (tid == 0) {
@@ -1118,8 +1118,8 @@ int bcx_launch_optimize_lh(bcx_solver* s, double tol, int k, const int32_t* warm
   const int kcap = (k + 1 + 63) / 64 * 64;
   const size_t lds = (size_t)kcap * (8 * sizeof(double) + 3 * sizeof(int));
   if (lds > OMPL_LDS_MAX) return 1;
-  if (!s->grid_counter) BCX_HIP(hipMalloc((void**)&s->grid_counter, 2 * sizeof(unsigned long long)));
-  BCX_HIP(hipMemsetAsync(s->grid_counter, 0, 2 * sizeof(unsigned long long), s->stream));
+  if (!s->grid_counter) BCX_HIP(hipMalloc((void**)&s->grid_counter, BCX_GRID_WORDS * sizeof(unsigned long long)));
+  BCX_HIP(hipMemsetAsync(s->grid_counter, 0, BCX_GRID_WORDS * sizeof(unsigned long long), s->stream));
   s->grid_epoch = 0;
   NnlsArgs n;
   fill_nnls_args(s, n, nullptr);
@@ -1138,6 +1138,8 @@ int bcx_launch_optimize_lh(bcx_solver* s, double tol, int k, const int32_t* warm
   // give one outcome in both forms (tests/race_hunt.py, tests/race_hunt_warm.py).
   static const bool fence = bcx_dev_env("BCX_GRID_FENCE") != nullptr;
   gs.fences = fence ? 1 : 0;
+  static const bool flat = bcx_dev_env("BCX_GRID_FLAT") != nullptr;    // dev: every workgroup polls the arrival counter (the form of the other kernels)
+  gs.gen = flat ? nullptr : s->grid_counter + 16;
   static const int forced_wgs = bcx_dev_env("BCX_OPT_WGS") ? atoi(bcx_dev_env("BCX_OPT_WGS")) : 0;     // dev
   // Workgroup shape (round 6, tools/optimize_ab.sh, k = 1497, d = 1024, 311 columns enter and 311 leave): what bounds a pivot is
   // the number of dependent round trips of its passes over H, and the batches that cut them (OMPL_NB) need registers --
@@ -1185,6 +1187,7 @@ int bcx_launch_omp_lh(bcx_solver* s, NnlsArgs& n, const ResolveArgs* fused) {
   // fences are not what bounds these kernels (unlike csrc/lrpost.hip, where they sat on a 5 us critical path), so they stay.
   static const bool nofence = bcx_dev_env("BCX_GRID_NOFENCE") != nullptr;
   gs.fences = nofence ? 0 : 1;
+  gs.gen = nullptr;
   s->grid_epoch += 1;
   const int fr = (force > 0 && (s->grid_epoch % force) == 0) ? 1 : 0;
   // Workgroup width.  The step is a chain of short latency-bound phases separated by workgroup barriers and block

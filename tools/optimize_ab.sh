@@ -11,6 +11,11 @@ for cfg in "0 0" "1024 64" "512 64" "512 128" "256 128" "256 256" "512 96"; do
   ( [ $T -gt 0 ] && export BCX_OPT_THREADS=$T; [ $W -gt 0 ] && export BCX_OPT_WGS=$W
     timeout 300 python tools/optimize_bench.py 1,1000000,1024,1500 2>&1 | grep -v amdgpu.ids >> $O )
 done
+echo "== the barriers' forms at the library's shape (512 x 128): fences back (BCX_GRID_FENCE=1), every workgroup polling the arrival counter (BCX_GRID_FLAT=1), both, the default again" >> $O
+for env in "BCX_GRID_FENCE=1" "BCX_GRID_FLAT=1" "BCX_GRID_FENCE=1 BCX_GRID_FLAT=1" "BCX_NONE=1"; do
+  echo "-- $env" >> $O
+  ( export $env; timeout 300 python tools/optimize_bench.py 1,1000000,1024,1500 2>&1 | grep -v amdgpu.ids >> $O )
+done
 echo "== k = 999, d = 512 (GIGA)" >> $O
 for cfg in "0 0" "512 64" "256 64" "512 32"; do
   set -- $cfg; T=$1; W=$2
