@@ -413,7 +413,7 @@ extern "C" int bcx_build_begin(bcx_solver* s, int64_t itrs, double tol, int32_t*
   if ((rc = ensure_slots(s, (int64_t)h.k + itrs))) return rc;
   if (s->cfg.alg == BCX_ALG_OMP) {
     if ((rc = bcx_ensure_gram(s, (int64_t)h.k + itrs))) return rc;
-    if (!s->grid_counter && dev_alloc(&s->grid_counter, BCX_GRID_WORDS) != hipSuccess) { s->err = "grid counter allocation failed"; return BCX_ERR_NOMEM; }
+    if (!s->grid_counter && dev_alloc(&s->grid_counter, 32 /* = BCX_GRID_WORDS, nnls_common.h */) != hipSuccess) { s->err = "grid counter allocation failed"; return BCX_ERR_NOMEM; }
     BCX_HIP(hipMemsetAsync(s->grid_counter, 0, 2 * sizeof(unsigned long long), s->stream));
     s->grid_epoch = 0;
     s->grid_dirty = false;

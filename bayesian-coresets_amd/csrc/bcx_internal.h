@@ -161,7 +161,6 @@ struct bcx_solver {
   size_t warm_bytes = 0;
   int64_t opt_warm = 0, opt_warm_failed = 0;   // optimize() calls that started warm / whose warm start was rejected by the closing check
   int64_t k_ub = 0;              // host upper bound of the slot count (grid sizing of the multi-kernel OMP step)
-#define BCX_GRID_WORDS 32        // [0], [1] below; [16] (its own 128-byte line): the barrier index word of the split form (nnls_common.h)
   unsigned long long* grid_counter = nullptr;   // [0] arrival counter of the grid barriers, [1] barrier base of the next OMP step
   uint64_t grid_epoch = 0;       // fused OMP launches since the counter was reset (bcx_build_begin)
   int64_t opt_fallbacks = 0;     // optimize() calls that took the refined solve after the incremental one's check failed (bcx_omp_stats)

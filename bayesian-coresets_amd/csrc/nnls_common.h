@@ -5,6 +5,9 @@
 #include "apply_common.h"
 
 #define NN_THREADS 1024
+// words behind bcx_solver::grid_counter: [0] arrivals, [1] barrier base of the next OMP step, [16] (its own 128-byte line) the
+// barrier index word of the split form (GridSync::gen)
+#define BCX_GRID_WORDS 32
 #define FLAG_INS 1
 #define FLAG_REJ 2
 #define FLAG_RM 4
