@@ -1183,11 +1183,11 @@ int bcx_launch_omp_lh(bcx_solver* s, NnlsArgs& n, const ResolveArgs* fused) {
   gs.timeout_ticks = 1000000000LL;     // 10 s
   // dev: BCX_GRID_NOFENCE=1 drops the barriers' release / acquire fences (every cross-workgroup datum of this file is an
   // exchange vector written write-through and read with sc1 loads, so they order nothing that is read).  Measured round 6:
-  // optimize() k = 1497, d = 1024 34.5 ms without against 36.3 with, the OMP step of configs[2] 35.9 us either way -- the
-  // fences are not what bounds these kernels (unlike csrc/lrpost.hip, where they sat on a 5 us critical path), so they stay.
+  // the OMP step of configs[2] takes 35.9 us either way (16 workgroups, an inverse of a few hundred KB), so here they stay;
+  // optimize_lh_kernel above, whose inverse is 16 MB, runs without them.
   static const bool nofence = bcx_dev_env("BCX_GRID_NOFENCE") != nullptr;
   gs.fences = nofence ? 0 : 1;
-  gs.gen = nullptr;
+  gs.gen = nullptr;                    // (16 workgroups poll the arrival counter itself)
   s->grid_epoch += 1;
   const int fr = (force > 0 && (s->grid_epoch % force) == 0) ? 1 : 0;
   // Workgroup width.  The step is a chain of short latency-bound phases separated by workgroup barriers and block
