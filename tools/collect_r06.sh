@@ -12,7 +12,7 @@ for f in $(ls $O | grep -v "\.err$" | grep -v "_under_pmc.json$" | grep -v "proj
   case $f in
     scan_traffic.json) cp $O/$f profiles/scan_traffic.json;;
     c5_adam_k*.txt) { echo "# rocprofv3 --kernel-trace --stats -- python tools/c5_ksweep.py --ks K --reps 2 --rows 200000  (SparseVI weight optimisation of a coreset SEEDED with K points: 3 x 100 ADAM steps, D = 301, S = 256, closed-form column sums); source digest $D, head $H"; head -18 $O/$f | cut -c1-175; } > profiles/r06_$f;;
-    lrp_chol_timeline.txt|f64_chain_probe.txt|xcd_handoff_probe.txt|bench_c5_moments_kernels_after_setup.txt|svi_laplace_bench.txt|race_hunt_lrpost.txt|gram_times.txt|optimize_times.txt|optimize_ab.txt|persist_ab.txt)
+    lrp_chol_timeline.txt|f64_chain_probe.txt|xcd_handoff_probe.txt|bench_c5_moments_kernels_after_setup.txt|svi_laplace_bench.txt|race_hunt_lrpost.txt|gram_times.txt|optimize_times.txt|optimize_ab.txt|persist_ab.txt|race_hunt_optimize.txt)
       { echo "# source digest $D, head $H"; cat $O/$f; } > profiles/r06_$f;;
     *) cp $O/$f profiles/r06_$f;;
   esac

@@ -20,6 +20,7 @@ python tools/svi_laplace_bench.py --family poisson --steps 4 2>/dev/null | tail 
 { python tests/race_hunt_lrpost.py 2000 301 300; python tests/race_hunt_lrpost.py 400 1000 1000; python tests/race_hunt_lrpost.py 600 97 40; } 2>&1 | grep "^lrpost" > $P/race_hunt_lrpost.txt
 python tools/gram_bench.py 2>&1 | grep -v amdgpu.ids > $P/gram_times.txt
 python tools/optimize_bench.py 2>&1 | grep -v amdgpu.ids > $P/optimize_times.txt
+{ timeout 400 python tests/race_hunt_warm.py 80; timeout 300 python tests/race_hunt.py 80; } 2>&1 | grep -v amdgpu > $P/race_hunt_optimize.txt
 tools/optimize_ab.sh > /dev/null 2>&1; cp gpurun_out/optimize_ab.txt $P/optimize_ab.txt
 tools/persist_ab.sh 1 > /dev/null 2>&1; cp gpurun_out/persist_ab.txt $P/persist_ab.txt
 ls $P | wc -l
