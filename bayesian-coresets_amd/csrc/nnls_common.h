@@ -58,7 +58,7 @@ static __device__ __forceinline__ ArgBest block_argbest(double v, int i, double*
 // ---- grid barrier: an arrival counter in device memory ---------------------------------------------------
 // Barrier `index` (1, 2, ...) of a launch is "counter >= base + index * gridDim.x"; every workgroup arrives
 // exactly once per barrier (or the same number of times by grid_arrive when it skips some).  All workgroups
-// of the launch must be co-resident (grids of <= 64 workgroups on 256 CUs, nothing else on the stream).
+// of the launch must be co-resident (grids of <= 128 workgroups, one per CU, on 256 CUs; nothing else on the stream).
 struct GridSync {
   unsigned long long* counter;
   unsigned long long base;
